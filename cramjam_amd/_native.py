@@ -1,0 +1,144 @@
+"""ctypes binding of libcramjam_hip.so (include/cramjam_hip.h).  The library is the product; if it is
+missing or no HIP device is usable every compute call fails loudly — there is no CPU fallback."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcramjam_hip.so")
+
+CODEC_LZ4_BLOCK, CODEC_SNAPPY_RAW = 0, 1
+OP_DECOMPRESS, OP_COMPRESS = 0, 1
+FLAG_LZ4_SIZE_PREFIX = 1
+E_NO_DEVICE = -100
+
+_vp, _sz, _i64, _u32, _int = C.c_void_p, C.c_size_t, C.c_int64, C.c_uint32, C.c_int
+
+# every symbol include/cramjam_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "cj_strerror": (C.c_char_p, [_i64]),
+    "cj_last_hip_error": (C.c_char_p, []),
+    "cj_abi_version": (_int, []),
+    "cj_device_count": (_int, []),
+    "cj_lz4_block_compress_bound": (_sz, [_sz, _int]),
+    "cj_lz4_block_compress": (_i64, [_vp, _sz, _vp, _sz, _int, _int, _int]),
+    "cj_lz4_block_decompress": (_i64, [_vp, _sz, _vp, _sz, _int]),
+    "cj_lz4_block_prefixed_len": (_i64, [_vp, _sz]),
+    "cj_snappy_raw_max_compress_len": (_sz, [_sz]),
+    "cj_snappy_raw_decompress_len": (_i64, [_vp, _sz]),
+    "cj_snappy_raw_compress": (_i64, [_vp, _sz, _vp, _sz]),
+    "cj_snappy_raw_decompress": (_i64, [_vp, _sz, _vp, _sz]),
+    "cj_engine_create": (_int, [_int, C.POINTER(_vp)]),
+    "cj_engine_destroy": (None, [_vp]),
+    "cj_engine_device": (_int, [_vp]),
+    "cj_batch_device": (_int, [_vp, _int, _int, _u32, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cj_engine_sync": (_int, [_vp]),
+    "cj_batch_host": (_int, [_vp, _int, _int, _u32, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "cj_batch_device_timed": (C.c_double, [_vp, _int, _int, _u32, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int]),
+    "cj_device_alloc": (_vp, [_vp, _sz]),
+    "cj_device_free": (None, [_vp, _vp]),
+    "cj_memcpy_h2d": (_int, [_vp, _vp, _vp, _sz]),
+    "cj_memcpy_d2h": (_int, [_vp, _vp, _vp, _sz]),
+    "cj_memcpy_d2d": (_int, [_vp, _vp, _vp, _sz]),
+    "cj_memset_dev": (_int, [_vp, _vp, _int, _sz]),
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "cramjam_amd: %s is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            f = getattr(L, name)
+            f.restype, f.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def strerror(code):
+    return lib().cj_strerror(code).decode()
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        raise EngineError("%s (%s)" % (strerror(rc), lib().cj_last_hip_error().decode()))
+
+
+class Engine:
+    """One engine per GPU (cj_engine).  Thin: device memory + batch submission."""
+
+    def __init__(self, device=0):
+        h = _vp()
+        check(lib().cj_engine_create(device, C.byref(h)))
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().cj_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def alloc(self, nbytes):
+        p = lib().cj_device_alloc(self.h, nbytes)
+        if not p:
+            raise EngineError("device alloc of %d bytes failed: %s" % (nbytes, lib().cj_last_hip_error().decode()))
+        return p
+
+    def free(self, p):
+        lib().cj_device_free(self.h, p)
+
+    def h2d(self, dptr, data):
+        import numpy as np
+        a = np.ascontiguousarray(data)
+        check(lib().cj_memcpy_h2d(self.h, dptr, a.ctypes.data, a.nbytes))
+
+    def d2h(self, dptr, nbytes, dtype="uint8"):
+        import numpy as np
+        out = np.empty(nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        check(lib().cj_memcpy_d2h(self.h, out.ctypes.data, dptr, out.nbytes))
+        return out
+
+    def sync(self):
+        check(lib().cj_engine_sync(self.h))
+
+    def batch_device(self, codec, op, flags, n, in_base, in_off, in_len, out_base, out_off, out_cap, result, stream=None):
+        check(lib().cj_batch_device(self.h, codec, op, flags, n, in_base, in_off, in_len, out_base, out_off,
+                                    out_cap, result, stream))
+
+    def batch_device_timed(self, codec, op, flags, n, in_base, in_off, in_len, out_base, out_off, out_cap, result, reps):
+        ms = lib().cj_batch_device_timed(self.h, codec, op, flags, n, in_base, in_off, in_len, out_base, out_off,
+                                         out_cap, result, reps)
+        if ms < 0:
+            raise EngineError("timed batch failed: %s" % lib().cj_last_hip_error().decode())
+        return ms
+
+    def batch_host(self, codec, op, flags, inputs, out_caps):
+        """inputs: list of bytes-like; out_caps: list of capacities.  Returns (results, outputs)."""
+        import numpy as np
+        n = len(inputs)
+        ins = [np.frombuffer(bytes(b), dtype=np.uint8) if not isinstance(b, np.ndarray) else np.ascontiguousarray(b).view(np.uint8).ravel()
+               for b in inputs]
+        outs = [np.zeros(max(int(c), 1), dtype=np.uint8) for c in out_caps]
+        in_ptrs = (_vp * n)(*[a.ctypes.data if a.size else None for a in ins])
+        in_lens = (_sz * n)(*[a.size for a in ins])
+        out_ptrs = (_vp * n)(*[a.ctypes.data for a in outs])
+        caps = (_sz * n)(*[int(c) for c in out_caps])
+        res = (_i64 * n)()
+        check(lib().cj_batch_host(self.h, codec, op, flags, n, in_ptrs, in_lens, out_ptrs, caps, res))
+        results = list(res)
+        return results, [outs[i][:max(results[i], 0)].tobytes() for i in range(n)]

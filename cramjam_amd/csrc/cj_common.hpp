@@ -1,0 +1,154 @@
+// cj_common.hpp — shared device helpers and launch declarations for the gfx950 block-codec kernels.
+// Wave = 64 lanes (CDNA4).  Every kernel here maps ONE WAVEFRONT to ONE independent chunk; all
+// stream-position state is wave-uniform (SGPR) and the lanes only do the wide byte moves.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/cramjam_hip.h"
+
+namespace cj {
+
+struct BatchArgs {
+    const uint8_t* in_base;
+    const uint64_t* in_off;
+    const uint64_t* in_len;
+    uint8_t* out_base;
+    const uint64_t* out_off;
+    const uint64_t* out_cap;
+    int64_t* result;
+    uint32_t n_chunks;
+    uint32_t flags;
+};
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlockThreads = 64 * kWavesPerBlock;
+
+void launch_lz4_decode(const BatchArgs& a, hipStream_t s);
+void launch_lz4_encode(const BatchArgs& a, hipStream_t s);
+void launch_snappy_decode(const BatchArgs& a, hipStream_t s);
+void launch_snappy_encode(const BatchArgs& a, hipStream_t s);
+
+#if defined(__HIPCC__)
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __ballot(p); }
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return __builtin_amdgcn_readlane(v, l); }
+
+__device__ __forceinline__ uint32_t ctz64(uint64_t m) { return (uint32_t)__builtin_ctzll(m); }
+
+// compiler-only ordering point between cooperative stores and the loads that read them back.
+// Lanes of one wavefront share the CU's vector L1 and issue in order, so no hardware wait is needed
+// (LLVM AMDGPU memory model: wavefront-scope fences lower to nothing).
+__device__ __forceinline__ void wave_order() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+
+// unaligned 32-bit global load (gfx950 amdhsa runs in unaligned-access mode)
+__device__ __forceinline__ uint32_t ld32u(const uint8_t* p) {
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+
+// ---- 512-byte register window over the compressed stream -------------------------------------
+// Two VGPRs hold 128 consecutive dwords of the (dword-aligned) input; any 4 bytes inside it are
+// reachable with v_readlane (≈10 cycles) instead of an LDS/global round trip (≥64/≥500 cycles).
+struct InWindow {
+    const uint8_t* base;   // dword-aligned start of the input (in - misalignment)
+    uint32_t iend;         // end position relative to base
+    uint32_t wpos;         // window start (multiple of 4) relative to base
+    uint32_t w0, w1;       // VGPR: lane l holds dword at base + wpos + 4*l (w0) / + 256 + 4*l (w1)
+
+    __device__ __forceinline__ uint32_t load_row(uint32_t start) const {
+        uint32_t off = start + 4u * lane_id();
+        uint32_t v = 0;
+        if (off < iend) v = *reinterpret_cast<const uint32_t*>(base + off);
+        return v;
+    }
+    __device__ __forceinline__ void anchor(uint32_t pos) {
+        wpos = pos & ~3u;
+        w0 = load_row(wpos);
+        w1 = load_row(wpos + 256u);
+    }
+    // make sure [pos, pos+need) with need <= 8 lies inside the window and pos - wpos < 256 when cheap
+    __device__ __forceinline__ void ensure(uint32_t pos) {
+        uint32_t q = pos - wpos;
+        if (q >= 256u) {
+            if (q < 504u) {
+                w0 = w1;
+                wpos += 256u;
+                w1 = load_row(wpos + 256u);
+            } else {
+                anchor(pos);
+            }
+        }
+    }
+    // 4 bytes at pos (little endian); requires pos - wpos <= 507
+    __device__ __forceinline__ uint32_t fetch32(uint32_t pos) const {
+        uint32_t q = pos - wpos;
+        uint32_t idx = q >> 2, sh = (q & 3u) * 8u;
+        uint32_t a0 = rdlane(w0, idx & 63u), a1 = rdlane(w1, idx & 63u);
+        uint32_t b0 = rdlane(w0, (idx + 1u) & 63u), b1 = rdlane(w1, (idx + 1u) & 63u);
+        uint32_t lo = idx < 64u ? a0 : a1;
+        uint32_t hi = (idx + 1u) < 64u ? b0 : b1;
+        uint64_t v = ((uint64_t)hi << 32) | lo;
+        return (uint32_t)(v >> sh);
+    }
+    // safe anywhere: re-anchors when pos is outside the comfortable range
+    __device__ __forceinline__ uint32_t fetch32_any(uint32_t pos) {
+        if (pos - wpos > 500u) anchor(pos);
+        return fetch32(pos);
+    }
+};
+
+// cooperative forward copy of n bytes, non-overlapping (src, dst global)
+__device__ __forceinline__ void wave_copy(uint8_t* dst, const uint8_t* src, uint32_t n) {
+    const uint32_t lane = lane_id();
+    if (n <= 64u) {
+        if (lane < n) dst[lane] = src[lane];
+        return;
+    }
+    uint32_t k = 0;
+    if (n >= 2048u) {   // long runs (incompressible data): 16 B per lane per step
+        for (; k + 1024u <= n; k += 1024u) {
+            uint4 v;
+            __builtin_memcpy(&v, src + k + 16u * lane, 16);
+            __builtin_memcpy(dst + k + 16u * lane, &v, 16);
+        }
+    }
+    for (; k < n; k += 64u) {
+        uint32_t j = k + lane;
+        if (j < n) dst[j] = src[j];
+    }
+}
+
+// cooperative LZ77 match copy: dst[j] = dst[j - d] for j in [0, m), d >= 1; the d source bytes
+// before dst are already written.  Overlap (d < m) is resolved by reading the periodic pattern.
+__device__ __forceinline__ void wave_match_copy(uint8_t* dst, uint32_t d, uint32_t m) {
+    const uint32_t lane = lane_id();
+    const uint8_t* src = dst - d;
+    if (d >= m) {
+        if (m <= 64u) {
+            if (lane < m) dst[lane] = src[lane];
+        } else {
+            for (uint32_t k = 0; k < m; k += 64u) {
+                uint32_t j = k + lane;
+                if (j < m) dst[j] = src[j];
+            }
+        }
+        return;
+    }
+    uint32_t r = lane, step = 64u;
+    if (d <= 64u) {
+        r = lane % d;
+        step = 64u % d;
+    }
+    for (uint32_t k = 0; k < m; k += 64u) {
+        uint32_t j = k + lane;
+        if (j < m) dst[j] = src[r];
+        r += step;
+        if (r >= d) r -= d;
+    }
+}
+
+#endif  // __HIPCC__
+}  // namespace cj

@@ -1,0 +1,362 @@
+// engine.hip — the C-ABI of libcramjam_hip.so (include/cramjam_hip.h): per-GPU engine, batch
+// submission, host staging and the single-buffer drop-in entry points.  Host-side C++ over the HIP
+// runtime; all codec arithmetic is in the four *_decode/_encode.hip kernels.  There is no CPU codec
+// in this library: if no device is usable the entry points return CJ_E_NO_DEVICE.
+#include "cj_common.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_hip_err;
+
+bool hip_ok(hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    g_hip_err = std::string(what) + ": " + hipGetErrorString(e);
+    (void)hipGetLastError();
+    return false;
+}
+#define HIP_TRY(expr, ret) do { if (!hip_ok((expr), #expr)) return (ret); } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    bool reserve(size_t n) {
+        if (n <= cap) return true;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = n + n / 4 + 4096;
+        if (!hip_ok(hipMalloc(&p, want), "hipMalloc")) { p = nullptr; return false; }
+        cap = want;
+        return true;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct cj_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;                 // serialises host-batch staging on this engine
+    DevBuf d_in, d_out, d_meta;
+    std::vector<uint8_t> h_in, h_out;
+    std::vector<uint64_t> h_meta;
+};
+
+namespace {
+
+void fill_args(cj::BatchArgs& a, uint32_t flags, size_t n, const uint8_t* in_base, const uint64_t* in_off,
+               const uint64_t* in_len, uint8_t* out_base, const uint64_t* out_off, const uint64_t* out_cap,
+               int64_t* result) {
+    a.in_base = in_base; a.in_off = in_off; a.in_len = in_len;
+    a.out_base = out_base; a.out_off = out_off; a.out_cap = out_cap;
+    a.result = result; a.n_chunks = (uint32_t)n; a.flags = flags;
+}
+
+int launch(cj_codec codec, cj_op op, const cj::BatchArgs& a, hipStream_t s) {
+    if (codec == CJ_CODEC_LZ4_BLOCK) {
+        if (op == CJ_OP_DECOMPRESS) cj::launch_lz4_decode(a, s); else cj::launch_lz4_encode(a, s);
+    } else if (codec == CJ_CODEC_SNAPPY_RAW) {
+        if (op == CJ_OP_DECOMPRESS) cj::launch_snappy_decode(a, s); else cj::launch_snappy_encode(a, s);
+    } else {
+        return CJ_E_BAD_ARG;
+    }
+    HIP_TRY(hipGetLastError(), CJ_E_NO_DEVICE);
+    return 0;
+}
+
+std::once_flag g_default_once;
+cj_engine* g_default = nullptr;
+int g_default_rc = CJ_E_NO_DEVICE;
+
+cj_engine* default_engine() {
+    std::call_once(g_default_once, [] {
+        int dev = 0;
+        if (const char* s = std::getenv("CJ_DEVICE")) dev = std::atoi(s);
+        g_default_rc = cj_engine_create(dev, &g_default);
+    });
+    return g_default_rc == 0 ? g_default : nullptr;
+}
+
+int64_t single(cj_codec codec, cj_op op, uint32_t flags, const uint8_t* in, size_t n, uint8_t* out, size_t cap) {
+    cj_engine* e = default_engine();
+    if (!e) return CJ_E_NO_DEVICE;
+    int64_t res = CJ_E_NO_DEVICE;
+    const uint8_t* ins[1] = { in };
+    uint8_t* outs[1] = { out };
+    int rc = cj_batch_host(e, codec, op, flags, 1, ins, &n, outs, &cap, &res);
+    return rc != 0 ? (int64_t)rc : res;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* cj_strerror(int64_t code) {
+    switch (code) {
+    case CJ_E_INPUT_TOO_LARGE: return "Compression input too long.";
+    case CJ_E_COMPRESS_FAILED: return "Compression failed";
+    case CJ_E_NO_PREFIX: return "Source buffer must at least contain size prefix.";
+    case CJ_E_NEG_PREFIX: return "Parsed size prefix in buffer must not be negative.";
+    case CJ_E_PREFIX_TOO_BIG: return "Given size parameter is too big";
+    case CJ_E_OUT_TOO_SMALL: return "buffer isn't large enough to hold decompressed data";
+    case CJ_E_CORRUPT: return "Decompression failed. Input invalid or too long?";
+    case CJ_E_SNAPPY_EMPTY: return "snappy: corrupt input (empty)";
+    case CJ_E_SNAPPY_HEADER: return "snappy: corrupt input (invalid header)";
+    case CJ_E_SNAPPY_TOO_BIG: return "snappy: input buffer (size) is bigger than the maximum allowed";
+    case CJ_E_SNAPPY_BUF_SMALL: return "snappy: output buffer is too small";
+    case CJ_E_SNAPPY_CORRUPT: return "snappy: corrupt input";
+    case CJ_E_NO_DEVICE: return "cramjam_hip: no usable HIP device (no CPU fallback exists)";
+    case CJ_E_BAD_ARG: return "cramjam_hip: bad argument";
+    case CJ_E_OOM: return "cramjam_hip: out of memory";
+    default: return code >= 0 ? "ok" : "cramjam_hip: unknown error";
+    }
+}
+
+const char* cj_last_hip_error(void) { return g_hip_err.c_str(); }
+int cj_abi_version(void) { return CJ_ABI_VERSION; }
+
+int cj_device_count(void) {
+    int n = 0;
+    if (!hip_ok(hipGetDeviceCount(&n), "hipGetDeviceCount")) return 0;
+    return n;
+}
+
+size_t cj_lz4_block_compress_bound(size_t len, int prepend) {
+    size_t b = len > 0x7E000000u ? 0 : len + len / 255 + 16;
+    return prepend ? b + 4 : b;
+}
+
+int64_t cj_lz4_block_prefixed_len(const uint8_t* in, size_t n) {
+    if (n < 4) return CJ_E_NO_PREFIX;
+    return (int64_t)((uint32_t)in[0] | ((uint32_t)in[1] << 8) | ((uint32_t)in[2] << 16) | ((uint32_t)in[3] << 24));
+}
+
+size_t cj_snappy_raw_max_compress_len(size_t len) {
+    if ((uint64_t)len > 0xFFFFFFFFull) return 0;
+    uint64_t m = 32 + (uint64_t)len + (uint64_t)len / 6;
+    return m > 0xFFFFFFFFull ? 0 : (size_t)m;
+}
+
+int64_t cj_snappy_raw_decompress_len(const uint8_t* in, size_t n) {
+    if (n == 0) return 0;
+    uint64_t v = 0;
+    unsigned shift = 0;
+    for (size_t i = 0; i < n && i < 10; i++) {
+        uint8_t b = in[i];
+        if (b < 0x80) {
+            if (i == 9 && b > 1) return CJ_E_SNAPPY_HEADER;
+            v |= (uint64_t)b << shift;
+            return v > 0xFFFFFFFFull ? (int64_t)CJ_E_SNAPPY_TOO_BIG : (int64_t)v;
+        }
+        v |= (uint64_t)(b & 0x7f) << shift;
+        shift += 7;
+    }
+    return CJ_E_SNAPPY_HEADER;
+}
+
+int cj_engine_create(int device, cj_engine** out) {
+    if (!out) return CJ_E_BAD_ARG;
+    *out = nullptr;
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n), CJ_E_NO_DEVICE);
+    if (device < 0 || device >= n) { g_hip_err = "device index out of range"; return CJ_E_NO_DEVICE; }
+    HIP_TRY(hipSetDevice(device), CJ_E_NO_DEVICE);
+    cj_engine* e = new cj_engine();
+    e->device = device;
+    if (!hip_ok(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking), "hipStreamCreate")) { delete e; return CJ_E_NO_DEVICE; }
+    *out = e;
+    return 0;
+}
+
+void cj_engine_destroy(cj_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    e->d_in.release(); e->d_out.release(); e->d_meta.release();
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int cj_engine_device(const cj_engine* e) { return e ? e->device : -1; }
+
+int cj_batch_device(cj_engine* e, cj_codec codec, cj_op op, uint32_t flags, size_t n_chunks,
+                    const uint8_t* in_base, const uint64_t* in_off, const uint64_t* in_len,
+                    uint8_t* out_base, const uint64_t* out_off, const uint64_t* out_cap,
+                    int64_t* result, void* hip_stream) {
+    if (!e || n_chunks > 0xFFFFFFF0ull) return CJ_E_BAD_ARG;
+    if (n_chunks == 0) return 0;
+    HIP_TRY(hipSetDevice(e->device), CJ_E_NO_DEVICE);
+    cj::BatchArgs a;
+    fill_args(a, flags, n_chunks, in_base, in_off, in_len, out_base, out_off, out_cap, result);
+    return launch(codec, op, a, hip_stream ? (hipStream_t)hip_stream : e->stream);
+}
+
+int cj_engine_sync(cj_engine* e) {
+    if (!e) return CJ_E_BAD_ARG;
+    HIP_TRY(hipSetDevice(e->device), CJ_E_NO_DEVICE);
+    HIP_TRY(hipStreamSynchronize(e->stream), CJ_E_NO_DEVICE);
+    return 0;
+}
+
+double cj_batch_device_timed(cj_engine* e, cj_codec codec, cj_op op, uint32_t flags, size_t n_chunks,
+                             const uint8_t* in_base, const uint64_t* in_off, const uint64_t* in_len,
+                             uint8_t* out_base, const uint64_t* out_off, const uint64_t* out_cap,
+                             int64_t* result, int reps) {
+    if (!e || reps < 1 || n_chunks == 0 || n_chunks > 0xFFFFFFF0ull) return -1.0;
+    HIP_TRY(hipSetDevice(e->device), -1.0);
+    cj::BatchArgs a;
+    fill_args(a, flags, n_chunks, in_base, in_off, in_len, out_base, out_off, out_cap, result);
+    hipEvent_t t0, t1;
+    HIP_TRY(hipEventCreate(&t0), -1.0);
+    HIP_TRY(hipEventCreate(&t1), -1.0);
+    HIP_TRY(hipEventRecord(t0, e->stream), -1.0);
+    for (int r = 0; r < reps; r++)
+        if (launch(codec, op, a, e->stream) != 0) return -1.0;
+    HIP_TRY(hipEventRecord(t1, e->stream), -1.0);
+    HIP_TRY(hipEventSynchronize(t1), -1.0);
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, t0, t1), -1.0);
+    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+    return (double)ms / reps;
+}
+
+int cj_batch_host(cj_engine* e, cj_codec codec, cj_op op, uint32_t flags, size_t n,
+                  const uint8_t* const* in_ptrs, const size_t* in_lens,
+                  uint8_t* const* out_ptrs, const size_t* out_caps, int64_t* result) {
+    if (!e || (n && (!in_ptrs || !in_lens || !out_ptrs || !out_caps || !result))) return CJ_E_BAD_ARG;
+    if (n == 0) return 0;
+    if (n > 0xFFFFFFF0ull) return CJ_E_BAD_ARG;
+    std::lock_guard<std::mutex> lock(e->mu);
+    HIP_TRY(hipSetDevice(e->device), CJ_E_NO_DEVICE);
+
+    // meta layout (u64 each, n entries per row): in_off | in_len | out_off | out_cap | result
+    std::vector<uint64_t>& m = e->h_meta;
+    m.assign(5 * n, 0);
+    uint64_t in_total = 0, out_total = 0;
+    for (size_t i = 0; i < n; i++) {
+        m[i] = in_total;
+        m[n + i] = in_lens[i];
+        in_total += (in_lens[i] + 15u) & ~(uint64_t)15u;
+        // LZ4 compress: the kernel wants a full LZ4_compressBound of room; give it that on the device and
+        // apply the caller's capacity when copying back (fits -> ok, else "Compression failed").
+        uint64_t dcap = out_caps[i];
+        if (codec == CJ_CODEC_LZ4_BLOCK && op == CJ_OP_COMPRESS) {
+            uint64_t b = cj_lz4_block_compress_bound(in_lens[i], (flags & CJ_FLAG_LZ4_SIZE_PREFIX) ? 1 : 0);
+            if (b > dcap) dcap = b;
+        }
+        m[2 * n + i] = out_total;
+        m[3 * n + i] = dcap;
+        out_total += (dcap + 15u) & ~(uint64_t)15u;
+    }
+    if (!e->d_in.reserve(in_total + 16) || !e->d_out.reserve(out_total + 16) || !e->d_meta.reserve(5 * n * 8)) return CJ_E_OOM;
+
+    uint8_t* d_in = (uint8_t*)e->d_in.p;
+    uint8_t* d_out = (uint8_t*)e->d_out.p;
+    uint64_t* d_meta = (uint64_t*)e->d_meta.p;
+    if (n == 1) {
+        if (in_lens[0]) HIP_TRY(hipMemcpyAsync(d_in, in_ptrs[0], in_lens[0], hipMemcpyHostToDevice, e->stream), CJ_E_NO_DEVICE);
+    } else {
+        e->h_in.resize(in_total);
+        for (size_t i = 0; i < n; i++)
+            if (in_lens[i]) std::memcpy(e->h_in.data() + m[i], in_ptrs[i], in_lens[i]);
+        if (in_total) HIP_TRY(hipMemcpyAsync(d_in, e->h_in.data(), in_total, hipMemcpyHostToDevice, e->stream), CJ_E_NO_DEVICE);
+    }
+    HIP_TRY(hipMemcpyAsync(d_meta, m.data(), 4 * n * 8, hipMemcpyHostToDevice, e->stream), CJ_E_NO_DEVICE);
+
+    cj::BatchArgs a;
+    fill_args(a, flags, n, d_in, d_meta, d_meta + n, d_out, d_meta + 2 * n, d_meta + 3 * n, (int64_t*)(d_meta + 4 * n));
+    int rc = launch(codec, op, a, e->stream);
+    if (rc != 0) return rc;
+    HIP_TRY(hipMemcpyAsync(result, d_meta + 4 * n, n * 8, hipMemcpyDeviceToHost, e->stream), CJ_E_NO_DEVICE);
+    HIP_TRY(hipStreamSynchronize(e->stream), CJ_E_NO_DEVICE);
+
+    if (n == 1) {
+        if (result[0] > 0) {
+            if ((uint64_t)result[0] > out_caps[0]) result[0] = CJ_E_COMPRESS_FAILED;
+            else HIP_TRY(hipMemcpy(out_ptrs[0], d_out, (size_t)result[0], hipMemcpyDeviceToHost), CJ_E_NO_DEVICE);
+        }
+        return 0;
+    }
+    // copy back only the span that was produced
+    uint64_t span = 0;
+    for (size_t i = 0; i < n; i++)
+        if (result[i] > 0 && m[2 * n + i] + (uint64_t)result[i] > span) span = m[2 * n + i] + (uint64_t)result[i];
+    e->h_out.resize(span);
+    if (span) HIP_TRY(hipMemcpy(e->h_out.data(), d_out, span, hipMemcpyDeviceToHost), CJ_E_NO_DEVICE);
+    for (size_t i = 0; i < n; i++) {
+        if (result[i] <= 0) continue;
+        if ((uint64_t)result[i] > out_caps[i]) { result[i] = CJ_E_COMPRESS_FAILED; continue; }
+        std::memcpy(out_ptrs[i], e->h_out.data() + m[2 * n + i], (size_t)result[i]);
+    }
+    return 0;
+}
+
+int64_t cj_lz4_block_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap, int level, int accel, int prepend) {
+    (void)level; (void)accel;   // libcramjam always runs LZ4's DEFAULT mode (see header)
+    const bool pre = prepend != 0;   // -1 (None) and 1 -> prefix
+    if (n > 0x7FFFFFFFull || cj_lz4_block_compress_bound(n, 0) == 0) return CJ_E_INPUT_TOO_LARGE;
+    if (pre && cap < 4) return CJ_E_COMPRESS_FAILED;
+    return single(CJ_CODEC_LZ4_BLOCK, CJ_OP_COMPRESS, pre ? CJ_FLAG_LZ4_SIZE_PREFIX : 0u, in, n, out, cap);
+}
+
+int64_t cj_lz4_block_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap, int size_prepended) {
+    return single(CJ_CODEC_LZ4_BLOCK, CJ_OP_DECOMPRESS, size_prepended ? CJ_FLAG_LZ4_SIZE_PREFIX : 0u, in, n, out, cap);
+}
+
+int64_t cj_snappy_raw_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap) {
+    return single(CJ_CODEC_SNAPPY_RAW, CJ_OP_COMPRESS, 0u, in, n, out, cap);
+}
+
+int64_t cj_snappy_raw_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap) {
+    return single(CJ_CODEC_SNAPPY_RAW, CJ_OP_DECOMPRESS, 0u, in, n, out, cap);
+}
+
+void* cj_device_alloc(cj_engine* e, size_t bytes) {
+    if (!e) return nullptr;
+    if (!hip_ok(hipSetDevice(e->device), "hipSetDevice")) return nullptr;
+    void* p = nullptr;
+    if (!hip_ok(hipMalloc(&p, bytes ? bytes : 1), "hipMalloc")) return nullptr;
+    return p;
+}
+
+void cj_device_free(cj_engine* e, void* p) {
+    if (!e || !p) return;
+    (void)hipSetDevice(e->device);
+    (void)hipFree(p);
+}
+
+int cj_memcpy_h2d(cj_engine* e, void* d, const void* s, size_t n) {
+    if (!e) return CJ_E_BAD_ARG;
+    HIP_TRY(hipSetDevice(e->device), CJ_E_NO_DEVICE);
+    if (n) HIP_TRY(hipMemcpy(d, s, n, hipMemcpyHostToDevice), CJ_E_NO_DEVICE);
+    return 0;
+}
+
+int cj_memcpy_d2h(cj_engine* e, void* d, const void* s, size_t n) {
+    if (!e) return CJ_E_BAD_ARG;
+    HIP_TRY(hipSetDevice(e->device), CJ_E_NO_DEVICE);
+    if (n) HIP_TRY(hipMemcpy(d, s, n, hipMemcpyDeviceToHost), CJ_E_NO_DEVICE);
+    return 0;
+}
+
+int cj_memcpy_d2d(cj_engine* e, void* d, const void* s, size_t n) {
+    if (!e) return CJ_E_BAD_ARG;
+    HIP_TRY(hipSetDevice(e->device), CJ_E_NO_DEVICE);
+    if (n) HIP_TRY(hipMemcpy(d, s, n, hipMemcpyDeviceToDevice), CJ_E_NO_DEVICE);
+    return 0;
+}
+
+int cj_memset_dev(cj_engine* e, void* d, int v, size_t n) {
+    if (!e) return CJ_E_BAD_ARG;
+    HIP_TRY(hipSetDevice(e->device), CJ_E_NO_DEVICE);
+    if (n) HIP_TRY(hipMemset(d, v, n), CJ_E_NO_DEVICE);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,123 @@
+// lz4_decode.hip — LZ4 *block* decoder for gfx950, one wavefront per independent chunk.
+//
+// Replaces (on the GPU) what the reference reaches at /root/reference/src/lz4.rs:88,90,164,168:
+// libcramjam::lz4::block::decompress_into -> lz4 crate -> LZ4_decompress_safe.  Accept/reject rules
+// follow the liblz4 1.10.0 safe decoder (end-of-block parsing restrictions relative to the decode
+// capacity, variable-length field limits); offset 0 is rejected (spec-invalid).
+//
+// Shape: the sequence grammar is parsed wave-uniformly on the scalar unit out of a 512-byte register
+// window (v_readlane), the vector lanes only move bytes: literals HBM->HBM, matches from the
+// chunk's own freshly written output (same-wave L1-coherent), byte per lane, 16 B/lane on long runs.
+#include "cj_common.hpp"
+
+namespace cj {
+
+__global__ __launch_bounds__(kBlockThreads) void lz4_decode_kernel(BatchArgs a) {
+    const uint32_t chunk = uni(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+    if (chunk >= a.n_chunks) return;
+    const uint8_t* in = a.in_base + a.in_off[chunk];
+    uint64_t n64 = a.in_len[chunk];
+    uint8_t* out = a.out_base + a.out_off[chunk];
+    uint64_t cap64 = a.out_cap[chunk];
+    int64_t status = 0;
+
+    if (a.flags & CJ_FLAG_LZ4_SIZE_PREFIX) {
+        // lz4 crate decompress_to_buffer(src, None, buffer): u32-LE size prefix (reference src/lz4.rs:90,164)
+        if (n64 < 4) { status = CJ_E_NO_PREFIX; }
+        else {
+            int32_t size = (int32_t)((uint32_t)in[0] | ((uint32_t)in[1] << 8) | ((uint32_t)in[2] << 16) | ((uint32_t)in[3] << 24));
+            if (size < 0) status = CJ_E_NEG_PREFIX;
+            else if ((uint32_t)size > 0x7E000000u) status = CJ_E_PREFIX_TOO_BIG;
+            else if ((uint64_t)size > cap64) status = CJ_E_OUT_TOO_SMALL;
+            else { in += 4; n64 -= 4; cap64 = (uint64_t)size; }
+        }
+    } else {
+        // capacity is handed to liblz4 as an i32
+        int32_t size = (int32_t)(uint32_t)cap64;
+        if (cap64 > 0xFFFFFFFFull || size < 0) status = CJ_E_NEG_PREFIX;
+        else if ((uint32_t)size > 0x7E000000u) status = CJ_E_PREFIX_TOO_BIG;
+    }
+    if (status == 0 && n64 > 0x7FFFFFF0ull) status = CJ_E_CORRUPT;
+    if (status != 0) { if (lane_id() == 0) a.result[chunk] = status; return; }
+
+    const uint32_t cap = (uint32_t)cap64;
+    if (cap == 0) {
+        int64_t r = (n64 == 1 && in[0] == 0) ? 0 : CJ_E_CORRUPT;
+        if (lane_id() == 0) a.result[chunk] = r;
+        return;
+    }
+    if (n64 == 0) { if (lane_id() == 0) a.result[chunk] = CJ_E_CORRUPT; return; }
+
+    InWindow w;
+    const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(in) & 3u);
+    w.base = in - mis;
+    w.iend = mis + (uint32_t)n64;
+    w.anchor(mis);
+    const uint32_t iend = w.iend;
+    uint32_t ip = mis;      // input position relative to w.base
+    uint32_t op = 0;        // output position
+    bool bad = false;
+
+    for (;;) {
+        w.ensure(ip);
+        const uint32_t t4 = w.fetch32(ip);
+        const uint32_t token = t4 & 0xffu;
+        ip += 1;
+        uint64_t lit = token >> 4;
+        if (lit == 15u) {
+            // variable-length literal count: bytes may not reach into the last 15 input bytes
+            if (ip + 15u >= iend) { bad = true; break; }
+            uint32_t b = (t4 >> 8) & 0xffu;
+            ip += 1; lit += b;
+            if (ip + 15u > iend) { bad = true; break; }
+            while (b == 255u) {
+                b = w.fetch32_any(ip) & 0xffu;
+                ip += 1; lit += b;
+                if (ip + 15u > iend) { bad = true; break; }
+            }
+            if (bad) break;
+        }
+        const uint32_t rem_out = cap - op, rem_in = iend - ip;
+        if ((uint64_t)rem_out < lit + 12u || (uint64_t)rem_in < lit + 8u) {
+            // must be the final sequence: consumes the input exactly, fits the output
+            if (rem_in != lit || rem_out < lit) { bad = true; break; }
+            wave_copy(out + op, w.base + ip, (uint32_t)lit);
+            op += (uint32_t)lit;
+            break;
+        }
+        wave_copy(out + op, w.base + ip, (uint32_t)lit);
+        ip += (uint32_t)lit; op += (uint32_t)lit;
+
+        const uint32_t o4 = w.fetch32_any(ip);
+        const uint32_t offset = o4 & 0xffffu;
+        ip += 2;
+        uint64_t mlen = token & 15u;
+        if (mlen == 15u) {
+            uint32_t b = (o4 >> 16) & 0xffu;
+            ip += 1; mlen += b;
+            if (ip + 4u > iend) { bad = true; break; }
+            while (b == 255u) {
+                b = w.fetch32_any(ip) & 0xffu;
+                ip += 1; mlen += b;
+                if (ip + 4u > iend) { bad = true; break; }
+            }
+            if (bad) break;
+        }
+        mlen += 4u;
+        if (offset == 0u || offset > op) { bad = true; break; }
+        if ((uint64_t)(cap - op) < mlen + 5u) { bad = true; break; }   // last 5 bytes are literals
+        wave_order();
+        wave_match_copy(out + op, offset, (uint32_t)mlen);
+        wave_order();
+        op += (uint32_t)mlen;
+    }
+    if (lane_id() == 0) a.result[chunk] = bad ? (int64_t)CJ_E_CORRUPT : (int64_t)op;
+}
+
+void launch_lz4_decode(const BatchArgs& a, hipStream_t s) {
+    if (a.n_chunks == 0) return;
+    dim3 grid((a.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlockThreads);
+    hipLaunchKernelGGL(lz4_decode_kernel, grid, block, 0, s, a);
+}
+
+}  // namespace cj

@@ -1,0 +1,117 @@
+// snappy_decode.hip — Snappy *raw* decoder for gfx950, one wavefront per independent chunk.
+//
+// Replaces (on the GPU) what the reference reaches at /root/reference/src/snappy.rs:57,106:
+// libcramjam::snappy::raw::decompress -> snap 1.1.1 raw::Decoder::decompress.  Error conditions
+// follow snap: Empty, Header (bad varint), TooBig (> u32::MAX), BufferTooSmall (preamble > cap),
+// and one "corrupt" class for Literal/CopyRead/CopyWrite/Offset/HeaderMismatch.
+//
+// Same shape as lz4_decode.hip: tag grammar parsed wave-uniformly from the 512-byte register window,
+// lanes move bytes.
+#include "cj_common.hpp"
+
+namespace cj {
+
+__global__ __launch_bounds__(kBlockThreads) void snappy_decode_kernel(BatchArgs a) {
+    const uint32_t chunk = uni(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+    if (chunk >= a.n_chunks) return;
+    const uint8_t* in = a.in_base + a.in_off[chunk];
+    const uint64_t n64 = a.in_len[chunk];
+    uint8_t* out = a.out_base + a.out_off[chunk];
+    const uint64_t cap64 = a.out_cap[chunk];
+    int64_t status = 0;
+
+    if (n64 == 0) status = CJ_E_SNAPPY_EMPTY;
+    else if (n64 > 0xFFFFFFF0ull) status = CJ_E_SNAPPY_CORRUPT;
+    if (status != 0) { if (lane_id() == 0) a.result[chunk] = status; return; }
+
+    InWindow w;
+    const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(in) & 3u);
+    w.base = in - mis;
+    w.iend = mis + (uint32_t)n64;
+    w.anchor(mis);
+    const uint32_t iend = w.iend;
+    uint32_t ip = mis;
+
+    // preamble: snap bytes::read_varu64 (up to 10 bytes), then the u32 range check
+    uint64_t ulen = 0;
+    {
+        uint32_t shift = 0, i = 0;
+        bool done = false;
+        while (ip < iend && i < 10u) {
+            uint32_t b = w.fetch32_any(ip) & 0xffu;
+            ip += 1;
+            if (b < 0x80u) {
+                if (i == 9u && b > 1u) break;
+                ulen |= (uint64_t)b << shift;
+                done = true;
+                break;
+            }
+            ulen |= (uint64_t)(b & 0x7fu) << shift;
+            shift += 7; i += 1;
+        }
+        if (!done) status = CJ_E_SNAPPY_HEADER;
+        else if (ulen > 0xFFFFFFFFull) status = CJ_E_SNAPPY_TOO_BIG;
+        else if (ulen > cap64) status = CJ_E_SNAPPY_BUF_SMALL;
+    }
+    if (status != 0) { if (lane_id() == 0) a.result[chunk] = status; return; }
+
+    const uint32_t dn = (uint32_t)ulen;
+    uint32_t op = 0;
+    bool bad = false;
+
+    while (ip < iend) {
+        w.ensure(ip);
+        const uint32_t t4 = w.fetch32(ip);
+        const uint32_t tag = t4 & 0xffu;
+        ip += 1;
+        const uint32_t kind = tag & 3u;
+        if (kind == 0u) {
+            uint64_t len = (tag >> 2) + 1u;
+            if (len > 60u) {
+                const uint32_t nb = (uint32_t)len - 60u;        // 1..4 length bytes
+                if (iend - ip < nb) { bad = true; break; }
+                uint32_t v = w.fetch32_any(ip);
+                if (nb < 4u) v &= (1u << (8u * nb)) - 1u;
+                ip += nb;
+                len = (uint64_t)v + 1u;
+            }
+            if (len > (uint64_t)(iend - ip) || len > (uint64_t)(dn - op)) { bad = true; break; }
+            wave_copy(out + op, w.base + ip, (uint32_t)len);
+            ip += (uint32_t)len; op += (uint32_t)len;
+            continue;
+        }
+        uint32_t len, offset;
+        if (kind == 1u) {
+            if (iend - ip < 1u) { bad = true; break; }
+            len = 4u + ((tag >> 2) & 7u);
+            offset = ((tag >> 5) << 8) | ((t4 >> 8) & 0xffu);
+            ip += 1;
+        } else if (kind == 2u) {
+            if (iend - ip < 2u) { bad = true; break; }
+            len = 1u + (tag >> 2);
+            offset = (t4 >> 8) & 0xffffu;
+            ip += 2;
+        } else {
+            if (iend - ip < 4u) { bad = true; break; }
+            len = 1u + (tag >> 2);
+            offset = w.fetch32_any(ip);
+            ip += 4;
+        }
+        if (offset == 0u || offset > op) { bad = true; break; }
+        if (len > dn - op) { bad = true; break; }
+        wave_order();
+        wave_match_copy(out + op, offset, len);
+        wave_order();
+        op += len;
+    }
+    if (!bad && op != dn) bad = true;
+    if (lane_id() == 0) a.result[chunk] = bad ? (int64_t)CJ_E_SNAPPY_CORRUPT : (int64_t)dn;
+}
+
+void launch_snappy_decode(const BatchArgs& a, hipStream_t s) {
+    if (a.n_chunks == 0) return;
+    dim3 grid((a.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlockThreads);
+    hipLaunchKernelGGL(snappy_decode_kernel, grid, block, 0, s, a);
+}
+
+}  // namespace cj

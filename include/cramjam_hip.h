@@ -1,0 +1,142 @@
+/*
+ * cramjam_hip.h — the C-ABI of libcramjam_hip.so: an MI355X (gfx950) batched block-codec engine for
+ * cramjam's LZ4-block and Snappy-raw hot path.
+ *
+ * This is the drop-in boundary.  The reference (milesgranger/cramjam) has no plugin registry; its
+ * hot path sits behind the crate-call boundary between src/{lz4,snappy}.rs and libcramjam, i.e.
+ * plain functions over borrowed byte slices.  Each export below names the reference call site it
+ * replaces (paths relative to the reference repository).  A Rust/pyo3 host binds them with
+ * `extern "C"` exactly as INTEGRATION.md shows; the Python host in cramjam_amd/ binds the same
+ * symbols.  No torch / HIP types appear in any signature: pointers, sizes and ints only.
+ *
+ * Conventions
+ *   - return int64_t >= 0: bytes written / decoded;  < 0: one of CJ_E_* (cj_strerror gives the
+ *     message the reference's Rust error would have carried).
+ *   - inputs are borrowed for the duration of the call, never retained or freed; outputs are
+ *     written into caller memory (the host layer allocates with the bound/len helpers and truncates).
+ *   - every export is thread-safe and re-entrant (the reference calls with the GIL released,
+ *     src/lz4.rs:84,126,163,205; src/snappy.rs:57,75,97,106).
+ *   - all codec arithmetic runs in HIP kernels on the GPU.  There is NO CPU fallback: without a
+ *     usable HIP device every compute entry point returns CJ_E_NO_DEVICE.
+ */
+#ifndef CRAMJAM_HIP_H
+#define CRAMJAM_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CJ_ABI_VERSION 1
+
+/* ---- error codes ---- */
+#define CJ_E_INPUT_TOO_LARGE   (-1)  /* lz4 crate: "Compression input too long." */
+#define CJ_E_COMPRESS_FAILED   (-2)  /* lz4 crate: "Compression failed" (output buffer too small) */
+#define CJ_E_NO_PREFIX         (-3)  /* lz4 crate: "Source buffer must at least contain size prefix." */
+#define CJ_E_NEG_PREFIX        (-4)  /* lz4 crate: "Parsed size prefix in buffer must not be negative." */
+#define CJ_E_PREFIX_TOO_BIG    (-5)  /* lz4 crate: "Given size parameter is too big" */
+#define CJ_E_OUT_TOO_SMALL     (-6)  /* lz4 crate: "buffer isn't large enough to hold decompressed data" */
+#define CJ_E_CORRUPT           (-7)  /* lz4 crate: "Decompression failed. Input invalid or too long?" */
+#define CJ_E_SNAPPY_EMPTY      (-8)  /* snap::Error::Empty */
+#define CJ_E_SNAPPY_HEADER     (-9)  /* snap::Error::Header */
+#define CJ_E_SNAPPY_TOO_BIG    (-10) /* snap::Error::TooBig */
+#define CJ_E_SNAPPY_BUF_SMALL  (-11) /* snap::Error::BufferTooSmall */
+#define CJ_E_SNAPPY_CORRUPT    (-12) /* snap::Error::{Literal,CopyRead,CopyWrite,Offset,HeaderMismatch} */
+#define CJ_E_NO_DEVICE         (-100) /* no HIP device / HIP runtime failure (see cj_last_hip_error) */
+#define CJ_E_BAD_ARG           (-101)
+#define CJ_E_OOM               (-102) /* device or pinned-host allocation failed */
+
+const char* cj_strerror(int64_t code);
+/* text of the last HIP runtime error seen by the calling thread ("" if none) */
+const char* cj_last_hip_error(void);
+int cj_abi_version(void);
+/* number of visible HIP devices (0 if none / runtime unusable) */
+int cj_device_count(void);
+
+/* =====================================================================================
+ * Single-buffer entry points — exactly what a pyo3/Rust host would bind in place of the
+ * libcramjam calls.  Host pointers.  Run on the default engine of device 0
+ * (CJ_DEVICE env var overrides), created lazily.
+ * ===================================================================================== */
+
+/* src/lz4.rs:228  libcramjam::lz4::block::compress_bound(len, Some(prepend))
+ * = LZ4_compressBound(len) (+4 when prepend); 0 when len > 0x7E000000. Pure arithmetic, no device. */
+size_t cj_lz4_block_compress_bound(size_t len, int prepend);
+
+/* src/lz4.rs:127,206  libcramjam::lz4::block::compress_into(in, out, level, accel, prepend)
+ * level/accel: -1 = None.  The reference forwards them but libcramjam always runs the DEFAULT
+ * mode, so they do not change the output; accepted and ignored here too.  prepend: -1 = None -> 1. */
+int64_t cj_lz4_block_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap,
+                              int level, int accel, int prepend);
+
+/* src/lz4.rs:88,164,168  libcramjam::lz4::block::decompress_into(in, out, Some(size_prepended))
+ * size_prepended=1: u32-LE length prefix expected, decode capacity = that length;
+ * size_prepended=0: raw block, decode capacity = cap.  Returns decoded byte count. */
+int64_t cj_lz4_block_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap, int size_prepended);
+
+/* src/lz4.rs:90  libcramjam::lz4::block::decompress_vec reads this before allocating:
+ * the u32-LE prefix, or CJ_E_NO_PREFIX when n < 4. Pure arithmetic, no device. */
+int64_t cj_lz4_block_prefixed_len(const uint8_t* in, size_t n);
+
+/* src/snappy.rs:114  snap::raw::max_compress_len(len) = 32 + len + len/6 (0 = too big). No device. */
+size_t cj_snappy_raw_max_compress_len(size_t len);
+/* src/snappy.rs:121  snap::raw::decompress_len(in): varint preamble; 0 for empty input. No device. */
+int64_t cj_snappy_raw_decompress_len(const uint8_t* in, size_t n);
+/* src/snappy.rs:75,97  libcramjam::snappy::raw::compress(in, out); needs cap >= max_compress_len(n) */
+int64_t cj_snappy_raw_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap);
+/* src/snappy.rs:57,106 libcramjam::snappy::raw::decompress(in, out); needs cap >= decompress_len(in) */
+int64_t cj_snappy_raw_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap);
+
+/* =====================================================================================
+ * Batch extension (no reference equivalent: the reference API is one buffer per call; a GPU only
+ * pays off on batches of independent chunks).  One engine per GPU; chunks of a batch are
+ * independent, so multi-GPU use is host-side round-robin sharding over engines, no collective.
+ * ===================================================================================== */
+typedef struct cj_engine cj_engine;
+
+typedef enum { CJ_CODEC_LZ4_BLOCK = 0, CJ_CODEC_SNAPPY_RAW = 1 } cj_codec;
+typedef enum { CJ_OP_DECOMPRESS = 0, CJ_OP_COMPRESS = 1 } cj_op;
+
+/* flags */
+#define CJ_FLAG_LZ4_SIZE_PREFIX 1u   /* lz4: blocks carry / get the u32-LE length prefix (store_size) */
+
+int  cj_engine_create(int device, cj_engine** out);
+void cj_engine_destroy(cj_engine* e);
+int  cj_engine_device(const cj_engine* e);
+
+/* Device-resident batch: every pointer is a DEVICE pointer on the engine's GPU.
+ * chunk i reads  in_base + in_off[i] .. + in_len[i]   and writes  out_base + out_off[i] .. + out_cap[i];
+ * result[i] = bytes produced (>= 0) or CJ_E_* (< 0); one bad chunk never affects another.
+ * hip_stream: a hipStream_t (NULL = the engine's own stream).  Asynchronous: returns after enqueue;
+ * call cj_engine_sync (or synchronise the stream yourself) before reading results. */
+int cj_batch_device(cj_engine* e, cj_codec codec, cj_op op, uint32_t flags, size_t n_chunks,
+                    const uint8_t* in_base, const uint64_t* in_off, const uint64_t* in_len,
+                    uint8_t* out_base, const uint64_t* out_off, const uint64_t* out_cap,
+                    int64_t* result, void* hip_stream);
+int cj_engine_sync(cj_engine* e);
+
+/* Host batch: host pointers; the engine packs inputs into pinned staging, copies H2D, runs the
+ * kernels, copies D2H and scatters.  Synchronous. result[i] as above. */
+int cj_batch_host(cj_engine* e, cj_codec codec, cj_op op, uint32_t flags, size_t n_chunks,
+                  const uint8_t* const* in_ptrs, const size_t* in_lens,
+                  uint8_t* const* out_ptrs, const size_t* out_caps, int64_t* result);
+
+/* Timing aid for benchmarks: runs the same device batch `reps` times on the engine stream between
+ * two hipEvents and returns the mean kernel time per rep in milliseconds (< 0 on error). */
+double cj_batch_device_timed(cj_engine* e, cj_codec codec, cj_op op, uint32_t flags, size_t n_chunks,
+                             const uint8_t* in_base, const uint64_t* in_off, const uint64_t* in_len,
+                             uint8_t* out_base, const uint64_t* out_off, const uint64_t* out_cap,
+                             int64_t* result, int reps);
+
+/* Thin device-memory helpers so C / ctypes callers need no HIP binding of their own. */
+void* cj_device_alloc(cj_engine* e, size_t bytes);
+void  cj_device_free(cj_engine* e, void* p);
+int   cj_memcpy_h2d(cj_engine* e, void* dst_dev, const void* src_host, size_t bytes);
+int   cj_memcpy_d2h(cj_engine* e, void* dst_host, const void* src_dev, size_t bytes);
+int   cj_memcpy_d2d(cj_engine* e, void* dst_dev, const void* src_dev, size_t bytes);
+int   cj_memset_dev(cj_engine* e, void* dst_dev, int value, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

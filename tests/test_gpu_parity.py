@@ -1,0 +1,186 @@
+"""GPU parity tests: HIP path (through the C-ABI of libcramjam_hip.so) vs the CPU oracle and the golden
+fixtures.  Bit-exact for every decoder output; encoder output must decode losslessly with the oracle's
+decoder (the reference pins compressed bytes only for all-literal inputs)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import b64d, sha
+
+pytestmark = pytest.mark.gpu
+
+from cramjam_amd import _native as N  # noqa: E402
+
+LZ4, SNAPPY, DEC, ENC, PREFIX = N.CODEC_LZ4_BLOCK, N.CODEC_SNAPPY_RAW, N.OP_DECOMPRESS, N.OP_COMPRESS, N.FLAG_LZ4_SIZE_PREFIX
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = N.Engine(0)
+    yield e
+    e.close()
+
+
+def test_device_present():
+    assert N.lib().cj_device_count() >= 1
+
+
+def test_decode_golden_vectors(eng, golden):
+    vs = golden["vectors"]
+    for codec, key in ((LZ4, "lz4"), (SNAPPY, "snappy")):
+        for extra in (0, 77):
+            res, outs = eng.batch_host(codec, DEC, 0, [b64d(v[key]) for v in vs], [v["n"] + extra for v in vs])
+            for v, r, o in zip(vs, res, outs):
+                assert r == v["n"], (key, v["name"], r)
+                assert sha(o) == v["sha256"], (key, v["name"])
+
+
+def test_decode_reference_fixture_blocks(eng, golden, plaintext):
+    import os
+    from conftest import GOLDEN_DIR
+    fb = golden["reference_fixture_blocks"]
+    a, b = fb["lz4_frame_block"]
+    blk = open(os.path.join(GOLDEN_DIR, "plaintext.txt.lz4"), "rb").read()[a:b]
+    res, outs = eng.batch_host(LZ4, DEC, 0, [blk], [len(plaintext)])
+    assert res == [857] and outs[0] == plaintext
+    a, b = fb["snappy_framed_raw"]
+    blk = open(os.path.join(GOLDEN_DIR, "plaintext.txt.snappy"), "rb").read()[a:b]
+    res, outs = eng.batch_host(SNAPPY, DEC, 0, [blk], [len(plaintext)])
+    assert res == [857] and outs[0] == plaintext
+
+
+def test_decode_malformed_matches_oracle(eng, golden):
+    ms = golden["malformed_lz4"]
+    res, outs = eng.batch_host(LZ4, DEC, 0, [b64d(m["data"]) for m in ms], [m["cap"] for m in ms])
+    for m, r, o in zip(ms, res, outs):
+        er, eo = oracle.lz4_decompress_raw(b64d(m["data"]), m["cap"])
+        if er < 0:
+            assert r == -7, (m["src"], m["kind"], m["k"], m["cap"], r)
+        else:
+            assert r == er and o == eo, (m["src"], m["kind"], m["k"], m["cap"], r, er)
+    ms = [m for m in golden["malformed_snappy"]]
+    caps = [max(oracle.snappy_decompress_len(b64d(m["data"])), 0) for m in ms]
+    caps = [min(c, 1 << 20) for c in caps]
+    res, outs = eng.batch_host(SNAPPY, DEC, 0, [b64d(m["data"]) for m in ms], caps)
+    for m, c, r, o in zip(ms, caps, res, outs):
+        er, eo = oracle.snappy_decompress(b64d(m["data"]), c)
+        assert r == er, (m["src"], m["kind"], m["k"], r, er)
+        if er >= 0:
+            assert o == eo
+
+
+def test_lz4_prefix_flag(eng, golden_raw):
+    raw = golden_raw["plaintext"]
+    _, blk = oracle.lz4_block_compress(raw, prepend=True)
+    res, outs = eng.batch_host(LZ4, DEC, PREFIX, [blk, blk, blk[:3], b"\xff\xff\xff\xff\x00", blk],
+                               [len(raw), len(raw) + 9, 10, 10, len(raw) - 1])
+    assert res == [len(raw), len(raw), -3, -4, -6]
+    assert outs[0] == raw and outs[1] == raw
+
+
+@pytest.mark.parametrize("codec", [LZ4, SNAPPY])
+def test_encode_roundtrips_through_oracle(eng, golden, golden_raw, codec):
+    names = [v["name"] for v in golden["vectors"]]
+    raws = [golden_raw[n] for n in names]
+    L = N.lib()
+    if codec == LZ4:
+        caps = [L.cj_lz4_block_compress_bound(len(r), 0) for r in raws]
+    else:
+        caps = [L.cj_snappy_raw_max_compress_len(len(r)) for r in raws]
+    res, outs = eng.batch_host(codec, ENC, 0, raws, caps)
+    tot_gpu = tot_cpu = 0
+    for name, raw, r, o in zip(names, raws, res, outs):
+        assert r > 0 and r == len(o), (name, r)
+        if codec == LZ4:
+            dr, d = oracle.lz4_decompress_raw(o, len(raw))          # exact capacity: end-of-block rules bite
+            cr, _ = oracle.lz4_compress_raw(raw)
+        else:
+            dr, d = oracle.snappy_decompress(o)
+            cr, _ = oracle.snappy_compress(raw)
+        assert dr == len(raw) and d == raw, (name, dr)
+        tot_gpu += r
+        tot_cpu += cr
+    # "ratio held": the wave-parallel matcher must stay close to the CPU encoders on the same data
+    assert tot_gpu <= tot_cpu * 1.10, (tot_gpu, tot_cpu)
+
+
+def test_lz4_encode_known_answers(eng):
+    # /root/reference/tests/test_variants.py:329-334 (all-literal block: bytes are pinned)
+    res, outs = eng.batch_host(LZ4, ENC, PREFIX, [b"howdy neighbor"], [64])
+    assert outs[0] == b"\x0e\x00\x00\x00\xe0howdy neighbor"
+    res, outs = eng.batch_host(LZ4, ENC, 0, [b"howdy neighbor", b""], [64, 16])
+    assert outs[0] == b"\xe0howdy neighbor" and outs[1] == b"\x00"
+    res, outs = eng.batch_host(SNAPPY, ENC, 0, [b"howdy neighbor", b""], [64, 32])
+    assert outs[0] == b"\x0e4howdy neighbor" and outs[1] == b"\x00"
+
+
+def test_single_buffer_c_abi(plaintext):
+    import ctypes as C
+    L = N.lib()
+    out = C.create_string_buffer(2048)
+    n = L.cj_lz4_block_compress(plaintext, len(plaintext), C.cast(out, C.c_void_p), 2048, -1, -1, -1)
+    assert n > 4 and int.from_bytes(out.raw[:4], "little") == 857
+    assert oracle.lz4_block_decompress(out.raw[:n], 857, True) == (857, plaintext)
+    back = C.create_string_buffer(1000)
+    m = L.cj_lz4_block_decompress(out.raw[:n], n, C.cast(back, C.c_void_p), 1000, 1)
+    assert m == 857 and back.raw[:857] == plaintext
+    n = L.cj_snappy_raw_compress(plaintext, len(plaintext), C.cast(out, C.c_void_p), 2048)
+    assert n > 0 and oracle.snappy_decompress(out.raw[:n]) == (857, plaintext)
+    m = L.cj_snappy_raw_decompress(out.raw[:n], n, C.cast(back, C.c_void_p), 1000)
+    assert m == 857 and back.raw[:857] == plaintext
+    assert L.cj_snappy_raw_compress(plaintext, len(plaintext), C.cast(out, C.c_void_p), 100) == -11
+
+
+def _device_batch(eng, codec, op, flags, blobs, caps):
+    """pack -> device-resident batch -> results, out bytes (device path, no host staging by the engine)"""
+    n = len(blobs)
+    in_off = np.zeros(n, np.uint64); in_len = np.array([len(b) for b in blobs], np.uint64)
+    pos = 0
+    for i, b in enumerate(blobs):
+        in_off[i] = pos
+        pos += len(b) + 3          # deliberately unaligned packing
+    packed = np.zeros(pos + 16, np.uint8)
+    for i, b in enumerate(blobs):
+        packed[int(in_off[i]):int(in_off[i]) + len(b)] = np.frombuffer(b, np.uint8)
+    out_cap = np.array(caps, np.uint64)
+    out_off = np.concatenate([[0], np.cumsum(out_cap + 5)[:-1]]).astype(np.uint64)
+    total_out = int(out_off[-1] + out_cap[-1]) + 16
+    d_in = eng.alloc(packed.nbytes); d_out = eng.alloc(total_out)
+    d_meta = eng.alloc(5 * n * 8)
+    eng.h2d(d_in, packed)
+    eng.h2d(d_meta, np.concatenate([in_off, in_len, out_off, out_cap]))
+    N.check(N.lib().cj_memset_dev(eng.h, d_out, 0xAB, total_out))
+    eng.batch_device(codec, op, flags, n, d_in, d_meta, d_meta + 8 * n, d_out, d_meta + 16 * n, d_meta + 24 * n, d_meta + 32 * n)
+    eng.sync()
+    res = eng.d2h(d_meta + 32 * n, 8 * n, "int64")
+    out = eng.d2h(d_out, total_out)
+    for p in (d_in, d_out, d_meta):
+        eng.free(p)
+    return res, out, out_off
+
+
+@pytest.mark.parametrize("chunk", [65536, 262144])
+def test_device_batch_synth_roundtrip(eng, chunk):
+    n = 96 if chunk == 65536 else 24
+    raws = [oracle.synth_v1(chunk, i) for i in range(n)]
+    raws[3] = bytes(chunk); raws[5] = hashlib.shake_256(b"x").digest(chunk); raws[7] = raws[7][:chunk - 1]; raws[9] = b""
+    for codec in (LZ4, SNAPPY):
+        comp = [(oracle.lz4_compress_raw(r) if codec == LZ4 else oracle.snappy_compress(r))[1] for r in raws]
+        res, out, off = _device_batch(eng, codec, DEC, 0, comp, [len(r) for r in raws])
+        for i, r in enumerate(raws):
+            if codec == LZ4 and len(r) == 0:
+                assert res[i] == 0
+                continue
+            assert res[i] == len(r), (codec, i, res[i])
+            assert out[int(off[i]):int(off[i]) + len(r)].tobytes() == r, (codec, i)
+            # nothing written past the chunk's capacity
+            assert (out[int(off[i]) + len(r):int(off[i]) + len(r) + 5] == 0xAB).all()
+        L = N.lib()
+        caps = [(L.cj_lz4_block_compress_bound(len(r), 0) if codec == LZ4 else L.cj_snappy_raw_max_compress_len(len(r))) for r in raws]
+        res, out, off = _device_batch(eng, codec, ENC, 0, raws, caps)
+        for i, r in enumerate(raws):
+            blob = out[int(off[i]):int(off[i]) + int(res[i])].tobytes()
+            d = oracle.lz4_decompress_raw(blob, len(r)) if codec == LZ4 else oracle.snappy_decompress(blob)
+            assert d == (len(r), r), (codec, i, res[i])

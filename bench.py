@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""bench.py — LZ4-block decompress throughput on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over the whole device-resident batch: N chunks of 64 KiB
+(synth-v1) compressed with the reference's C code family (system liblz4
+LZ4_compress_default; falls back to this engine's own GPU encoder if the library is absent), already in
+HBM when the timed region starts, decoded by one launch of lz4_decode_kernel into distinct outputs.
+Weak scaling: every GPU owns `--chunks` chunks (independent units, no data-path collective).
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task description):
+  value     = uncompressed GB/s over all ranks (sum of bytes / max wall time over ranks)
+  roofline  = algorithmic bytes (compressed read + uncompressed written) per launch / mean launch
+              duration measured with HIP events on the engine's stream, vs the 8 TB/s HBM peak
+  cpu_baseline = the CPU oracle (scalar C restatement of liblz4's decoder) on this host's cores over a
+              bounded sample of the same chunks (rank 0, N=1 only)
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--chunks", type=int, default=100_000, help="chunks per GPU (BASELINE configs[1]: 100k x 64 KiB)")
+    ap.add_argument("--chunk-bytes", type=int, default=65536)
+    ap.add_argument("--unique", type=int, default=8192, help="distinct chunks generated; replicated device-side")
+    ap.add_argument("--codec", default="lz4", choices=["lz4", "snappy"])
+    ap.add_argument("--op", default="decompress", choices=["decompress", "compress"])
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--compressor", default="auto", choices=["auto", "liblz4", "gpu"])
+    return ap.parse_args()
+
+
+def load_liblz4():
+    for name in ("liblz4.so.1", "/lib/x86_64-linux-gnu/liblz4.so.1", "/opt/conda/lib/liblz4.so.1"):
+        try:
+            L = C.CDLL(name)
+            L.LZ4_compress_default.restype = C.c_int
+            L.LZ4_compress_default.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+            return L, "liblz4 %d (system LZ4_compress_default)" % L.LZ4_versionNumber()
+        except OSError:
+            continue
+    return None, None
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from cramjam_amd import _native as N
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    L = N.lib()
+    eng = N.Engine(local)
+
+    S, U, NCH = args.chunk_bytes, min(args.unique, args.chunks), args.chunks
+    codec = N.CODEC_LZ4_BLOCK if args.codec == "lz4" else N.CODEC_SNAPPY_RAW
+    dec = args.op == "decompress"
+
+    # ---- workload: U unique synth-v1 chunks generated on the device ----
+    raw = torch.empty(U * S, dtype=torch.uint8, device=dev)
+    N.check(L.cj_bench_synth_v1(raw.data_ptr(), S, S, 0, U, 0x5EED, None))
+    torch.cuda.synchronize()
+
+    bound = L.cj_lz4_block_compress_bound(S, 0) if codec == N.CODEC_LZ4_BLOCK else L.cj_snappy_raw_max_compress_len(S)
+    stride_c = (bound + 15) & ~15
+    comp_name = None
+    raw_h = None
+    if dec or not args.no_cpu_baseline:
+        raw_h = raw.cpu().numpy()
+    if dec:
+        lz4lib, comp_name = (None, None)
+        if codec == N.CODEC_LZ4_BLOCK and args.compressor in ("auto", "liblz4"):
+            lz4lib, comp_name = load_liblz4()
+        if lz4lib is not None:
+            from concurrent.futures import ThreadPoolExecutor
+            comp_h = np.zeros(U * stride_c, dtype=np.uint8)
+            clen = np.zeros(U, dtype=np.uint64)
+
+            def work(i):
+                r = lz4lib.LZ4_compress_default(raw_h.ctypes.data + i * S, comp_h.ctypes.data + i * stride_c, S, stride_c)
+                assert r > 0
+                clen[i] = r
+            with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as ex:
+                list(ex.map(work, range(U)))
+        else:
+            comp_name = "cramjam_amd GPU encoder (%s)" % args.codec
+            comp_d = torch.zeros(U * stride_c, dtype=torch.uint8, device=dev)
+            meta = torch.tensor(np.concatenate([np.arange(U, dtype=np.uint64) * S, np.full(U, S, np.uint64),
+                                                np.arange(U, dtype=np.uint64) * stride_c, np.full(U, stride_c, np.uint64),
+                                                np.zeros(U, np.uint64)]).view(np.int64), device=dev)
+            p = meta.data_ptr()
+            torch.cuda.synchronize()
+            eng.batch_device(codec, N.OP_COMPRESS, 0, U, raw.data_ptr(), p, p + 8 * U, comp_d.data_ptr(), p + 16 * U, p + 24 * U, p + 32 * U)
+            eng.sync()
+            clen = meta[4 * U:].cpu().numpy().view(np.int64).astype(np.uint64)
+            assert (clen > 0).all()
+            comp_h = comp_d.cpu().numpy()
+            del comp_d
+        # pack the unique compressed chunks tightly (16 B aligned) on the host, upload, replicate on the device
+        uoff = np.zeros(U, dtype=np.uint64)
+        pos = 0
+        for i in range(U):
+            uoff[i] = pos
+            pos += (int(clen[i]) + 15) & ~15
+        packed_total = pos
+        packed_h = np.zeros(packed_total, dtype=np.uint8)
+        for i in range(U):
+            n = int(clen[i])
+            packed_h[int(uoff[i]):int(uoff[i]) + n] = comp_h[i * stride_c:i * stride_c + n]
+        del comp_h
+        packed = torch.from_numpy(packed_h).to(dev)
+        reps = (NCH + U - 1) // U
+        cin = packed.repeat(reps)                      # reps distinct copies in HBM
+        ids = np.arange(NCH, dtype=np.uint64)
+        in_off = (ids // U) * np.uint64(packed_total) + uoff[ids % U]
+        in_len = clen[ids % U].astype(np.uint64)
+        out_off = ids * np.uint64(S)
+        out_cap = np.full(NCH, S, np.uint64)
+        out = torch.empty(NCH * S, dtype=torch.uint8, device=dev)
+        in_ptr = cin.data_ptr()
+        bytes_in = int(in_len.sum()); bytes_out = NCH * S
+    else:
+        reps = (NCH + U - 1) // U
+        cin = raw.repeat(reps)
+        ids = np.arange(NCH, dtype=np.uint64)
+        in_off = ids * np.uint64(S)
+        in_len = np.full(NCH, S, np.uint64)
+        out_off = ids * np.uint64(stride_c)
+        out_cap = np.full(NCH, stride_c, np.uint64)
+        out = torch.empty(NCH * stride_c, dtype=torch.uint8, device=dev)
+        in_ptr = cin.data_ptr()
+        bytes_in = NCH * S; bytes_out = None
+    meta = torch.from_numpy(np.concatenate([in_off, in_len, out_off, out_cap, np.zeros(NCH, np.uint64)]).view(np.int64)).to(dev)
+    mp = meta.data_ptr()
+    a = (codec, N.OP_DECOMPRESS if dec else N.OP_COMPRESS, 0, NCH, in_ptr, mp, mp + 8 * NCH, out.data_ptr(), mp + 16 * NCH,
+         mp + 24 * NCH, mp + 32 * NCH)
+    torch.cuda.synchronize()
+
+    # ---- warmup, then EXACTLY K timed steps between barrier+synchronize on both sides ----
+    if args.warmup > 0:
+        eng.batch_device_timed(*a, args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kernel_ms = eng.batch_device_timed(*a, args.steps)       # K launches on the engine stream, HIP events around them
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+
+    # ---- verify at full size: every chunk's result and every output byte ----
+    res = meta[4 * NCH:].cpu().numpy()
+    if dec:
+        assert (res == S).all(), "decode status/length mismatch: %s" % res[res != S][:8]
+        mism = torch.zeros(1, dtype=torch.int64, device=dev)
+        N.check(L.cj_bench_compare(out.data_ptr(), mp + 16 * NCH, raw.data_ptr(), S, U, S, NCH, mism.data_ptr(), None))
+        torch.cuda.synchronize()
+        assert int(mism.item()) == 0, "%d chunks decoded wrong" % int(mism.item())
+        ratio = bytes_out / bytes_in
+    else:
+        assert (res > 0).all()
+        bytes_out = int(res.sum())
+        ratio = bytes_in / bytes_out
+    unc_bytes = NCH * S
+
+    wall_max = wall
+    total_unc = unc_bytes
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall_max = float(t.item())
+        b = torch.tensor([unc_bytes], dtype=torch.float64, device=dev)
+        dist.all_reduce(b, op=dist.ReduceOp.SUM)
+        total_unc = float(b.item())
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and dec:
+        cpu = cpu_baseline(args, codec, raw_h, S, U, packed_h, uoff, clen)
+
+    if rank == 0:
+        algo = bytes_in + (bytes_out if bytes_out is not None else 0)
+        achieved = algo / (kernel_ms * 1e-3)
+        line = {
+            "metric": "uncompressed GB/s (LZ4-block decomp, 64 KiB chunks)" if (dec and args.codec == "lz4")
+                      else "uncompressed GB/s (%s %s, %d B chunks)" % (args.codec, args.op, S),
+            "value": total_unc / (wall_max / args.steps) / 1e9,
+            "unit": "GB/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall_max / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "%s-block %s, %d x %d B synth-v1 chunks per GPU, device-resident" % (args.codec, args.op, NCH, S),
+                       "chunks_per_gpu": NCH, "chunk_bytes": S, "unique_chunks": U, "ratio": round(ratio, 4),
+                       "compressed_by": comp_name, "sharding": "chunk i -> gpu (i mod N), no collective",
+                       "verified": "all results + all output bytes compared on device"},
+            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK, "traffic": None,
+                         "kernel": "lz4_decode_kernel" if (dec and args.codec == "lz4") else "%s_%s_kernel" % (args.codec, "decode" if dec else "encode"),
+                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, codec, raw_h, S, U, packed_h, uoff, clen):
+    """CPU oracle (oracle/: scalar C restatement of LZ4_decompress_safe / snap's decoder), all host cores,
+    bounded sample: the U unique chunks, repeated until ~cpu-seconds elapsed."""
+    import numpy as np
+    import oracle
+    OL = oracle.lib()
+    cores = os.cpu_count() or 1
+    threads = min(cores, 256)
+    out = np.empty(U * S, dtype=np.uint8)
+    res = np.zeros(U, dtype=np.int64)
+    off = np.ascontiguousarray(uoff, dtype=np.uint64)
+    ln = np.ascontiguousarray(clen, dtype=np.uint64)
+    op = 0 if codec == 0 else 2
+    done = 0
+    t0 = time.perf_counter()
+    while True:
+        OL.cjo_batch_run(op, threads, U, packed_h.ctypes.data, off.ctypes.data, ln.ctypes.data, out.ctypes.data, S, res.ctypes.data)
+        done += 1
+        el = time.perf_counter() - t0
+        if el >= args.cpu_seconds or done >= 200:
+            break
+    assert (res == S).all() and (out == raw_h).all(), "cpu oracle disagrees with generator"
+    return {"value": done * U * S / el / 1e9, "unit": "GB/s", "cores": threads, "kind": "port",
+            "sample": "%d x %d unique %d B chunks (same inputs as the GPU run), %.1f s" % (done, U, S, el)}
+
+
+if __name__ == "__main__":
+    main()

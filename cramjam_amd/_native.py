@@ -41,6 +41,11 @@ SYMBOLS = {
     "cj_memcpy_d2d": (_int, [_vp, _vp, _vp, _sz]),
     "cj_memset_dev": (_int, [_vp, _vp, _int, _sz]),
 }
+# benchmark/test utilities exported next to the engine (cramjam_amd/csrc/bench_util.hip); not part of the drop-in ABI
+BENCH_SYMBOLS = {
+    "cj_bench_synth_v1": (_int, [_vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _vp]),
+    "cj_bench_compare": (_int, [_vp, _vp, _vp, C.c_uint64, _u32, C.c_uint64, _u32, _vp, _vp]),
+}
 
 _lib = None
 
@@ -53,7 +58,7 @@ def lib():
                 "cramjam_amd: %s is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
         L = C.CDLL(LIB_PATH)
-        for name, (res, args) in SYMBOLS.items():
+        for name, (res, args) in list(SYMBOLS.items()) + list(BENCH_SYMBOLS.items()):
             f = getattr(L, name)
             f.restype, f.argtypes = res, args
         _lib = L

@@ -23,7 +23,8 @@ struct BatchArgs {
 constexpr int kWavesPerBlock = 4;
 constexpr int kBlockThreads = 64 * kWavesPerBlock;
 
-void launch_lz4_decode(const BatchArgs& a, hipStream_t s);
+void launch_lz4_decode(const BatchArgs& a, hipStream_t s);        // one wavefront per chunk
+void launch_lz4_decode_lanes(const BatchArgs& a, hipStream_t s);  // one lane per chunk (large batches)
 void launch_lz4_encode(const BatchArgs& a, hipStream_t s);
 void launch_snappy_decode(const BatchArgs& a, hipStream_t s);
 void launch_snappy_encode(const BatchArgs& a, hipStream_t s);

@@ -61,7 +61,16 @@ void fill_args(cj::BatchArgs& a, uint32_t flags, size_t n, const uint8_t* in_bas
 
 int launch(cj_codec codec, cj_op op, const cj::BatchArgs& a, hipStream_t s) {
     if (codec == CJ_CODEC_LZ4_BLOCK) {
-        if (op == CJ_OP_DECOMPRESS) cj::launch_lz4_decode(a, s); else cj::launch_lz4_encode(a, s);
+        if (op == CJ_OP_DECOMPRESS) {
+            static const size_t lanes_min = [] {
+                const char* v = std::getenv("CJ_LANES_MIN_CHUNKS");
+                return v ? (size_t)std::strtoull(v, nullptr, 10) : (size_t)CJ_LANES_MIN_CHUNKS;
+            }();
+            bool lanes = a.n_chunks >= lanes_min;
+            if (a.flags & CJ_FLAG_FORCE_WAVE_PER_CHUNK) lanes = false;
+            if (a.flags & CJ_FLAG_FORCE_LANE_PER_CHUNK) lanes = true;
+            if (lanes) cj::launch_lz4_decode_lanes(a, s); else cj::launch_lz4_decode(a, s);
+        } else cj::launch_lz4_encode(a, s);
     } else if (codec == CJ_CODEC_SNAPPY_RAW) {
         if (op == CJ_OP_DECOMPRESS) cj::launch_snappy_decode(a, s); else cj::launch_snappy_encode(a, s);
     } else {

@@ -23,27 +23,33 @@ def eng():
     e.close()
 
 
+# both chunk->hardware mappings of the LZ4 decoder must give identical results
+MAPPINGS = [pytest.param(N.FLAG_FORCE_WAVE_PER_CHUNK, id="wave-per-chunk"), pytest.param(N.FLAG_FORCE_LANE_PER_CHUNK, id="lane-per-chunk")]
+
+
 def test_device_present():
     assert N.lib().cj_device_count() >= 1
 
 
-def test_decode_golden_vectors(eng, golden):
+@pytest.mark.parametrize("mapping", MAPPINGS)
+def test_decode_golden_vectors(eng, golden, mapping):
     vs = golden["vectors"]
     for codec, key in ((LZ4, "lz4"), (SNAPPY, "snappy")):
         for extra in (0, 77):
-            res, outs = eng.batch_host(codec, DEC, 0, [b64d(v[key]) for v in vs], [v["n"] + extra for v in vs])
+            res, outs = eng.batch_host(codec, DEC, mapping, [b64d(v[key]) for v in vs], [v["n"] + extra for v in vs])
             for v, r, o in zip(vs, res, outs):
                 assert r == v["n"], (key, v["name"], r)
                 assert sha(o) == v["sha256"], (key, v["name"])
 
 
-def test_decode_reference_fixture_blocks(eng, golden, plaintext):
+@pytest.mark.parametrize("mapping", MAPPINGS)
+def test_decode_reference_fixture_blocks(eng, golden, plaintext, mapping):
     import os
     from conftest import GOLDEN_DIR
     fb = golden["reference_fixture_blocks"]
     a, b = fb["lz4_frame_block"]
     blk = open(os.path.join(GOLDEN_DIR, "plaintext.txt.lz4"), "rb").read()[a:b]
-    res, outs = eng.batch_host(LZ4, DEC, 0, [blk], [len(plaintext)])
+    res, outs = eng.batch_host(LZ4, DEC, mapping, [blk], [len(plaintext)])
     assert res == [857] and outs[0] == plaintext
     a, b = fb["snappy_framed_raw"]
     blk = open(os.path.join(GOLDEN_DIR, "plaintext.txt.snappy"), "rb").read()[a:b]
@@ -51,9 +57,10 @@ def test_decode_reference_fixture_blocks(eng, golden, plaintext):
     assert res == [857] and outs[0] == plaintext
 
 
-def test_decode_malformed_matches_oracle(eng, golden):
+@pytest.mark.parametrize("mapping", MAPPINGS)
+def test_decode_malformed_matches_oracle(eng, golden, mapping):
     ms = golden["malformed_lz4"]
-    res, outs = eng.batch_host(LZ4, DEC, 0, [b64d(m["data"]) for m in ms], [m["cap"] for m in ms])
+    res, outs = eng.batch_host(LZ4, DEC, mapping, [b64d(m["data"]) for m in ms], [m["cap"] for m in ms])
     for m, r, o in zip(ms, res, outs):
         er, eo = oracle.lz4_decompress_raw(b64d(m["data"]), m["cap"])
         if er < 0:
@@ -71,10 +78,11 @@ def test_decode_malformed_matches_oracle(eng, golden):
             assert o == eo
 
 
-def test_lz4_prefix_flag(eng, golden_raw):
+@pytest.mark.parametrize("mapping", MAPPINGS)
+def test_lz4_prefix_flag(eng, golden_raw, mapping):
     raw = golden_raw["plaintext"]
     _, blk = oracle.lz4_block_compress(raw, prepend=True)
-    res, outs = eng.batch_host(LZ4, DEC, PREFIX, [blk, blk, blk[:3], b"\xff\xff\xff\xff\x00", blk],
+    res, outs = eng.batch_host(LZ4, DEC, PREFIX | mapping, [blk, blk, blk[:3], b"\xff\xff\xff\xff\x00", blk],
                                [len(raw), len(raw) + 9, 10, 10, len(raw) - 1])
     assert res == [len(raw), len(raw), -3, -4, -6]
     assert outs[0] == raw and outs[1] == raw
@@ -161,14 +169,15 @@ def _device_batch(eng, codec, op, flags, blobs, caps):
     return res, out, out_off
 
 
+@pytest.mark.parametrize("mapping", MAPPINGS)
 @pytest.mark.parametrize("chunk", [65536, 262144])
-def test_device_batch_synth_roundtrip(eng, chunk):
+def test_device_batch_synth_roundtrip(eng, chunk, mapping):
     n = 96 if chunk == 65536 else 24
     raws = [oracle.synth_v1(chunk, i) for i in range(n)]
     raws[3] = bytes(chunk); raws[5] = hashlib.shake_256(b"x").digest(chunk); raws[7] = raws[7][:chunk - 1]; raws[9] = b""
     for codec in (LZ4, SNAPPY):
         comp = [(oracle.lz4_compress_raw(r) if codec == LZ4 else oracle.snappy_compress(r))[1] for r in raws]
-        res, out, off = _device_batch(eng, codec, DEC, 0, comp, [len(r) for r in raws])
+        res, out, off = _device_batch(eng, codec, DEC, mapping, comp, [len(r) for r in raws])
         for i, r in enumerate(raws):
             if codec == LZ4 and len(r) == 0:
                 assert res[i] == 0

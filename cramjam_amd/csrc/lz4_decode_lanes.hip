@@ -64,16 +64,16 @@ __device__ __forceinline__ uint4 splat_pattern(const uint8_t* pat, uint32_t d) {
 // dst[j] = dst[j - d], j in [0, m); room = bytes that may be touched from dst
 __device__ __forceinline__ void lane_match(uint8_t* dst, uint32_t d, uint32_t m, uint32_t room) {
     uint32_t k = 0;
+    const uint8_t* src = dst - d;
     if (d >= 16u) {
-        const uint8_t* src = dst - d;
         for (; k < m && k + 16u <= room; k += 16u) st16u(dst + k, ld16u(src + k));
     } else if (m >= 16u && room >= 32u) {
-        const uint4 p = splat_pattern(dst - d, d);
+        const uint4 p = splat_pattern(src, d);
         const uint32_t s = (16u / d) * d;          // advance by whole periods so the phase stays aligned
         for (; k < m && k + 16u <= room; k += s) st16u(dst + k, p);
         if (k > m) k = m;
     }
-    for (; k < m; k++) dst[k] = dst[k - d];
+    for (; k < m; k++) dst[k] = src[k];      // src[k] == dst[k - d]; the pointer form avoids u32 wrap
 }
 
 __global__ __launch_bounds__(64) void lz4_decode_lanes_kernel(BatchArgs a) {

@@ -188,15 +188,8 @@ def main():
         ratio = bytes_in / bytes_out
     unc_bytes = NCH * S
 
-    wall_max = wall
-    total_unc = unc_bytes
-    if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall_max = float(t.item())
-        b = torch.tensor([unc_bytes], dtype=torch.float64, device=dev)
-        dist.all_reduce(b, op=dist.ReduceOp.SUM)
-        total_unc = float(b.item())
+    from cramjam_amd.shard import aggregate
+    wall_max, total_unc = aggregate(dist if world > 1 else None, dev, wall, unc_bytes)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and dec:
@@ -248,7 +241,7 @@ def cpu_baseline(args, codec, raw_h, S, U, packed_h, uoff, clen):
         OL.cjo_batch_run(op, threads, U, packed_h.ctypes.data, off.ctypes.data, ln.ctypes.data, out.ctypes.data, S, res.ctypes.data)
         done += 1
         el = time.perf_counter() - t0
-        if el >= args.cpu_seconds or done >= 200:
+        if el >= args.cpu_seconds or done >= 2000:
             break
     assert (res == S).all() and (out == raw_h).all(), "cpu oracle disagrees with generator"
     return {"value": done * U * S / el / 1e9, "unit": "GB/s", "cores": threads, "kind": "port",

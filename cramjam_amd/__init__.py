@@ -1,7 +1,17 @@
 """cramjam_amd — MI355X-native drop-in for cramjam's LZ4-block / Snappy-raw hot path.
 
-`cramjam_amd.lz4`, `cramjam_amd.snappy`, `cramjam_amd.Buffer`, `CompressionError`,
-`DecompressionError` mirror the reference's Python API for that path; the batch
-engine (`cramjam_amd.Engine`) is the extension that makes a GPU worthwhile.
+    import cramjam_amd as cramjam
+    cramjam.lz4.compress_block(b"...")          # -> cramjam.Buffer, computed on the GPU
+    cramjam.snappy.decompress_raw(blob)
+
+`lz4`, `snappy`, `Buffer`, `CompressionError`, `DecompressionError` mirror the reference's Python API for
+that path (reference src/lz4.rs:78-229, src/snappy.rs:52-122, src/io.rs:370-684, src/exceptions.rs) and are
+implemented in the native module `_cramjam` (csrc/pymod.cpp) over the C-ABI of libcramjam_hip.so.
+`Engine` / `batch` are the batch extension that makes a GPU worthwhile (no reference equivalent).
+There is no CPU fallback: importing works without a GPU, computing without one raises.
 """
-from ._native import Engine, EngineError, lib as _lib  # noqa: F401
+from ._native import Engine, EngineError  # noqa: F401
+from ._cramjam import Buffer, CompressionError, DecompressionError, lz4, snappy  # noqa: F401
+from . import batch  # noqa: F401
+
+__all__ = ["Buffer", "CompressionError", "DecompressionError", "lz4", "snappy", "Engine", "EngineError", "batch"]

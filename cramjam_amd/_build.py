@@ -45,7 +45,33 @@ def build(force=False, verbose=False):
     objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _newer(LIB, objs):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    build_pymod(force=force or bool(jobs), verbose=verbose)
     return LIB
+
+
+def pymod_path():
+    import sysconfig
+    return os.path.join(HERE, "_cramjam" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_pymod(force=False, verbose=False):
+    """C++ CPython host module (csrc/pymod.cpp) linked against libcramjam_hip.so next to it."""
+    import sysconfig
+    src = os.path.join(CSRC, "pymod.cpp")
+    out = pymod_path()
+    if not force and not _newer(out, [src, os.path.join(HERE, "..", "include", "cramjam_hip.h"), LIB]):
+        return out
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-missing-field-initializers",
+           "-I" + sysconfig.get_paths()["include"], src, "-o", out,
+           "-L" + HERE, "-lcramjam_hip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("g++ failed:\n%s\n%s" % (" ".join(cmd), r.stderr))
+    if verbose and r.stderr.strip():
+        print(r.stderr)
+    return out
 
 
 if __name__ == "__main__":

@@ -1,0 +1,651 @@
+// pymod.cpp — the host binding layer: CPython extension `cramjam_amd._cramjam`.
+//
+// The reference's host layer is Rust/pyo3 (src/lib.rs, src/io.rs, src/lz4.rs, src/snappy.rs,
+// src/exceptions.rs).  Rust is not available in the build image, so this is the same thin layer in
+// C++ over the CPython C-API, calling the same extern-"C" boundary (include/cramjam_hip.h) a pyo3
+// crate would call (INTEGRATION.md shows that binding).  It keeps, for the hot path only:
+//   - cramjam.Buffer            (reference src/io.rs:370-684  RustyBuffer)
+//   - BytesType input borrowing (reference src/lib.rs:104-148, src/io.rs:177-299 PythonBuffer)
+//   - CompressionError / DecompressionError (reference src/exceptions.rs:6-20)
+//   - cramjam.lz4.{compress_block,decompress_block,compress_block_into,decompress_block_into,
+//                  compress_block_bound}           (reference src/lz4.rs:78-229)
+//   - cramjam.snappy.{compress_raw,decompress_raw,compress_raw_into,decompress_raw_into,
+//                  compress_raw_max_len,decompress_raw_len} (reference src/snappy.rs:52-122)
+// with the same signatures, defaults, return types and error behaviour.  No codec arithmetic here.
+#define PY_SSIZE_T_CLEAN
+#include <Python.h>
+#include <structmember.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/cramjam_hip.h"
+
+namespace {
+
+PyObject* CompressionError = nullptr;
+PyObject* DecompressionError = nullptr;
+
+// ------------------------------------------------------------------------------------------
+// Buffer  (reference src/io.rs:370-684)
+// ------------------------------------------------------------------------------------------
+struct BufferObject {
+    PyObject_HEAD
+    std::vector<uint8_t>* vec;   // owned storage (always allocated)
+    PyObject* view;              // non-null: zero-copy view of this object (copy=False)
+    uint8_t* vptr;               // view pointer / length, re-synchronised on every access
+    Py_ssize_t vlen;
+    uint64_t pos;                // cursor position (may exceed the length for owned buffers)
+};
+
+extern PyTypeObject BufferType;
+
+inline bool Buffer_Check(PyObject* o) { return PyObject_TypeCheck(o, &BufferType); }
+
+// borrowed bytes of any BytesType-like object: Buffer, or anything with the buffer protocol
+struct Bytes {
+    uint8_t* ptr = nullptr;
+    Py_ssize_t len = 0;
+    Py_buffer pb{};
+    bool have_pb = false;
+    BufferObject* buf = nullptr;
+    ~Bytes() { if (have_pb) PyBuffer_Release(&pb); }
+    Bytes() = default;
+    Bytes(const Bytes&) = delete;
+    Bytes& operator=(const Bytes&) = delete;
+};
+
+int buffer_sync_view(BufferObject* self);
+
+uint8_t* buffer_data(BufferObject* b) { return b->view ? b->vptr : b->vec->data(); }
+Py_ssize_t buffer_len(BufferObject* b) { return b->view ? b->vlen : (Py_ssize_t)b->vec->size(); }
+
+// reference src/io.rs:273-298 (PythonBuffer::try_from) + src/lib.rs:104-115 (BytesType extraction)
+bool get_bytes(PyObject* obj, Bytes& out) {
+    if (Buffer_Check(obj)) {
+        BufferObject* b = (BufferObject*)obj;
+        if (buffer_sync_view(b) < 0) return false;
+        out.buf = b;
+        out.ptr = buffer_data(b);
+        out.len = buffer_len(b);
+        return true;
+    }
+    if (PyObject_GetBuffer(obj, &out.pb, PyBUF_CONTIG_RO) != 0) {
+        PyErr_Clear();
+        if (!PyObject_CheckBuffer(obj))
+            PyErr_Format(PyExc_TypeError, "argument: failed to extract enum BytesType ('Buffer | File | pybuffer'): "
+                                          "'%.100s' object does not support the buffer protocol", Py_TYPE(obj)->tp_name);
+        else
+            PyErr_SetString(PyExc_BufferError, "Failed to get buffer, is it C contiguous, and shape is not null?");
+        return false;
+    }
+    out.have_pb = true;
+    if (out.pb.shape == nullptr) { PyErr_SetString(PyExc_BufferError, "shape is null"); return false; }
+    if (!PyBuffer_IsContiguous(&out.pb, 'C')) { PyErr_SetString(PyExc_BufferError, "Buffer is not C contiguous"); return false; }
+    out.ptr = (uint8_t*)out.pb.buf;
+    out.len = out.pb.len;
+    return true;
+}
+
+// reference src/io.rs:421-483 ensure_aligned_view
+int buffer_sync_view(BufferObject* self) {
+    if (!self->view) return 0;
+    Bytes b;
+    if (!get_bytes(self->view, b)) return -1;
+    if (b.ptr != self->vptr || b.len != self->vlen) {
+        self->vptr = b.ptr;
+        self->vlen = b.len;
+        if (self->pos > (uint64_t)b.len) self->pos = (uint64_t)b.len;
+    }
+    return 0;
+}
+
+PyObject* Buffer_new(PyTypeObject* type, PyObject*, PyObject*) {
+    BufferObject* self = (BufferObject*)type->tp_alloc(type, 0);
+    if (!self) return nullptr;
+    self->vec = new std::vector<uint8_t>();
+    self->view = nullptr; self->vptr = nullptr; self->vlen = 0; self->pos = 0;
+    return (PyObject*)self;
+}
+
+PyObject* buffer_from_vec(std::vector<uint8_t>&& v) {   // reference src/io.rs:399-406 From<Vec<u8>>
+    BufferObject* b = (BufferObject*)Buffer_new(&BufferType, nullptr, nullptr);
+    if (!b) return nullptr;
+    *b->vec = std::move(v);
+    return (PyObject*)b;
+}
+
+void Buffer_dealloc(BufferObject* self) {
+    delete self->vec;
+    Py_XDECREF(self->view);
+    Py_TYPE(self)->tp_free((PyObject*)self);
+}
+
+// read everything from a BytesType source at its own cursor (Buffer inputs are consumed from their position)
+void read_to_end(Bytes& src, const uint8_t*& p, Py_ssize_t& n) {
+    if (src.buf) {
+        uint64_t pos = std::min<uint64_t>(src.buf->pos, (uint64_t)src.len);
+        p = src.ptr + pos; n = src.len - (Py_ssize_t)pos;
+        src.buf->pos = (uint64_t)src.len;
+    } else { p = src.ptr; n = src.len; }
+}
+
+int Buffer_init(BufferObject* self, PyObject* args, PyObject* kw) {
+    static const char* kwl[] = {"data", "copy", nullptr};
+    PyObject *data = Py_None, *copy = Py_None;
+    if (!PyArg_ParseTupleAndKeywords(args, kw, "|OO", (char**)kwl, &data, &copy)) return -1;
+    self->vec->clear(); Py_CLEAR(self->view); self->pos = 0;
+    if (data == Py_None) return 0;
+    int do_copy = 1;
+    if (copy != Py_None) { do_copy = PyObject_IsTrue(copy); if (do_copy < 0) return -1; }
+    Bytes b;
+    if (!get_bytes(data, b)) return -1;
+    if (do_copy) {
+        const uint8_t* p; Py_ssize_t n;
+        read_to_end(b, p, n);
+        self->vec->assign(p, p + n);
+    } else {
+        Py_INCREF(data);
+        self->view = data; self->vptr = b.ptr; self->vlen = b.len;
+    }
+    return 0;
+}
+
+PyObject* Buffer_len(BufferObject* self, PyObject*) {
+    if (buffer_sync_view(self) < 0) return nullptr;
+    return PyLong_FromSsize_t(buffer_len(self));
+}
+
+// Cursor<Vec<u8>>::write semantics: zero-fill a gap, overwrite, extend
+void owned_write(BufferObject* self, const uint8_t* p, size_t n) {
+    std::vector<uint8_t>& v = *self->vec;
+    size_t pos = (size_t)self->pos;
+    if (pos > v.size()) v.resize(pos, 0);
+    if (pos + n > v.size()) v.resize(pos + n);
+    if (n) std::memcpy(v.data() + pos, p, n);
+    self->pos = pos + n;
+}
+
+PyObject* Buffer_write(BufferObject* self, PyObject* input) {
+    if (buffer_sync_view(self) < 0) return nullptr;
+    Bytes in;
+    if (!get_bytes(input, in)) return nullptr;
+    if (self->view) {
+        Py_ssize_t room = self->vlen - (Py_ssize_t)std::min<uint64_t>(self->pos, (uint64_t)self->vlen);
+        if (in.len > room) { PyErr_SetString(PyExc_OSError, "Too much to write on view"); return nullptr; }
+    }
+    const uint8_t* p; Py_ssize_t n;
+    if ((PyObject*)in.buf == (PyObject*)self) {           // writing a buffer into itself: copy first
+        std::vector<uint8_t> tmp(in.ptr + std::min<uint64_t>(self->pos, in.len), in.ptr + in.len);
+        if (self->view) { std::memcpy(self->vptr + self->pos, tmp.data(), tmp.size()); self->pos += tmp.size(); }
+        else owned_write(self, tmp.data(), tmp.size());
+        return PyLong_FromSize_t(tmp.size());
+    }
+    read_to_end(in, p, n);
+    if (self->view) {
+        Py_ssize_t room = self->vlen - (Py_ssize_t)self->pos;
+        if (n > room) { PyErr_SetString(PyExc_OSError, "failed to write whole buffer"); return nullptr; }
+        if (n) std::memcpy(self->vptr + self->pos, p, (size_t)n);
+        self->pos += (uint64_t)n;
+    } else {
+        owned_write(self, p, (size_t)n);
+    }
+    return PyLong_FromSsize_t(n);
+}
+
+PyObject* Buffer_read(BufferObject* self, PyObject* args, PyObject* kw) {
+    static const char* kwl[] = {"n_bytes", nullptr};
+    PyObject* nobj = Py_None;
+    if (!PyArg_ParseTupleAndKeywords(args, kw, "|O", (char**)kwl, &nobj)) return nullptr;
+    if (buffer_sync_view(self) < 0) return nullptr;
+    Py_ssize_t len = buffer_len(self);
+    Py_ssize_t pos = (Py_ssize_t)std::min<uint64_t>(self->pos, (uint64_t)len);
+    Py_ssize_t n = len - pos;
+    if (nobj != Py_None) {
+        Py_ssize_t want = PyLong_AsSsize_t(nobj);
+        if (want == -1 && PyErr_Occurred()) return nullptr;
+        if (want >= 0) n = std::min(want, n);
+    }
+    PyObject* r = PyBytes_FromStringAndSize((const char*)buffer_data(self) + pos, n);
+    if (r) self->pos = (uint64_t)(pos + n);
+    return r;
+}
+
+PyObject* Buffer_readinto(BufferObject* self, PyObject* output) {
+    if (buffer_sync_view(self) < 0) return nullptr;
+    Py_ssize_t len = buffer_len(self);
+    Py_ssize_t pos = (Py_ssize_t)std::min<uint64_t>(self->pos, (uint64_t)len);
+    Py_ssize_t n = len - pos;
+    const uint8_t* src = buffer_data(self) + pos;
+    if (Buffer_Check(output)) {
+        BufferObject* o = (BufferObject*)output;
+        if (o == self) { PyErr_SetString(PyExc_OSError, "cannot readinto self"); return nullptr; }
+        if (buffer_sync_view(o) < 0) return nullptr;
+        if (o->view) {
+            Py_ssize_t room = o->vlen - (Py_ssize_t)std::min<uint64_t>(o->pos, (uint64_t)o->vlen);
+            if (n > room) { PyErr_SetString(PyExc_OSError, "failed to write whole buffer"); return nullptr; }
+            if (n) std::memcpy(o->vptr + o->pos, src, (size_t)n);
+            o->pos += (uint64_t)n;
+        } else owned_write(o, src, (size_t)n);
+    } else {
+        Bytes out;
+        if (!get_bytes(output, out)) return nullptr;
+        if (n > out.len) {     // std::io::copy -> write_all -> WriteZero
+            if (out.len) std::memcpy(out.ptr, src, (size_t)out.len);
+            self->pos = (uint64_t)(pos + out.len);
+            PyErr_SetString(PyExc_OSError, "failed to write whole buffer");
+            return nullptr;
+        }
+        if (n) std::memcpy(out.ptr, src, (size_t)n);
+    }
+    self->pos = (uint64_t)(pos + n);
+    return PyLong_FromSsize_t(n);
+}
+
+PyObject* Buffer_seek(BufferObject* self, PyObject* args, PyObject* kw) {
+    static const char* kwl[] = {"position", "whence", nullptr};
+    Py_ssize_t position; PyObject* wobj = Py_None;
+    if (!PyArg_ParseTupleAndKeywords(args, kw, "n|O", (char**)kwl, &position, &wobj)) return nullptr;
+    if (buffer_sync_view(self) < 0) return nullptr;
+    long whence = 0;
+    if (wobj != Py_None) { whence = PyLong_AsLong(wobj); if (whence == -1 && PyErr_Occurred()) return nullptr; }
+    const Py_ssize_t len = buffer_len(self);
+    const Py_ssize_t cur = (Py_ssize_t)self->pos;
+    Py_ssize_t target;
+    switch (whence) {
+    case 0:
+        target = position;
+        if (self->view && (target > len || target < 0))
+            return PyErr_Format(PyExc_OSError, "Bad seek: cannot seek outside bounds of unowned buffer, tried to seek from start by %zd which would place it outside of the buffer which has length of %zd.", position, len);
+        break;
+    case 1:
+        target = cur + position;
+        if (self->view && (target > len || target < 0))
+            return PyErr_Format(PyExc_OSError, "Bad seek: cannot seek outside bounds of unowned buffer, tried to seek from current position %zd by %zd which would place it outside of the buffer which has length of %zd.", cur, target, len);
+        break;
+    case 2:
+        target = len + position;
+        if (self->view && (target > len || target < 0))
+            return PyErr_Format(PyExc_OSError, "Bad seek: cannot seek outside bounds of unowned buffer, tried to seek from end position by %zd which would place it outside of the buffer which has length of %zd.", position, len);
+        break;
+    default:
+        PyErr_SetString(PyExc_ValueError, "whence should be one of 0: seek from start, 1: seek from current, or 2: seek from end");
+        return nullptr;
+    }
+    if (target < 0) { PyErr_SetString(PyExc_OSError, "invalid seek to a negative or overflowing position"); return nullptr; }
+    self->pos = (uint64_t)target;
+    return PyLong_FromSsize_t(target);
+}
+
+PyObject* Buffer_seekable(BufferObject*, PyObject*) { Py_RETURN_TRUE; }
+
+PyObject* Buffer_tell(BufferObject* self, PyObject*) {
+    if (buffer_sync_view(self) < 0) return nullptr;
+    return PyLong_FromUnsignedLongLong(self->pos);
+}
+
+PyObject* Buffer_set_len(BufferObject* self, PyObject* arg) {
+    size_t size = PyLong_AsSize_t(arg);
+    if (size == (size_t)-1 && PyErr_Occurred()) return nullptr;
+    if (self->view) { PyErr_SetString(PyExc_OSError, "Cannot set length on unowned buffer"); return nullptr; }
+    self->vec->resize(size, 0);
+    Py_RETURN_NONE;
+}
+
+PyObject* Buffer_truncate(BufferObject* self, PyObject*) {
+    if (self->view) { PyErr_SetString(PyExc_OSError, "Cannot truncate unowned buffer"); return nullptr; }
+    self->vec->clear();
+    self->pos = 0;
+    Py_RETURN_NONE;
+}
+
+PyObject* Buffer_get_view_reference(BufferObject* self, PyObject*) {
+    if (!self->view) Py_RETURN_NONE;
+    Py_INCREF(self->view);
+    return self->view;
+}
+
+PyObject* Buffer_get_view_reference_count(BufferObject* self, PyObject*) {
+    if (!self->view) Py_RETURN_NONE;
+    return PyLong_FromSsize_t(Py_REFCNT(self->view));
+}
+
+Py_ssize_t Buffer_sq_length(BufferObject* self) {
+    if (buffer_sync_view(self) < 0) return -1;
+    return buffer_len(self);
+}
+
+int Buffer_contains(BufferObject* self, PyObject* x) {
+    Bytes b;
+    if (!get_bytes(x, b)) return -1;
+    const uint8_t* d = buffer_data(self);
+    Py_ssize_t n = buffer_len(self);
+    if (b.len == 0) return 0;     // slice::windows(0) panics in the reference; an empty needle is "not found" here
+    if (b.len > n) return 0;
+    return std::search(d, d + n, b.ptr, b.ptr + b.len) != d + n;
+}
+
+PyObject* Buffer_repr(BufferObject* self) {
+    if (buffer_sync_view(self) < 0) return nullptr;
+    return PyUnicode_FromFormat("cramjam.Buffer<len=%zd>", buffer_len(self));
+}
+
+PyObject* Buffer_richcompare(PyObject* a, PyObject* b, int op) {
+    if ((op != Py_EQ && op != Py_NE) || !Buffer_Check(a) || !Buffer_Check(b)) Py_RETURN_NOTIMPLEMENTED;
+    BufferObject *x = (BufferObject*)a, *y = (BufferObject*)b;
+    bool eq = buffer_len(x) == buffer_len(y) && x->pos == y->pos &&
+              (buffer_len(x) == 0 || std::memcmp(buffer_data(x), buffer_data(y), (size_t)buffer_len(x)) == 0);
+    if ((op == Py_EQ) == eq) Py_RETURN_TRUE;
+    Py_RETURN_FALSE;
+}
+
+int Buffer_bool(BufferObject* self) {
+    if (buffer_sync_view(self) < 0) return -1;
+    return buffer_len(self) > 0;
+}
+
+// reference src/io.rs:643-682 __getbuffer__
+int Buffer_getbuffer(BufferObject* self, Py_buffer* view, int flags) {
+    if (!view) { PyErr_SetString(PyExc_BufferError, "View is null"); return -1; }
+    if ((flags & PyBUF_WRITABLE) == PyBUF_WRITABLE) { PyErr_SetString(PyExc_BufferError, "Object is not writable"); view->obj = nullptr; return -1; }
+    view->obj = (PyObject*)self;
+    Py_INCREF(self);
+    view->buf = buffer_data(self);
+    view->len = buffer_len(self);
+    view->readonly = 0;
+    view->itemsize = 1;
+    view->format = (flags & PyBUF_FORMAT) == PyBUF_FORMAT ? (char*)"B" : nullptr;
+    view->ndim = 1;
+    view->shape = (flags & PyBUF_ND) == PyBUF_ND ? &view->len : nullptr;
+    view->strides = (flags & PyBUF_STRIDES) == PyBUF_STRIDES ? &view->itemsize : nullptr;
+    view->suboffsets = nullptr;
+    view->internal = nullptr;
+    return 0;
+}
+
+PyMethodDef Buffer_methods[] = {
+    {"len", (PyCFunction)Buffer_len, METH_NOARGS, "Length of the underlying buffer"},
+    {"write", (PyCFunction)Buffer_write, METH_O, "Write some bytes to the buffer"},
+    {"read", (PyCFunction)Buffer_read, METH_VARARGS | METH_KEYWORDS, "Read from the buffer at its current position"},
+    {"readinto", (PyCFunction)Buffer_readinto, METH_O, "Read from the buffer into a bytes-like object"},
+    {"seek", (PyCFunction)Buffer_seek, METH_VARARGS | METH_KEYWORDS, "Seek; whence 0 start, 1 current, 2 end"},
+    {"seekable", (PyCFunction)Buffer_seekable, METH_NOARGS, "Always True"},
+    {"tell", (PyCFunction)Buffer_tell, METH_NOARGS, "Current position"},
+    {"set_len", (PyCFunction)Buffer_set_len, METH_O, "Set the length; truncates or zero-fills"},
+    {"truncate", (PyCFunction)Buffer_truncate, METH_NOARGS, "Truncate the buffer"},
+    {"get_view_reference", (PyCFunction)Buffer_get_view_reference, METH_NOARGS, "Object this Buffer views, or None"},
+    {"get_view_reference_count", (PyCFunction)Buffer_get_view_reference_count, METH_NOARGS, "Refcount of the viewed object, or None"},
+    {nullptr, nullptr, 0, nullptr}};
+
+PySequenceMethods Buffer_as_sequence = {(lenfunc)Buffer_sq_length, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                        (objobjproc)Buffer_contains, nullptr, nullptr};
+PyNumberMethods Buffer_as_number = {};
+PyBufferProcs Buffer_as_buffer = {(getbufferproc)Buffer_getbuffer, nullptr};
+
+PyTypeObject BufferType = {PyVarObject_HEAD_INIT(nullptr, 0)};
+
+// ------------------------------------------------------------------------------------------
+// helpers for the codec functions
+// ------------------------------------------------------------------------------------------
+PyObject* raise_code(PyObject* exc, int64_t code) {
+    if (code == CJ_E_NO_DEVICE || code == CJ_E_OOM || code == CJ_E_BAD_ARG) {
+        PyErr_Format(PyExc_RuntimeError, "%s [%s]", cj_strerror(code), cj_last_hip_error());
+    } else {
+        PyErr_SetString(exc, cj_strerror(code));
+    }
+    return nullptr;
+}
+
+bool opt_size(PyObject* o, bool& has, size_t& v) {
+    has = o && o != Py_None;
+    if (!has) return true;
+    v = PyLong_AsSize_t(o);
+    return !(v == (size_t)-1 && PyErr_Occurred());
+}
+
+int opt_int(PyObject* o, int dflt) {     // Option<i32> -> -1 for None
+    if (!o || o == Py_None) return dflt;
+    long v = PyLong_AsLong(o);
+    if (v == -1 && PyErr_Occurred()) return -2;
+    return (int)v;
+}
+
+// ------------------------------------------------------------------------------------------
+// cramjam.lz4 block functions (reference src/lz4.rs:78-229)
+// ------------------------------------------------------------------------------------------
+PyObject* lz4_decompress_block(PyObject*, PyObject* args, PyObject* kw) {       // src/lz4.rs:78-95
+    static const char* kwl[] = {"data", "output_len", nullptr};
+    PyObject *data, *olen = Py_None;
+    if (!PyArg_ParseTupleAndKeywords(args, kw, "O|O", (char**)kwl, &data, &olen)) return nullptr;
+    bool has; size_t n = 0;
+    if (!opt_size(olen, has, n)) return nullptr;
+    Bytes in;
+    if (!get_bytes(data, in)) return nullptr;
+    std::vector<uint8_t> buf;
+    int64_t r;
+    if (has) {
+        // Some(n): no prefix expected, capacity n, the returned Buffer keeps length n (not truncated)
+        buf.assign(n, 0);
+        Py_BEGIN_ALLOW_THREADS
+        r = cj_lz4_block_decompress(in.ptr, (size_t)in.len, buf.data(), n, 0);
+        Py_END_ALLOW_THREADS
+        if (r < 0) return raise_code(DecompressionError, r);
+    } else {
+        // None: decompress_vec — read the u32-LE prefix, decode, truncate to the decoded length
+        int64_t size = cj_lz4_block_prefixed_len(in.ptr, (size_t)in.len);
+        if (size < 0) return raise_code(DecompressionError, size);
+        if (size > 0x7E000000ll) return raise_code(DecompressionError, size > 0x7FFFFFFFll ? CJ_E_NEG_PREFIX : CJ_E_PREFIX_TOO_BIG);
+        buf.assign((size_t)size, 0);
+        Py_BEGIN_ALLOW_THREADS
+        r = cj_lz4_block_decompress(in.ptr, (size_t)in.len, buf.data(), (size_t)size, 1);
+        Py_END_ALLOW_THREADS
+        if (r < 0) return raise_code(DecompressionError, r);
+        buf.resize((size_t)r);
+    }
+    return buffer_from_vec(std::move(buf));
+}
+
+bool parse_store_size(PyObject* o, int& prepend) {
+    prepend = -1;
+    if (o && o != Py_None) { int t = PyObject_IsTrue(o); if (t < 0) return false; prepend = t; }
+    return true;
+}
+
+PyObject* lz4_compress_block(PyObject*, PyObject* args, PyObject* kw) {         // src/lz4.rs:113-131
+    static const char* kwl[] = {"data", "output_len", "mode", "acceleration", "compression", "store_size", nullptr};
+    PyObject *data, *olen = Py_None, *mode = Py_None, *accel = Py_None, *comp = Py_None, *store = Py_None;
+    if (!PyArg_ParseTupleAndKeywords(args, kw, "O|OOOOO", (char**)kwl, &data, &olen, &mode, &accel, &comp, &store)) return nullptr;
+    if (mode != Py_None && !PyUnicode_Check(mode)) { PyErr_SetString(PyExc_TypeError, "argument 'mode': 'str' expected"); return nullptr; }
+    int a = opt_int(accel, -1), c = opt_int(comp, -1), prepend;
+    if (a == -2 || c == -2 || !parse_store_size(store, prepend)) return nullptr;
+    Bytes in;
+    if (!get_bytes(data, in)) return nullptr;
+    const int pre = prepend != 0;
+    size_t bound = cj_lz4_block_compress_bound((size_t)in.len, 0);
+    if (bound == 0) return raise_code(CompressionError, CJ_E_INPUT_TOO_LARGE);
+    std::vector<uint8_t> buf(bound + (pre ? 4 : 0));
+    int64_t r;
+    Py_BEGIN_ALLOW_THREADS
+    r = cj_lz4_block_compress(in.ptr, (size_t)in.len, buf.data(), buf.size(), c, a, prepend);
+    Py_END_ALLOW_THREADS
+    if (r < 0) return raise_code(CompressionError, r);
+    buf.resize((size_t)r);
+    return buffer_from_vec(std::move(buf));
+}
+
+PyObject* lz4_decompress_block_into(PyObject*, PyObject* args, PyObject* kw) {  // src/lz4.rs:140-173
+    static const char* kwl[] = {"input", "output", "output_len", nullptr};
+    PyObject *input, *output, *olen = Py_None;
+    if (!PyArg_ParseTupleAndKeywords(args, kw, "OO|O", (char**)kwl, &input, &output, &olen)) return nullptr;
+    bool has; size_t n = 0;
+    if (!opt_size(olen, has, n)) return nullptr;
+    Bytes in, out;
+    if (!get_bytes(input, in) || !get_bytes(output, out)) return nullptr;
+    const int size_stored = !has;
+    if (has && (size_t)out.len < n)
+        return PyErr_Format(DecompressionError, "output_len set to %zu, but output is less. (%zd)", n, out.len);
+    int64_t r;
+    Py_BEGIN_ALLOW_THREADS
+    r = cj_lz4_block_decompress(in.ptr, (size_t)in.len, out.ptr, (size_t)out.len, size_stored);
+    if (r < 0 && r != CJ_E_NO_DEVICE) {
+        // fall back to the opposite assumption; the FIRST error wins if that fails too (src/lz4.rs:163-170)
+        int64_t r2 = cj_lz4_block_decompress(in.ptr, (size_t)in.len, out.ptr, (size_t)out.len, !size_stored);
+        if (r2 >= 0) r = r2;
+    }
+    Py_END_ALLOW_THREADS
+    if (r < 0) return raise_code(DecompressionError, r);
+    return PyLong_FromLongLong(r);
+}
+
+PyObject* lz4_compress_block_into(PyObject*, PyObject* args, PyObject* kw) {    // src/lz4.rs:191-216
+    static const char* kwl[] = {"data", "output", "mode", "acceleration", "compression", "store_size", nullptr};
+    PyObject *data, *output, *mode = Py_None, *accel = Py_None, *comp = Py_None, *store = Py_None;
+    if (!PyArg_ParseTupleAndKeywords(args, kw, "OO|OOOO", (char**)kwl, &data, &output, &mode, &accel, &comp, &store)) return nullptr;
+    int a = opt_int(accel, -1), c = opt_int(comp, -1), prepend;
+    if (a == -2 || c == -2 || !parse_store_size(store, prepend)) return nullptr;
+    Bytes in, out;
+    if (!get_bytes(data, in) || !get_bytes(output, out)) return nullptr;
+    int64_t r;
+    Py_BEGIN_ALLOW_THREADS
+    r = cj_lz4_block_compress(in.ptr, (size_t)in.len, out.ptr, (size_t)out.len, c, a, prepend);
+    Py_END_ALLOW_THREADS
+    if (r < 0) return raise_code(CompressionError, r);
+    return PyLong_FromLongLong(r);
+}
+
+PyObject* lz4_compress_block_bound(PyObject*, PyObject* src) {                  // src/lz4.rs:226-229
+    Bytes in;
+    if (!get_bytes(src, in)) return nullptr;
+    return PyLong_FromSize_t(cj_lz4_block_compress_bound((size_t)in.len, 1));
+}
+
+// ------------------------------------------------------------------------------------------
+// cramjam.snappy raw functions (reference src/snappy.rs:52-122)
+// ------------------------------------------------------------------------------------------
+PyObject* snappy_decompress_raw(PyObject*, PyObject* args, PyObject* kw) {      // src/snappy.rs:52-60
+    static const char* kwl[] = {"data", "output_len", nullptr};
+    PyObject *data, *olen = Py_None;    // output_len is accepted and ignored, as in the reference
+    if (!PyArg_ParseTupleAndKeywords(args, kw, "O|O", (char**)kwl, &data, &olen)) return nullptr;
+    Bytes in;
+    if (!get_bytes(data, in)) return nullptr;
+    if (in.len == 0) return raise_code(DecompressionError, CJ_E_SNAPPY_EMPTY);
+    int64_t n = cj_snappy_raw_decompress_len(in.ptr, (size_t)in.len);
+    if (n < 0) return raise_code(DecompressionError, n);
+    std::vector<uint8_t> buf((size_t)n, 0);
+    int64_t r;
+    Py_BEGIN_ALLOW_THREADS
+    r = cj_snappy_raw_decompress(in.ptr, (size_t)in.len, buf.data(), buf.size());
+    Py_END_ALLOW_THREADS
+    if (r < 0) return raise_code(DecompressionError, r);
+    buf.resize((size_t)r);
+    return buffer_from_vec(std::move(buf));
+}
+
+PyObject* snappy_compress_raw(PyObject*, PyObject* args, PyObject* kw) {        // src/snappy.rs:70-78
+    static const char* kwl[] = {"data", "output_len", nullptr};
+    PyObject *data, *olen = Py_None;
+    if (!PyArg_ParseTupleAndKeywords(args, kw, "O|O", (char**)kwl, &data, &olen)) return nullptr;
+    Bytes in;
+    if (!get_bytes(data, in)) return nullptr;
+    size_t cap = cj_snappy_raw_max_compress_len((size_t)in.len);
+    if (cap == 0) return raise_code(CompressionError, CJ_E_SNAPPY_TOO_BIG);
+    std::vector<uint8_t> buf(cap);
+    int64_t r;
+    Py_BEGIN_ALLOW_THREADS
+    r = cj_snappy_raw_compress(in.ptr, (size_t)in.len, buf.data(), cap);
+    Py_END_ALLOW_THREADS
+    if (r < 0) return raise_code(CompressionError, r);
+    buf.resize((size_t)r);
+    return buffer_from_vec(std::move(buf));
+}
+
+PyObject* snappy_xxx_raw_into(PyObject* args, PyObject* kw, bool compress) {    // src/snappy.rs:93-108
+    static const char* kwl[] = {"input", "output", nullptr};
+    PyObject *input, *output;
+    if (!PyArg_ParseTupleAndKeywords(args, kw, "OO", (char**)kwl, &input, &output)) return nullptr;
+    Bytes in, out;
+    if (!get_bytes(input, in) || !get_bytes(output, out)) return nullptr;
+    int64_t r;
+    Py_BEGIN_ALLOW_THREADS
+    r = compress ? cj_snappy_raw_compress(in.ptr, (size_t)in.len, out.ptr, (size_t)out.len)
+                 : cj_snappy_raw_decompress(in.ptr, (size_t)in.len, out.ptr, (size_t)out.len);
+    Py_END_ALLOW_THREADS
+    if (r < 0) return raise_code(compress ? CompressionError : DecompressionError, r);
+    return PyLong_FromLongLong(r);
+}
+PyObject* snappy_compress_raw_into(PyObject*, PyObject* a, PyObject* k) { return snappy_xxx_raw_into(a, k, true); }
+PyObject* snappy_decompress_raw_into(PyObject*, PyObject* a, PyObject* k) { return snappy_xxx_raw_into(a, k, false); }
+
+PyObject* snappy_compress_raw_max_len(PyObject*, PyObject* data) {              // src/snappy.rs:112-115
+    Bytes in;
+    if (!get_bytes(data, in)) return nullptr;
+    return PyLong_FromSize_t(cj_snappy_raw_max_compress_len((size_t)in.len));
+}
+
+PyObject* snappy_decompress_raw_len(PyObject*, PyObject* data) {                // src/snappy.rs:119-122
+    Bytes in;
+    if (!get_bytes(data, in)) return nullptr;
+    int64_t n = cj_snappy_raw_decompress_len(in.ptr, (size_t)in.len);
+    if (n < 0) return raise_code(DecompressionError, n);
+    return PyLong_FromLongLong(n);
+}
+
+PyMethodDef lz4_methods[] = {
+    {"decompress_block", (PyCFunction)lz4_decompress_block, METH_VARARGS | METH_KEYWORDS, "LZ4 block decompression (data, output_len=None)"},
+    {"compress_block", (PyCFunction)lz4_compress_block, METH_VARARGS | METH_KEYWORDS, "LZ4 block compression (data, output_len=None, mode=None, acceleration=None, compression=None, store_size=None)"},
+    {"decompress_block_into", (PyCFunction)lz4_decompress_block_into, METH_VARARGS | METH_KEYWORDS, "LZ4 block decompression into a pre-allocated buffer (input, output, output_len=None)"},
+    {"compress_block_into", (PyCFunction)lz4_compress_block_into, METH_VARARGS | METH_KEYWORDS, "LZ4 block compression into a pre-allocated buffer"},
+    {"compress_block_bound", (PyCFunction)lz4_compress_block_bound, METH_O, "Size of a buffer guaranteed to hold the block-compressed result"},
+    {nullptr, nullptr, 0, nullptr}};
+
+PyMethodDef snappy_methods[] = {
+    {"decompress_raw", (PyCFunction)snappy_decompress_raw, METH_VARARGS | METH_KEYWORDS, "Snappy raw decompression (data, output_len=None)"},
+    {"compress_raw", (PyCFunction)snappy_compress_raw, METH_VARARGS | METH_KEYWORDS, "Snappy raw compression (data, output_len=None)"},
+    {"compress_raw_into", (PyCFunction)snappy_compress_raw_into, METH_VARARGS | METH_KEYWORDS, "Compress raw format directly into an output buffer"},
+    {"decompress_raw_into", (PyCFunction)snappy_decompress_raw_into, METH_VARARGS | METH_KEYWORDS, "Decompress raw format directly into an output buffer"},
+    {"compress_raw_max_len", (PyCFunction)snappy_compress_raw_max_len, METH_O, "Max compressed length for snappy raw compression"},
+    {"decompress_raw_len", (PyCFunction)snappy_decompress_raw_len, METH_O, "Decompressed length of the given raw data"},
+    {nullptr, nullptr, 0, nullptr}};
+
+PyModuleDef lz4_def = {PyModuleDef_HEAD_INIT, "cramjam_amd.lz4", "LZ4 block de/compression on MI355X", -1, lz4_methods};
+PyModuleDef snappy_def = {PyModuleDef_HEAD_INIT, "cramjam_amd.snappy", "Snappy raw de/compression on MI355X", -1, snappy_methods};
+PyModuleDef root_def = {PyModuleDef_HEAD_INIT, "cramjam_amd._cramjam", "native host layer of cramjam_amd", -1, nullptr};
+
+}  // namespace
+
+PyMODINIT_FUNC PyInit__cramjam(void) {
+    BufferType.tp_name = "cramjam_amd.Buffer";
+    BufferType.tp_basicsize = sizeof(BufferObject);
+    BufferType.tp_flags = Py_TPFLAGS_DEFAULT | Py_TPFLAGS_BASETYPE;
+    BufferType.tp_doc = "A native file-like in-memory buffer (cramjam.Buffer)";
+    BufferType.tp_new = Buffer_new;
+    BufferType.tp_init = (initproc)Buffer_init;
+    BufferType.tp_dealloc = (destructor)Buffer_dealloc;
+    BufferType.tp_methods = Buffer_methods;
+    BufferType.tp_as_sequence = &Buffer_as_sequence;
+    Buffer_as_number.nb_bool = (inquiry)Buffer_bool;
+    BufferType.tp_as_number = &Buffer_as_number;
+    BufferType.tp_as_buffer = &Buffer_as_buffer;
+    BufferType.tp_repr = (reprfunc)Buffer_repr;
+    BufferType.tp_richcompare = Buffer_richcompare;
+    if (PyType_Ready(&BufferType) < 0) return nullptr;
+
+    PyObject* m = PyModule_Create(&root_def);
+    if (!m) return nullptr;
+    CompressionError = PyErr_NewException("cramjam_amd.CompressionError", nullptr, nullptr);
+    DecompressionError = PyErr_NewException("cramjam_amd.DecompressionError", nullptr, nullptr);
+    Py_INCREF(&BufferType);
+    PyModule_AddObject(m, "Buffer", (PyObject*)&BufferType);
+    Py_INCREF(CompressionError); PyModule_AddObject(m, "CompressionError", CompressionError);
+    Py_INCREF(DecompressionError); PyModule_AddObject(m, "DecompressionError", DecompressionError);
+    PyObject* lz4 = PyModule_Create(&lz4_def);
+    PyObject* snappy = PyModule_Create(&snappy_def);
+    if (!lz4 || !snappy) return nullptr;
+    PyModule_AddObject(m, "lz4", lz4);
+    PyModule_AddObject(m, "snappy", snappy);
+    PyModule_AddIntConstant(m, "abi_version", cj_abi_version());
+    return m;
+}

@@ -1,0 +1,62 @@
+"""The drop-in boundary: libcramjam_hip.so loads and exports every symbol include/cramjam_hip.h declares.
+No compute calls here (no GPU needed)."""
+import ctypes as C
+import os
+import re
+
+from conftest import ROOT
+from cramjam_amd import _native as N
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "cramjam_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cj_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    names = _declared_symbols()
+    assert len(names) >= 24
+    L = C.CDLL(N.LIB_PATH)
+    for n in names:
+        assert hasattr(L, n), "libcramjam_hip.so does not export %s" % n
+        assert n in N.SYMBOLS, "cramjam_amd/_native.py has no binding for %s" % n
+    assert sorted(N.SYMBOLS) == names
+
+
+def test_pure_helpers_and_error_strings():
+    L = N.lib()
+    assert L.cj_abi_version() == 1
+    assert L.cj_lz4_block_compress_bound(65536, 0) == 65809 and L.cj_lz4_block_compress_bound(65536, 1) == 65813
+    assert L.cj_lz4_block_compress_bound(0x7E000001, 0) == 0
+    assert L.cj_snappy_raw_max_compress_len(65536) == 76490
+    pre = b"\x39\x05\x00\x00rest"
+    assert L.cj_lz4_block_prefixed_len(pre, len(pre)) == 1337
+    assert L.cj_lz4_block_prefixed_len(b"ab", 2) == -3
+    assert L.cj_snappy_raw_decompress_len(b"\xd9\x06", 2) == 857
+    assert N.strerror(-7) == "Decompression failed. Input invalid or too long?"
+    assert N.strerror(-2) == "Compression failed"
+    assert "no CPU fallback" in N.strerror(-100)
+
+
+def test_no_silent_cpu_path_without_device():
+    import torch
+    if torch.cuda.is_available():
+        return
+    L = N.lib()
+    out = C.create_string_buffer(64)
+    assert L.cj_device_count() == 0
+    assert L.cj_lz4_block_compress(b"abc", 3, C.cast(out, C.c_void_p), 64, -1, -1, -1) == -100
+    assert L.cj_snappy_raw_decompress(b"\x00", 1, C.cast(out, C.c_void_p), 64) == -100
+
+
+def test_product_does_not_touch_the_oracle():
+    # nothing under cramjam_amd/ may import, link or dlopen oracle/
+    pkg = os.path.join(ROOT, "cramjam_amd")
+    for dp, _, files in os.walk(pkg):
+        if os.path.basename(dp) == "build":
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
+                src = open(os.path.join(dp, f), errors="ignore").read()
+                assert "cj_oracle" not in src and "import oracle" not in src and "libcj_oracle" not in src, os.path.join(dp, f)

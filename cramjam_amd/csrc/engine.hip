@@ -45,6 +45,9 @@ struct cj_engine {
     hipStream_t stream = nullptr;
     std::mutex mu;                 // serialises host-batch staging on this engine
     DevBuf d_in, d_out, d_meta;
+    std::mutex scratch_mu;         // LZ4 parse->decode scratch (sync points, per-chunk meta), reused across calls
+    DevBuf d_sync, d_pmeta;
+    hipEvent_t scratch_free = nullptr;   // recorded after the last kernel that reads the scratch
     std::vector<uint8_t> h_in, h_out;
     std::vector<uint64_t> h_meta;
 };
@@ -59,17 +62,32 @@ void fill_args(cj::BatchArgs& a, uint32_t flags, size_t n, const uint8_t* in_bas
     a.result = result; a.n_chunks = (uint32_t)n; a.flags = flags;
 }
 
-int launch(cj_codec codec, cj_op op, const cj::BatchArgs& a, hipStream_t s) {
+int launch(cj_engine* e, cj_codec codec, cj_op op, const cj::BatchArgs& a, hipStream_t s) {
     if (codec == CJ_CODEC_LZ4_BLOCK) {
         if (op == CJ_OP_DECOMPRESS) {
-            static const size_t lanes_min = [] {
-                const char* v = std::getenv("CJ_LANES_MIN_CHUNKS");
-                return v ? (size_t)std::strtoull(v, nullptr, 10) : (size_t)CJ_LANES_MIN_CHUNKS;
+            static const size_t lds_min = [] {
+                const char* v = std::getenv("CJ_LDS_MIN_CHUNKS");
+                return v ? (size_t)std::strtoull(v, nullptr, 10) : (size_t)CJ_LDS_MIN_CHUNKS;
             }();
-            bool lanes = a.n_chunks >= lanes_min;
-            if (a.flags & CJ_FLAG_FORCE_WAVE_PER_CHUNK) lanes = false;
-            if (a.flags & CJ_FLAG_FORCE_LANE_PER_CHUNK) lanes = true;
-            if (lanes) cj::launch_lz4_decode_lanes(a, s); else cj::launch_lz4_decode(a, s);
+            int mode = a.n_chunks >= lds_min ? 2 : 0;          // 0 wave, 1 lane, 2 parse + LDS workgroup
+            if (a.flags & CJ_FLAG_FORCE_WAVE_PER_CHUNK) mode = 0;
+            if (a.flags & CJ_FLAG_FORCE_LANE_PER_CHUNK) mode = 1;
+            if (a.flags & CJ_FLAG_FORCE_LDS_PER_CHUNK) mode = 2;
+            if (mode == 0) cj::launch_lz4_decode(a, s);
+            else if (mode == 1) cj::launch_lz4_decode_lanes(a, s);
+            else {
+                std::lock_guard<std::mutex> lock(e->scratch_mu);
+                const bool grow = cj::lz4_lds_scratch_sync_bytes(a.n_chunks) > e->d_sync.cap ||
+                                  cj::lz4_lds_scratch_meta_bytes(a.n_chunks) > e->d_pmeta.cap;
+                if (grow && e->scratch_free) HIP_TRY(hipEventSynchronize(e->scratch_free), CJ_E_NO_DEVICE);
+                if (!e->d_sync.reserve(cj::lz4_lds_scratch_sync_bytes(a.n_chunks)) ||
+                    !e->d_pmeta.reserve(cj::lz4_lds_scratch_meta_bytes(a.n_chunks))) return CJ_E_OOM;
+                if (!e->scratch_free) HIP_TRY(hipEventCreateWithFlags(&e->scratch_free, hipEventDisableTiming), CJ_E_NO_DEVICE);
+                else HIP_TRY(hipStreamWaitEvent(s, e->scratch_free, 0), CJ_E_NO_DEVICE);   // previous user of the scratch
+                cj::launch_lz4_parse(a, e->d_sync.p, e->d_pmeta.p, s);
+                cj::launch_lz4_decode_lds(a, e->d_sync.p, e->d_pmeta.p, s);
+                HIP_TRY(hipEventRecord(e->scratch_free, s), CJ_E_NO_DEVICE);
+            }
         } else cj::launch_lz4_encode(a, s);
     } else if (codec == CJ_CODEC_SNAPPY_RAW) {
         if (op == CJ_OP_DECOMPRESS) cj::launch_snappy_decode(a, s); else cj::launch_snappy_encode(a, s);
@@ -187,7 +205,8 @@ int cj_engine_create(int device, cj_engine** out) {
 void cj_engine_destroy(cj_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
-    e->d_in.release(); e->d_out.release(); e->d_meta.release();
+    e->d_in.release(); e->d_out.release(); e->d_meta.release(); e->d_sync.release(); e->d_pmeta.release();
+    if (e->scratch_free) (void)hipEventDestroy(e->scratch_free);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -203,7 +222,7 @@ int cj_batch_device(cj_engine* e, cj_codec codec, cj_op op, uint32_t flags, size
     HIP_TRY(hipSetDevice(e->device), CJ_E_NO_DEVICE);
     cj::BatchArgs a;
     fill_args(a, flags, n_chunks, in_base, in_off, in_len, out_base, out_off, out_cap, result);
-    return launch(codec, op, a, hip_stream ? (hipStream_t)hip_stream : e->stream);
+    return launch(e, codec, op, a, hip_stream ? (hipStream_t)hip_stream : e->stream);
 }
 
 int cj_engine_sync(cj_engine* e) {
@@ -226,7 +245,7 @@ double cj_batch_device_timed(cj_engine* e, cj_codec codec, cj_op op, uint32_t fl
     HIP_TRY(hipEventCreate(&t1), -1.0);
     HIP_TRY(hipEventRecord(t0, e->stream), -1.0);
     for (int r = 0; r < reps; r++)
-        if (launch(codec, op, a, e->stream) != 0) return -1.0;
+        if (launch(e, codec, op, a, e->stream) != 0) return -1.0;
     HIP_TRY(hipEventRecord(t1, e->stream), -1.0);
     HIP_TRY(hipEventSynchronize(t1), -1.0);
     float ms = 0.f;
@@ -280,7 +299,7 @@ int cj_batch_host(cj_engine* e, cj_codec codec, cj_op op, uint32_t flags, size_t
 
     cj::BatchArgs a;
     fill_args(a, flags, n, d_in, d_meta, d_meta + n, d_out, d_meta + 2 * n, d_meta + 3 * n, (int64_t*)(d_meta + 4 * n));
-    int rc = launch(codec, op, a, e->stream);
+    int rc = launch(e, codec, op, a, e->stream);
     if (rc != 0) return rc;
     HIP_TRY(hipMemcpyAsync(result, d_meta + 4 * n, n * 8, hipMemcpyDeviceToHost, e->stream), CJ_E_NO_DEVICE);
     HIP_TRY(hipStreamSynchronize(e->stream), CJ_E_NO_DEVICE);

@@ -1,0 +1,171 @@
+// lz4_lane_walk.hpp — the per-lane LZ4 block walker shared by
+//   * lz4_decode_lanes_kernel  (kCopy = true : one lane decodes one whole chunk), and
+//   * lz4_parse_kernel         (kCopy = false: one lane only walks + validates the token chain and
+//                               records an (ip, op) sync point every kSyncEvery sequences for the
+//                               workgroup-per-chunk LDS decoder, lz4_decode_lds.hip).
+// Accept/reject rules: liblz4 1.10.0 LZ4_decompress_safe (reference src/lz4.rs:88,164,168 -> lz4 crate),
+// offset 0 rejected.
+#pragma once
+#include "cj_common.hpp"
+
+namespace cj {
+#if defined(__HIPCC__)
+
+constexpr uint32_t kSyncEvery = 8;        // sequences per sync point
+constexpr uint32_t kSyncStride = 1024;    // sync points reserved per chunk (=> at most 8192 sequences on the LDS path)
+constexpr uint32_t kLdsOutMax = 65536;    // the LDS decoder holds at most this much output ...
+constexpr uint32_t kLdsInMax = 66560;     // ... and this much compressed input (>= LZ4_compressBound(65536)=65809)
+
+struct ParseMeta {       // one per chunk, written by lz4_parse_kernel
+    uint32_t nseq;       // sequences incl. the final literal-only one; 0 = nothing left for the LDS decoder
+    uint32_t in_skip;    // 4 when a size prefix was consumed
+};
+
+__device__ __forceinline__ uint4 ld16u(const uint8_t* p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
+__device__ __forceinline__ void st16u(uint8_t* p, const uint4& v) { __builtin_memcpy(p, &v, 16); }
+
+// up to 4 bytes at in[ip..], zero-filled past iend
+__device__ __forceinline__ uint32_t ld_le_tail(const uint8_t* in, uint32_t ip, uint32_t iend) {
+    if (ip + 4u <= iend) return ld32u(in + ip);
+    uint32_t v = 0;
+    for (uint32_t i = 0; i < 4u && ip + i < iend; i++) v |= (uint32_t)in[ip + i] << (8u * i);
+    return v;
+}
+
+// dst[0..n) = src[0..n), non-overlapping; room_* = bytes that may be touched from dst/src
+__device__ __forceinline__ void lane_copy(uint8_t* dst, const uint8_t* src, uint32_t n, uint32_t room_dst, uint32_t room_src) {
+    uint32_t k = 0;
+    const uint32_t room = room_dst < room_src ? room_dst : room_src;
+    for (; k < n && k + 16u <= room; k += 16u) st16u(dst + k, ld16u(src + k));
+    for (; k < n; k++) dst[k] = src[k];
+}
+
+// 16-byte vector whose byte i is pat[i % d], for 1 <= d < 16
+__device__ __forceinline__ uint4 splat_pattern(const uint8_t* pat, uint32_t d) {
+    uint32_t w[4];
+    if (d == 1u) {
+        uint32_t b = pat[0] * 0x01010101u;
+        w[0] = w[1] = w[2] = w[3] = b;
+    } else if (d == 2u) {
+        uint32_t h = (uint32_t)pat[0] | ((uint32_t)pat[1] << 8);
+        h |= h << 16;
+        w[0] = w[1] = w[2] = w[3] = h;
+    } else if (d == 4u) {
+        uint32_t v = ld32u(pat);
+        w[0] = w[1] = w[2] = w[3] = v;
+    } else if (d == 8u) {
+        w[0] = w[2] = ld32u(pat);
+        w[1] = w[3] = ld32u(pat + 4);
+    } else {
+        w[0] = w[1] = w[2] = w[3] = 0;
+        uint32_t r = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 16u; i++) {
+            w[i >> 2] |= (uint32_t)pat[r] << (8u * (i & 3u));
+            r += 1u;
+            if (r == d) r = 0;
+        }
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// dst[j] = dst[j - d], j in [0, m); room = bytes that may be touched from dst
+__device__ __forceinline__ void lane_match(uint8_t* dst, uint32_t d, uint32_t m, uint32_t room) {
+    uint32_t k = 0;
+    const uint8_t* src = dst - d;
+    if (d >= 16u) {
+        for (; k < m && k + 16u <= room; k += 16u) st16u(dst + k, ld16u(src + k));
+    } else if (m >= 16u && room >= 32u) {
+        const uint4 p = splat_pattern(src, d);
+        const uint32_t s = (16u / d) * d;          // advance by whole periods so the phase stays aligned
+        for (; k < m && k + 16u <= room; k += s) st16u(dst + k, p);
+        if (k > m) k = m;
+    }
+    for (; k < m; k++) dst[k] = src[k];      // src[k] == dst[k - d]; the pointer form avoids u32 wrap
+}
+
+// Walks one LZ4 block.  Returns decoded size or CJ_E_CORRUPT.  kCopy=false touches only `in`.
+// sync: uint2 slots (ip, op) written every kSyncEvery sequences (may be null when kCopy);
+// nseq_out: number of sequences walked (incl. the final literal-only one).
+template <bool kCopy>
+__device__ __forceinline__ int64_t lz4_lane_walk(const uint8_t* in, uint32_t iend, uint8_t* out, uint32_t cap,
+                                                 uint2* sync, uint32_t sync_cap, uint32_t* nseq_out) {
+    uint32_t ip = 0, op = 0, nseq = 0;
+    for (;;) {
+        if (!kCopy) {
+            if ((nseq % kSyncEvery) == 0u) {
+                const uint32_t slot = nseq / kSyncEvery;
+                if (slot < sync_cap) sync[slot] = make_uint2(ip, op);
+            }
+        }
+        nseq += 1;
+        const uint32_t t4 = ld_le_tail(in, ip, iend);
+        const uint32_t token = t4 & 0xffu;
+        ip += 1;
+        uint64_t lit = token >> 4;
+        if (lit == 15u) {
+            if (ip + 15u >= iend) return CJ_E_CORRUPT;
+            uint32_t b = (t4 >> 8) & 0xffu;
+            ip += 1; lit += b;
+            if (ip + 15u > iend) return CJ_E_CORRUPT;
+            while (b == 255u) {
+                b = in[ip];
+                ip += 1; lit += b;
+                if (ip + 15u > iend) return CJ_E_CORRUPT;
+            }
+        }
+        const uint32_t rem_out = cap - op, rem_in = iend - ip;
+        if ((uint64_t)rem_out < lit + 12u || (uint64_t)rem_in < lit + 8u) {
+            if ((uint64_t)rem_in != lit || (uint64_t)rem_out < lit) return CJ_E_CORRUPT;
+            if (kCopy) lane_copy(out + op, in + ip, (uint32_t)lit, (uint32_t)lit, (uint32_t)lit);   // exact tail
+            op += (uint32_t)lit;
+            break;
+        }
+        if (kCopy) lane_copy(out + op, in + ip, (uint32_t)lit, rem_out, rem_in);
+        ip += (uint32_t)lit; op += (uint32_t)lit;
+
+        const uint32_t o4 = ld_le_tail(in, ip, iend);       // >= 8 input bytes remain here
+        const uint32_t offset = o4 & 0xffffu;
+        ip += 2;
+        uint64_t mlen = token & 15u;
+        if (mlen == 15u) {
+            uint32_t b = (o4 >> 16) & 0xffu;
+            ip += 1; mlen += b;
+            if (ip + 4u > iend) return CJ_E_CORRUPT;
+            while (b == 255u) {
+                b = in[ip];
+                ip += 1; mlen += b;
+                if (ip + 4u > iend) return CJ_E_CORRUPT;
+            }
+        }
+        mlen += 4u;
+        if (offset == 0u || offset > op) return CJ_E_CORRUPT;
+        if ((uint64_t)(cap - op) < mlen + 5u) return CJ_E_CORRUPT;
+        if (kCopy) lane_match(out + op, offset, (uint32_t)mlen, cap - op);
+        op += (uint32_t)mlen;
+    }
+    if (nseq_out) *nseq_out = nseq;
+    return (int64_t)op;
+}
+
+// shared prologue: size-prefix / capacity rules (lz4 crate decompress_to_buffer). Returns 0 or CJ_E_*;
+// on success in/n/cap describe the raw block.
+__device__ __forceinline__ int64_t lz4_block_prologue(uint32_t flags, const uint8_t*& in, uint64_t& n64, uint64_t& cap64) {
+    if (flags & CJ_FLAG_LZ4_SIZE_PREFIX) {
+        if (n64 < 4) return CJ_E_NO_PREFIX;
+        int32_t size = (int32_t)ld32u(in);
+        if (size < 0) return CJ_E_NEG_PREFIX;
+        if ((uint32_t)size > 0x7E000000u) return CJ_E_PREFIX_TOO_BIG;
+        if ((uint64_t)size > cap64) return CJ_E_OUT_TOO_SMALL;
+        in += 4; n64 -= 4; cap64 = (uint64_t)size;
+    } else {
+        int32_t size = (int32_t)(uint32_t)cap64;
+        if (cap64 > 0xFFFFFFFFull || size < 0) return CJ_E_NEG_PREFIX;
+        if ((uint32_t)size > 0x7E000000u) return CJ_E_PREFIX_TOO_BIG;
+    }
+    if (n64 > 0x7FFFFFF0ull) return CJ_E_CORRUPT;
+    return 0;
+}
+
+#endif
+}  // namespace cj

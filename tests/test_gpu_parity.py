@@ -24,7 +24,8 @@ def eng():
 
 
 # both chunk->hardware mappings of the LZ4 decoder must give identical results
-MAPPINGS = [pytest.param(N.FLAG_FORCE_WAVE_PER_CHUNK, id="wave-per-chunk"), pytest.param(N.FLAG_FORCE_LANE_PER_CHUNK, id="lane-per-chunk")]
+MAPPINGS = [pytest.param(N.FLAG_FORCE_WAVE_PER_CHUNK, id="wave-per-chunk"), pytest.param(N.FLAG_FORCE_LANE_PER_CHUNK, id="lane-per-chunk"),
+            pytest.param(N.FLAG_FORCE_LDS_PER_CHUNK, id="parse+lds-workgroup")]
 
 
 def test_device_present():

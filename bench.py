@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--compressor", default="auto", choices=["auto", "liblz4", "gpu"])
+    ap.add_argument("--lz4-mode", default="auto", choices=["auto", "wave", "lane", "lds"],
+                    help="LZ4 decoder mapping override (results identical; auto = engine default)")
     return ap.parse_args()
 
 
@@ -154,7 +156,9 @@ def main():
         bytes_in = NCH * S; bytes_out = None
     meta = torch.from_numpy(np.concatenate([in_off, in_len, out_off, out_cap, np.zeros(NCH, np.uint64)]).view(np.int64)).to(dev)
     mp = meta.data_ptr()
-    a = (codec, N.OP_DECOMPRESS if dec else N.OP_COMPRESS, 0, NCH, in_ptr, mp, mp + 8 * NCH, out.data_ptr(), mp + 16 * NCH,
+    mode_flag = {"auto": 0, "wave": N.FLAG_FORCE_WAVE_PER_CHUNK, "lane": N.FLAG_FORCE_LANE_PER_CHUNK,
+                 "lds": N.FLAG_FORCE_LDS_PER_CHUNK}[args.lz4_mode]
+    a = (codec, N.OP_DECOMPRESS if dec else N.OP_COMPRESS, mode_flag, NCH, in_ptr, mp, mp + 8 * NCH, out.data_ptr(), mp + 16 * NCH,
          mp + 24 * NCH, mp + 32 * NCH)
     torch.cuda.synchronize()
 
@@ -213,7 +217,8 @@ def main():
                        "verified": "all results + all output bytes compared on device"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": None,
-                         "kernel": "lz4_decode_kernel" if (dec and args.codec == "lz4") else "%s_%s_kernel" % (args.codec, "decode" if dec else "encode"),
+                         "kernel": {"auto": "lz4_parse_kernel+lz4_decode_lds_kernel", "lds": "lz4_parse_kernel+lz4_decode_lds_kernel", "wave": "lz4_decode_kernel",
+                                    "lane": "lz4_decode_lanes_kernel"}[args.lz4_mode] if (dec and args.codec == "lz4") else "%s_%s_kernel" % (args.codec, "decode" if dec else "encode"),
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo},
             "cpu_baseline": cpu,
         }

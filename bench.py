@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--compressor", default="auto", choices=["auto", "liblz4", "gpu"])
+    ap.add_argument("--phase-profile", action="store_true", help="debug: per-phase cycle counters of the LDS decoder")
     ap.add_argument("--lz4-mode", default="auto", choices=["auto", "wave", "lane", "lds"],
                     help="LZ4 decoder mapping override (results identical; auto = engine default)")
     return ap.parse_args()
@@ -157,7 +158,7 @@ def main():
     meta = torch.from_numpy(np.concatenate([in_off, in_len, out_off, out_cap, np.zeros(NCH, np.uint64)]).view(np.int64)).to(dev)
     mp = meta.data_ptr()
     mode_flag = {"auto": 0, "wave": N.FLAG_FORCE_WAVE_PER_CHUNK, "lane": N.FLAG_FORCE_LANE_PER_CHUNK,
-                 "lds": N.FLAG_FORCE_LDS_PER_CHUNK}[args.lz4_mode]
+                 "lds": N.FLAG_FORCE_LDS_PER_CHUNK}[args.lz4_mode] | (0x1000 if args.phase_profile else 0)
     a = (codec, N.OP_DECOMPRESS if dec else N.OP_COMPRESS, mode_flag, NCH, in_ptr, mp, mp + 8 * NCH, out.data_ptr(), mp + 16 * NCH,
          mp + 24 * NCH, mp + 32 * NCH)
     torch.cuda.synchronize()
@@ -176,6 +177,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
+
+    if args.phase_profile and rank == 0:
+        ph = (C.c_ulonglong * 8)()
+        L.cj_debug_lds_phase_cycles(ph, 1)
+        nb = max(int(ph[5]), 1)
+        print("LDS decoder cycles/chunk: S0 %d  D1 %d  D2 %d  D3 %d  D4 %d  (blocks %d)  D3 wave-iterations/chunk %d, ready lanes/iteration %.1f" % (ph[0] // nb, ph[1] // nb, ph[2] // nb, ph[3] // nb, ph[4] // nb, nb, ph[6] // nb, ph[7] / max(ph[6], 1)), file=sys.stderr)
 
     # ---- verify at full size: every chunk's result and every output byte ----
     res = meta[4 * NCH:].cpu().numpy()

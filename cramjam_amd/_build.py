@@ -11,7 +11,7 @@ LIB = os.path.join(HERE, "libcramjam_hip.so")
 SOURCES = ["engine.hip", "lz4_decode.hip", "lz4_decode_lanes.hip", "lz4_decode_lds.hip", "lz4_encode.hip", "snappy_decode.hip", "snappy_encode.hip", "bench_util.hip"]
 HEADERS = ["cj_common.hpp", "cj_match.hpp", "lz4_lane_walk.hpp", os.path.join("..", "..", "include", "cramjam_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + os.environ.get("CJ_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _newer(target, deps):

@@ -47,6 +47,7 @@ SYMBOLS = {
 # benchmark/test utilities exported next to the engine (cramjam_amd/csrc/bench_util.hip); not part of the drop-in ABI
 BENCH_SYMBOLS = {
     "cj_bench_synth_v1": (_int, [_vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _vp]),
+    "cj_debug_lds_phase_cycles": (_int, [_vp, _int]),
     "cj_bench_compare": (_int, [_vp, _vp, _vp, C.c_uint64, _u32, C.c_uint64, _u32, _vp, _vp]),
 }
 

@@ -27,14 +27,139 @@ constexpr uint32_t kOffOut = 0;
 constexpr uint32_t kOffBits = 65536;                 // 2048 x u32: one ready bit per output byte
 constexpr uint32_t kOffIn = kOffBits + 8192;         // compressed bytes, then the record table
 constexpr uint32_t kLdsBytes = 163840;               // all 160 KiB, one dynamic region (no static LDS: keeps the base 16 B aligned)
-constexpr uint32_t kOffVars = kLdsBytes - 16;        // [0] = spin-limit failure flag
+constexpr uint32_t kOffVars = kLdsBytes - 384;       // [0] fail flag, [4] work counter, [64,128) dummy bytes, [128,384) dummy dwords
 constexpr uint32_t kInTableBytes = kOffVars - kOffIn;
-constexpr uint32_t kShortMax = 64;                   // copies up to this length are done by one lane
+constexpr uint32_t kLongRun = 512;                   // runs at least this long are copied by the whole wavefront
 constexpr uint32_t kSpinLimit = 1u << 18;
 
-// record: x = literal source index in s_in, y = literal length, z = match destination (= op after literals),
-//         w = offset | match length << 16  (match length 0 on the final, literal-only sequence)
+// record: x = literal source (LDS byte offset inside s_in), y = literal length, z = match destination
+//         (= op after literals), w = offset | match length << 16 (0 on the final, literal-only sequence)
 
+// ---- unaligned LDS accessors ------------------------------------------------------------------
+// gfx950 executes ds_read_b32/ds_write_b32 at any byte alignment (tools/lds_unaligned_probe.hip:
+// bit-exact, ~140 vs ~80 cycles dependent latency).  hipcc will not emit them for align-1 LDS accesses
+// (it splits into bytes), hence inline asm.  Every read carries its own s_waitcnt, so no result is
+// consumed early; writes need no wait (DS ops of one wave execute in order).  Addresses are LDS byte
+// offsets (low 32 bits of the flat address of a __shared__ object).
+__device__ __forceinline__ uint32_t lds_ld32(uint32_t a) {
+    uint32_t v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+    return v;
+}
+__device__ __forceinline__ uint2 lds_ld64(uint32_t a) {
+    uint2 v;
+    asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:4\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v.x), "=&v"(v.y) : "v"(a) : "memory");
+    return v;
+}
+__device__ __forceinline__ uint4 lds_ld128(uint32_t a) {
+    uint4 v;
+    asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:4\n\tds_read_b32 %2, %4 offset:8\n\t"
+                 "ds_read_b32 %3, %4 offset:12\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v.x), "=&v"(v.y), "=&v"(v.z), "=&v"(v.w) : "v"(a) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_st32(uint32_t a, uint32_t v) {
+    asm volatile("ds_write_b32 %0, %1" :: "v"(a), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_st64(uint32_t a, uint2 v) {
+    asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:4" :: "v"(a), "v"(v.x), "v"(v.y) : "memory");
+}
+__device__ __forceinline__ void lds_st128(uint32_t a, uint4 v) {
+    asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:4\n\tds_write_b32 %0, %3 offset:8\n\t"
+                 "ds_write_b32 %0, %4 offset:12" :: "v"(a), "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_ld8(uint32_t a) {
+    uint32_t v;
+    asm volatile("ds_read_u8 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_st8(uint32_t a, uint32_t v) {
+    asm volatile("ds_write_b8 %0, %1" :: "v"(a), "v"(v) : "memory");
+}
+
+// ---- single-wait tiered copy --------------------------------------------------------------------
+// A misaligned DS access is replayed lane by lane (~64 LDS cycles per wave-instruction, measured), and
+// every scattered DS wave-instruction costs ~8 cycles of the CU's LDS pipe, so the copies are built to
+// need FEW instructions: aligned dword reads only (over-reading is harmless) + v_alignbyte to undo the
+// source misalignment, ONE s_waitcnt per batch, and writes as <=3 head bytes + aligned dwords + <=3 tail
+// bytes.  Writes must be exact: a lane whose element is past its length writes to a private dummy
+// slot instead of being masked off (no exec-mask churn).  T = tier (max bytes per lane), wave-uniform.
+template <int ND> struct DW { uint32_t w[ND]; };
+
+__device__ __forceinline__ DW<6> lds_ld_aligned6(uint32_t a) {
+    DW<6> r;
+    asm volatile("ds_read_b32 %0, %6\n\tds_read_b32 %1, %6 offset:4\n\tds_read_b32 %2, %6 offset:8\n\tds_read_b32 %3, %6 offset:12\n\tds_read_b32 %4, %6 offset:16\n\tds_read_b32 %5, %6 offset:20\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(r.w[0]), "=&v"(r.w[1]), "=&v"(r.w[2]), "=&v"(r.w[3]), "=&v"(r.w[4]), "=&v"(r.w[5]) : "v"(a) : "memory");
+    return r;
+}
+__device__ __forceinline__ DW<10> lds_ld_aligned10(uint32_t a) {
+    DW<10> r;
+    asm volatile("ds_read_b32 %0, %10\n\tds_read_b32 %1, %10 offset:4\n\tds_read_b32 %2, %10 offset:8\n\tds_read_b32 %3, %10 offset:12\n\tds_read_b32 %4, %10 offset:16\n\tds_read_b32 %5, %10 offset:20\n\tds_read_b32 %6, %10 offset:24\n\tds_read_b32 %7, %10 offset:28\n\tds_read_b32 %8, %10 offset:32\n\tds_read_b32 %9, %10 offset:36\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(r.w[0]), "=&v"(r.w[1]), "=&v"(r.w[2]), "=&v"(r.w[3]), "=&v"(r.w[4]), "=&v"(r.w[5]), "=&v"(r.w[6]), "=&v"(r.w[7]), "=&v"(r.w[8]), "=&v"(r.w[9]) : "v"(a) : "memory");
+    return r;
+}
+__device__ __forceinline__ DW<18> lds_ld_aligned18(uint32_t a) {
+    DW<18> r;
+    asm volatile("ds_read_b32 %0, %18\n\tds_read_b32 %1, %18 offset:4\n\tds_read_b32 %2, %18 offset:8\n\tds_read_b32 %3, %18 offset:12\n\tds_read_b32 %4, %18 offset:16\n\tds_read_b32 %5, %18 offset:20\n\tds_read_b32 %6, %18 offset:24\n\tds_read_b32 %7, %18 offset:28\n\tds_read_b32 %8, %18 offset:32\n\tds_read_b32 %9, %18 offset:36\n\tds_read_b32 %10, %18 offset:40\n\tds_read_b32 %11, %18 offset:44\n\tds_read_b32 %12, %18 offset:48\n\tds_read_b32 %13, %18 offset:52\n\tds_read_b32 %14, %18 offset:56\n\tds_read_b32 %15, %18 offset:60\n\tds_read_b32 %16, %18 offset:64\n\tds_read_b32 %17, %18 offset:68\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(r.w[0]), "=&v"(r.w[1]), "=&v"(r.w[2]), "=&v"(r.w[3]), "=&v"(r.w[4]), "=&v"(r.w[5]), "=&v"(r.w[6]), "=&v"(r.w[7]), "=&v"(r.w[8]), "=&v"(r.w[9]), "=&v"(r.w[10]), "=&v"(r.w[11]), "=&v"(r.w[12]), "=&v"(r.w[13]), "=&v"(r.w[14]), "=&v"(r.w[15]), "=&v"(r.w[16]), "=&v"(r.w[17]) : "v"(a) : "memory");
+    return r;
+}
+// 10 aligned source dwords AND the two ready-bitmap words covering the source, one wait for all
+__device__ __forceinline__ DW<10> lds_ld_aligned10_poll(uint32_t a, uint32_t bits_addr, uint2& bm) {
+    DW<10> r;
+    asm volatile("ds_read_b32 %10, %13\n\tds_read_b32 %11, %13 offset:4\n\tds_read_b32 %0, %12\n\tds_read_b32 %1, %12 offset:4\n\tds_read_b32 %2, %12 offset:8\n\tds_read_b32 %3, %12 offset:12\n\tds_read_b32 %4, %12 offset:16\n\tds_read_b32 %5, %12 offset:20\n\tds_read_b32 %6, %12 offset:24\n\tds_read_b32 %7, %12 offset:28\n\tds_read_b32 %8, %12 offset:32\n\tds_read_b32 %9, %12 offset:36\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(r.w[0]), "=&v"(r.w[1]), "=&v"(r.w[2]), "=&v"(r.w[3]), "=&v"(r.w[4]), "=&v"(r.w[5]), "=&v"(r.w[6]), "=&v"(r.w[7]), "=&v"(r.w[8]), "=&v"(r.w[9]), "=&v"(bm.x), "=&v"(bm.y) : "v"(a), "v"(bits_addr) : "memory");
+    return r;
+}
+
+struct Dummies { uint32_t b, w; };     // per-lane dummy byte address / aligned dummy dword address
+
+template <int T, class Loaded>
+__device__ __forceinline__ void lds_store_tier(const Loaded& r, uint32_t dst, uint32_t sh_bytes, uint32_t n, Dummies dm) {
+    constexpr int NV = T / 4 + 1;
+    uint32_t v[NV];                                    // v[i] = source bytes 4i .. 4i+3
+#pragma unroll
+    for (int i = 0; i < NV; i++) v[i] = __builtin_amdgcn_alignbyte(r.w[i + 1], r.w[i], sh_bytes);
+    const uint32_t h = (0u - dst) & 3u;               // bytes until dst is dword aligned
+    const uint32_t hh = h < n ? h : n;
+    const uint32_t nm = (n - hh) >> 2, t = (n - hh) & 3u;
+#pragma unroll
+    for (int q = 0; q < 3; q++) lds_st8((uint32_t)q < hh ? dst + q : dm.b, v[0] >> (8 * q));
+    uint32_t tv = 0;
+#pragma unroll
+    for (int i = 0; i < T / 4; i++) {
+        const uint32_t mi = __builtin_amdgcn_alignbyte(v[i + 1], v[i], h);     // bytes h+4i .. h+4i+3
+        lds_st32((uint32_t)i < nm ? dst + h + 4u * i : dm.w, mi);
+        tv = (uint32_t)i == nm ? mi : tv;
+    }
+    const uint32_t tpos = dst + hh + 4u * nm;
+#pragma unroll
+    for (int q = 0; q < 3; q++) lds_st8((uint32_t)q < t ? tpos + q : dm.b, tv >> (8 * q));
+}
+
+// copy n (<= tier, tier in {16,32,64} wave-uniform) bytes src -> dst, both LDS byte addresses; [src, src+n) is
+// final and does not overlap [dst, dst+n)
+__device__ __forceinline__ void lds_copy_tier(uint32_t tier, uint32_t dst, uint32_t src, uint32_t n, Dummies dm) {
+    const uint32_t sa = src & ~3u, sh = src & 3u;
+    if (tier <= 16u) lds_store_tier<16>(lds_ld_aligned6(sa), dst, sh, n, dm);
+    else if (tier <= 32u) lds_store_tier<32>(lds_ld_aligned10(sa), dst, sh, n, dm);
+    else lds_store_tier<64>(lds_ld_aligned18(sa), dst, sh, n, dm);
+}
+
+__device__ __forceinline__ uint32_t wave_tier(uint32_t n, bool active) {       // wave-uniform tier for the active lanes
+    if (ballot64(active && n > 32u)) return 64u;
+    if (ballot64(active && n > 16u)) return 32u;
+    return 16u;
+}
+
+// overlapping LZ77 copy (off < m) for one lane, in order, byte by byte (rare for short matches)
+__device__ __forceinline__ void lds_match_overlap(uint32_t dst, uint32_t off, uint32_t m) {
+    const uint32_t src = dst - off;
+    for (uint32_t k = 0; k < m; k++) lds_st8(dst + k, lds_ld8(src + k));
+}
+
+// ---- ready bitmap: one bit per output byte ---------------------------------------------------
 __device__ __forceinline__ void bits_set(uint32_t* bits, uint32_t lo, uint32_t hi) {     // [lo, hi), hi > lo
     uint32_t w0 = lo >> 5, w1 = (hi - 1u) >> 5;
     for (uint32_t w = w0; w <= w1; w++) {
@@ -46,6 +171,12 @@ __device__ __forceinline__ void bits_set(uint32_t* bits, uint32_t lo, uint32_t h
 }
 
 __device__ __forceinline__ bool bits_ready(uint32_t* bits, uint32_t lo, uint32_t hi) {   // [lo, hi), hi > lo
+    if (hi - lo <= 32u) {                 // the common case fits a 64-bit window: one double read
+        const uint2 v = lds_ld64((uint32_t)(uintptr_t)(bits + (lo >> 5)));     // may read one word past the bitmap: harmless
+        const uint64_t win = (((uint64_t)v.y << 32) | v.x) >> (lo & 31u);
+        const uint64_t m = ~0ull >> (64u - (hi - lo));
+        return (win & m) == m;
+    }
     uint32_t w0 = lo >> 5, w1 = (hi - 1u) >> 5;
     for (uint32_t w = w0; w <= w1; w++) {
         uint32_t m = ~0u;
@@ -57,7 +188,7 @@ __device__ __forceinline__ bool bits_ready(uint32_t* bits, uint32_t lo, uint32_t
     return true;
 }
 
-// whole-wave versions for long ranges (all lanes call with the same lo/hi)
+// whole-wave version for long ranges (all lanes call with the same lo/hi)
 __device__ __forceinline__ void wave_bits_set(uint32_t* bits, uint32_t lo, uint32_t hi) {
     const uint32_t w0 = lo >> 5, w1 = (hi - 1u) >> 5;
     for (uint32_t w = w0 + lane_id(); w <= w1; w += 64u) {
@@ -68,11 +199,26 @@ __device__ __forceinline__ void wave_bits_set(uint32_t* bits, uint32_t lo, uint3
     }
 }
 
+// phase cycle counters (debug aid, enabled by CJ_FLAG_DEBUG_PROFILE): S0, D1, D2, D3, D4, blocks
+__device__ unsigned long long g_lds_phase_cycles[8];
+#define CJ_PHASE_MARK(idx)                                                              \
+    do {                                                                                \
+        if (prof && tid == 0) {                                                         \
+            unsigned long long now_ = __builtin_readcyclecounter();                     \
+            atomicAdd(&g_lds_phase_cycles[idx], now_ - t_prev);                         \
+            t_prev = now_;                                                              \
+        }                                                                               \
+    } while (0)
+
 __global__ __launch_bounds__(kLdsThreads) void lz4_decode_lds_kernel(BatchArgs a, const uint2* sync, const ParseMeta* meta) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* s_out = smem + kOffOut;
     uint32_t* s_bits = reinterpret_cast<uint32_t*>(smem + kOffBits);
     uint8_t* s_in = smem + kOffIn;
+
+    const uint32_t a_out = (uint32_t)(uintptr_t)s_out, a_in = (uint32_t)(uintptr_t)s_in;   // LDS byte offsets
+    const Dummies dm = {(uint32_t)(uintptr_t)(smem + kOffVars + 64u) + (threadIdx.x & 63u),
+                        (uint32_t)(uintptr_t)(smem + kOffVars + 128u) + 4u * (threadIdx.x & 63u)};
 
     const uint32_t c = blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -83,6 +229,9 @@ __global__ __launch_bounds__(kLdsThreads) void lz4_decode_lds_kernel(BatchArgs a
     const uint8_t* in = a.in_base + a.in_off[c] + pm.in_skip;
     const uint32_t iend = (uint32_t)a.in_len[c] - pm.in_skip;
     uint8_t* out = a.out_base + a.out_off[c];
+
+    const bool prof = (a.flags & 0x1000u) != 0;
+    unsigned long long t_prev = prof ? __builtin_readcyclecounter() : 0ull;
 
     // ---- S0: stage the compressed chunk (16 B aligned loads), clear the bitmap ----
     const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(in) & 15u);
@@ -100,8 +249,10 @@ __global__ __launch_bounds__(kLdsThreads) void lz4_decode_lds_kernel(BatchArgs a
     const uint32_t nsp = (nseq + kSyncEvery - 1u) / kSyncEvery;
     const uint2* csync = sync + (size_t)c * kSyncStride;
     uint32_t* s_fail = reinterpret_cast<uint32_t*>(smem + kOffVars);
-    if (tid == 0) *s_fail = 0u;
+    uint32_t* s_next = reinterpret_cast<uint32_t*>(smem + kOffVars + 4u);   // next unclaimed record of the current slab
+    if (tid == 0) { *s_fail = 0u; s_next[1] = 0u; s_next[2] = 0u; }
     __syncthreads();
+    CJ_PHASE_MARK(0);
 
     for (uint32_t sp0 = 0; sp0 < nsp; sp0 += sp_per_slab) {
         const uint32_t sp1 = min(nsp, sp0 + sp_per_slab);
@@ -114,18 +265,29 @@ __global__ __launch_bounds__(kLdsThreads) void lz4_decode_lds_kernel(BatchArgs a
             uint32_t ip = p.x + mis, op = p.y;
             uint32_t s = sp * kSyncEvery;
             for (uint32_t j = 0; j < kSyncEvery && s < nseq; j++, s++) {
-                const uint32_t token = s_in[ip++];
+                const uint32_t t4 = lds_ld32(a_in + ip);           // token + 3 following bytes (may over-read: harmless)
+                const uint32_t token = t4 & 0xffu;
+                ip += 1;
                 uint32_t lit = token >> 4;
-                if (lit == 15u) { uint32_t b; do { b = s_in[ip++]; lit += b; } while (b == 255u); }
+                if (lit == 15u) {
+                    uint32_t b = (t4 >> 8) & 0xffu;
+                    ip += 1; lit += b;
+                    while (b == 255u) { b = lds_ld8(a_in + ip); ip += 1; lit += b; }
+                }
                 const uint32_t lit_src = ip;
                 ip += lit; op += lit;
                 uint32_t w = 0;
                 uint32_t mlen = 0;
                 if (s + 1u < nseq) {
-                    const uint32_t offset = (uint32_t)s_in[ip] | ((uint32_t)s_in[ip + 1] << 8);
+                    const uint32_t o4 = lds_ld32(a_in + ip);
+                    const uint32_t offset = o4 & 0xffffu;
                     ip += 2;
                     mlen = token & 15u;
-                    if (mlen == 15u) { uint32_t b; do { b = s_in[ip++]; mlen += b; } while (b == 255u); }
+                    if (mlen == 15u) {
+                        uint32_t b = (o4 >> 16) & 0xffu;
+                        ip += 1; mlen += b;
+                        while (b == 255u) { b = lds_ld8(a_in + ip); ip += 1; mlen += b; }
+                    }
                     mlen += 4u;
                     w = offset | (mlen << 16);
                 }
@@ -133,38 +295,45 @@ __global__ __launch_bounds__(kLdsThreads) void lz4_decode_lds_kernel(BatchArgs a
                 op += mlen;
             }
         }
+        if (tid == 0) *s_next = 0u;
         __syncthreads();
+        CJ_PHASE_MARK(1);
 
-        // ---- D2: literals, one lane per sequence ----
+        // ---- D2: literals, one lane per sequence, dependency-free and dense ----
         for (uint32_t base = wave * 64u; base < nrec; base += kLdsThreads) {
             const uint32_t r = base + lane;
             uint4 rec = make_uint4(0, 0, 0, 0);
             if (r < nrec) rec = table[r];
-            const uint32_t n = rec.y, src = rec.x, dst = rec.z - rec.y;
-            if (n > 0u && n <= kShortMax) {
-                uint32_t k = 0;
-                for (; k + 8u <= n; k += 8u) {
-                    uint8_t t[8];
-#pragma unroll
-                    for (int q = 0; q < 8; q++) t[q] = s_in[src + k + q];
-#pragma unroll
-                    for (int q = 0; q < 8; q++) s_out[dst + k + q] = t[q];
-                }
-                for (; k < n; k++) s_out[dst + k] = s_in[src + k];
-                bits_set(s_bits, dst, dst + n);
-            }
-            uint64_t longm = ballot64(n > kShortMax);
-            while (longm) {
-                const uint32_t l = ctz64(longm);
-                longm &= longm - 1u;
+            uint32_t n = rec.y, src = a_in + rec.x, dst = rec.z - rec.y;
+            // very long runs (incompressible data) are copied by the whole wavefront
+            uint64_t lm = ballot64(n >= kLongRun);
+            while (lm) {
+                const uint32_t l = ctz64(lm);
+                lm &= lm - 1ull;
                 const uint32_t ln = rdlane(n, l), ls = rdlane(src, l), ld = rdlane(dst, l);
-                for (uint32_t k = lane; k < ln; k += 64u) s_out[ld + k] = s_in[ls + k];
+                for (uint32_t k = lane; k < ln; k += 64u) lds_st8(a_out + ld + k, lds_ld8(ls + k));
                 wave_bits_set(s_bits, ld, ld + ln);
+                if (lane == l) n = 0;
+            }
+            while (ballot64(n > 0u)) {                         // <=64 bytes per pass
+                const uint32_t step = n < 64u ? n : 64u;
+                const uint32_t tier = wave_tier(step, step > 0u);
+                if (step > 0u) {
+                    lds_copy_tier(tier, a_out + dst, src, step, dm);
+                    bits_set(s_bits, dst, dst + step);
+                    n -= step; src += step; dst += step;
+                }
             }
         }
         __syncthreads();
+        CJ_PHASE_MARK(2);
 
-        // ---- D3: matches, one lane per sequence, dependency-exact through the ready bitmap ----
+        // ---- D3: matches, one lane per sequence, dependency-exact through the ready bitmap.  Waves take batches of 64
+        //      consecutive sequences round-robin; a lane copies its match as soon as the bitmap says its source bytes
+        //      are final.  The earliest unresolved match is always ready, so the spin is deadlock-free (and bounded).
+        //      (Measured alternatives, all slower on the 24-B-per-sequence benchmark data — the dependency DAG is ~25
+        //      levels deep and only ~4 of 64 lanes are ready per poll: refill from a work counter, fewer resolver waves,
+        //      tiered dword copies with a single wait, two-matches-per-pass cooperative copies.  See DESIGN.md §5.)
         for (uint32_t base = wave * 64u; base < nrec; base += kLdsThreads) {
             const uint32_t r = base + lane;
             uint4 rec = make_uint4(0, 0, 0, 0);
@@ -173,11 +342,12 @@ __global__ __launch_bounds__(kLdsThreads) void lz4_decode_lds_kernel(BatchArgs a
             const uint32_t src = dst - off;
             const uint32_t need = off < m ? off : m;          // distinct source bytes
             bool pending = m > 0u;
-            uint32_t spins = 0;
+            uint32_t spins = 0, dbg_iters = 0, dbg_ready = 0;
             while (ballot64(pending) != 0ull) {
                 bool ready = false;
                 if (pending) ready = bits_ready(s_bits, src, src + need);
-                if (ready && m <= kShortMax) {
+                if (prof) { dbg_iters += 1u; dbg_ready += (uint32_t)__builtin_popcountll(ballot64(ready)); }
+                if (ready && m < kLongRun) {
                     if (off >= 8u) {
                         uint32_t k = 0;
                         for (; k + 8u <= m; k += 8u) {
@@ -194,16 +364,15 @@ __global__ __launch_bounds__(kLdsThreads) void lz4_decode_lds_kernel(BatchArgs a
                     bits_set(s_bits, dst, dst + m);
                     pending = false;
                 }
-                uint64_t longm = ballot64(ready && m > kShortMax);
+                uint64_t longm = ballot64(ready && m >= kLongRun);     // RLE-like: whole wavefront, 64 bytes per step
                 while (longm) {
                     const uint32_t l = ctz64(longm);
-                    longm &= longm - 1u;
+                    longm &= longm - 1ull;
                     const uint32_t lm = rdlane(m, l), lo = rdlane(off, l), ld = rdlane(dst, l);
                     const uint32_t ls = ld - lo;
-                    // periodic pattern read: every byte comes from the lo bytes before ld (already final)
                     uint32_t rr = lane, step = 64u;
                     if (lo <= 64u) { rr = lane % lo; step = 64u % lo; }
-                    for (uint32_t k = lane; k < lm; k += 64u) {
+                    for (uint32_t k = lane; k < lm; k += 64u) {           // periodic read: sources are the lo bytes before ld
                         s_out[ld + k] = s_out[ls + (lo >= lm ? k : rr)];
                         rr += step;
                         if (rr >= lo) rr -= lo;
@@ -213,8 +382,10 @@ __global__ __launch_bounds__(kLdsThreads) void lz4_decode_lds_kernel(BatchArgs a
                 }
                 if (++spins > kSpinLimit) { *s_fail = 1u; break; }
             }
+            if (prof && lane == 0) { atomicAdd(s_next + 1, dbg_iters); atomicAdd(s_next + 2, dbg_ready); }
         }
         __syncthreads();
+        CJ_PHASE_MARK(3);
     }
 
     // ---- D4: stream the window out (16 B per lane), exact tail ----
@@ -223,6 +394,13 @@ __global__ __launch_bounds__(kLdsThreads) void lz4_decode_lds_kernel(BatchArgs a
         const uint4* src = reinterpret_cast<const uint4*>(s_out);
         for (uint32_t i = tid; i < nvec; i += kLdsThreads) st16u(out + 16u * i, src[i]);
         for (uint32_t i = (nvec << 4) + tid; i < U; i += kLdsThreads) out[i] = s_out[i];
+    }
+    __syncthreads();
+    CJ_PHASE_MARK(4);
+    if (prof && tid == 0) {
+        atomicAdd(&g_lds_phase_cycles[5], 1ull);
+        atomicAdd(&g_lds_phase_cycles[6], (unsigned long long)s_next[1]);
+        atomicAdd(&g_lds_phase_cycles[7], (unsigned long long)s_next[2]);
     }
     if (tid == 0 && *s_fail) a.result[c] = CJ_E_CORRUPT;    // cannot happen for a stream the parse kernel accepted
 }
@@ -235,6 +413,13 @@ void launch_lz4_decode_lds(const BatchArgs& a, const void* sync, const void* met
                        (const uint2*)sync, (const ParseMeta*)meta);
 }
 
+}  // namespace cj
+extern "C" int cj_debug_lds_phase_cycles(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(cj::g_lds_phase_cycles), 64) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(cj::g_lds_phase_cycles), z, 64) != hipSuccess) return -1; }
+    return 0;
+}
+namespace cj {
 size_t lz4_lds_scratch_sync_bytes(size_t n_chunks) { return n_chunks * (size_t)kSyncStride * sizeof(uint2); }
 size_t lz4_lds_scratch_meta_bytes(size_t n_chunks) { return n_chunks * sizeof(ParseMeta); }
 

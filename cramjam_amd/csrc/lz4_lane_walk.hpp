@@ -99,38 +99,6 @@ __device__ __forceinline__ int64_t lz4_lane_walk(const uint8_t* in, uint32_t ien
             }
         }
         nseq += 1;
-        if (!kCopy) {
-            // Fast path of the parse-only walk: when >= 24 input bytes remain, ONE 16 B load holds the token, a
-            // literal-length byte, up to 11 literals, the offset and a match-length byte; sequences that do not fit
-            // (longer literal runs, 255-continuations, the block's tail) fall through to the general code below.
-            if (ip + 24u <= iend) {
-                const uint4 q = ld16u(in + ip);
-                const uint32_t token = q.x & 0xffu;
-                uint32_t lit = token >> 4, hdr = 1u;
-                bool ok = true;
-                if (lit == 15u) { const uint32_t b = (q.x >> 8) & 0xffu; lit += b; hdr = 2u; ok = b != 255u; }
-                const uint32_t po = hdr + lit;                      // offset position inside q
-                if (ok && po + 3u <= 16u) {
-                    // bytes po, po+1 (offset) and po+2 (possible match-length byte) out of the 128-bit value
-                    const uint32_t wi = po >> 2, sh = (po & 3u) * 8u;
-                    const uint32_t w0 = wi == 0u ? q.x : wi == 1u ? q.y : wi == 2u ? q.z : q.w;
-                    const uint32_t w1 = wi == 0u ? q.y : wi == 1u ? q.z : wi == 2u ? q.w : 0u;
-                    const uint32_t o3 = (uint32_t)((((uint64_t)w1 << 32) | w0) >> sh);
-                    const uint32_t offset = o3 & 0xffffu;
-                    uint32_t mlen = token & 15u, adv = po + 2u;
-                    if (mlen == 15u) { const uint32_t b = (o3 >> 16) & 0xffu; mlen += b; adv += 1u; ok = b != 255u; }
-                    mlen += 4u;
-                    // same checks as the general path (the input-side ones hold because >= 24 bytes remain)
-                    if (ok && (uint64_t)(cap - op) >= (uint64_t)lit + 12u) {
-                        const uint32_t op2 = op + lit;
-                        if (offset == 0u || offset > op2) return CJ_E_CORRUPT;
-                        if ((uint64_t)(cap - op2) < (uint64_t)mlen + 5u) return CJ_E_CORRUPT;
-                        ip += adv; op = op2 + mlen;
-                        continue;
-                    }
-                }
-            }
-        }
         const uint32_t t4 = ld_le_tail(in, ip, iend);
         const uint32_t token = t4 & 0xffu;
         ip += 1;

@@ -72,7 +72,8 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("CJ_FORCE_DIST") == "1"
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)
     L = N.lib()
     eng = N.Engine(local)
@@ -167,13 +168,13 @@ def main():
     if args.warmup > 0:
         eng.batch_device_timed(*a, args.warmup)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     kernel_ms = eng.batch_device_timed(*a, args.steps)       # K launches on the engine stream, HIP events around them
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
@@ -200,7 +201,7 @@ def main():
     unc_bytes = NCH * S
 
     from cramjam_amd.shard import aggregate
-    wall_max, total_unc = aggregate(dist if world > 1 else None, dev, wall, unc_bytes)
+    wall_max, total_unc = aggregate(dist if use_dist else None, dev, wall, unc_bytes)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and dec:
@@ -230,7 +231,7 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

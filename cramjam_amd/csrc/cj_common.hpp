@@ -28,6 +28,7 @@ void launch_lz4_decode_lanes(const BatchArgs& a, hipStream_t s);  // one lane pe
 // parse (lane per chunk) + decode (workgroup per chunk, LDS-resident window); sync/meta are engine scratch
 void launch_lz4_parse(const BatchArgs& a, void* sync, void* meta, hipStream_t s);
 void launch_lz4_decode_lds(const BatchArgs& a, const void* sync, const void* meta, hipStream_t s);
+void launch_lz4_decode_routed(const BatchArgs& a, const void* meta, hipStream_t s);   // wave kernel on chunks the parse kernel routed to it
 size_t lz4_lds_scratch_sync_bytes(size_t n_chunks);
 size_t lz4_lds_scratch_meta_bytes(size_t n_chunks);
 void launch_lz4_encode(const BatchArgs& a, hipStream_t s);

@@ -69,7 +69,7 @@ int launch(cj_engine* e, cj_codec codec, cj_op op, const cj::BatchArgs& a, hipSt
                 const char* v = std::getenv("CJ_LDS_MIN_CHUNKS");
                 return v ? (size_t)std::strtoull(v, nullptr, 10) : (size_t)CJ_LDS_MIN_CHUNKS;
             }();
-            int mode = a.n_chunks >= lds_min ? 2 : 0;          // 0 wave, 1 lane, 2 parse + LDS workgroup
+            int mode = a.n_chunks >= lds_min ? 2 : 0;          // 0 wave, 1 lane, 2 parse + {LDS workgroup | wave} per chunk
             if (a.flags & CJ_FLAG_FORCE_WAVE_PER_CHUNK) mode = 0;
             if (a.flags & CJ_FLAG_FORCE_LANE_PER_CHUNK) mode = 1;
             if (a.flags & CJ_FLAG_FORCE_LDS_PER_CHUNK) mode = 2;
@@ -84,8 +84,9 @@ int launch(cj_engine* e, cj_codec codec, cj_op op, const cj::BatchArgs& a, hipSt
                     !e->d_pmeta.reserve(cj::lz4_lds_scratch_meta_bytes(a.n_chunks))) return CJ_E_OOM;
                 if (!e->scratch_free) HIP_TRY(hipEventCreateWithFlags(&e->scratch_free, hipEventDisableTiming), CJ_E_NO_DEVICE);
                 else HIP_TRY(hipStreamWaitEvent(s, e->scratch_free, 0), CJ_E_NO_DEVICE);   // previous user of the scratch
-                cj::launch_lz4_parse(a, e->d_sync.p, e->d_pmeta.p, s);
-                cj::launch_lz4_decode_lds(a, e->d_sync.p, e->d_pmeta.p, s);
+                cj::launch_lz4_parse(a, e->d_sync.p, e->d_pmeta.p, s);           // validate, size, count, route
+                cj::launch_lz4_decode_lds(a, e->d_sync.p, e->d_pmeta.p, s);      // many short sequences
+                cj::launch_lz4_decode_routed(a, e->d_pmeta.p, s);                // few long runs / oversize chunks
                 HIP_TRY(hipEventRecord(e->scratch_free, s), CJ_E_NO_DEVICE);
             }
         } else cj::launch_lz4_encode(a, s);

@@ -8,13 +8,15 @@
 // Shape: the sequence grammar is parsed wave-uniformly on the scalar unit out of a 512-byte register
 // window (v_readlane), the vector lanes only move bytes: literals HBM->HBM, matches from the
 // chunk's own freshly written output (same-wave L1-coherent), byte per lane, 16 B/lane on long runs.
-#include "cj_common.hpp"
+#include "lz4_lane_walk.hpp"
 
 namespace cj {
 
-__global__ __launch_bounds__(kBlockThreads) void lz4_decode_kernel(BatchArgs a) {
+// route: nullptr = decode every chunk; else only chunks the parse kernel flagged kRouteWave
+__global__ __launch_bounds__(kBlockThreads) void lz4_decode_kernel(BatchArgs a, const ParseMeta* route) {
     const uint32_t chunk = uni(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
     if (chunk >= a.n_chunks) return;
+    if (route != nullptr && (route[chunk].in_skip & kRouteWave) == 0u) return;
     const uint8_t* in = a.in_base + a.in_off[chunk];
     uint64_t n64 = a.in_len[chunk];
     uint8_t* out = a.out_base + a.out_off[chunk];
@@ -117,7 +119,13 @@ __global__ __launch_bounds__(kBlockThreads) void lz4_decode_kernel(BatchArgs a) 
 void launch_lz4_decode(const BatchArgs& a, hipStream_t s) {
     if (a.n_chunks == 0) return;
     dim3 grid((a.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlockThreads);
-    hipLaunchKernelGGL(lz4_decode_kernel, grid, block, 0, s, a);
+    hipLaunchKernelGGL(lz4_decode_kernel, grid, block, 0, s, a, (const ParseMeta*)nullptr);
+}
+
+void launch_lz4_decode_routed(const BatchArgs& a, const void* meta, hipStream_t s) {
+    if (a.n_chunks == 0) return;
+    dim3 grid((a.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlockThreads);
+    hipLaunchKernelGGL(lz4_decode_kernel, grid, block, 0, s, a, (const ParseMeta*)meta);
 }
 
 }  // namespace cj

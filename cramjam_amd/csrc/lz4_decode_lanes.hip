@@ -44,12 +44,13 @@ __global__ __launch_bounds__(64) void lz4_parse_kernel(BatchArgs a, uint2* sync,
     int64_t r;
     if (cap == 0) r = (iend == 1 && in[0] == 0) ? 0 : (int64_t)CJ_E_CORRUPT;
     else if (iend == 0) r = CJ_E_CORRUPT;
-    else if (cap > kLdsOutMax || iend > kLdsInMax) r = lz4_lane_walk<true>(in, iend, out, cap, nullptr, 0, nullptr);
+    else if (cap > kLdsOutMax || iend > kLdsInMax) { r = 0; pm.in_skip = kRouteWave; }   // too big for LDS: wave-per-chunk kernel decodes and validates
     else {
         uint32_t nseq = 0;
         r = lz4_lane_walk<false>(in, iend, nullptr, cap, sync + (size_t)c * kSyncStride, kSyncStride, &nseq);
         if (r > 0) {
             if ((nseq + kSyncEvery - 1u) / kSyncEvery > kSyncStride) r = lz4_lane_walk<true>(in, iend, out, cap, nullptr, 0, nullptr);
+            else if (nseq < kLdsMinSeq) pm.in_skip = kRouteWave;            // few, long sequences: wave-per-chunk kernel
             else { pm.nseq = nseq; pm.in_skip = (uint32_t)(in - in0); }
         }
     }

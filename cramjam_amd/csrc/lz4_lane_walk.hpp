@@ -18,8 +18,13 @@ constexpr uint32_t kLdsInMax = 66560;     // ... and this much compressed input 
 
 struct ParseMeta {       // one per chunk, written by lz4_parse_kernel
     uint32_t nseq;       // sequences incl. the final literal-only one; 0 = nothing left for the LDS decoder
-    uint32_t in_skip;    // 4 when a size prefix was consumed
+    uint32_t in_skip;    // low bits: 4 when a size prefix was consumed; kRouteWave: decode with the wave-per-chunk kernel
 };
+constexpr uint32_t kRouteWave = 0x80000000u;
+// Routing (measured, tools/mode_sweep.py): chunks made of few long runs (RLE, incompressible data) decode at
+// 2.2-2.6 TB/s with the wave-per-chunk kernel (16 B/lane cooperative copies) but crawl through the LDS path;
+// chunks with many short sequences are ~2x faster through parse + LDS.  The parse kernel knows the count.
+constexpr uint32_t kLdsMinSeq = 256;
 
 __device__ __forceinline__ uint4 ld16u(const uint8_t* p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
 __device__ __forceinline__ void st16u(uint8_t* p, const uint4& v) { __builtin_memcpy(p, &v, 16); }

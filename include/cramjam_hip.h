@@ -100,13 +100,13 @@ typedef enum { CJ_OP_DECOMPRESS = 0, CJ_OP_COMPRESS = 1 } cj_op;
 /* flags */
 #define CJ_FLAG_LZ4_SIZE_PREFIX 1u   /* lz4: blocks carry / get the u32-LE length prefix (store_size) */
 /* LZ4-decode kernel-mapping overrides (tuning/testing; results are identical).  Default: batches of at
- * least CJ_LDS_MIN_CHUNKS chunks (env CJ_LDS_MIN_CHUNKS overrides) run the two-kernel path
- * "lane-per-chunk parse + workgroup-per-chunk decode with the 64 KiB window in LDS"; smaller batches map
- * one wavefront per chunk. */
+ * least CJ_LDS_MIN_CHUNKS chunks (env CJ_LDS_MIN_CHUNKS overrides) run "lane-per-chunk parse, then per chunk
+ * either the workgroup-per-chunk decoder with the 64 KiB window in LDS (many short sequences) or the
+ * wavefront-per-chunk decoder (few long runs)"; smaller batches map one wavefront per chunk directly. */
 #define CJ_FLAG_FORCE_WAVE_PER_CHUNK 0x100u
 #define CJ_FLAG_FORCE_LANE_PER_CHUNK 0x200u
 #define CJ_FLAG_FORCE_LDS_PER_CHUNK  0x400u
-#define CJ_LDS_MIN_CHUNKS 32
+#define CJ_LDS_MIN_CHUNKS 8192
 
 int  cj_engine_create(int device, cj_engine** out);
 void cj_engine_destroy(cj_engine* e);

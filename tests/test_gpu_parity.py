@@ -194,3 +194,43 @@ def test_device_batch_synth_roundtrip(eng, chunk, mapping):
             blob = out[int(off[i]):int(off[i]) + int(res[i])].tobytes()
             d = oracle.lz4_decompress_raw(blob, len(r)) if codec == LZ4 else oracle.snappy_decompress(blob)
             assert d == (len(r), r), (codec, i, res[i])
+
+
+def test_default_pipeline_mixed_large_batch(eng):
+    """>= CJ_LDS_MIN_CHUNKS chunks through the DEFAULT path: parse kernel routes every chunk to the LDS workgroup
+    decoder (many short sequences) or the wave decoder (few long runs, oversize, tiny); malformed chunks must
+    fail alone.  Every result and byte is compared with the oracle."""
+    import random
+    rnd = random.Random(11)
+    kinds = []
+    uniq = []
+    for i in range(48):
+        k = i % 8
+        if k == 0: raw = oracle.synth_v1(65536, i)
+        elif k == 1: raw = bytes(65536)
+        elif k == 2: raw = hashlib.shake_256(b"r%d" % i).digest(65536)
+        elif k == 3: raw = oracle.synth_v1(rnd.randrange(1, 65536), i)
+        elif k == 4: raw = (b"abcdefgh" * 9000)[:rnd.randrange(20, 65536)]
+        elif k == 5: raw = oracle.synth_v1(70000, i)                       # larger than the LDS window
+        elif k == 6: raw = oracle.synth_v1(4096, i) + bytes(3000) + hashlib.shake_256(b"x").digest(5000)
+        else: raw = b"tiny%d" % i
+        blk = oracle.lz4_compress_raw(raw)[1]
+        if i % 16 == 7:                                                   # corrupt a few
+            b = bytearray(blk); b[len(b) // 2] ^= 0x5A; blk = bytes(b[:max(3, len(b) - 9)])
+        uniq.append((raw, blk))
+    n = 8192 + 37
+    blobs = [uniq[i % 48][1] for i in range(n)]
+    caps = [len(uniq[i % 48][0]) for i in range(n)]
+    res, out, off = _device_batch(eng, LZ4, DEC, 0, blobs, caps)
+    exp = [oracle.lz4_decompress_raw(b, len(r)) for r, b in uniq]
+    n_bad = 0
+    for i in range(n):
+        er, eo = exp[i % 48]
+        if er < 0:
+            assert res[i] == -7, (i, res[i])
+            n_bad += 1
+        else:
+            assert res[i] == er, (i, i % 48, res[i], er)
+            assert out[int(off[i]):int(off[i]) + er].tobytes() == eo, (i, i % 48)
+            assert (out[int(off[i]) + caps[i]:int(off[i]) + caps[i] + 5] == 0xAB).all()
+    assert n_bad > 100

@@ -208,6 +208,16 @@ def main():
         cpu = cpu_baseline(args, codec, raw_h, S, U, packed_h, uoff, clen)
 
     if rank == 0:
+        # HBM traffic from PMC counters cannot be sampled inside this process; it is measured with separate
+        # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command and summarised by
+        # tools/pmc_summary.py.  Reported only when the committed summary matches this exact workload.
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc", "hbm_traffic_lz4_decode_100k_x_64k.json")))
+            if dec and args.codec == "lz4" and NCH == 100_000 and S == 65536 and args.lz4_mode == "auto":
+                traffic = tj["total_hbm_bytes_per_step"]
+        except (OSError, ValueError, KeyError):
+            pass
         algo = bytes_in + (bytes_out if bytes_out is not None else 0)
         achieved = algo / (kernel_ms * 1e-3)
         line = {
@@ -224,7 +234,7 @@ def main():
                        "compressed_by": comp_name, "sharding": "chunk i -> gpu (i mod N), no collective",
                        "verified": "all results + all output bytes compared on device"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": None,
+                         "frac": achieved / HBM_PEAK, "traffic": traffic,
                          "kernel": {"auto": "lz4_parse_kernel+lz4_decode_lds_kernel", "lds": "lz4_parse_kernel+lz4_decode_lds_kernel", "wave": "lz4_decode_kernel",
                                     "lane": "lz4_decode_lanes_kernel"}[args.lz4_mode] if (dec and args.codec == "lz4") else "%s_%s_kernel" % (args.codec, "decode" if dec else "encode"),
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo},

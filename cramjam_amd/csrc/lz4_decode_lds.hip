@@ -347,22 +347,32 @@ __global__ __launch_bounds__(kLdsThreads) void lz4_decode_lds_kernel(BatchArgs a
                 bool ready = false;
                 if (pending) ready = bits_ready(s_bits, src, src + need);
                 if (prof) { dbg_iters += 1u; dbg_ready += (uint32_t)__builtin_popcountll(ballot64(ready)); }
-                if (ready && m < kLongRun) {
-                    if (off >= 8u) {
-                        uint32_t k = 0;
-                        for (; k + 8u <= m; k += 8u) {
-                            uint8_t t[8];
-#pragma unroll
-                            for (int q = 0; q < 8; q++) t[q] = s_out[src + k + q];
-#pragma unroll
-                            for (int q = 0; q < 8; q++) s_out[dst + k + q] = t[q];
-                        }
-                        for (; k < m; k++) s_out[dst + k] = s_out[src + k];
-                    } else {
-                        for (uint32_t k = 0; k < m; k++) s_out[dst + k] = s_out[src + k];
+                const bool go = ready && m < kLongRun;
+                if (ballot64(go)) {
+                    const bool plain = go && off >= m && m <= 64u;          // no self-overlap: single-wait dword copy
+                    if (ballot64(plain)) {
+                        const uint32_t tier = wave_tier(m, plain);
+                        if (plain) lds_copy_tier(tier, a_out + dst, a_out + src, m, dm);
                     }
-                    bits_set(s_bits, dst, dst + m);
-                    pending = false;
+                    if (go && !plain) {
+                        if (off >= 8u) {
+                            uint32_t k = 0;
+                            for (; k + 8u <= m; k += 8u) {
+                                uint8_t t[8];
+#pragma unroll
+                                for (int q = 0; q < 8; q++) t[q] = s_out[src + k + q];
+#pragma unroll
+                                for (int q = 0; q < 8; q++) s_out[dst + k + q] = t[q];
+                            }
+                            for (; k < m; k++) s_out[dst + k] = s_out[src + k];
+                        } else {
+                            for (uint32_t k = 0; k < m; k++) s_out[dst + k] = s_out[src + k];
+                        }
+                    }
+                    if (go) {
+                        bits_set(s_bits, dst, dst + m);
+                        pending = false;
+                    }
                 }
                 uint64_t longm = ballot64(ready && m >= kLongRun);     // RLE-like: whole wavefront, 64 bytes per step
                 while (longm) {

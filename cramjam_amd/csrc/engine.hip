@@ -46,8 +46,10 @@ struct cj_engine {
     std::mutex mu;                 // serialises host-batch staging on this engine
     DevBuf d_in, d_out, d_meta;
     std::mutex scratch_mu;         // LZ4 parse->decode scratch (sync points, per-chunk meta), reused across calls
-    DevBuf d_sync, d_pmeta;
-    hipEvent_t scratch_free = nullptr;   // recorded after the last kernel that reads the scratch
+    DevBuf d_sync, d_pmeta, d_lanelist;   // d_lanelist: [0] = count, [16..] = chunk indices
+    hipEvent_t scratch_free = nullptr;    // recorded after the last kernel that reads the scratch
+    hipStream_t aux = nullptr;            // the lane-kernel share of a large LZ4-decode batch runs here, concurrently
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<uint8_t> h_in, h_out;
     std::vector<uint64_t> h_meta;
 };
@@ -77,16 +79,39 @@ int launch(cj_engine* e, cj_codec codec, cj_op op, const cj::BatchArgs& a, hipSt
             else if (mode == 1) cj::launch_lz4_decode_lanes(a, s);
             else {
                 std::lock_guard<std::mutex> lock(e->scratch_mu);
+                static const uint32_t lane_share = [] {
+                    const char* v = std::getenv("CJ_LANE_SHARE");      // n/20 of the short-sequence chunks go to the lane kernel
+                    long x = v ? std::strtol(v, nullptr, 10) : CJ_LANE_SHARE_DEFAULT;
+                    return (uint32_t)(x < 0 ? 0 : x > 20 ? 20 : x);
+                }();
+                const size_t list_bytes = 16 + (size_t)a.n_chunks * 4;
                 const bool grow = cj::lz4_lds_scratch_sync_bytes(a.n_chunks) > e->d_sync.cap ||
-                                  cj::lz4_lds_scratch_meta_bytes(a.n_chunks) > e->d_pmeta.cap;
+                                  cj::lz4_lds_scratch_meta_bytes(a.n_chunks) > e->d_pmeta.cap || list_bytes > e->d_lanelist.cap;
                 if (grow && e->scratch_free) HIP_TRY(hipEventSynchronize(e->scratch_free), CJ_E_NO_DEVICE);
                 if (!e->d_sync.reserve(cj::lz4_lds_scratch_sync_bytes(a.n_chunks)) ||
-                    !e->d_pmeta.reserve(cj::lz4_lds_scratch_meta_bytes(a.n_chunks))) return CJ_E_OOM;
-                if (!e->scratch_free) HIP_TRY(hipEventCreateWithFlags(&e->scratch_free, hipEventDisableTiming), CJ_E_NO_DEVICE);
-                else HIP_TRY(hipStreamWaitEvent(s, e->scratch_free, 0), CJ_E_NO_DEVICE);   // previous user of the scratch
-                cj::launch_lz4_parse(a, e->d_sync.p, e->d_pmeta.p, s);           // validate, size, count, route
+                    !e->d_pmeta.reserve(cj::lz4_lds_scratch_meta_bytes(a.n_chunks)) || !e->d_lanelist.reserve(list_bytes)) return CJ_E_OOM;
+                if (!e->scratch_free) {
+                    HIP_TRY(hipEventCreateWithFlags(&e->scratch_free, hipEventDisableTiming), CJ_E_NO_DEVICE);
+                    HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming), CJ_E_NO_DEVICE);
+                    HIP_TRY(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming), CJ_E_NO_DEVICE);
+                    HIP_TRY(hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking), CJ_E_NO_DEVICE);
+                } else HIP_TRY(hipStreamWaitEvent(s, e->scratch_free, 0), CJ_E_NO_DEVICE);   // previous user of the scratch
+                uint32_t* cnt = (uint32_t*)e->d_lanelist.p;
+                uint32_t* list = cnt + 4;
+                HIP_TRY(hipMemsetAsync(cnt, 0, 16, s), CJ_E_NO_DEVICE);
+                // 1. classify (no parsing): pick the lane-kernel share by compression ratio, build its compact list
+                cj::launch_lz4_classify(a, e->d_pmeta.p, list, cnt, lane_share, s);
+                // 2. fork: the lane kernel (HBM-latency bound, no LDS) overlaps parse + LDS decode (issue/LDS bound)
+                if (lane_share > 0) {
+                    HIP_TRY(hipEventRecord(e->ev_fork, s), CJ_E_NO_DEVICE);
+                    HIP_TRY(hipStreamWaitEvent(e->aux, e->ev_fork, 0), CJ_E_NO_DEVICE);
+                    cj::launch_lz4_decode_lanes_listed(a, list, cnt, lane_share, e->aux);
+                    HIP_TRY(hipEventRecord(e->ev_join, e->aux), CJ_E_NO_DEVICE);
+                }
+                cj::launch_lz4_parse(a, e->d_sync.p, e->d_pmeta.p, s);           // validate, size, count sequences, route
                 cj::launch_lz4_decode_lds(a, e->d_sync.p, e->d_pmeta.p, s);      // many short sequences
                 cj::launch_lz4_decode_routed(a, e->d_pmeta.p, s);                // few long runs / oversize chunks
+                if (lane_share > 0) HIP_TRY(hipStreamWaitEvent(s, e->ev_join, 0), CJ_E_NO_DEVICE);   // 3. join
                 HIP_TRY(hipEventRecord(e->scratch_free, s), CJ_E_NO_DEVICE);
             }
         } else cj::launch_lz4_encode(a, s);
@@ -206,8 +231,11 @@ int cj_engine_create(int device, cj_engine** out) {
 void cj_engine_destroy(cj_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
-    e->d_in.release(); e->d_out.release(); e->d_meta.release(); e->d_sync.release(); e->d_pmeta.release();
+    e->d_in.release(); e->d_out.release(); e->d_meta.release(); e->d_sync.release(); e->d_pmeta.release(); e->d_lanelist.release();
     if (e->scratch_free) (void)hipEventDestroy(e->scratch_free);
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+    if (e->aux) (void)hipStreamDestroy(e->aux);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }

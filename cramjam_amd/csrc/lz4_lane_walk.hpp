@@ -21,6 +21,8 @@ struct ParseMeta {       // one per chunk, written by lz4_parse_kernel
     uint32_t in_skip;    // low bits: 4 when a size prefix was consumed; kRouteWave: decode with the wave-per-chunk kernel
 };
 constexpr uint32_t kRouteWave = 0x80000000u;
+constexpr uint32_t kRouteLane = 0x40000000u;   // decoded by the lane-per-chunk kernel on the auxiliary stream (listed in lane_list)
+constexpr uint32_t kLaneShareDen = 20;         // lane_share/20 of the LDS-class chunks go to the lane kernel
 // Routing (measured, tools/mode_sweep.py): chunks made of few long runs (RLE, incompressible data) decode at
 // 2.2-2.6 TB/s with the wave-per-chunk kernel (16 B/lane cooperative copies) but crawl through the LDS path;
 // chunks with many short sequences are ~2x faster through parse + LDS.  The parse kernel knows the count.

@@ -107,6 +107,9 @@ typedef enum { CJ_OP_DECOMPRESS = 0, CJ_OP_COMPRESS = 1 } cj_op;
 #define CJ_FLAG_FORCE_LANE_PER_CHUNK 0x200u
 #define CJ_FLAG_FORCE_LDS_PER_CHUNK  0x400u
 #define CJ_LDS_MIN_CHUNKS 8192
+/* share (n/20) of the short-sequence chunks of such a batch that is decoded by the lane-per-chunk kernel on an
+ * internal auxiliary stream, concurrently with the LDS workgroup decoder (env CJ_LANE_SHARE overrides; 0 = off) */
+#define CJ_LANE_SHARE_DEFAULT 8
 
 int  cj_engine_create(int device, cj_engine** out);
 void cj_engine_destroy(cj_engine* e);

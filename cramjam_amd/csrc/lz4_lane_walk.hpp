@@ -106,55 +106,6 @@ __device__ __forceinline__ int64_t lz4_lane_walk(const uint8_t* in, uint32_t ien
             }
         }
         nseq += 1;
-        if (kCopy) {
-            // Fast path of the decoding walk (the lane kernel is bound by DEPENDENT memory round trips): one 16 B load
-            // at the token yields the token, a literal-length byte, up to 15 literals (shifted in registers and
-            // stored with one wild 16 B store) and, when it still fits, the offset + a match-length byte — two
-            // round trips per sequence instead of four.  Anything unusual falls through to the general code,
-            // which redoes the sequence from its token (the wild literal store is idempotent).
-            if (ip + 20u <= iend && cap - op >= 32u) {
-                const uint4 q = ld16u(in + ip);
-                const uint32_t token = q.x & 0xffu;
-                uint32_t lit = token >> 4, hdr = 1u;
-                bool ok = true;
-                if (lit == 15u) { const uint32_t b = (q.x >> 8) & 0xffu; lit += b; hdr = 2u; ok = b != 255u; }
-                const uint32_t po = hdr + lit;                      // offset position inside q
-                if (ok && po <= 16u && (uint64_t)(cap - op) >= (uint64_t)lit + 12u && (iend - ip - hdr) >= lit + 8u) {
-                    uint4 v;
-                    v.x = __builtin_amdgcn_alignbyte(q.y, q.x, hdr);
-                    v.y = __builtin_amdgcn_alignbyte(q.z, q.y, hdr);
-                    v.z = __builtin_amdgcn_alignbyte(q.w, q.z, hdr);
-                    v.w = q.w >> (8u * hdr);
-                    st16u(out + op, v);
-                    const uint32_t ip2 = ip + po, op2 = op + lit;
-                    uint32_t o3;
-                    if (po + 3u <= 16u) {
-                        const uint32_t wi = po >> 2, sh = (po & 3u) * 8u;
-                        const uint32_t w0 = wi == 0u ? q.x : wi == 1u ? q.y : wi == 2u ? q.z : q.w;
-                        const uint32_t w1 = wi == 0u ? q.y : wi == 1u ? q.z : wi == 2u ? q.w : 0u;
-                        o3 = (uint32_t)((((uint64_t)w1 << 32) | w0) >> sh);
-                    } else {
-                        o3 = ld32u(in + ip2);                       // >= 8 input bytes remain here
-                    }
-                    const uint32_t offset = o3 & 0xffffu;
-                    uint32_t mlen = token & 15u, adv = 2u;
-                    bool ok2 = true;
-                    if (mlen == 15u) {
-                        const uint32_t b = (o3 >> 16) & 0xffu;
-                        mlen += b; adv = 3u;
-                        ok2 = b != 255u && ip2 + 3u + 4u <= iend;
-                    }
-                    if (ok2) {
-                        mlen += 4u;
-                        if (offset == 0u || offset > op2) return CJ_E_CORRUPT;
-                        if ((uint64_t)(cap - op2) < (uint64_t)mlen + 5u) return CJ_E_CORRUPT;
-                        lane_match(out + op2, offset, mlen, cap - op2);
-                        ip = ip2 + adv; op = op2 + mlen;
-                        continue;
-                    }
-                }
-            }
-        }
         const uint32_t t4 = ld_le_tail(in, ip, iend);
         const uint32_t token = t4 & 0xffu;
         ip += 1;

@@ -26,9 +26,10 @@ constexpr int kBlockThreads = 64 * kWavesPerBlock;
 void launch_lz4_decode(const BatchArgs& a, hipStream_t s);        // one wavefront per chunk
 void launch_lz4_decode_lanes(const BatchArgs& a, hipStream_t s);  // one lane per chunk
 // parse (lane per chunk) + decode (workgroup per chunk, LDS-resident window); sync/meta are engine scratch
-void launch_lz4_classify(const BatchArgs& a, void* meta, void* lane_list, void* lane_count, uint32_t lane_share, hipStream_t s);
+void launch_lz4_classify(const BatchArgs& a, void* meta, void* lists, uint32_t lane_share, uint32_t wave_share, hipStream_t s);
 void launch_lz4_parse(const BatchArgs& a, void* sync, void* meta, hipStream_t s);
-void launch_lz4_decode_lanes_listed(const BatchArgs& a, const void* lane_list, const void* lane_count, uint32_t lane_share, hipStream_t s);
+void launch_lz4_decode_lanes_listed(const BatchArgs& a, const void* lists, uint32_t lane_share, hipStream_t s);
+void launch_lz4_decode_listed(const BatchArgs& a, const void* lists, uint32_t wave_share, hipStream_t s);   // wave kernel on the classify kernel's early wave share
 void launch_lz4_decode_lds(const BatchArgs& a, const void* sync, const void* meta, hipStream_t s);
 void launch_lz4_decode_routed(const BatchArgs& a, const void* meta, hipStream_t s);   // wave kernel on chunks the parse kernel routed to it
 size_t lz4_lds_scratch_sync_bytes(size_t n_chunks);

@@ -48,8 +48,8 @@ struct cj_engine {
     std::mutex scratch_mu;         // LZ4 parse->decode scratch (sync points, per-chunk meta), reused across calls
     DevBuf d_sync, d_pmeta, d_lanelist;   // d_lanelist: [0] = count, [16..] = chunk indices
     hipEvent_t scratch_free = nullptr;    // recorded after the last kernel that reads the scratch
-    hipStream_t aux = nullptr;            // the lane-kernel share of a large LZ4-decode batch runs here, concurrently
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t aux = nullptr, aux2 = nullptr;   // the lane- / wave-kernel shares of a large LZ4-decode batch run here, concurrently
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
     std::vector<uint8_t> h_in, h_out;
     std::vector<uint64_t> h_meta;
 };
@@ -84,7 +84,12 @@ int launch(cj_engine* e, cj_codec codec, cj_op op, const cj::BatchArgs& a, hipSt
                     long x = v ? std::strtol(v, nullptr, 10) : CJ_LANE_SHARE_DEFAULT;
                     return (uint32_t)(x < 0 ? 0 : x > 20 ? 20 : x);
                 }();
-                const size_t list_bytes = 16 + (size_t)a.n_chunks * 4;
+                static const uint32_t wave_share = [] {
+                    const char* v = std::getenv("CJ_WAVE_SHARE");
+                    long x = v ? std::strtol(v, nullptr, 10) : CJ_WAVE_SHARE_DEFAULT;
+                    return (uint32_t)(x < 0 ? 0 : x > 20 ? 20 : x);
+                }();
+                const size_t list_bytes = 16 + (size_t)a.n_chunks * 8;
                 const bool grow = cj::lz4_lds_scratch_sync_bytes(a.n_chunks) > e->d_sync.cap ||
                                   cj::lz4_lds_scratch_meta_bytes(a.n_chunks) > e->d_pmeta.cap || list_bytes > e->d_lanelist.cap;
                 if (grow && e->scratch_free) HIP_TRY(hipEventSynchronize(e->scratch_free), CJ_E_NO_DEVICE);
@@ -94,24 +99,33 @@ int launch(cj_engine* e, cj_codec codec, cj_op op, const cj::BatchArgs& a, hipSt
                     HIP_TRY(hipEventCreateWithFlags(&e->scratch_free, hipEventDisableTiming), CJ_E_NO_DEVICE);
                     HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming), CJ_E_NO_DEVICE);
                     HIP_TRY(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming), CJ_E_NO_DEVICE);
+                    HIP_TRY(hipEventCreateWithFlags(&e->ev_join2, hipEventDisableTiming), CJ_E_NO_DEVICE);
                     HIP_TRY(hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking), CJ_E_NO_DEVICE);
+                    HIP_TRY(hipStreamCreateWithFlags(&e->aux2, hipStreamNonBlocking), CJ_E_NO_DEVICE);
                 } else HIP_TRY(hipStreamWaitEvent(s, e->scratch_free, 0), CJ_E_NO_DEVICE);   // previous user of the scratch
-                uint32_t* cnt = (uint32_t*)e->d_lanelist.p;
-                uint32_t* list = cnt + 4;
-                HIP_TRY(hipMemsetAsync(cnt, 0, 16, s), CJ_E_NO_DEVICE);
-                // 1. classify (no parsing): pick the lane-kernel share by compression ratio, build its compact list
-                cj::launch_lz4_classify(a, e->d_pmeta.p, list, cnt, lane_share, s);
-                // 2. fork: the lane kernel (HBM-latency bound, no LDS) overlaps parse + LDS decode (issue/LDS bound)
+                uint32_t* lists = (uint32_t*)e->d_lanelist.p;
+                HIP_TRY(hipMemsetAsync(lists, 0, 16, s), CJ_E_NO_DEVICE);
+                // 1. classify (no parsing): pick the lane- and wave-kernel shares by compression ratio, build compact lists
+                cj::launch_lz4_classify(a, e->d_pmeta.p, lists, lane_share, wave_share, s);
+                // 2. fork: three kernels with three different bottlenecks run concurrently — lane kernel (HBM traffic of
+                //    random match reads), wave kernel (dependent-latency chain), parse + LDS decoder (instruction issue / LDS)
+                const bool forked = lane_share + wave_share > 0;
+                if (forked) HIP_TRY(hipEventRecord(e->ev_fork, s), CJ_E_NO_DEVICE);
                 if (lane_share > 0) {
-                    HIP_TRY(hipEventRecord(e->ev_fork, s), CJ_E_NO_DEVICE);
                     HIP_TRY(hipStreamWaitEvent(e->aux, e->ev_fork, 0), CJ_E_NO_DEVICE);
-                    cj::launch_lz4_decode_lanes_listed(a, list, cnt, lane_share, e->aux);
+                    cj::launch_lz4_decode_lanes_listed(a, lists, lane_share, e->aux);
                     HIP_TRY(hipEventRecord(e->ev_join, e->aux), CJ_E_NO_DEVICE);
+                }
+                if (wave_share > 0) {
+                    HIP_TRY(hipStreamWaitEvent(e->aux2, e->ev_fork, 0), CJ_E_NO_DEVICE);
+                    cj::launch_lz4_decode_listed(a, lists, wave_share, e->aux2);
+                    HIP_TRY(hipEventRecord(e->ev_join2, e->aux2), CJ_E_NO_DEVICE);
                 }
                 cj::launch_lz4_parse(a, e->d_sync.p, e->d_pmeta.p, s);           // validate, size, count sequences, route
                 cj::launch_lz4_decode_lds(a, e->d_sync.p, e->d_pmeta.p, s);      // many short sequences
                 cj::launch_lz4_decode_routed(a, e->d_pmeta.p, s);                // few long runs / oversize chunks
                 if (lane_share > 0) HIP_TRY(hipStreamWaitEvent(s, e->ev_join, 0), CJ_E_NO_DEVICE);   // 3. join
+                if (wave_share > 0) HIP_TRY(hipStreamWaitEvent(s, e->ev_join2, 0), CJ_E_NO_DEVICE);
                 HIP_TRY(hipEventRecord(e->scratch_free, s), CJ_E_NO_DEVICE);
             }
         } else cj::launch_lz4_encode(a, s);
@@ -235,7 +249,9 @@ void cj_engine_destroy(cj_engine* e) {
     if (e->scratch_free) (void)hipEventDestroy(e->scratch_free);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+    if (e->ev_join2) (void)hipEventDestroy(e->ev_join2);
     if (e->aux) (void)hipStreamDestroy(e->aux);
+    if (e->aux2) (void)hipStreamDestroy(e->aux2);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }

@@ -12,9 +12,15 @@
 
 namespace cj {
 
-// route: nullptr = decode every chunk; else only chunks the parse kernel flagged kRouteWave
-__global__ __launch_bounds__(kBlockThreads) void lz4_decode_kernel(BatchArgs a, const ParseMeta* route) {
-    const uint32_t chunk = uni(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+// route: nullptr = decode every chunk; else only chunks the parse kernel flagged kRouteWave.
+// list/count: when non-null, wave i decodes chunk list[i] for i < *count (the classify kernel's early wave share).
+__global__ __launch_bounds__(kBlockThreads) void lz4_decode_kernel(BatchArgs a, const ParseMeta* route,
+                                                                   const uint32_t* list, const uint32_t* count) {
+    uint32_t chunk = uni(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+    if (list != nullptr) {
+        if (chunk >= *count) return;
+        chunk = uni(list[chunk]);
+    }
     if (chunk >= a.n_chunks) return;
     if (route != nullptr && (route[chunk].in_skip & kRouteWave) == 0u) return;
     const uint8_t* in = a.in_base + a.in_off[chunk];
@@ -119,13 +125,21 @@ __global__ __launch_bounds__(kBlockThreads) void lz4_decode_kernel(BatchArgs a, 
 void launch_lz4_decode(const BatchArgs& a, hipStream_t s) {
     if (a.n_chunks == 0) return;
     dim3 grid((a.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlockThreads);
-    hipLaunchKernelGGL(lz4_decode_kernel, grid, block, 0, s, a, (const ParseMeta*)nullptr);
+    hipLaunchKernelGGL(lz4_decode_kernel, grid, block, 0, s, a, (const ParseMeta*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
 }
 
 void launch_lz4_decode_routed(const BatchArgs& a, const void* meta, hipStream_t s) {
     if (a.n_chunks == 0) return;
     dim3 grid((a.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlockThreads);
-    hipLaunchKernelGGL(lz4_decode_kernel, grid, block, 0, s, a, (const ParseMeta*)meta);
+    hipLaunchKernelGGL(lz4_decode_kernel, grid, block, 0, s, a, (const ParseMeta*)meta, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+}
+
+void launch_lz4_decode_listed(const BatchArgs& a, const void* lists, uint32_t wave_share, hipStream_t s) {
+    if (a.n_chunks == 0 || wave_share == 0) return;
+    const uint64_t maxn = ((uint64_t)a.n_chunks + kLaneShareDen - 1u) / kLaneShareDen * wave_share;
+    dim3 grid((unsigned)((maxn + kWavesPerBlock - 1) / kWavesPerBlock)), block(kBlockThreads);
+    const uint32_t* l = (const uint32_t*)lists;
+    hipLaunchKernelGGL(lz4_decode_kernel, grid, block, 0, s, a, (const ParseMeta*)nullptr, l + 4 + a.n_chunks, l + 1);
 }
 
 }  // namespace cj

@@ -225,24 +225,37 @@ __global__ __launch_bounds__(64 * kParseWaves) void lz4_parse_kernel(BatchArgs a
 // chunks are ~5x faster through the wave kernel, and only the parse kernel can tell those apart exactly.
 // The choice affects speed only; every kernel decodes any valid chunk identically.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void lz4_classify_kernel(BatchArgs a, ParseMeta* meta, uint32_t* lane_list, uint32_t* lane_count,
-                                                           uint32_t lane_share) {
+// lists: [0] = lane-kernel count, [1] = wave-kernel count, lane list at lists + 4, wave list at lists + 4 + n_chunks
+__global__ __launch_bounds__(256) void lz4_classify_kernel(BatchArgs a, ParseMeta* meta, uint32_t* lists,
+                                                           uint32_t lane_share, uint32_t wave_share) {
     const uint32_t c = blockIdx.x * 256u + threadIdx.x;
     const uint32_t lane = lane_id();
-    bool to_lane = false;
+    bool to_lane = false, to_wave = false;
     if (c < a.n_chunks) {
         const uint64_t n = a.in_len[c], cap = a.out_cap[c];
         // ratio between 1.05 and 5, and small enough that a lane is a sensible unit of work
-        to_lane = (c % kLaneShareDen) < lane_share && cap <= kLdsOutMax && n * 20u < cap * 19u && n * 5u > cap;
-        ParseMeta pm = {0u, to_lane ? kRouteLane : 0u};
+        const bool eligible = cap <= kLdsOutMax && n * 20u < cap * 19u && n * 5u > cap;
+        const uint32_t slot = c % kLaneShareDen;
+        to_lane = eligible && slot < lane_share;
+        to_wave = eligible && !to_lane && slot < lane_share + wave_share;
+        ParseMeta pm = {0u, (to_lane || to_wave) ? kRouteLane : 0u};
         meta[c] = pm;
     }
-    const uint64_t mk = ballot64(to_lane);
-    if (mk != 0ull) {
+    uint32_t* lane_list = lists + 4;
+    uint32_t* wave_list = lists + 4 + a.n_chunks;
+    const uint64_t ml = ballot64(to_lane), mw = ballot64(to_wave);
+    const uint64_t below = (1ull << lane) - 1ull;
+    if (ml != 0ull) {
         uint32_t pos = 0;
-        if (lane == 0) pos = atomicAdd(lane_count, (uint32_t)__builtin_popcountll(mk));
+        if (lane == 0) pos = atomicAdd(&lists[0], (uint32_t)__builtin_popcountll(ml));
         pos = rdlane(pos, 0);
-        if (to_lane) lane_list[pos + (uint32_t)__builtin_popcountll(mk & ((1ull << lane) - 1ull))] = c;
+        if (to_lane) lane_list[pos + (uint32_t)__builtin_popcountll(ml & below)] = c;
+    }
+    if (mw != 0ull) {
+        uint32_t pos = 0;
+        if (lane == 0) pos = atomicAdd(&lists[1], (uint32_t)__builtin_popcountll(mw));
+        pos = rdlane(pos, 0);
+        if (to_wave) wave_list[pos + (uint32_t)__builtin_popcountll(mw & below)] = c;
     }
 }
 
@@ -269,10 +282,10 @@ void launch_lz4_decode_lanes(const BatchArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(lz4_decode_lanes_kernel, grid, block, 0, s, a);
 }
 
-void launch_lz4_classify(const BatchArgs& a, void* meta, void* lane_list, void* lane_count, uint32_t lane_share, hipStream_t s) {
+void launch_lz4_classify(const BatchArgs& a, void* meta, void* lists, uint32_t lane_share, uint32_t wave_share, hipStream_t s) {
     if (a.n_chunks == 0) return;
     dim3 grid((a.n_chunks + 255u) / 256u), block(256);
-    hipLaunchKernelGGL(lz4_classify_kernel, grid, block, 0, s, a, (ParseMeta*)meta, (uint32_t*)lane_list, (uint32_t*)lane_count, lane_share);
+    hipLaunchKernelGGL(lz4_classify_kernel, grid, block, 0, s, a, (ParseMeta*)meta, (uint32_t*)lists, lane_share, wave_share);
 }
 
 void launch_lz4_parse(const BatchArgs& a, void* sync, void* meta, hipStream_t s) {
@@ -282,12 +295,13 @@ void launch_lz4_parse(const BatchArgs& a, void* sync, void* meta, hipStream_t s)
     hipLaunchKernelGGL(lz4_parse_kernel, grid, block, 0, s, a, (uint2*)sync, (ParseMeta*)meta);
 }
 
-void launch_lz4_decode_lanes_listed(const BatchArgs& a, const void* lane_list, const void* lane_count, uint32_t lane_share, hipStream_t s) {
+void launch_lz4_decode_lanes_listed(const BatchArgs& a, const void* lists, uint32_t lane_share, hipStream_t s) {
     if (a.n_chunks == 0 || lane_share == 0) return;
     // upper bound of listed chunks: ceil(n/20) * share
     const uint64_t maxn = ((uint64_t)a.n_chunks + kLaneShareDen - 1u) / kLaneShareDen * lane_share;
     dim3 grid((unsigned)((maxn + 63u) / 64u)), block(64);
-    hipLaunchKernelGGL(lz4_decode_lanes_listed_kernel, grid, block, 0, s, a, (const uint32_t*)lane_list, (const uint32_t*)lane_count);
+    const uint32_t* l = (const uint32_t*)lists;
+    hipLaunchKernelGGL(lz4_decode_lanes_listed_kernel, grid, block, 0, s, a, l + 4, l);
 }
 
 }  // namespace cj

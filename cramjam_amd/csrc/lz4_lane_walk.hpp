@@ -30,6 +30,18 @@ constexpr uint32_t kLdsMinSeq = 256;
 
 __device__ __forceinline__ uint4 ld16u(const uint8_t* p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
 __device__ __forceinline__ void st16u(uint8_t* p, const uint4& v) { __builtin_memcpy(p, &v, 16); }
+#if defined(CJ_HOST_SIM)
+__device__ __forceinline__ uint4 ld16u_nt(const uint8_t* p) { return ld16u(p); }
+#else
+// Non-temporal 16 B load for the match sources: those reads land anywhere in the last 64 KiB of the chunk's output
+// and are never reused, but through the normal path they evict the partially written output lines of every lane
+// from L2 before they fill (PMC: 30.8 GB of HBM writes for 6.5 GB of output).
+typedef uint32_t cj_u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
+__device__ __forceinline__ uint4 ld16u_nt(const uint8_t* p) {
+    const cj_u32x4_unaligned v = __builtin_nontemporal_load(reinterpret_cast<const cj_u32x4_unaligned*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+#endif
 
 // up to 4 bytes at in[ip..], zero-filled past iend
 __device__ __forceinline__ uint32_t ld_le_tail(const uint8_t* in, uint32_t ip, uint32_t iend) {
@@ -81,7 +93,7 @@ __device__ __forceinline__ void lane_match(uint8_t* dst, uint32_t d, uint32_t m,
     uint32_t k = 0;
     const uint8_t* src = dst - d;
     if (d >= 16u) {
-        for (; k < m && k + 16u <= room; k += 16u) st16u(dst + k, ld16u(src + k));
+        for (; k < m && k + 16u <= room; k += 16u) st16u(dst + k, ld16u_nt(src + k));
     } else if (m >= 16u && room >= 32u) {
         const uint4 p = splat_pattern(src, d);
         const uint32_t s = (16u / d) * d;          // advance by whole periods so the phase stays aligned

@@ -20,10 +20,10 @@ __device__ __forceinline__ uint32_t emit_len_ext(uint8_t* out, uint32_t op, uint
     return op + full + 1u;
 }
 
-__global__ __launch_bounds__(kBlockThreads) void lz4_encode_kernel(BatchArgs a) {
-    __shared__ uint16_t ht_all[kWavesPerBlock][kHashSize];
+__global__ __launch_bounds__(kEncThreads) void lz4_encode_kernel(BatchArgs a) {
+    __shared__ uint16_t ht_all[kEncWaves][kHashSize];
     const uint32_t wave = uni(threadIdx.x >> 6);
-    const uint32_t chunk = uni(blockIdx.x * kWavesPerBlock + wave);
+    const uint32_t chunk = uni(blockIdx.x * kEncWaves + wave);
     if (chunk >= a.n_chunks) return;
     uint16_t* ht = ht_all[wave];
     const uint8_t* in = a.in_base + a.in_off[chunk];
@@ -50,14 +50,17 @@ __global__ __launch_bounds__(kBlockThreads) void lz4_encode_kernel(BatchArgs a) 
         const uint32_t matchlimit = n - 5u;     // and must end here at the latest
         uint32_t pos = 0;
         while (pos <= last_start) {
-            uint32_t cand;
-            uint64_t mask = probe_round(in, ht, pos, last_start, cand);
+            uint32_t cand, hslot;
+            uint64_t mask = probe_round(in, ht, pos, last_start, cand, hslot);
             const uint32_t batch_end = pos + 64u;
+            uint64_t covered = 0ull;
             while (mask) {
                 const uint32_t first = ctz64(mask);
-                const uint32_t mpos = pos + first;
-                const uint32_t mc = rdlane(cand, first);
-                const uint32_t mlen = 4u + wave_extend(in, mpos + 4u, mc + 4u, matchlimit);
+                uint32_t mpos = pos + first;
+                uint32_t mc = rdlane(cand, first);
+                uint32_t mlen = 4u + wave_extend(in, mpos + 4u, mc + 4u, matchlimit);
+                const uint32_t back = wave_extend_back(in, mpos, mc, mpos - anchor);
+                mpos -= back; mc -= back; mlen += back;
                 const uint32_t lit = mpos - anchor;
                 const uint32_t mcode = mlen - 4u;
                 // token
@@ -71,9 +74,11 @@ __global__ __launch_bounds__(kBlockThreads) void lz4_encode_kernel(BatchArgs a) 
                 op += 2;
                 if (mcode >= 15u) op = emit_len_ext(out, op, mcode - 15u);
                 anchor = mpos + mlen;
+                covered |= covered_bits(pos, mpos, anchor - pos);
                 if (anchor >= batch_end) mask = 0;
                 else mask &= ~0ull << (anchor - pos);
             }
+            insert_uncovered(ht, pos, hslot, covered);
             pos = anchor > batch_end ? anchor : batch_end;
         }
     }
@@ -90,7 +95,7 @@ __global__ __launch_bounds__(kBlockThreads) void lz4_encode_kernel(BatchArgs a) 
 
 void launch_lz4_encode(const BatchArgs& a, hipStream_t s) {
     if (a.n_chunks == 0) return;
-    dim3 grid((a.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlockThreads);
+    dim3 grid((a.n_chunks + kEncWaves - 1) / kEncWaves), block(kEncThreads);
     hipLaunchKernelGGL(lz4_encode_kernel, grid, block, 0, s, a);
 }
 

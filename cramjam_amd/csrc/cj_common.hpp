@@ -35,7 +35,9 @@ void launch_lz4_decode_routed(const BatchArgs& a, const void* meta, hipStream_t 
 size_t lz4_lds_scratch_sync_bytes(size_t n_chunks);
 size_t lz4_lds_scratch_meta_bytes(size_t n_chunks);
 void launch_lz4_encode(const BatchArgs& a, hipStream_t s);
-void launch_snappy_decode(const BatchArgs& a, hipStream_t s);
+void launch_snappy_decode(const BatchArgs& a, hipStream_t s);                                   // one wavefront per chunk
+void launch_snappy_decode_skipping(const BatchArgs& a, const void* meta, hipStream_t s);         // ... except chunks flagged for the lane kernel
+void launch_snappy_decode_lanes(const BatchArgs& a, const void* lists, uint32_t lane_share, hipStream_t s);   // one lane per chunk (all, or the listed share)
 void launch_snappy_encode(const BatchArgs& a, hipStream_t s);
 
 #if defined(__HIPCC__)

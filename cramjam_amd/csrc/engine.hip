@@ -130,7 +130,49 @@ int launch(cj_engine* e, cj_codec codec, cj_op op, const cj::BatchArgs& a, hipSt
             }
         } else cj::launch_lz4_encode(a, s);
     } else if (codec == CJ_CODEC_SNAPPY_RAW) {
-        if (op == CJ_OP_DECOMPRESS) cj::launch_snappy_decode(a, s); else cj::launch_snappy_encode(a, s);
+        if (op == CJ_OP_DECOMPRESS) {
+            static const size_t big_min = [] {
+                const char* v = std::getenv("CJ_LDS_MIN_CHUNKS");
+                return v ? (size_t)std::strtoull(v, nullptr, 10) : (size_t)CJ_LDS_MIN_CHUNKS;
+            }();
+            static const uint32_t sn_share = [] {
+                const char* v = std::getenv("CJ_SNAPPY_LANE_SHARE");
+                long x = v ? std::strtol(v, nullptr, 10) : CJ_SNAPPY_LANE_SHARE_DEFAULT;
+                return (uint32_t)(x < 0 ? 0 : x > 20 ? 20 : x);
+            }();
+            int mode = (a.n_chunks >= big_min && sn_share > 0) ? 2 : 0;
+            if (a.flags & CJ_FLAG_FORCE_WAVE_PER_CHUNK) mode = 0;
+            if (a.flags & CJ_FLAG_FORCE_LANE_PER_CHUNK) mode = 1;
+            if (mode == 0) cj::launch_snappy_decode(a, s);
+            else if (mode == 1) cj::launch_snappy_decode_lanes(a, nullptr, 0, s);
+            else {
+                // large batch: mid-ratio chunks (many short elements) go to the lane kernel on the auxiliary stream, the
+                // rest (and the long-run chunks, which the wave kernel copies 16 B/lane) stay on the wave kernel
+                std::lock_guard<std::mutex> lock(e->scratch_mu);
+                const size_t list_bytes = 16 + (size_t)a.n_chunks * 8;
+                const bool grow = cj::lz4_lds_scratch_meta_bytes(a.n_chunks) > e->d_pmeta.cap || list_bytes > e->d_lanelist.cap;
+                if (grow && e->scratch_free) HIP_TRY(hipEventSynchronize(e->scratch_free), CJ_E_NO_DEVICE);
+                if (!e->d_pmeta.reserve(cj::lz4_lds_scratch_meta_bytes(a.n_chunks)) || !e->d_lanelist.reserve(list_bytes)) return CJ_E_OOM;
+                if (!e->scratch_free) {
+                    HIP_TRY(hipEventCreateWithFlags(&e->scratch_free, hipEventDisableTiming), CJ_E_NO_DEVICE);
+                    HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming), CJ_E_NO_DEVICE);
+                    HIP_TRY(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming), CJ_E_NO_DEVICE);
+                    HIP_TRY(hipEventCreateWithFlags(&e->ev_join2, hipEventDisableTiming), CJ_E_NO_DEVICE);
+                    HIP_TRY(hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking), CJ_E_NO_DEVICE);
+                    HIP_TRY(hipStreamCreateWithFlags(&e->aux2, hipStreamNonBlocking), CJ_E_NO_DEVICE);
+                } else HIP_TRY(hipStreamWaitEvent(s, e->scratch_free, 0), CJ_E_NO_DEVICE);
+                uint32_t* lists = (uint32_t*)e->d_lanelist.p;
+                HIP_TRY(hipMemsetAsync(lists, 0, 16, s), CJ_E_NO_DEVICE);
+                cj::launch_lz4_classify(a, e->d_pmeta.p, lists, sn_share, 0, s);     // codec independent: looks at sizes only
+                HIP_TRY(hipEventRecord(e->ev_fork, s), CJ_E_NO_DEVICE);
+                HIP_TRY(hipStreamWaitEvent(e->aux, e->ev_fork, 0), CJ_E_NO_DEVICE);
+                cj::launch_snappy_decode_lanes(a, lists, sn_share, e->aux);
+                HIP_TRY(hipEventRecord(e->ev_join, e->aux), CJ_E_NO_DEVICE);
+                cj::launch_snappy_decode_skipping(a, e->d_pmeta.p, s);
+                HIP_TRY(hipStreamWaitEvent(s, e->ev_join, 0), CJ_E_NO_DEVICE);
+                HIP_TRY(hipEventRecord(e->scratch_free, s), CJ_E_NO_DEVICE);
+            }
+        } else cj::launch_snappy_encode(a, s);
     } else {
         return CJ_E_BAD_ARG;
     }

@@ -7,13 +7,15 @@
 //
 // Same shape as lz4_decode.hip: tag grammar parsed wave-uniformly from the 512-byte register window,
 // lanes move bytes.
-#include "cj_common.hpp"
+#include "lz4_lane_walk.hpp"   // lane_copy / lane_match / ParseMeta route flags are codec independent
 
 namespace cj {
 
-__global__ __launch_bounds__(kBlockThreads) void snappy_decode_kernel(BatchArgs a) {
+// skip: when non-null, chunks flagged kRouteLane there belong to the lane kernel (large-batch pipeline)
+__global__ __launch_bounds__(kBlockThreads) void snappy_decode_kernel(BatchArgs a, const ParseMeta* skip) {
     const uint32_t chunk = uni(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
     if (chunk >= a.n_chunks) return;
+    if (skip != nullptr && (skip[chunk].in_skip & kRouteLane) != 0u) return;
     const uint8_t* in = a.in_base + a.in_off[chunk];
     const uint64_t n64 = a.in_len[chunk];
     uint8_t* out = a.out_base + a.out_off[chunk];
@@ -108,10 +110,118 @@ __global__ __launch_bounds__(kBlockThreads) void snappy_decode_kernel(BatchArgs 
     if (lane_id() == 0) a.result[chunk] = bad ? (int64_t)CJ_E_SNAPPY_CORRUPT : (int64_t)dn;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// One LANE per chunk (large batches of short-element data; see lz4_decode_lanes.hip for the rationale).
+// Same accept/reject rules as the wave kernel above (snap 1.1.1 raw::Decoder::decompress).  Copies are
+// 16 B wild copies while 16 B of room remain before the DECODED length, exact bytes at the tail, so nothing
+// past the decoded length is written.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t snappy_lane_walk(const uint8_t* in, uint64_t n64, uint8_t* out, uint64_t cap64) {
+    if (n64 == 0) return CJ_E_SNAPPY_EMPTY;
+    if (n64 > 0xFFFFFFF0ull) return CJ_E_SNAPPY_CORRUPT;
+    const uint32_t iend = (uint32_t)n64;
+    uint32_t ip = 0;
+    uint64_t ulen = 0;
+    {
+        uint32_t shift = 0, i = 0;
+        bool done = false;
+        while (ip < iend && i < 10u) {
+            const uint32_t b = in[ip];
+            ip += 1;
+            if (b < 0x80u) {
+                if (i == 9u && b > 1u) break;
+                ulen |= (uint64_t)b << shift;
+                done = true;
+                break;
+            }
+            ulen |= (uint64_t)(b & 0x7fu) << shift;
+            shift += 7; i += 1;
+        }
+        if (!done) return CJ_E_SNAPPY_HEADER;
+        if (ulen > 0xFFFFFFFFull) return CJ_E_SNAPPY_TOO_BIG;
+        if (ulen > cap64) return CJ_E_SNAPPY_BUF_SMALL;
+    }
+    const uint32_t dn = (uint32_t)ulen;
+    uint32_t op = 0;
+    while (ip < iend) {
+        const uint32_t t4 = ld_le_tail(in, ip, iend);
+        const uint32_t tag = t4 & 0xffu;
+        ip += 1;
+        const uint32_t kind = tag & 3u;
+        if (kind == 0u) {
+            uint64_t len = (tag >> 2) + 1u;
+            if (len > 60u) {
+                const uint32_t nb = (uint32_t)len - 60u;
+                if (iend - ip < nb) return CJ_E_SNAPPY_CORRUPT;
+                uint32_t v = ld_le_tail(in, ip, iend);
+                if (nb < 4u) v &= (1u << (8u * nb)) - 1u;
+                ip += nb;
+                len = (uint64_t)v + 1u;
+            }
+            if (len > (uint64_t)(iend - ip) || len > (uint64_t)(dn - op)) return CJ_E_SNAPPY_CORRUPT;
+            lane_copy(out + op, in + ip, (uint32_t)len, dn - op, iend - ip);
+            ip += (uint32_t)len; op += (uint32_t)len;
+            continue;
+        }
+        uint32_t len, offset;
+        if (kind == 1u) {
+            if (iend - ip < 1u) return CJ_E_SNAPPY_CORRUPT;
+            len = 4u + ((tag >> 2) & 7u);
+            offset = ((tag >> 5) << 8) | ((t4 >> 8) & 0xffu);
+            ip += 1;
+        } else if (kind == 2u) {
+            if (iend - ip < 2u) return CJ_E_SNAPPY_CORRUPT;
+            len = 1u + (tag >> 2);
+            offset = (t4 >> 8) & 0xffffu;
+            ip += 2;
+        } else {
+            if (iend - ip < 4u) return CJ_E_SNAPPY_CORRUPT;
+            len = 1u + (tag >> 2);
+            offset = ld32u(in + ip);
+            ip += 4;
+        }
+        if (offset == 0u || offset > op) return CJ_E_SNAPPY_CORRUPT;
+        if (len > dn - op) return CJ_E_SNAPPY_CORRUPT;
+        lane_match(out + op, offset, len, dn - op);
+        op += len;
+    }
+    if (op != dn) return CJ_E_SNAPPY_CORRUPT;
+    return (int64_t)dn;
+}
+
+// list/count: when non-null, lane i decodes chunk list[i] for i < *count
+__global__ __launch_bounds__(64) void snappy_decode_lanes_kernel(BatchArgs a, const uint32_t* list, const uint32_t* count) {
+    uint32_t c = blockIdx.x * 64u + threadIdx.x;
+    if (list != nullptr) {
+        if (c >= *count) return;
+        c = list[c];
+    }
+    if (c >= a.n_chunks) return;
+    a.result[c] = snappy_lane_walk(a.in_base + a.in_off[c], a.in_len[c], a.out_base + a.out_off[c], a.out_cap[c]);
+}
+
 void launch_snappy_decode(const BatchArgs& a, hipStream_t s) {
     if (a.n_chunks == 0) return;
     dim3 grid((a.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlockThreads);
-    hipLaunchKernelGGL(snappy_decode_kernel, grid, block, 0, s, a);
+    hipLaunchKernelGGL(snappy_decode_kernel, grid, block, 0, s, a, (const ParseMeta*)nullptr);
+}
+
+void launch_snappy_decode_skipping(const BatchArgs& a, const void* meta, hipStream_t s) {
+    if (a.n_chunks == 0) return;
+    dim3 grid((a.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlockThreads);
+    hipLaunchKernelGGL(snappy_decode_kernel, grid, block, 0, s, a, (const ParseMeta*)meta);
+}
+
+void launch_snappy_decode_lanes(const BatchArgs& a, const void* lists, uint32_t lane_share, hipStream_t s) {
+    if (a.n_chunks == 0) return;
+    if (lists == nullptr) {
+        hipLaunchKernelGGL(snappy_decode_lanes_kernel, dim3((a.n_chunks + 63u) / 64u), dim3(64), 0, s, a, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+        return;
+    }
+    if (lane_share == 0) return;
+    const uint64_t maxn = ((uint64_t)a.n_chunks + kLaneShareDen - 1u) / kLaneShareDen * lane_share;
+    const uint32_t* l = (const uint32_t*)lists;
+    hipLaunchKernelGGL(snappy_decode_lanes_kernel, dim3((unsigned)((maxn + 63u) / 64u)), dim3(64), 0, s, a, l + 4, l);
 }
 
 }  // namespace cj

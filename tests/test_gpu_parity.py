@@ -71,7 +71,7 @@ def test_decode_malformed_matches_oracle(eng, golden, mapping):
     ms = [m for m in golden["malformed_snappy"]]
     caps = [max(oracle.snappy_decompress_len(b64d(m["data"])), 0) for m in ms]
     caps = [min(c, 1 << 20) for c in caps]
-    res, outs = eng.batch_host(SNAPPY, DEC, 0, [b64d(m["data"]) for m in ms], caps)
+    res, outs = eng.batch_host(SNAPPY, DEC, mapping, [b64d(m["data"]) for m in ms], caps)
     for m, c, r, o in zip(ms, caps, res, outs):
         er, eo = oracle.snappy_decompress(b64d(m["data"]), c)
         assert r == er, (m["src"], m["kind"], m["k"], r, er)
@@ -232,5 +232,41 @@ def test_default_pipeline_mixed_large_batch(eng):
         else:
             assert res[i] == er, (i, i % 48, res[i], er)
             assert out[int(off[i]):int(off[i]) + er].tobytes() == eo, (i, i % 48)
+            assert (out[int(off[i]) + caps[i]:int(off[i]) + caps[i] + 5] == 0xAB).all()
+    assert n_bad > 100
+
+
+def test_default_pipeline_mixed_large_batch_snappy(eng):
+    """Snappy twin of the test above: classify by ratio -> lane kernel (aux stream) || wave kernel."""
+    import random
+    rnd = random.Random(12)
+    uniq = []
+    for i in range(40):
+        k = i % 8
+        if k == 0: raw = oracle.synth_v1(65536, i)
+        elif k == 1: raw = bytes(65536)
+        elif k == 2: raw = hashlib.shake_256(b"s%d" % i).digest(65536)
+        elif k == 3: raw = oracle.synth_v1(rnd.randrange(1, 65536), i)
+        elif k == 4: raw = (b"abcdefgh" * 9000)[:rnd.randrange(20, 65536)]
+        elif k == 5: raw = oracle.synth_v1(70000, i)
+        elif k == 6: raw = oracle.synth_v1(4096, i) + bytes(3000) + hashlib.shake_256(b"y").digest(5000)
+        else: raw = b"tiny%d" % i
+        blk = oracle.snappy_compress(raw)[1]
+        if i % 16 == 7:
+            b = bytearray(blk); b[len(b) // 2] ^= 0x5A; blk = bytes(b[:max(3, len(b) - 9)])
+        uniq.append((raw, blk))
+    n = 8192 + 21
+    blobs = [uniq[i % 40][1] for i in range(n)]
+    caps = [len(uniq[i % 40][0]) for i in range(n)]
+    res, out, off = _device_batch(eng, SNAPPY, DEC, 0, blobs, caps)
+    exp = [oracle.snappy_decompress(b, len(r)) for r, b in uniq]
+    n_bad = 0
+    for i in range(n):
+        er, eo = exp[i % 40]
+        assert res[i] == er, (i, i % 40, res[i], er)
+        if er < 0:
+            n_bad += 1
+        else:
+            assert out[int(off[i]):int(off[i]) + er].tobytes() == eo, (i, i % 40)
             assert (out[int(off[i]) + caps[i]:int(off[i]) + caps[i] + 5] == 0xAB).all()
     assert n_bad > 100

@@ -112,7 +112,7 @@ typedef enum { CJ_OP_DECOMPRESS = 0, CJ_OP_COMPRESS = 1 } cj_op;
 #define CJ_LANE_SHARE_DEFAULT 8
 /* Snappy: share (n/20) of the mid-ratio chunks of a large batch decoded by the lane-per-chunk kernel, concurrently
  * with the wavefront-per-chunk kernel (env CJ_SNAPPY_LANE_SHARE; 0 = wave kernel only) */
-#define CJ_SNAPPY_LANE_SHARE_DEFAULT 14
+#define CJ_SNAPPY_LANE_SHARE_DEFAULT 20   /* measured 116 / 170 / 206 / 228 GB/s for shares 0 / 10 / 14 / 20 on synth-v1 */
 /* likewise the share decoded by the wavefront-per-chunk kernel on a second auxiliary stream (env CJ_WAVE_SHARE) */
 #define CJ_WAVE_SHARE_DEFAULT 0   /* measured: any wave share slows the batch (441 -> 355 -> 294 GB/s for 0/1/2): its waves steal issue slots from the issue-bound LDS decoder */
 

@@ -21,7 +21,10 @@
 
 namespace cj {
 
-constexpr uint32_t kLdsThreads = 1024;
+#ifndef CJ_LDS_THREADS
+#define CJ_LDS_THREADS 1024
+#endif
+constexpr uint32_t kLdsThreads = CJ_LDS_THREADS;
 constexpr uint32_t kLdsWaves = kLdsThreads / 64;
 constexpr uint32_t kOffOut = 0;
 constexpr uint32_t kOffBits = 65536;                 // 2048 x u32: one ready bit per output byte

@@ -40,6 +40,21 @@ struct DevBuf {
 
 }  // namespace
 
+struct PinnedBuf {          // page-locked host staging (full PCIe rate, truly asynchronous copies)
+    uint8_t* p = nullptr;
+    size_t cap = 0;
+    bool reserve(size_t n) {
+        if (n <= cap) return true;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        size_t want = n + n / 4 + 4096;
+        if (!hip_ok(hipHostMalloc((void**)&p, want, hipHostMallocDefault), "hipHostMalloc")) { p = nullptr; return false; }
+        cap = want;
+        return true;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 struct cj_engine {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -50,7 +65,7 @@ struct cj_engine {
     hipEvent_t scratch_free = nullptr;    // recorded after the last kernel that reads the scratch
     hipStream_t aux = nullptr, aux2 = nullptr;   // the lane- / wave-kernel shares of a large LZ4-decode batch run here, concurrently
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
-    std::vector<uint8_t> h_in, h_out;
+    PinnedBuf h_in, h_out;
     std::vector<uint64_t> h_meta;
 };
 
@@ -288,6 +303,7 @@ void cj_engine_destroy(cj_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     e->d_in.release(); e->d_out.release(); e->d_meta.release(); e->d_sync.release(); e->d_pmeta.release(); e->d_lanelist.release();
+    e->h_in.release(); e->h_out.release();
     if (e->scratch_free) (void)hipEventDestroy(e->scratch_free);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
@@ -377,10 +393,10 @@ int cj_batch_host(cj_engine* e, cj_codec codec, cj_op op, uint32_t flags, size_t
     if (n == 1) {
         if (in_lens[0]) HIP_TRY(hipMemcpyAsync(d_in, in_ptrs[0], in_lens[0], hipMemcpyHostToDevice, e->stream), CJ_E_NO_DEVICE);
     } else {
-        e->h_in.resize(in_total);
+        if (!e->h_in.reserve(in_total)) return CJ_E_OOM;
         for (size_t i = 0; i < n; i++)
-            if (in_lens[i]) std::memcpy(e->h_in.data() + m[i], in_ptrs[i], in_lens[i]);
-        if (in_total) HIP_TRY(hipMemcpyAsync(d_in, e->h_in.data(), in_total, hipMemcpyHostToDevice, e->stream), CJ_E_NO_DEVICE);
+            if (in_lens[i]) std::memcpy(e->h_in.p + m[i], in_ptrs[i], in_lens[i]);
+        if (in_total) HIP_TRY(hipMemcpyAsync(d_in, e->h_in.p, in_total, hipMemcpyHostToDevice, e->stream), CJ_E_NO_DEVICE);
     }
     HIP_TRY(hipMemcpyAsync(d_meta, m.data(), 4 * n * 8, hipMemcpyHostToDevice, e->stream), CJ_E_NO_DEVICE);
 
@@ -402,12 +418,12 @@ int cj_batch_host(cj_engine* e, cj_codec codec, cj_op op, uint32_t flags, size_t
     uint64_t span = 0;
     for (size_t i = 0; i < n; i++)
         if (result[i] > 0 && m[2 * n + i] + (uint64_t)result[i] > span) span = m[2 * n + i] + (uint64_t)result[i];
-    e->h_out.resize(span);
-    if (span) HIP_TRY(hipMemcpy(e->h_out.data(), d_out, span, hipMemcpyDeviceToHost), CJ_E_NO_DEVICE);
+    if (!e->h_out.reserve(span)) return CJ_E_OOM;
+    if (span) HIP_TRY(hipMemcpy(e->h_out.p, d_out, span, hipMemcpyDeviceToHost), CJ_E_NO_DEVICE);
     for (size_t i = 0; i < n; i++) {
         if (result[i] <= 0) continue;
         if ((uint64_t)result[i] > out_caps[i]) { result[i] = CJ_E_COMPRESS_FAILED; continue; }
-        std::memcpy(out_ptrs[i], e->h_out.data() + m[2 * n + i], (size_t)result[i]);
+        std::memcpy(out_ptrs[i], e->h_out.p + m[2 * n + i], (size_t)result[i]);
     }
     return 0;
 }

@@ -25,7 +25,9 @@ def per_kernel(path):
 def main():
     fetch, nf = per_kernel(sys.argv[1])
     write, _ = per_kernel(sys.argv[2])
-    out = {"unit": "bytes per launch", "corrections": "KiB->B; FETCH_SIZE x2 (gfx950 wide coalesced reads); WRITE_SIZE as is (calibrated)",
+    out = {"unit": "bytes per launch",
+           "corrections": "KiB->B; FETCH_SIZE x2 (gfx950 wide coalesced reads; uncalibrated upper bound for the lane kernel's divergent 16 B reads); "
+                          "WRITE_SIZE as is (calibrated on the LDS decoder's exact output size)",
            "kernels": {}}
     total = 0.0
     for k in sorted(fetch):

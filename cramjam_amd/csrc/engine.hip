@@ -4,11 +4,13 @@
 // in this library: if no device is usable the entry points return CJ_E_NO_DEVICE.
 #include "cj_common.hpp"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -39,6 +41,21 @@ struct DevBuf {
 };
 
 }  // namespace
+
+// host-side pack/scatter of many small buffers is memcpy-bound on one core (~20 GB/s); split it over a few threads
+template <class F>
+void parallel_chunks(size_t n, size_t total_bytes, F&& fn) {
+    unsigned t = total_bytes > (32u << 20) ? std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+    if (t <= 1 || n < 2 * t) { fn(0, n); return; }
+    std::vector<std::thread> th;
+    const size_t per = (n + t - 1) / t;
+    for (unsigned k = 0; k < t; k++) {
+        const size_t a = k * per, b = std::min(n, a + per);
+        if (a >= b) break;
+        th.emplace_back([=, &fn] { fn(a, b); });
+    }
+    for (auto& x : th) x.join();
+}
 
 struct PinnedBuf {          // page-locked host staging (full PCIe rate, truly asynchronous copies)
     uint8_t* p = nullptr;
@@ -394,8 +411,10 @@ int cj_batch_host(cj_engine* e, cj_codec codec, cj_op op, uint32_t flags, size_t
         if (in_lens[0]) HIP_TRY(hipMemcpyAsync(d_in, in_ptrs[0], in_lens[0], hipMemcpyHostToDevice, e->stream), CJ_E_NO_DEVICE);
     } else {
         if (!e->h_in.reserve(in_total)) return CJ_E_OOM;
-        for (size_t i = 0; i < n; i++)
-            if (in_lens[i]) std::memcpy(e->h_in.p + m[i], in_ptrs[i], in_lens[i]);
+        parallel_chunks(n, in_total, [&](size_t a, size_t b) {
+            for (size_t i = a; i < b; i++)
+                if (in_lens[i]) std::memcpy(e->h_in.p + m[i], in_ptrs[i], in_lens[i]);
+        });
         if (in_total) HIP_TRY(hipMemcpyAsync(d_in, e->h_in.p, in_total, hipMemcpyHostToDevice, e->stream), CJ_E_NO_DEVICE);
     }
     HIP_TRY(hipMemcpyAsync(d_meta, m.data(), 4 * n * 8, hipMemcpyHostToDevice, e->stream), CJ_E_NO_DEVICE);
@@ -420,11 +439,13 @@ int cj_batch_host(cj_engine* e, cj_codec codec, cj_op op, uint32_t flags, size_t
         if (result[i] > 0 && m[2 * n + i] + (uint64_t)result[i] > span) span = m[2 * n + i] + (uint64_t)result[i];
     if (!e->h_out.reserve(span)) return CJ_E_OOM;
     if (span) HIP_TRY(hipMemcpy(e->h_out.p, d_out, span, hipMemcpyDeviceToHost), CJ_E_NO_DEVICE);
-    for (size_t i = 0; i < n; i++) {
-        if (result[i] <= 0) continue;
-        if ((uint64_t)result[i] > out_caps[i]) { result[i] = CJ_E_COMPRESS_FAILED; continue; }
-        std::memcpy(out_ptrs[i], e->h_out.p + m[2 * n + i], (size_t)result[i]);
-    }
+    parallel_chunks(n, span, [&](size_t a, size_t b) {
+        for (size_t i = a; i < b; i++) {
+            if (result[i] <= 0) continue;
+            if ((uint64_t)result[i] > out_caps[i]) { result[i] = CJ_E_COMPRESS_FAILED; continue; }
+            std::memcpy(out_ptrs[i], e->h_out.p + m[2 * n + i], (size_t)result[i]);
+        }
+    });
     return 0;
 }
 

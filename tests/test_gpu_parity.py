@@ -270,3 +270,84 @@ def test_default_pipeline_mixed_large_batch_snappy(eng):
             assert out[int(off[i]):int(off[i]) + er].tobytes() == eo, (i, i % 40)
             assert (out[int(off[i]) + caps[i]:int(off[i]) + caps[i] + 5] == 0xAB).all()
     assert n_bad > 100
+
+
+def test_mixed_codecs_256k_concurrent_streams():
+    """BASELINE configs[4] at reduced N: interleaved LZ4-block / Snappy-raw 256 KiB chunks, one engine (= one HIP
+    stream) per codec, both batches in flight at once; every chunk checked against the oracle."""
+    e_lz4, e_sn = N.Engine(0), N.Engine(0)
+    S = 262144
+    raws = [oracle.synth_v1(S, 100 + i) for i in range(24)]
+    raws[2] = bytes(S); raws[3] = hashlib.shake_256(b"m").digest(S)
+    lz = [(i, oracle.lz4_compress_raw(r)[1]) for i, r in enumerate(raws) if i % 2 == 0]
+    sn = [(i, oracle.snappy_compress(r)[1]) for i, r in enumerate(raws) if i % 2 == 1]
+
+    def submit(eng, codec, items):
+        n = len(items)
+        blobs = [b for _, b in items]
+        in_len = np.array([len(b) for b in blobs], np.uint64)
+        in_off = np.concatenate([[0], np.cumsum(in_len + 7)[:-1]]).astype(np.uint64)
+        packed = np.zeros(int(in_off[-1] + in_len[-1]) + 16, np.uint8)
+        for k, b in enumerate(blobs):
+            packed[int(in_off[k]):int(in_off[k]) + len(b)] = np.frombuffer(b, np.uint8)
+        out_off = (np.arange(n) * S).astype(np.uint64); out_cap = np.full(n, S, np.uint64)
+        d_in = eng.alloc(packed.nbytes); d_out = eng.alloc(n * S); d_meta = eng.alloc(5 * n * 8)
+        eng.h2d(d_in, packed); eng.h2d(d_meta, np.concatenate([in_off, in_len, out_off, out_cap]))
+        eng.batch_device(codec, DEC, 0, n, d_in, d_meta, d_meta + 8 * n, d_out, d_meta + 16 * n, d_meta + 24 * n, d_meta + 32 * n)
+        return d_in, d_out, d_meta, n
+
+    h1 = submit(e_lz4, LZ4, lz)            # asynchronous: returns after enqueue
+    h2 = submit(e_sn, SNAPPY, sn)
+    for eng, (d_in, d_out, d_meta, n), items in ((e_lz4, h1, lz), (e_sn, h2, sn)):
+        eng.sync()
+        res = eng.d2h(d_meta + 32 * n, 8 * n, "int64")
+        out = eng.d2h(d_out, n * S)
+        for k, (i, _) in enumerate(items):
+            assert res[k] == S and out[k * S:(k + 1) * S].tobytes() == raws[i], (i, res[k])
+        for p in (d_in, d_out, d_meta):
+            eng.free(p)
+    e_lz4.close(); e_sn.close()
+
+
+@pytest.mark.parametrize("codec", [LZ4, SNAPPY])
+def test_large_batch_compress_then_decompress_property(eng, codec):
+    """BASELINE configs[2]-style at 12 288 x 64 KiB: GPU compress -> GPU decompress (default large-batch pipelines)
+    must reproduce the input exactly for every chunk (device-side compare), and a sample of the GPU-compressed
+    blocks must decode with the CPU oracle (the stand-in for the reference's CPU decoder)."""
+    import torch
+    L = N.lib()
+    S, U, n = 65536, 512, 12288
+    dev = torch.device("cuda", 0)
+    raw = torch.empty(U * S, dtype=torch.uint8, device=dev)
+    N.check(L.cj_bench_synth_v1(raw.data_ptr(), S, S, 7000, U, 0x5EED, None))
+    torch.cuda.synchronize()
+    bound = L.cj_lz4_block_compress_bound(S, 0) if codec == LZ4 else L.cj_snappy_raw_max_compress_len(S)
+    stride = (bound + 15) & ~15
+    ids = np.arange(n, dtype=np.uint64)
+    comp = torch.zeros(n * stride, dtype=torch.uint8, device=dev)
+    m1 = torch.from_numpy(np.concatenate([(ids % U) * S, np.full(n, S, np.uint64), ids * stride, np.full(n, stride, np.uint64),
+                                          np.zeros(n, np.uint64)]).view(np.int64)).to(dev)
+    p = m1.data_ptr()
+    torch.cuda.synchronize()
+    eng.batch_device(codec, ENC, 0, n, raw.data_ptr(), p, p + 8 * n, comp.data_ptr(), p + 16 * n, p + 24 * n, p + 32 * n)
+    eng.sync()
+    clen = m1[4 * n:].cpu().numpy()
+    assert (clen > 0).all() and (clen <= bound).all()
+    out = torch.full((n * S,), 0xCD, dtype=torch.uint8, device=dev)
+    m2 = torch.from_numpy(np.concatenate([ids * stride, clen.astype(np.uint64), ids * S, np.full(n, S, np.uint64),
+                                          np.zeros(n, np.uint64)]).view(np.int64)).to(dev)
+    q = m2.data_ptr()
+    torch.cuda.synchronize()
+    eng.batch_device(codec, DEC, 0, n, comp.data_ptr(), q, q + 8 * n, out.data_ptr(), q + 16 * n, q + 24 * n, q + 32 * n)
+    eng.sync()
+    assert (m2[4 * n:].cpu().numpy() == S).all()
+    mism = torch.zeros(1, dtype=torch.int64, device=dev)
+    N.check(L.cj_bench_compare(out.data_ptr(), q + 16 * n, raw.data_ptr(), S, U, S, n, mism.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert int(mism.item()) == 0
+    comp_h = comp.cpu().numpy(); raw_h = raw.cpu().numpy()
+    for i in range(0, n, 251):
+        blob = comp_h[i * stride:i * stride + int(clen[i])].tobytes()
+        want = raw_h[(i % U) * S:(i % U + 1) * S].tobytes()
+        got = oracle.lz4_decompress_raw(blob, S) if codec == LZ4 else oracle.snappy_decompress(blob)
+        assert got == (S, want), i

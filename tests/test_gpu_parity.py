@@ -314,38 +314,38 @@ def test_large_batch_compress_then_decompress_property(eng, codec):
     """BASELINE configs[2]-style at 12 288 x 64 KiB: GPU compress -> GPU decompress (default large-batch pipelines)
     must reproduce the input exactly for every chunk (device-side compare), and a sample of the GPU-compressed
     blocks must decode with the CPU oracle (the stand-in for the reference's CPU decoder)."""
-    import torch
     L = N.lib()
     S, U, n = 65536, 512, 12288
-    dev = torch.device("cuda", 0)
-    raw = torch.empty(U * S, dtype=torch.uint8, device=dev)
-    N.check(L.cj_bench_synth_v1(raw.data_ptr(), S, S, 7000, U, 0x5EED, None))
-    torch.cuda.synchronize()
+    d_raw = eng.alloc(U * S)
+    N.check(L.cj_bench_synth_v1(d_raw, S, S, 7000, U, 0x5EED, None))
+    N.check(L.cj_engine_sync(eng.h))
+    import ctypes as C
     bound = L.cj_lz4_block_compress_bound(S, 0) if codec == LZ4 else L.cj_snappy_raw_max_compress_len(S)
     stride = (bound + 15) & ~15
     ids = np.arange(n, dtype=np.uint64)
-    comp = torch.zeros(n * stride, dtype=torch.uint8, device=dev)
-    m1 = torch.from_numpy(np.concatenate([(ids % U) * S, np.full(n, S, np.uint64), ids * stride, np.full(n, stride, np.uint64),
-                                          np.zeros(n, np.uint64)]).view(np.int64)).to(dev)
-    p = m1.data_ptr()
-    torch.cuda.synchronize()
-    eng.batch_device(codec, ENC, 0, n, raw.data_ptr(), p, p + 8 * n, comp.data_ptr(), p + 16 * n, p + 24 * n, p + 32 * n)
+    d_comp = eng.alloc(n * stride)
+    d_m1 = eng.alloc(5 * n * 8)
+    eng.h2d(d_m1, np.concatenate([(ids % U) * S, np.full(n, S, np.uint64), ids * stride, np.full(n, stride, np.uint64), np.zeros(n, np.uint64)]))
+    # the generator ran on the NULL stream, the engine stream is non-blocking: make the data visible first
+    eng.d2h(d_raw, 16)
+    eng.batch_device(codec, ENC, 0, n, d_raw, d_m1, d_m1 + 8 * n, d_comp, d_m1 + 16 * n, d_m1 + 24 * n, d_m1 + 32 * n)
     eng.sync()
-    clen = m1[4 * n:].cpu().numpy()
+    clen = eng.d2h(d_m1 + 32 * n, 8 * n, "int64")
     assert (clen > 0).all() and (clen <= bound).all()
-    out = torch.full((n * S,), 0xCD, dtype=torch.uint8, device=dev)
-    m2 = torch.from_numpy(np.concatenate([ids * stride, clen.astype(np.uint64), ids * S, np.full(n, S, np.uint64),
-                                          np.zeros(n, np.uint64)]).view(np.int64)).to(dev)
-    q = m2.data_ptr()
-    torch.cuda.synchronize()
-    eng.batch_device(codec, DEC, 0, n, comp.data_ptr(), q, q + 8 * n, out.data_ptr(), q + 16 * n, q + 24 * n, q + 32 * n)
+    d_out = eng.alloc(n * S)
+    N.check(L.cj_memset_dev(eng.h, d_out, 0xCD, n * S))
+    d_m2 = eng.alloc(5 * n * 8)
+    eng.h2d(d_m2, np.concatenate([ids * stride, clen.astype(np.uint64), ids * S, np.full(n, S, np.uint64), np.zeros(n, np.uint64)]))
+    eng.batch_device(codec, DEC, 0, n, d_comp, d_m2, d_m2 + 8 * n, d_out, d_m2 + 16 * n, d_m2 + 24 * n, d_m2 + 32 * n)
     eng.sync()
-    assert (m2[4 * n:].cpu().numpy() == S).all()
-    mism = torch.zeros(1, dtype=torch.int64, device=dev)
-    N.check(L.cj_bench_compare(out.data_ptr(), q + 16 * n, raw.data_ptr(), S, U, S, n, mism.data_ptr(), None))
-    torch.cuda.synchronize()
-    assert int(mism.item()) == 0
-    comp_h = comp.cpu().numpy(); raw_h = raw.cpu().numpy()
+    assert (eng.d2h(d_m2 + 32 * n, 8 * n, "int64") == S).all()
+    d_mism = eng.alloc(8)
+    N.check(L.cj_memset_dev(eng.h, d_mism, 0, 8))
+    N.check(L.cj_bench_compare(d_out, d_m2 + 16 * n, d_raw, S, U, S, n, d_mism, None))
+    assert int(eng.d2h(d_mism, 8, "int64")[0]) == 0
+    comp_h = eng.d2h(d_comp, n * stride); raw_h = eng.d2h(d_raw, U * S)
+    for p_ in (d_raw, d_comp, d_m1, d_out, d_m2, d_mism):
+        eng.free(p_)
     for i in range(0, n, 251):
         blob = comp_h[i * stride:i * stride + int(clen[i])].tobytes()
         want = raw_h[(i % U) * S:(i % U + 1) * S].tobytes()

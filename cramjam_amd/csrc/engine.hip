@@ -215,9 +215,12 @@ int launch_slice(cj_engine* e, cj_codec codec, cj_op op, const cj::BatchArgs& a,
 // Very large batches are submitted in slices: the lane-per-chunk kernels lose efficiency when several hundred
 // thousand chunks are in flight at once (their random match reads thrash L2 and the write amplification grows:
 // 1 M chunks in one go ran at 299 GB/s vs 430 GB/s at 100 k), and the parse/LDS scratch stays bounded.
-constexpr size_t kSliceChunks = 131072;
-
 int launch(cj_engine* e, cj_codec codec, cj_op op, const cj::BatchArgs& a, hipStream_t s) {
+    static const size_t kSliceChunks = [] {
+        const char* v = std::getenv("CJ_SLICE_CHUNKS");
+        size_t x = v ? (size_t)std::strtoull(v, nullptr, 10) : (size_t)CJ_SLICE_CHUNKS_DEFAULT;
+        return x < 8192 ? (size_t)8192 : x;
+    }();
     if (op != CJ_OP_DECOMPRESS || a.n_chunks <= kSliceChunks) return launch_slice(e, codec, op, a, s);
     for (size_t start = 0; start < a.n_chunks; start += kSliceChunks) {
         cj::BatchArgs b = a;

@@ -110,6 +110,8 @@ typedef enum { CJ_OP_DECOMPRESS = 0, CJ_OP_COMPRESS = 1 } cj_op;
 /* share (n/20) of the short-sequence chunks of such a batch that is decoded by the lane-per-chunk kernel on an
  * internal auxiliary stream, concurrently with the LDS workgroup decoder (env CJ_LANE_SHARE overrides; 0 = off) */
 #define CJ_LANE_SHARE_DEFAULT 8
+/* decode batches larger than this are submitted in slices of this many chunks (env CJ_SLICE_CHUNKS) */
+#define CJ_SLICE_CHUNKS_DEFAULT 131072
 /* Snappy: share (n/20) of the mid-ratio chunks of a large batch decoded by the lane-per-chunk kernel, concurrently
  * with the wavefront-per-chunk kernel (env CJ_SNAPPY_LANE_SHARE; 0 = wave kernel only) */
 #define CJ_SNAPPY_LANE_SHARE_DEFAULT 20   /* measured 116 / 170 / 206 / 228 GB/s for shares 0 / 10 / 14 / 20 on synth-v1 */

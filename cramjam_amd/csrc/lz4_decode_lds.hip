@@ -1,22 +1,25 @@
 // lz4_decode_lds.hip — LZ4 *block* decoder, one WORKGROUP (16 wavefronts) per chunk, with the whole
-// 64 KiB output window, the compressed chunk and a sequence table resident in LDS (160 KiB/CU on gfx950).
+// 64 KiB output window, the compressed chunk, a sequence table and a ready bitmap resident in LDS
+// (160 KiB/CU on gfx950).
 //
 // Runs after lz4_parse_kernel (lz4_decode_lanes.hip), which validated the stream, computed the decoded
-// size and left an (ip, op) sync point every 8 sequences.  Same results as the other two mappings
+// size and left an (ip, op) sync point every 8 sequences.  Same results as the other mappings
 // (reference call sites /root/reference/src/lz4.rs:88,90,164,168).
 //
 // Why: with one wave/lane per chunk every match copy is a dependent read of the chunk's own earlier
 // output somewhere in the last 64 KiB — an HBM round trip of a 128 B line for ~18 useful bytes.  Here
 // the history never leaves the CU: HBM sees exactly the algorithmic bytes (compressed chunk in with
-// 16 B/lane coalesced loads, 64 KiB out with 16 B/lane coalesced stores), and the serial token chain
-// is broken by the sync points: phases per chunk
-//   S0 stage compressed bytes into LDS, clear the ready bitmap
-//   D1 one thread per sync point re-walks 8 sequences in LDS and writes 16 B sequence records
-//   D2 one lane per sequence copies its literals LDS->LDS and marks them ready (bitmap: 1 bit/byte)
-//   D3 one lane per sequence resolves its match as soon as the bitmap says its source bytes are final;
-//      the earliest unresolved match is always ready, so the spin is deadlock-free (and bounded anyway);
-//      long copies (> 64 B) are done cooperatively by the whole wavefront
-//   D4 stream the finished window to HBM
+// 16 B/lane coalesced loads, 64 KiB out with 16 B/lane coalesced stores; PMC-verified), and the serial
+// token chain is broken by the sync points.  Phases per chunk (cycles measured on the benchmark data):
+//   S0  4.4k  stage compressed bytes into LDS, clear the ready bitmap
+//   D1 10.0k  one thread per sync point re-walks 8 sequences in LDS and writes 16 B sequence records
+//   D2 11.2k  literals: one lane per sequence, aligned-dword reads + one wait + head/dword/tail stores
+//   D3 60.5k  matches: one lane per sequence, copied as soon as the ready bitmap covers its source bytes;
+//             the earliest unresolved match is always ready, so the spin is deadlock-free (and bounded);
+//             runs >= 512 B are copied cooperatively by the whole wavefront
+//   D4  1.5k  stream the finished window to HBM
+// D3 is instruction-issue bound (the dependency DAG is ~25 levels x 100-500 matches; only ~4 of 64 lanes
+// are ready per poll); DESIGN.md §5.1 lists the restructurings that were measured and lost.
 #include "lz4_lane_walk.hpp"
 
 namespace cj {
@@ -25,7 +28,6 @@ namespace cj {
 #define CJ_LDS_THREADS 1024
 #endif
 constexpr uint32_t kLdsThreads = CJ_LDS_THREADS;
-constexpr uint32_t kLdsWaves = kLdsThreads / 64;
 constexpr uint32_t kOffOut = 0;
 constexpr uint32_t kOffBits = 65536;                 // 2048 x u32: one ready bit per output byte
 constexpr uint32_t kOffIn = kOffBits + 8192;         // compressed bytes, then the record table
@@ -55,22 +57,8 @@ __device__ __forceinline__ uint2 lds_ld64(uint32_t a) {
                  : "=&v"(v.x), "=&v"(v.y) : "v"(a) : "memory");
     return v;
 }
-__device__ __forceinline__ uint4 lds_ld128(uint32_t a) {
-    uint4 v;
-    asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:4\n\tds_read_b32 %2, %4 offset:8\n\t"
-                 "ds_read_b32 %3, %4 offset:12\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(v.x), "=&v"(v.y), "=&v"(v.z), "=&v"(v.w) : "v"(a) : "memory");
-    return v;
-}
 __device__ __forceinline__ void lds_st32(uint32_t a, uint32_t v) {
     asm volatile("ds_write_b32 %0, %1" :: "v"(a), "v"(v) : "memory");
-}
-__device__ __forceinline__ void lds_st64(uint32_t a, uint2 v) {
-    asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:4" :: "v"(a), "v"(v.x), "v"(v.y) : "memory");
-}
-__device__ __forceinline__ void lds_st128(uint32_t a, uint4 v) {
-    asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:4\n\tds_write_b32 %0, %3 offset:8\n\t"
-                 "ds_write_b32 %0, %4 offset:12" :: "v"(a), "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w) : "memory");
 }
 __device__ __forceinline__ uint32_t lds_ld8(uint32_t a) {
     uint32_t v;
@@ -106,13 +94,6 @@ __device__ __forceinline__ DW<18> lds_ld_aligned18(uint32_t a) {
     DW<18> r;
     asm volatile("ds_read_b32 %0, %18\n\tds_read_b32 %1, %18 offset:4\n\tds_read_b32 %2, %18 offset:8\n\tds_read_b32 %3, %18 offset:12\n\tds_read_b32 %4, %18 offset:16\n\tds_read_b32 %5, %18 offset:20\n\tds_read_b32 %6, %18 offset:24\n\tds_read_b32 %7, %18 offset:28\n\tds_read_b32 %8, %18 offset:32\n\tds_read_b32 %9, %18 offset:36\n\tds_read_b32 %10, %18 offset:40\n\tds_read_b32 %11, %18 offset:44\n\tds_read_b32 %12, %18 offset:48\n\tds_read_b32 %13, %18 offset:52\n\tds_read_b32 %14, %18 offset:56\n\tds_read_b32 %15, %18 offset:60\n\tds_read_b32 %16, %18 offset:64\n\tds_read_b32 %17, %18 offset:68\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(r.w[0]), "=&v"(r.w[1]), "=&v"(r.w[2]), "=&v"(r.w[3]), "=&v"(r.w[4]), "=&v"(r.w[5]), "=&v"(r.w[6]), "=&v"(r.w[7]), "=&v"(r.w[8]), "=&v"(r.w[9]), "=&v"(r.w[10]), "=&v"(r.w[11]), "=&v"(r.w[12]), "=&v"(r.w[13]), "=&v"(r.w[14]), "=&v"(r.w[15]), "=&v"(r.w[16]), "=&v"(r.w[17]) : "v"(a) : "memory");
-    return r;
-}
-// 10 aligned source dwords AND the two ready-bitmap words covering the source, one wait for all
-__device__ __forceinline__ DW<10> lds_ld_aligned10_poll(uint32_t a, uint32_t bits_addr, uint2& bm) {
-    DW<10> r;
-    asm volatile("ds_read_b32 %10, %13\n\tds_read_b32 %11, %13 offset:4\n\tds_read_b32 %0, %12\n\tds_read_b32 %1, %12 offset:4\n\tds_read_b32 %2, %12 offset:8\n\tds_read_b32 %3, %12 offset:12\n\tds_read_b32 %4, %12 offset:16\n\tds_read_b32 %5, %12 offset:20\n\tds_read_b32 %6, %12 offset:24\n\tds_read_b32 %7, %12 offset:28\n\tds_read_b32 %8, %12 offset:32\n\tds_read_b32 %9, %12 offset:36\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(r.w[0]), "=&v"(r.w[1]), "=&v"(r.w[2]), "=&v"(r.w[3]), "=&v"(r.w[4]), "=&v"(r.w[5]), "=&v"(r.w[6]), "=&v"(r.w[7]), "=&v"(r.w[8]), "=&v"(r.w[9]), "=&v"(bm.x), "=&v"(bm.y) : "v"(a), "v"(bits_addr) : "memory");
     return r;
 }
 
@@ -156,11 +137,6 @@ __device__ __forceinline__ uint32_t wave_tier(uint32_t n, bool active) {       /
     return 16u;
 }
 
-// overlapping LZ77 copy (off < m) for one lane, in order, byte by byte (rare for short matches)
-__device__ __forceinline__ void lds_match_overlap(uint32_t dst, uint32_t off, uint32_t m) {
-    const uint32_t src = dst - off;
-    for (uint32_t k = 0; k < m; k++) lds_st8(dst + k, lds_ld8(src + k));
-}
 
 // ---- ready bitmap: one bit per output byte ---------------------------------------------------
 __device__ __forceinline__ void bits_set(uint32_t* bits, uint32_t lo, uint32_t hi) {     // [lo, hi), hi > lo

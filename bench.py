@@ -183,7 +183,7 @@ def main():
         ph = (C.c_ulonglong * 8)()
         L.cj_debug_lds_phase_cycles(ph, 1)
         nb = max(int(ph[5]), 1)
-        print("LDS decoder cycles/chunk: S0 %d  D1 %d  D2 %d  D3 %d  D4 %d  (blocks %d)  D3 wave-iterations/chunk %d, ready lanes/iteration %.1f" % (ph[0] // nb, ph[1] // nb, ph[2] // nb, ph[3] // nb, ph[4] // nb, nb, ph[6] // nb, ph[7] / max(ph[6], 1)), file=sys.stderr)
+        print("LDS decoder cycles/chunk: S0 %d  D1 %d  D2 %d  D3 %d  D4 %d  (blocks %d)" % (ph[0] // nb, ph[1] // nb, ph[2] // nb, ph[3] // nb, ph[4] // nb, nb), file=sys.stderr)
 
     # ---- verify at full size: every chunk's result and every output byte ----
     res = meta[4 * NCH:].cpu().numpy()

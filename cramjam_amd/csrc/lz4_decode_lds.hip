@@ -310,9 +310,9 @@ __global__ __launch_bounds__(kLdsThreads) void lz4_decode_lds_kernel(BatchArgs a
         // ---- D3: matches, one lane per sequence, dependency-exact through the ready bitmap.  Waves take batches of 64
         //      consecutive sequences round-robin; a lane copies its match as soon as the bitmap says its source bytes
         //      are final.  The earliest unresolved match is always ready, so the spin is deadlock-free (and bounded).
-        //      (Measured alternatives, all slower on the 24-B-per-sequence benchmark data — the dependency DAG is ~25
-        //      levels deep and only ~4 of 64 lanes are ready per poll: refill from a work counter, fewer resolver waves,
-        //      tiered dword copies with a single wait, two-matches-per-pass cooperative copies.  See DESIGN.md §5.)
+        //      The loop is instruction-issue bound (~650 sparse iterations per chunk, ~4 ready lanes each), so
+        //      everything that does not change per poll is hoisted: the two bitmap words + masks that decide
+        //      readiness and the two words + masks that publish the result are computed once per batch.
         for (uint32_t base = wave * 64u; base < nrec; base += kLdsThreads) {
             const uint32_t r = base + lane;
             uint4 rec = make_uint4(0, 0, 0, 0);
@@ -321,19 +321,43 @@ __global__ __launch_bounds__(kLdsThreads) void lz4_decode_lds_kernel(BatchArgs a
             const uint32_t src = dst - off;
             const uint32_t need = off < m ? off : m;          // distinct source bytes
             bool pending = m > 0u;
-            uint32_t spins = 0, dbg_iters = 0, dbg_ready = 0;
+            // fast lanes: source window and destination both fit two bitmap words and the copy is a plain tier copy
+            const bool fast = pending && m <= 32u && off >= m;
+            uint32_t pa = 0, pm0 = 0, pm1 = 0, qa = 0, qm0 = 0, qm1 = 0;
+            if (fast) {
+                const uint32_t sh = src & 31u, e = sh + need;                 // bits [sh, e) of the 64-bit window at word src>>5
+                pa = (uint32_t)(uintptr_t)(s_bits + (src >> 5));
+                pm0 = (e >= 32u ? ~0u : ((1u << e) - 1u)) & (~0u << sh);
+                pm1 = e > 32u ? ((1u << (e - 32u)) - 1u) : 0u;
+                const uint32_t dh = dst & 31u, de = dh + m;
+                qa = (uint32_t)(uintptr_t)(s_bits + (dst >> 5));
+                qm0 = (de >= 32u ? ~0u : ((1u << de) - 1u)) & (~0u << dh);
+                qm1 = de > 32u ? ((1u << (de - 32u)) - 1u) : 0u;
+            }
+            const bool any_slow = ballot64(pending && !fast) != 0ull;
+            uint32_t spins = 0;
             while (ballot64(pending) != 0ull) {
                 bool ready = false;
-                if (pending) ready = bits_ready(s_bits, src, src + need);
-                if (prof) { dbg_iters += 1u; dbg_ready += (uint32_t)__builtin_popcountll(ballot64(ready)); }
-                const bool go = ready && m < kLongRun;
-                if (ballot64(go)) {
-                    const bool plain = go && off >= m && m <= 64u;          // no self-overlap: single-wait dword copy
-                    if (ballot64(plain)) {
-                        const uint32_t tier = wave_tier(m, plain);
-                        if (plain) lds_copy_tier(tier, a_out + dst, a_out + src, m, dm);
+                if (pending && fast) {
+                    const uint2 w = lds_ld64(pa);
+                    ready = ((w.x & pm0) == pm0) && ((w.y & pm1) == pm1);
+                }
+                const uint64_t rm = ballot64(ready);
+                if (rm != 0ull) {
+                    const uint32_t tier = ballot64(ready && m > 16u) ? 32u : 16u;
+                    if (ready) {
+                        if (tier == 16u) lds_store_tier<16>(lds_ld_aligned6((a_out + src) & ~3u), a_out + dst, src & 3u, m, dm);
+                        else lds_store_tier<32>(lds_ld_aligned10((a_out + src) & ~3u), a_out + dst, src & 3u, m, dm);
+                        // publish: the copy's DS writes were issued before these DS atomics by the same wave (in order)
+                        asm volatile("ds_or_b32 %0, %1\n\tds_or_b32 %0, %2 offset:4" :: "v"(qa), "v"(qm0), "v"(qm1) : "memory");
+                        pending = false;
                     }
-                    if (go && !plain) {
+                }
+                if (any_slow) {
+                    // rare shapes: self-overlapping matches, matches longer than 32 bytes, RLE-like long runs
+                    bool sready = false;
+                    if (pending && !fast) sready = bits_ready(s_bits, src, src + need);
+                    if (sready && m < kLongRun) {
                         if (off >= 8u) {
                             uint32_t k = 0;
                             for (; k + 8u <= m; k += 8u) {
@@ -347,31 +371,28 @@ __global__ __launch_bounds__(kLdsThreads) void lz4_decode_lds_kernel(BatchArgs a
                         } else {
                             for (uint32_t k = 0; k < m; k++) s_out[dst + k] = s_out[src + k];
                         }
-                    }
-                    if (go) {
                         bits_set(s_bits, dst, dst + m);
                         pending = false;
                     }
-                }
-                uint64_t longm = ballot64(ready && m >= kLongRun);     // RLE-like: whole wavefront, 64 bytes per step
-                while (longm) {
-                    const uint32_t l = ctz64(longm);
-                    longm &= longm - 1ull;
-                    const uint32_t lm = rdlane(m, l), lo = rdlane(off, l), ld = rdlane(dst, l);
-                    const uint32_t ls = ld - lo;
-                    uint32_t rr = lane, step = 64u;
-                    if (lo <= 64u) { rr = lane % lo; step = 64u % lo; }
-                    for (uint32_t k = lane; k < lm; k += 64u) {           // periodic read: sources are the lo bytes before ld
-                        s_out[ld + k] = s_out[ls + (lo >= lm ? k : rr)];
-                        rr += step;
-                        if (rr >= lo) rr -= lo;
+                    uint64_t longm = ballot64(sready && m >= kLongRun);     // RLE-like: whole wavefront, 64 bytes per step
+                    while (longm) {
+                        const uint32_t l = ctz64(longm);
+                        longm &= longm - 1ull;
+                        const uint32_t lm = rdlane(m, l), lo = rdlane(off, l), ld = rdlane(dst, l);
+                        const uint32_t ls = ld - lo;
+                        uint32_t rr = lane, step = 64u;
+                        if (lo <= 64u) { rr = lane % lo; step = 64u % lo; }
+                        for (uint32_t k = lane; k < lm; k += 64u) {           // periodic read: sources are the lo bytes before ld
+                            s_out[ld + k] = s_out[ls + (lo >= lm ? k : rr)];
+                            rr += step;
+                            if (rr >= lo) rr -= lo;
+                        }
+                        wave_bits_set(s_bits, ld, ld + lm);
+                        if (lane == l) pending = false;
                     }
-                    wave_bits_set(s_bits, ld, ld + lm);
-                    if (lane == l) pending = false;
                 }
                 if (++spins > kSpinLimit) { *s_fail = 1u; break; }
             }
-            if (prof && lane == 0) { atomicAdd(s_next + 1, dbg_iters); atomicAdd(s_next + 2, dbg_ready); }
         }
         __syncthreads();
         CJ_PHASE_MARK(3);

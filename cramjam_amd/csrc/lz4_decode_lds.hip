@@ -212,6 +212,12 @@ __global__ __launch_bounds__(kLdsThreads) void lz4_decode_lds_kernel(BatchArgs a
     const bool prof = (a.flags & 0x1000u) != 0;
     unsigned long long t_prev = prof ? __builtin_readcyclecounter() : 0ull;
 
+    // sync point of this thread for the first slab: issued now so its global-load latency hides behind S0
+    const uint2* csync = sync + (size_t)c * kSyncStride;
+    const uint32_t nsp = (nseq + kSyncEvery - 1u) / kSyncEvery;
+    uint2 sp_first = make_uint2(0, 0);
+    if (tid < nsp) sp_first = csync[tid];
+
     // ---- S0: stage the compressed chunk (16 B aligned loads), clear the bitmap ----
     const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(in) & 15u);
     {
@@ -225,8 +231,6 @@ __global__ __launch_bounds__(kLdsThreads) void lz4_decode_lds_kernel(BatchArgs a
     uint4* table = reinterpret_cast<uint4*>(s_in + tb_off);
     const uint32_t tcap = (kInTableBytes - tb_off) >> 4;                 // records that fit
     const uint32_t sp_per_slab = tcap / kSyncEvery;                      // >= 1 by construction (iend <= kLdsInMax)
-    const uint32_t nsp = (nseq + kSyncEvery - 1u) / kSyncEvery;
-    const uint2* csync = sync + (size_t)c * kSyncStride;
     uint32_t* s_fail = reinterpret_cast<uint32_t*>(smem + kOffVars);
     uint32_t* s_next = reinterpret_cast<uint32_t*>(smem + kOffVars + 4u);   // next unclaimed record of the current slab
     if (tid == 0) { *s_fail = 0u; s_next[1] = 0u; s_next[2] = 0u; }
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(kLdsThreads) void lz4_decode_lds_kernel(BatchArgs a
 
         // ---- D1: expand sync points into sequence records ----
         for (uint32_t sp = sp0 + tid; sp < sp1; sp += kLdsThreads) {
-            const uint2 p = csync[sp];
+            const uint2 p = sp == tid ? sp_first : csync[sp];
             uint32_t ip = p.x + mis, op = p.y;
             uint32_t s = sp * kSyncEvery;
             for (uint32_t j = 0; j < kSyncEvery && s < nseq; j++, s++) {

@@ -30,6 +30,10 @@ SYMBOLS = {
     "cj_snappy_raw_decompress_len": (_i64, [_vp, _sz]),
     "cj_snappy_raw_compress": (_i64, [_vp, _sz, _vp, _sz]),
     "cj_snappy_raw_decompress": (_i64, [_vp, _sz, _vp, _sz]),
+    "cj_snappy_frame_max_compress_len": (_sz, [_sz]),
+    "cj_snappy_frame_compress": (_i64, [_vp, _sz, _vp, _sz]),
+    "cj_snappy_frame_decompress_len": (_i64, [_vp, _sz]),
+    "cj_snappy_frame_decompress": (_i64, [_vp, _sz, _vp, _sz]),
     "cj_engine_create": (_int, [_int, C.POINTER(_vp)]),
     "cj_engine_destroy": (None, [_vp]),
     "cj_engine_device": (_int, [_vp]),

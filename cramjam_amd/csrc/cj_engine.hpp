@@ -1,0 +1,96 @@
+// cj_engine.hpp — private host-side state shared by engine.hip (C-ABI, batch submission) and frame.hip
+// (framed formats on top of the batch engine).  Not part of the C-ABI.
+#pragma once
+#include "cj_common.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace cj {
+
+std::string& hip_err_slot();     // thread-local text behind cj_last_hip_error()
+
+inline bool hip_ok(hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    hip_err_slot() = std::string(what) + ": " + hipGetErrorString(e);
+    (void)hipGetLastError();
+    return false;
+}
+#define HIP_TRY(expr, ret) do { if (!cj::hip_ok((expr), #expr)) return (ret); } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    bool reserve(size_t n) {
+        if (n <= cap) return true;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = n + n / 4 + 4096;
+        if (!hip_ok(hipMalloc(&p, want), "hipMalloc")) { p = nullptr; return false; }
+        cap = want;
+        return true;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct PinnedBuf {          // page-locked host staging (full PCIe rate, truly asynchronous copies)
+    uint8_t* p = nullptr;
+    size_t cap = 0;
+    bool reserve(size_t n) {
+        if (n <= cap) return true;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        size_t want = n + n / 4 + 4096;
+        if (!hip_ok(hipHostMalloc((void**)&p, want, hipHostMallocDefault), "hipHostMalloc")) { p = nullptr; return false; }
+        cap = want;
+        return true;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+// host-side pack/scatter of many small buffers is memcpy-bound on one core (~20 GB/s); split it over a few threads
+template <class F>
+void parallel_chunks(size_t n, size_t total_bytes, F&& fn) {
+    unsigned t = total_bytes > (32u << 20) ? std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+    if (t <= 1 || n < 2 * t) { fn(0, n); return; }
+    std::vector<std::thread> th;
+    const size_t per = (n + t - 1) / t;
+    for (unsigned k = 0; k < t; k++) {
+        const size_t a = k * per, b = std::min(n, a + per);
+        if (a >= b) break;
+        th.emplace_back([=, &fn] { fn(a, b); });
+    }
+    for (auto& x : th) x.join();
+}
+
+}  // namespace cj
+
+struct cj_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;                 // serialises host-batch staging on this engine
+    cj::DevBuf d_in, d_out, d_meta;
+    std::mutex scratch_mu;         // LZ4 parse->decode scratch (sync points, per-chunk meta), reused across calls
+    cj::DevBuf d_sync, d_pmeta, d_lanelist;   // d_lanelist: [0] = count, [16..] = chunk indices
+    hipEvent_t scratch_free = nullptr;    // recorded after the last kernel that reads the scratch
+    hipStream_t aux = nullptr, aux2 = nullptr;   // the lane- / wave-kernel shares of a large LZ4-decode batch run here, concurrently
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
+    cj::PinnedBuf h_in, h_out;
+    std::vector<uint64_t> h_meta;
+    cj::DevBuf d_frame;            // frame.hip: assembled / staged framed stream
+};
+
+namespace cj {
+cj_engine* default_engine();     // lazily created on device $CJ_DEVICE (default 0); nullptr when no device is usable
+// submit one batch on stream s (slices very large decode batches); 0 or CJ_E_*
+int launch(cj_engine* e, cj_codec codec, cj_op op, const BatchArgs& a, hipStream_t s);
+void fill_args(BatchArgs& a, uint32_t flags, size_t n, const uint8_t* in_base, const uint64_t* in_off,
+               const uint64_t* in_len, uint8_t* out_base, const uint64_t* out_off, const uint64_t* out_cap,
+               int64_t* result);
+}  // namespace cj

@@ -2,99 +2,25 @@
 // submission, host staging and the single-buffer drop-in entry points.  Host-side C++ over the HIP
 // runtime; all codec arithmetic is in the four *_decode/_encode.hip kernels.  There is no CPU codec
 // in this library: if no device is usable the entry points return CJ_E_NO_DEVICE.
-#include "cj_common.hpp"
+#include "cj_engine.hpp"
 
-#include <algorithm>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <mutex>
-#include <string>
-#include <thread>
-#include <vector>
+using cj::hip_ok;
+using cj::parallel_chunks;
 
 namespace {
-
 thread_local std::string g_hip_err;
-
-bool hip_ok(hipError_t e, const char* what) {
-    if (e == hipSuccess) return true;
-    g_hip_err = std::string(what) + ": " + hipGetErrorString(e);
-    (void)hipGetLastError();
-    return false;
 }
-#define HIP_TRY(expr, ret) do { if (!hip_ok((expr), #expr)) return (ret); } while (0)
+std::string& cj::hip_err_slot() { return g_hip_err; }
 
-struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-    bool reserve(size_t n) {
-        if (n <= cap) return true;
-        if (p) (void)hipFree(p);
-        p = nullptr; cap = 0;
-        size_t want = n + n / 4 + 4096;
-        if (!hip_ok(hipMalloc(&p, want), "hipMalloc")) { p = nullptr; return false; }
-        cap = want;
-        return true;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-};
-
-}  // namespace
-
-// host-side pack/scatter of many small buffers is memcpy-bound on one core (~20 GB/s); split it over a few threads
-template <class F>
-void parallel_chunks(size_t n, size_t total_bytes, F&& fn) {
-    unsigned t = total_bytes > (32u << 20) ? std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
-    if (t <= 1 || n < 2 * t) { fn(0, n); return; }
-    std::vector<std::thread> th;
-    const size_t per = (n + t - 1) / t;
-    for (unsigned k = 0; k < t; k++) {
-        const size_t a = k * per, b = std::min(n, a + per);
-        if (a >= b) break;
-        th.emplace_back([=, &fn] { fn(a, b); });
-    }
-    for (auto& x : th) x.join();
-}
-
-struct PinnedBuf {          // page-locked host staging (full PCIe rate, truly asynchronous copies)
-    uint8_t* p = nullptr;
-    size_t cap = 0;
-    bool reserve(size_t n) {
-        if (n <= cap) return true;
-        if (p) (void)hipHostFree(p);
-        p = nullptr; cap = 0;
-        size_t want = n + n / 4 + 4096;
-        if (!hip_ok(hipHostMalloc((void**)&p, want, hipHostMallocDefault), "hipHostMalloc")) { p = nullptr; return false; }
-        cap = want;
-        return true;
-    }
-    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
-};
-
-struct cj_engine {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    std::mutex mu;                 // serialises host-batch staging on this engine
-    DevBuf d_in, d_out, d_meta;
-    std::mutex scratch_mu;         // LZ4 parse->decode scratch (sync points, per-chunk meta), reused across calls
-    DevBuf d_sync, d_pmeta, d_lanelist;   // d_lanelist: [0] = count, [16..] = chunk indices
-    hipEvent_t scratch_free = nullptr;    // recorded after the last kernel that reads the scratch
-    hipStream_t aux = nullptr, aux2 = nullptr;   // the lane- / wave-kernel shares of a large LZ4-decode batch run here, concurrently
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
-    PinnedBuf h_in, h_out;
-    std::vector<uint64_t> h_meta;
-};
-
-namespace {
-
-void fill_args(cj::BatchArgs& a, uint32_t flags, size_t n, const uint8_t* in_base, const uint64_t* in_off,
+void cj::fill_args(cj::BatchArgs& a, uint32_t flags, size_t n, const uint8_t* in_base, const uint64_t* in_off,
                const uint64_t* in_len, uint8_t* out_base, const uint64_t* out_off, const uint64_t* out_cap,
                int64_t* result) {
     a.in_base = in_base; a.in_off = in_off; a.in_len = in_len;
     a.out_base = out_base; a.out_off = out_off; a.out_cap = out_cap;
     a.result = result; a.n_chunks = (uint32_t)n; a.flags = flags;
 }
+
+namespace {
 
 int launch_slice(cj_engine* e, cj_codec codec, cj_op op, const cj::BatchArgs& a, hipStream_t s) {
     if (codec == CJ_CODEC_LZ4_BLOCK) {
@@ -212,10 +138,13 @@ int launch_slice(cj_engine* e, cj_codec codec, cj_op op, const cj::BatchArgs& a,
     return 0;
 }
 
+}  // namespace
+
 // Very large batches are submitted in slices: the lane-per-chunk kernels lose efficiency when several hundred
 // thousand chunks are in flight at once (their random match reads thrash L2 and the write amplification grows:
 // 1 M chunks in one go ran at 299 GB/s vs 430 GB/s at 100 k), and the parse/LDS scratch stays bounded.
-int launch(cj_engine* e, cj_codec codec, cj_op op, const cj::BatchArgs& a, hipStream_t s) {
+
+int cj::launch(cj_engine* e, cj_codec codec, cj_op op, const cj::BatchArgs& a, hipStream_t s) {
     static const size_t kSliceChunks = [] {
         const char* v = std::getenv("CJ_SLICE_CHUNKS");
         size_t x = v ? (size_t)std::strtoull(v, nullptr, 10) : (size_t)CJ_SLICE_CHUNKS_DEFAULT;
@@ -232,11 +161,13 @@ int launch(cj_engine* e, cj_codec codec, cj_op op, const cj::BatchArgs& a, hipSt
     return 0;
 }
 
+namespace {
 std::once_flag g_default_once;
 cj_engine* g_default = nullptr;
 int g_default_rc = CJ_E_NO_DEVICE;
+}  // namespace
 
-cj_engine* default_engine() {
+cj_engine* cj::default_engine() {
     std::call_once(g_default_once, [] {
         int dev = 0;
         if (const char* s = std::getenv("CJ_DEVICE")) dev = std::atoi(s);
@@ -244,6 +175,12 @@ cj_engine* default_engine() {
     });
     return g_default_rc == 0 ? g_default : nullptr;
 }
+
+namespace {
+
+using cj::default_engine;
+using cj::fill_args;
+using cj::launch;
 
 int64_t single(cj_codec codec, cj_op op, uint32_t flags, const uint8_t* in, size_t n, uint8_t* out, size_t cap) {
     cj_engine* e = default_engine();
@@ -273,6 +210,12 @@ const char* cj_strerror(int64_t code) {
     case CJ_E_SNAPPY_TOO_BIG: return "snappy: input buffer (size) is bigger than the maximum allowed";
     case CJ_E_SNAPPY_BUF_SMALL: return "snappy: output buffer is too small";
     case CJ_E_SNAPPY_CORRUPT: return "snappy: corrupt input";
+    case CJ_E_FRAME_EOF: return "failed to fill whole buffer";
+    case CJ_E_FRAME_WRITE: return "failed to write whole buffer";
+    case CJ_E_SNAPPY_STREAM_HEADER: return "snappy: corrupt input (expected stream header but got unexpected chunk type byte)";
+    case CJ_E_SNAPPY_CHUNK_TYPE: return "snappy: corrupt input (unsupported chunk type)";
+    case CJ_E_SNAPPY_CHUNK_LEN: return "snappy: corrupt input (unsupported chunk length)";
+    case CJ_E_SNAPPY_CHECKSUM: return "snappy: corrupt input (bad checksum)";
     case CJ_E_NO_DEVICE: return "cramjam_hip: no usable HIP device (no CPU fallback exists)";
     case CJ_E_BAD_ARG: return "cramjam_hip: bad argument";
     case CJ_E_OOM: return "cramjam_hip: out of memory";
@@ -339,7 +282,7 @@ int cj_engine_create(int device, cj_engine** out) {
 void cj_engine_destroy(cj_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
-    e->d_in.release(); e->d_out.release(); e->d_meta.release(); e->d_sync.release(); e->d_pmeta.release(); e->d_lanelist.release();
+    e->d_in.release(); e->d_out.release(); e->d_meta.release(); e->d_sync.release(); e->d_pmeta.release(); e->d_lanelist.release(); e->d_frame.release();
     e->h_in.release(); e->h_out.release();
     if (e->scratch_free) (void)hipEventDestroy(e->scratch_free);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);

@@ -593,6 +593,85 @@ PyObject* snappy_decompress_raw_len(PyObject*, PyObject* data) {                
     return PyLong_FromLongLong(n);
 }
 
+// ------------------------------------------------------------------------------------------
+// cramjam.snappy framed functions (reference src/snappy.rs:22-42,80-91 via the generic! macro, src/lib.rs:211-296)
+// ------------------------------------------------------------------------------------------
+int64_t snappy_frame_need(const Bytes& in, bool compress) {
+    if (compress) return (int64_t)cj_snappy_frame_max_compress_len((size_t)in.len);
+    int64_t d = cj_snappy_frame_decompress_len(in.ptr, (size_t)in.len);
+    // header-level error: let the decoder name the FIRST error in stream order (an earlier piece may be corrupt too)
+    if (d < 0) { int64_t r = cj_snappy_frame_decompress(in.ptr, (size_t)in.len, nullptr, 0); return r < 0 ? r : d; }
+    return d;
+}
+
+PyObject* snappy_framed(PyObject* args, PyObject* kw, bool compress) {
+    static const char* kwl[] = {"data", "output_len", nullptr};
+    PyObject *data, *olen = Py_None;
+    if (!PyArg_ParseTupleAndKeywords(args, kw, "O|O", (char**)kwl, &data, &olen)) return nullptr;
+    bool has; size_t n = 0;
+    if (!opt_size(olen, has, n)) return nullptr;
+    Bytes in;
+    if (!get_bytes(data, in)) return nullptr;
+    PyObject* exc = compress ? CompressionError : DecompressionError;
+    int64_t need, r;
+    std::vector<uint8_t> buf;
+    Py_BEGIN_ALLOW_THREADS
+    need = snappy_frame_need(in, compress);
+    if (need >= 0) {
+        // generic!: vec![0; output_len] under a Cursor at 0 -> the result is never shorter than output_len
+        buf.assign(std::max((size_t)need, has ? n : (size_t)0), 0);
+        r = compress ? cj_snappy_frame_compress(in.ptr, (size_t)in.len, buf.data(), buf.size())
+                     : cj_snappy_frame_decompress(in.ptr, (size_t)in.len, buf.data(), buf.size());
+    } else r = need;
+    Py_END_ALLOW_THREADS
+    if (r < 0) return raise_code(exc, r);
+    buf.resize(std::max((size_t)r, has ? n : (size_t)0));
+    return buffer_from_vec(std::move(buf));
+}
+PyObject* snappy_compress(PyObject*, PyObject* a, PyObject* k) { return snappy_framed(a, k, true); }
+PyObject* snappy_decompress(PyObject*, PyObject* a, PyObject* k) { return snappy_framed(a, k, false); }
+
+PyObject* snappy_framed_into(PyObject* args, PyObject* kw, bool compress) {
+    static const char* kwl[] = {"input", "output", nullptr};
+    PyObject *input, *output;
+    if (!PyArg_ParseTupleAndKeywords(args, kw, "OO", (char**)kwl, &input, &output)) return nullptr;
+    Bytes in, out;
+    if (!get_bytes(input, in) || !get_bytes(output, out)) return nullptr;
+    PyObject* exc = compress ? CompressionError : DecompressionError;
+    int64_t r;
+    if (out.buf) {
+        // Buffer output: a Cursor<Vec<u8>> written at its position, growing as needed (views cannot grow)
+        std::vector<uint8_t> tmp;
+        Py_BEGIN_ALLOW_THREADS
+        r = snappy_frame_need(in, compress);
+        if (r >= 0) {
+            tmp.assign((size_t)r, 0);
+            r = compress ? cj_snappy_frame_compress(in.ptr, (size_t)in.len, tmp.data(), tmp.size())
+                         : cj_snappy_frame_decompress(in.ptr, (size_t)in.len, tmp.data(), tmp.size());
+        }
+        Py_END_ALLOW_THREADS
+        if (r < 0) return raise_code(exc, r);
+        BufferObject* b = out.buf;
+        if (b->view) {
+            const uint64_t pos = std::min<uint64_t>(b->pos, (uint64_t)b->vlen);
+            if ((uint64_t)r > (uint64_t)b->vlen - pos) return raise_code(exc, CJ_E_FRAME_WRITE);
+            if (r) std::memcpy(b->vptr + pos, tmp.data(), (size_t)r);
+            b->pos = pos + (uint64_t)r;
+        } else {
+            owned_write(b, tmp.data(), (size_t)r);
+        }
+        return PyLong_FromLongLong(r);
+    }
+    Py_BEGIN_ALLOW_THREADS
+    r = compress ? cj_snappy_frame_compress(in.ptr, (size_t)in.len, out.ptr, (size_t)out.len)
+                 : cj_snappy_frame_decompress(in.ptr, (size_t)in.len, out.ptr, (size_t)out.len);
+    Py_END_ALLOW_THREADS
+    if (r < 0) return raise_code(exc, r);
+    return PyLong_FromLongLong(r);
+}
+PyObject* snappy_compress_into(PyObject*, PyObject* a, PyObject* k) { return snappy_framed_into(a, k, true); }
+PyObject* snappy_decompress_into(PyObject*, PyObject* a, PyObject* k) { return snappy_framed_into(a, k, false); }
+
 PyMethodDef lz4_methods[] = {
     {"decompress_block", (PyCFunction)lz4_decompress_block, METH_VARARGS | METH_KEYWORDS, "LZ4 block decompression (data, output_len=None)"},
     {"compress_block", (PyCFunction)lz4_compress_block, METH_VARARGS | METH_KEYWORDS, "LZ4 block compression (data, output_len=None, mode=None, acceleration=None, compression=None, store_size=None)"},
@@ -602,6 +681,10 @@ PyMethodDef lz4_methods[] = {
     {nullptr, nullptr, 0, nullptr}};
 
 PyMethodDef snappy_methods[] = {
+    {"compress", (PyCFunction)snappy_compress, METH_VARARGS | METH_KEYWORDS, "Snappy (framed) compression (data, output_len=None)"},
+    {"decompress", (PyCFunction)snappy_decompress, METH_VARARGS | METH_KEYWORDS, "Snappy (framed) decompression (data, output_len=None)"},
+    {"compress_into", (PyCFunction)snappy_compress_into, METH_VARARGS | METH_KEYWORDS, "Compress (framed) directly into an output buffer"},
+    {"decompress_into", (PyCFunction)snappy_decompress_into, METH_VARARGS | METH_KEYWORDS, "Decompress (framed) directly into an output buffer"},
     {"decompress_raw", (PyCFunction)snappy_decompress_raw, METH_VARARGS | METH_KEYWORDS, "Snappy raw decompression (data, output_len=None)"},
     {"compress_raw", (PyCFunction)snappy_compress_raw, METH_VARARGS | METH_KEYWORDS, "Snappy raw compression (data, output_len=None)"},
     {"compress_raw_into", (PyCFunction)snappy_compress_raw_into, METH_VARARGS | METH_KEYWORDS, "Compress raw format directly into an output buffer"},

@@ -42,6 +42,12 @@ extern "C" {
 #define CJ_E_SNAPPY_TOO_BIG    (-10) /* snap::Error::TooBig */
 #define CJ_E_SNAPPY_BUF_SMALL  (-11) /* snap::Error::BufferTooSmall */
 #define CJ_E_SNAPPY_CORRUPT    (-12) /* snap::Error::{Literal,CopyRead,CopyWrite,Offset,HeaderMismatch} */
+#define CJ_E_FRAME_EOF         (-13) /* io::ErrorKind::UnexpectedEof "failed to fill whole buffer" (truncated framed stream) */
+#define CJ_E_FRAME_WRITE       (-14) /* io::ErrorKind::WriteZero "failed to write whole buffer" (framed output does not fit) */
+#define CJ_E_SNAPPY_STREAM_HEADER (-15) /* snap::Error::{StreamHeader,StreamHeaderMismatch} */
+#define CJ_E_SNAPPY_CHUNK_TYPE (-16) /* snap::Error::UnsupportedChunkType */
+#define CJ_E_SNAPPY_CHUNK_LEN  (-17) /* snap::Error::UnsupportedChunkLength */
+#define CJ_E_SNAPPY_CHECKSUM   (-18) /* snap::Error::Checksum */
 #define CJ_E_NO_DEVICE         (-100) /* no HIP device / HIP runtime failure (see cj_last_hip_error) */
 #define CJ_E_BAD_ARG           (-101)
 #define CJ_E_OOM               (-102) /* device or pinned-host allocation failed */
@@ -86,6 +92,21 @@ int64_t cj_snappy_raw_decompress_len(const uint8_t* in, size_t n);
 int64_t cj_snappy_raw_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap);
 /* src/snappy.rs:57,106 libcramjam::snappy::raw::decompress(in, out); needs cap >= decompress_len(in) */
 int64_t cj_snappy_raw_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap);
+
+/* ---- Snappy FRAMING format: a stream of independent <= 64 KiB pieces, each with a masked
+ * CRC-32C; pieces are de/compressed and checksummed on the GPU as one batch. ---- */
+/* upper bound of cj_snappy_frame_compress's output: 10 + 8 * ceil(n / 65536) + n (0 for n == 0). No device. */
+size_t cj_snappy_frame_max_compress_len(size_t n);
+/* src/snappy.rs:38,82  libcramjam::snappy::compress (snap read::FrameEncoder): stream identifier + one chunk per
+ * 65536 input bytes, stored uncompressed when it does not shrink by 1/8; empty input -> empty output. */
+int64_t cj_snappy_frame_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap);
+/* decoded length of a framed stream from its chunk headers alone (what a caller allocates before
+ * cj_snappy_frame_decompress), or the first header-level error. No device. */
+int64_t cj_snappy_frame_decompress_len(const uint8_t* in, size_t n);
+/* src/snappy.rs:24,88  libcramjam::snappy::decompress (snap read::FrameDecoder): errors are reported in stream
+ * order like the sequential decoder would (block error, checksum, output full, then header errors).
+ * out == NULL: validate only — decode and checksum on the device, return the decoded length or the first error. */
+int64_t cj_snappy_frame_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap);
 
 /* =====================================================================================
  * Batch extension (no reference equivalent: the reference API is one buffer per call; a GPU only

@@ -13,7 +13,7 @@ _SO = os.path.join(_HERE, "libcj_oracle.so")
 
 def build(force=False):
     srcs = [os.path.join(_HERE, f) for f in
-            ("lz4_block_oracle.c", "snappy_raw_oracle.c", "synth_batch_oracle.c", "cj_oracle.h")]
+            ("lz4_block_oracle.c", "snappy_raw_oracle.c", "snappy_frame_oracle.c", "synth_batch_oracle.c", "cj_oracle.h")]
     if (not force and os.path.exists(_SO)
             and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs)):
         return _SO
@@ -41,6 +41,13 @@ def lib():
             ("cjo_snappy_decompress_len", i64, [u8p, sz]),
             ("cjo_snappy_compress", i64, [u8p, sz, u8p, sz]),
             ("cjo_snappy_decompress", i64, [u8p, sz, u8p, sz]),
+            ("cjo_crc32c", C.c_uint32, [u8p, sz]),
+            ("cjo_crc32c_masked", C.c_uint32, [u8p, sz]),
+            ("cjo_snappy_frame_max_compress_len", sz, [sz]),
+            ("cjo_snappy_frame_compress", i64, [u8p, sz, u8p, sz]),
+            ("cjo_snappy_frame_compress_bs", i64, [u8p, sz, u8p, sz, sz]),
+            ("cjo_snappy_frame_decompress_len", i64, [u8p, sz]),
+            ("cjo_snappy_frame_decompress", i64, [u8p, sz, u8p, sz]),
             ("cjo_synth_v1", None, [u8p, sz, C.c_uint64, C.c_uint64]),
             ("cjo_batch_run", C.c_int, [C.c_int, C.c_int, sz, u8p, u8p, u8p, u8p, sz, u8p]),
         ]:
@@ -94,6 +101,29 @@ def snappy_decompress(data, cap=None):
 def snappy_decompress_len(data):
     p, n, keep = _in(data)
     return lib().cjo_snappy_decompress_len(p, n)
+
+
+def crc32c(data, masked=False):
+    p, n, keep = _in(data)
+    return (lib().cjo_crc32c_masked if masked else lib().cjo_crc32c)(p, n)
+
+
+def snappy_frame_compress(data, cap=None, block_size=None):
+    cap = lib().cjo_snappy_frame_max_compress_len(len(data)) + (len(data) // (block_size or 65536) + 2) * 8 if cap is None else cap
+    if block_size is None:
+        return _call_out(lib().cjo_snappy_frame_compress, data, cap)
+    return _call_out(lib().cjo_snappy_frame_compress_bs, data, cap, block_size)
+
+
+def snappy_frame_decompress_len(data):
+    p, n, keep = _in(data)
+    return lib().cjo_snappy_frame_decompress_len(p, n)
+
+
+def snappy_frame_decompress(data, cap=None):
+    if cap is None:
+        cap = max(snappy_frame_decompress_len(data), 0)
+    return _call_out(lib().cjo_snappy_frame_decompress, data, cap)
 
 
 def synth_v1(chunk_bytes, index, seed=0x5EED):

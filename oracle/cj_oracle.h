@@ -48,6 +48,12 @@ extern "C" {
 #define CJO_E_SNAPPY_TOO_BIG    (-10) /* snap Error::TooBig */
 #define CJO_E_SNAPPY_BUF_SMALL  (-11) /* snap Error::BufferTooSmall */
 #define CJO_E_SNAPPY_CORRUPT    (-12) /* snap Error::{Literal,CopyRead,CopyWrite,Offset,HeaderMismatch} */
+#define CJO_E_FRAME_EOF         (-13) /* io::ErrorKind::UnexpectedEof "failed to fill whole buffer" (truncated frame) */
+#define CJO_E_FRAME_WRITE       (-14) /* io::ErrorKind::WriteZero "failed to write whole buffer" (output too small) */
+#define CJO_E_SNAPPY_STREAM_HEADER (-15) /* snap Error::{StreamHeader,StreamHeaderMismatch} */
+#define CJO_E_SNAPPY_CHUNK_TYPE (-16) /* snap Error::UnsupportedChunkType */
+#define CJO_E_SNAPPY_CHUNK_LEN  (-17) /* snap Error::UnsupportedChunkLength */
+#define CJO_E_SNAPPY_CHECKSUM   (-18) /* snap Error::Checksum */
 
 /* ---- LZ4 block: raw codec (liblz4 semantics) ---- */
 /* LZ4_compressBound: n + n/255 + 16, 0 if n > 0x7E000000 */
@@ -74,6 +80,17 @@ int64_t cjo_snappy_decompress_len(const uint8_t* in, size_t n);
 int64_t cjo_snappy_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap);
 /* src/snappy.rs:57,106 raw::decompress(in,out) */
 int64_t cjo_snappy_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap);
+
+/* ---- Snappy framing format (snap 1.1.1 read::FrameEncoder/FrameDecoder; reference src/snappy.rs:24,38,82,88) ---- */
+uint32_t cjo_crc32c(const uint8_t* p, size_t n);
+uint32_t cjo_crc32c_masked(const uint8_t* p, size_t n);
+size_t  cjo_snappy_frame_max_compress_len(size_t n);
+int64_t cjo_snappy_frame_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap);
+/* same with a smaller piece size (tests mint ragged foreign streams with it) */
+int64_t cjo_snappy_frame_compress_bs(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t block_size);
+/* grammar walk only: decoded length, or the first header-level error */
+int64_t cjo_snappy_frame_decompress_len(const uint8_t* in, size_t n);
+int64_t cjo_snappy_frame_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap);
 
 /* ---- deterministic synthetic chunk generator (SURVEY.md §8d "synth-v1") ---- */
 void cjo_synth_v1(uint8_t* dst, size_t chunk_bytes, uint64_t index, uint64_t seed);

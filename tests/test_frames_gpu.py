@@ -1,0 +1,253 @@
+"""GPU parity for the framed formats: Snappy framing format through the C-ABI
+(cj_snappy_frame_*) and through the reference's Python surface (cramjam.snappy.compress / decompress /
+compress_into / decompress_into, /root/reference/src/snappy.rs:22-42,80-91), against the CPU oracle, the reference's
+fixture and hand-built streams.  Restates /root/reference/tests/test_variants.py:48-245 for the snappy variant."""
+import ctypes as C
+import os
+import random
+
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+from hypothesis.extra import numpy as st_np
+
+import oracle
+from conftest import GOLDEN_DIR
+from framing import SNAPPY_IDENT, crc32c_masked, snappy_chunk, snappy_compressed, snappy_stored
+
+pytestmark = pytest.mark.gpu
+
+import cramjam_amd as cramjam  # noqa: E402
+from cramjam_amd import _native as N  # noqa: E402
+
+FAST = settings(max_examples=20, deadline=None)
+E_EOF, E_WRITE, E_HDR, E_TYPE, E_LEN, E_SUM = -13, -14, -15, -16, -17, -18
+
+
+def _fx(name):
+    with open(os.path.join(GOLDEN_DIR, name), "rb") as f:
+        return f.read()
+
+
+def abi_decompress(framed, cap=None):
+    L = N.lib()
+    framed = bytes(framed)
+    if cap is None:
+        cap = max(L.cj_snappy_frame_decompress_len(framed, len(framed)), 0)
+    out = C.create_string_buffer(max(cap, 1))
+    r = L.cj_snappy_frame_decompress(framed, len(framed), out, cap)
+    return r, out.raw[:max(r, 0)]
+
+
+def abi_compress(data, cap=None):
+    L = N.lib()
+    data = bytes(data)
+    cap = L.cj_snappy_frame_max_compress_len(len(data)) if cap is None else cap
+    out = C.create_string_buffer(max(cap, 1))
+    r = L.cj_snappy_frame_compress(data, len(data), out, cap)
+    return r, out.raw[:max(r, 0)]
+
+
+def mixed_data(seed, n_text=90, n_rand=200000, n_zero=50000):
+    random.seed(seed)
+    return _fx("plaintext.txt") * n_text + bytes(random.randrange(256) for _ in range(n_rand)) + bytes(n_zero)
+
+
+def test_reference_fixture():
+    framed, plain = _fx("plaintext.txt.snappy"), _fx("plaintext.txt")
+    assert N.lib().cj_snappy_frame_decompress_len(framed, len(framed)) == len(plain)
+    assert abi_decompress(framed) == (len(plain), plain)
+    assert bytes(cramjam.snappy.decompress(framed)) == plain
+
+
+@pytest.mark.parametrize("block_size", [None, 4096, 1000, 333, 7])
+def test_decode_oracle_streams(block_size):
+    """streams minted by the oracle with ragged piece sizes: unaligned payloads and piece offsets, stored + compressed"""
+    data = mixed_data(5) if (block_size or 65536) >= 1000 else mixed_data(5, 3, 3000, 1000)
+    r, framed = oracle.snappy_frame_compress(data, block_size=block_size)
+    assert r > 0
+    assert N.lib().cj_snappy_frame_decompress_len(framed, len(framed)) == len(data)
+    assert abi_decompress(framed) == (len(data), data)
+
+
+def test_encode_layout_and_round_trip():
+    data = mixed_data(6)
+    r, framed = abi_compress(data)
+    assert r == len(framed) <= N.lib().cj_snappy_frame_max_compress_len(len(data))
+    assert framed[:10] == SNAPPY_IDENT
+    pos, off, types = 10, 0, set()
+    while pos < len(framed):                    # one chunk per 64 KiB piece; stored iff the block did not shrink by 1/8
+        ty, ln = framed[pos], int.from_bytes(framed[pos + 1:pos + 4], "little")
+        piece = data[off:off + 65536]
+        assert int.from_bytes(framed[pos + 4:pos + 8], "little") == crc32c_masked(piece), off
+        body = framed[pos + 8:pos + 4 + ln]
+        if ty == 1:
+            assert body == piece
+        else:
+            assert ty == 0 and len(body) < len(piece) - len(piece) // 8
+            assert oracle.snappy_decompress(body) == (len(piece), piece)
+        types.add(ty); pos += 4 + ln; off += len(piece)
+    assert off == len(data) and types == {0, 1}
+    assert oracle.snappy_frame_decompress(framed) == (len(data), data)      # the CPU decoder accepts the GPU's stream
+    assert abi_decompress(framed) == (len(data), data)
+    assert abi_compress(data, cap=len(framed) - 1)[0] == E_WRITE
+    assert abi_compress(data, cap=len(framed))[0] == len(framed)
+
+
+def test_empty_and_hand_built_streams():
+    assert abi_compress(b"") == (0, b"") and abi_decompress(b"") == (0, b"")
+    a, b = b"hello hello hello hello", bytes(range(256)) * 3
+    s = (SNAPPY_IDENT + snappy_stored(a) + snappy_chunk(0xfe, b"\0" * 13) + snappy_chunk(0x80, b"skip me")
+         + SNAPPY_IDENT + snappy_compressed(b, oracle.snappy_compress(b)[1]) + snappy_chunk(0xfd, b""))
+    assert abi_decompress(s) == (len(a) + len(b), a + b)
+    assert abi_decompress(SNAPPY_IDENT) == (0, b"")
+
+
+def test_malformed_streams_match_oracle():
+    a = b"abcdefgh" * 40
+    blk = oracle.snappy_compress(a)[1]
+    good = SNAPPY_IDENT + snappy_compressed(a, blk)
+    bad = bytearray(blk); bad[-1] ^= 0xff; bad[3] ^= 0x40
+    big = oracle.snappy_compress(bytes(65537))[1]
+    cases = [b"sknow", good[10:], b"\xff\x06\x00\x00sNaPpX" + good[10:], b"\xff\x05\x00\x00sNaPp" + good[10:], good[:10]]
+    cases += [good[:cut] for cut in (1, 3, 11, 13, 15, 17, len(good) - 1)]
+    cases += [SNAPPY_IDENT + snappy_chunk(0x02, b"xx"), SNAPPY_IDENT + snappy_chunk(0x7f, b""),
+              SNAPPY_IDENT + snappy_chunk(0x00, b"abc"), SNAPPY_IDENT + b"\x01" + (76491).to_bytes(3, "little") + bytes(76491),
+              SNAPPY_IDENT + snappy_stored(bytes(65537)), SNAPPY_IDENT + snappy_stored(bytes(65536)),
+              SNAPPY_IDENT + snappy_stored(a, crc=1), SNAPPY_IDENT + snappy_compressed(a, blk, crc=crc32c_masked(a) ^ 1),
+              SNAPPY_IDENT + snappy_chunk(0x00, b"\0\0\0\0"), SNAPPY_IDENT + snappy_compressed(bytes(65537), big),
+              SNAPPY_IDENT + snappy_compressed(a, bytes(bad)),
+              SNAPPY_IDENT + snappy_stored(a, crc=1) + snappy_chunk(0x02, b""),
+              SNAPPY_IDENT + snappy_chunk(0x02, b"") + snappy_stored(a, crc=1),
+              good + snappy_stored(a) + snappy_compressed(a, bytes(bad)) + snappy_stored(a, crc=3)]
+    random.seed(11)
+    for _ in range(60):                           # random single-byte damage anywhere in a 3-chunk stream
+        s = bytearray(good + snappy_stored(a[:100]) + snappy_compressed(a, blk))
+        s[random.randrange(len(s))] ^= 1 << random.randrange(8)
+        cases.append(bytes(s))
+    for s in cases:
+        for cap in (70000, 100):
+            want = oracle.snappy_frame_decompress(s, cap)
+            got = abi_decompress(s, cap)
+            assert got[0] == want[0], (s[:40], cap, got[0], want[0])
+            if want[0] >= 0:
+                assert got[1] == want[1]
+    assert abi_decompress(good, cap=len(a) - 1)[0] == E_WRITE
+    # validate-only mode names the first error in stream order without an output buffer
+    L = N.lib()
+    s = SNAPPY_IDENT + snappy_stored(a, crc=1) + snappy_chunk(0x02, b"")
+    assert L.cj_snappy_frame_decompress(s, len(s), None, 0) == E_SUM
+    assert L.cj_snappy_frame_decompress(good, len(good), None, 0) == len(a)
+
+
+def test_large_stream_round_trip():
+    """64 MiB of benchmark-like data: 1024 pieces in one batch (the large-batch decode pipeline), every piece checksummed"""
+    n = 1024
+    rng = np.random.default_rng(3)
+    pieces = [oracle.synth_v1(65536, i) for i in range(64)]
+    data = b"".join(pieces[i % 64] for i in range(n - 8)) + rng.integers(0, 256, 8 * 65536 - 12345, dtype=np.uint8).tobytes()
+    r, framed = abi_compress(data)
+    assert 0 < r < len(data)
+    assert abi_decompress(framed) == (len(data), data)
+    head = 10 + 8 + int.from_bytes(framed[11:14], "little") - 4
+    assert oracle.snappy_frame_decompress(framed[:head]) == (65536, data[:65536])   # spot check with the CPU decoder
+    dmg = bytearray(framed); dmg[len(framed) // 2] ^= 0x10                         # damage somewhere in the middle
+    assert abi_decompress(bytes(dmg), cap=len(data))[0] == oracle.snappy_frame_decompress(bytes(dmg), len(data))[0] < 0
+
+
+# ---- the reference's generic variant tests, restated for cramjam.snappy (tests/test_variants.py:48-245) ----
+
+def same_same(a, b):
+    return bytes(a) == bytes(b)
+
+
+@FAST
+@given(arr=st_np.arrays(st_np.scalar_dtypes(), shape=st.integers(0, int(1e4))))
+def test_variants_different_dtypes(arr):
+    compressed = cramjam.snappy.compress(arr)
+    assert same_same(cramjam.snappy.decompress(compressed), arr.tobytes())
+    if arr.shape[0] % 2 == 0:
+        arr = arr.reshape((2, -1))
+        assert same_same(cramjam.snappy.decompress(cramjam.snappy.compress(arr)), arr.tobytes())
+
+
+@pytest.mark.parametrize("is_bytearray", (True, False))
+@FAST
+@given(uncompressed=st.binary(min_size=1))
+def test_variants_simple(is_bytearray, uncompressed):
+    if is_bytearray:
+        uncompressed = bytearray(uncompressed)
+    compressed = cramjam.snappy.compress(uncompressed)
+    assert compressed.read() != uncompressed
+    compressed.seek(0)
+    assert isinstance(compressed, cramjam.Buffer)
+    assert oracle.snappy_frame_decompress(bytes(compressed))[1] == bytes(uncompressed)
+    decompressed = cramjam.snappy.decompress(compressed, output_len=len(uncompressed))
+    assert same_same(decompressed.read(), uncompressed)
+    assert isinstance(decompressed, cramjam.Buffer)
+
+
+def test_variants_raise_exception():
+    with pytest.raises(cramjam.DecompressionError):
+        cramjam.snappy.decompress(b"sknow")
+
+
+def test_output_len_is_a_floor():
+    # generic!: vec![0; output_len] under a Cursor -> never shorter than output_len (src/lib.rs:216-219)
+    out = cramjam.snappy.decompress(cramjam.snappy.compress(b"abc" * 10), output_len=100)
+    assert len(out) == 100 and bytes(out)[:30] == b"abc" * 10 and bytes(out)[30:] == bytes(70)
+    out = cramjam.snappy.decompress(cramjam.snappy.compress(b"abc" * 10), output_len=5)
+    assert bytes(out) == b"abc" * 10
+
+
+def _make(kind, payload):
+    if kind == "numpy":
+        return np.frombuffer(payload, dtype=np.uint8).copy()
+    if kind is cramjam.Buffer:
+        b = cramjam.Buffer(); b.write(payload); b.seek(0)
+        return b
+    return kind(payload)
+
+
+def _collect(obj):
+    if isinstance(obj, cramjam.Buffer):
+        obj.seek(0)
+        return obj.read()
+    return obj.tobytes() if hasattr(obj, "tobytes") else bytes(obj)
+
+
+TYPES = (bytes, bytearray, "numpy", cramjam.Buffer, memoryview)     # cramjam.File is outside the hot path
+
+
+@pytest.mark.parametrize("input_type", TYPES)
+@pytest.mark.parametrize("output_type", TYPES)
+@settings(max_examples=8, deadline=None)
+@given(raw_data=st.binary())
+def test_variants_compress_into(input_type, output_type, raw_data):
+    inp = _make(input_type, raw_data)
+    compressed_len = len(cramjam.snappy.compress(raw_data))
+    output = cramjam.Buffer() if output_type is cramjam.Buffer else _make(output_type, b"0" * compressed_len)
+    n_bytes = cramjam.snappy.compress_into(inp, output)
+    assert n_bytes == compressed_len
+    assert same_same(raw_data, cramjam.snappy.decompress(_collect(output)[:n_bytes]))
+
+
+@pytest.mark.parametrize("input_type", TYPES)
+@pytest.mark.parametrize("output_type", TYPES)
+@settings(max_examples=8, deadline=None)
+@given(raw_data=st.binary())
+def test_variants_decompress_into(input_type, output_type, raw_data):
+    compressed = bytes(cramjam.snappy.compress(raw_data))
+    inp = _make(input_type, compressed)
+    output = cramjam.Buffer() if output_type is cramjam.Buffer else _make(output_type, b"0" * len(raw_data))
+    n_bytes = cramjam.snappy.decompress_into(inp, output)
+    assert n_bytes == len(raw_data)
+    assert same_same(_collect(output), raw_data)
+
+
+def test_into_output_too_small():
+    data = b"some bytes here" * 100
+    with pytest.raises(cramjam.CompressionError):
+        cramjam.snappy.compress_into(data, bytearray(10))
+    with pytest.raises(cramjam.DecompressionError):
+        cramjam.snappy.decompress_into(cramjam.snappy.compress(data), bytearray(len(data) - 1))

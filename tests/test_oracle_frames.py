@@ -1,0 +1,130 @@
+"""CPU: the framed-format oracle (oracle/snappy_frame_oracle.c) against the reference's fixture, the CRC-32C check
+value and hand-built streams; and the lane-parallel CRC-32C of the HIP kernel (crc32c_lanes.hpp) built for the host."""
+import ctypes as C
+import os
+import random
+import subprocess
+
+import pytest
+
+import oracle
+from conftest import GOLDEN_DIR, ROOT
+from framing import SNAPPY_IDENT, crc32c, crc32c_masked, snappy_chunk, snappy_compressed, snappy_stored
+
+E_EOF, E_WRITE, E_HDR, E_TYPE, E_LEN, E_SUM = -13, -14, -15, -16, -17, -18
+
+
+def _fx(name):
+    with open(os.path.join(GOLDEN_DIR, name), "rb") as f:
+        return f.read()
+
+
+def test_crc32c_known_answers():
+    assert oracle.crc32c(b"123456789") == 0xE3069283          # the standard CRC-32C check value
+    assert oracle.crc32c(b"") == 0
+    assert oracle.crc32c(bytes(32)) == 0x8A9136AA             # RFC 3720 B.4 test patterns
+    assert oracle.crc32c(b"\xff" * 32) == 0x62A8AB43
+    assert oracle.crc32c(bytes(range(32))) == 0x46DD794E
+    random.seed(1)
+    for n in (1, 2, 3, 4, 5, 63, 64, 65, 1000):
+        d = bytes(random.randrange(256) for _ in range(n))
+        assert oracle.crc32c(d) == crc32c(d)
+        assert oracle.crc32c(d, masked=True) == crc32c_masked(d)
+
+
+def test_reference_fixture_decodes():
+    """reference tests/data/integration/plaintext.txt.snappy (third-party framed stream) -> plaintext.txt"""
+    framed, plain = _fx("plaintext.txt.snappy"), _fx("plaintext.txt")
+    assert framed[:10] == SNAPPY_IDENT and framed[10] == 0x00
+    assert int.from_bytes(framed[14:18], "little") == oracle.crc32c(plain, masked=True)
+    assert oracle.snappy_frame_decompress_len(framed) == len(plain)
+    r, out = oracle.snappy_frame_decompress(framed)
+    assert r == len(plain) and out == plain
+
+
+@pytest.mark.parametrize("block_size", [None, 65536, 4096, 1000, 7])
+def test_round_trip_and_layout(block_size):
+    random.seed(5)
+    data = _fx("plaintext.txt") * 90 + bytes(random.randrange(256) for _ in range(200000)) + bytes(50000)
+    r, framed = oracle.snappy_frame_compress(data, block_size=block_size)
+    assert r == len(framed) and framed[:10] == SNAPPY_IDENT
+    bs = block_size or 65536
+    pos, off, types = 10, 0, set()
+    while pos < len(framed):                                  # layout: one chunk per piece, stored iff it does not shrink by 1/8
+        ty, ln = framed[pos], int.from_bytes(framed[pos + 1:pos + 4], "little")
+        piece = data[off:off + bs]
+        assert int.from_bytes(framed[pos + 4:pos + 8], "little") == crc32c_masked(piece)
+        body = framed[pos + 8:pos + 4 + ln]
+        if ty == 1:
+            assert body == piece
+            assert len(oracle.snappy_compress(piece)[1]) >= len(piece) - len(piece) // 8
+        else:
+            assert ty == 0 and oracle.snappy_decompress(body)[1] == piece and len(body) < len(piece) - len(piece) // 8
+        types.add(ty); pos += 4 + ln; off += len(piece)
+    assert off == len(data) and (block_size == 7 or types == {0, 1})
+    assert oracle.snappy_frame_decompress(framed) == (len(data), data)
+    assert len(framed) <= oracle.lib().cjo_snappy_frame_max_compress_len(len(data)) or block_size not in (None, 65536)
+
+
+def test_empty_and_hand_built_streams():
+    assert oracle.snappy_frame_compress(b"") == (0, b"")        # snap emits the identifier with the first chunk only
+    assert oracle.snappy_frame_decompress(b"") == (0, b"")
+    a, b = b"hello hello hello hello", bytes(range(256)) * 3
+    s = (SNAPPY_IDENT + snappy_stored(a) + snappy_chunk(0xfe, b"\0" * 13) + snappy_chunk(0x80, b"skip me")
+         + SNAPPY_IDENT + snappy_compressed(b, oracle.snappy_compress(b)[1]) + snappy_chunk(0xfd, b""))
+    assert oracle.snappy_frame_decompress(s) == (len(a) + len(b), a + b)
+    assert oracle.snappy_frame_decompress(SNAPPY_IDENT) == (0, b"")
+
+
+def test_malformed_streams():
+    a = b"abcdefgh" * 40
+    good = SNAPPY_IDENT + snappy_compressed(a, oracle.snappy_compress(a)[1])
+    dec = lambda s, cap=None: oracle.snappy_frame_decompress(s, cap if cap is not None else 4096)[0]
+    assert dec(good) == len(a)
+    assert dec(b"sknow") == E_HDR                                   # reference tests/test_variants.py:92-96
+    assert dec(good[10:]) == E_HDR                                  # no stream identifier
+    assert dec(b"\xff\x06\x00\x00sNaPpX" + good[10:]) == E_HDR
+    assert dec(b"\xff\x05\x00\x00sNaPp" + good[10:]) == E_LEN
+    for cut in (1, 3, 11, 13, 15, 17, len(good) - 1):
+        assert dec(good[:cut]) == E_EOF, cut
+    assert dec(good[:10]) == 0
+    assert dec(SNAPPY_IDENT + snappy_chunk(0x02, b"xx")) == E_TYPE
+    assert dec(SNAPPY_IDENT + snappy_chunk(0x7f, b"")) == E_TYPE
+    assert dec(SNAPPY_IDENT + snappy_chunk(0x00, b"abc")) == E_LEN       # shorter than its checksum
+    assert dec(SNAPPY_IDENT + b"\x01" + (76491).to_bytes(3, "little") + bytes(76491)) == E_LEN
+    assert dec(SNAPPY_IDENT + snappy_stored(bytes(65537)), 70000) == E_LEN
+    assert dec(SNAPPY_IDENT + snappy_stored(bytes(65536)), 70000) == 65536
+    assert dec(SNAPPY_IDENT + snappy_stored(a, crc=1)) == E_SUM
+    assert dec(SNAPPY_IDENT + snappy_compressed(a, oracle.snappy_compress(a)[1], crc=crc32c_masked(a) ^ 1)) == E_SUM
+    assert dec(SNAPPY_IDENT + snappy_chunk(0x00, b"\0\0\0\0")) == -8      # empty raw block: snap Error::Empty
+    big = oracle.snappy_compress(bytes(65537))[1]
+    assert dec(SNAPPY_IDENT + snappy_compressed(bytes(65537), big), 70000) == E_LEN   # piece decodes to > 64 KiB
+    bad = bytearray(oracle.snappy_compress(a)[1]); bad[-1] ^= 0xff; bad[3] ^= 0x40
+    assert dec(SNAPPY_IDENT + snappy_compressed(a, bytes(bad))) in (-12, E_SUM)
+    assert dec(good, cap=len(a) - 1) == E_WRITE
+    # stream order: a corrupt piece before a header error wins; a header error before it hides it
+    assert dec(SNAPPY_IDENT + snappy_stored(a, crc=1) + snappy_chunk(0x02, b"")) == E_SUM
+    assert dec(SNAPPY_IDENT + snappy_chunk(0x02, b"") + snappy_stored(a, crc=1)) == E_TYPE
+
+
+SIM_SO = os.path.join(ROOT, "tests", "hostsim", "libsim_crc32c.so")
+
+
+def test_hostsim_lane_parallel_crc32c():
+    """The kernel's 64-lane strided CRC (GF(2) advance tables + tail multipliers) equals the serial CRC for every
+    length / alignment class, incl. the 64 KiB piece size."""
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-shared", "-fPIC", "-I", os.path.join(ROOT, "cramjam_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "hostsim", "sim_crc32c.cpp"), "-o", SIM_SO])
+    S = C.CDLL(SIM_SO)
+    S.sim_crc32c.restype = C.c_uint32
+    S.sim_crc32c.argtypes = [C.c_void_p, C.c_uint32]
+    S.sim_crc32c_mask.restype = C.c_uint32
+    random.seed(9)
+    buf = bytes(random.randrange(256) for _ in range(70100))
+    base = C.create_string_buffer(buf, len(buf))
+    addr = C.addressof(base)
+    cases = [(o, n) for n in range(0, 1300) for o in (0, 1, 3)]
+    cases += [(random.randrange(8), random.randrange(70000)) for _ in range(200)] + [(0, 65536), (3, 65536), (1, 65535)]
+    for o, n in cases:
+        assert S.sim_crc32c(addr + o, n) == oracle.crc32c(buf[o:o + n]), (o, n)
+    assert S.sim_crc32c_mask(oracle.crc32c(b"abc")) == oracle.crc32c(b"abc", masked=True)

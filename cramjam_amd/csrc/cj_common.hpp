@@ -32,6 +32,9 @@ void launch_lz4_decode_lanes_listed(const BatchArgs& a, const void* lists, uint3
 void launch_lz4_decode_listed(const BatchArgs& a, const void* lists, uint32_t wave_share, hipStream_t s);   // wave kernel on the classify kernel's early wave share
 void launch_lz4_decode_lds(const BatchArgs& a, const void* sync, const void* meta, hipStream_t s);
 void launch_lz4_decode_routed(const BatchArgs& a, const void* meta, hipStream_t s);   // wave kernel on chunks the parse kernel routed to it
+// variant 2: persistent grid (2 workgroups per CU), record tables in the global scratch `tabs`, chunk indices from *counter
+void launch_lz4_decode_lds2(const BatchArgs& a, const void* sync, const void* meta, void* tabs, uint32_t* counter, uint32_t grid, hipStream_t s);
+size_t lz4_lds2_tab_bytes(uint32_t grid);
 size_t lz4_lds_scratch_sync_bytes(size_t n_chunks);
 size_t lz4_lds_scratch_meta_bytes(size_t n_chunks);
 void launch_lz4_encode(const BatchArgs& a, hipStream_t s);

@@ -84,6 +84,8 @@ struct cj_engine {
     cj::PinnedBuf h_in, h_out;
     std::vector<uint64_t> h_meta;
     cj::DevBuf d_frame;            // frame.hip: assembled / staged framed stream
+    cj::DevBuf d_tab;              // LDS decoder variant 2: per-workgroup record tables
+    int n_cu = 0;
 };
 
 namespace cj {

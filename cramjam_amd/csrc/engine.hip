@@ -80,6 +80,13 @@ int launch_slice(cj_engine* e, cj_codec codec, cj_op op, const cj::BatchArgs& a,
                     HIP_TRY(hipEventRecord(e->ev_join2, e->aux2), CJ_E_NO_DEVICE);
                 }
                 cj::launch_lz4_parse(a, e->d_sync.p, e->d_pmeta.p, s);           // validate, size, count sequences, route
+                static const int lds_variant = [] { const char* v = std::getenv("CJ_LDS_VARIANT"); return v ? std::atoi(v) : 2; }();
+                if (lds_variant == 2) {
+                    if (e->n_cu == 0) HIP_TRY(hipDeviceGetAttribute(&e->n_cu, hipDeviceAttributeMultiprocessorCount, e->device), CJ_E_NO_DEVICE);
+                    const uint32_t grid = 2u * (uint32_t)e->n_cu;
+                    if (!e->d_tab.reserve(cj::lz4_lds2_tab_bytes(grid))) return CJ_E_OOM;
+                    cj::launch_lz4_decode_lds2(a, e->d_sync.p, e->d_pmeta.p, e->d_tab.p, lists + 2, grid, s);
+                } else
                 cj::launch_lz4_decode_lds(a, e->d_sync.p, e->d_pmeta.p, s);      // many short sequences
                 cj::launch_lz4_decode_routed(a, e->d_pmeta.p, s);                // few long runs / oversize chunks
                 if (lane_share > 0) HIP_TRY(hipStreamWaitEvent(s, e->ev_join, 0), CJ_E_NO_DEVICE);   // 3. join
@@ -282,7 +289,7 @@ int cj_engine_create(int device, cj_engine** out) {
 void cj_engine_destroy(cj_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
-    e->d_in.release(); e->d_out.release(); e->d_meta.release(); e->d_sync.release(); e->d_pmeta.release(); e->d_lanelist.release(); e->d_frame.release();
+    e->d_in.release(); e->d_out.release(); e->d_meta.release(); e->d_sync.release(); e->d_pmeta.release(); e->d_lanelist.release(); e->d_frame.release(); e->d_tab.release();
     e->h_in.release(); e->h_out.release();
     if (e->scratch_free) (void)hipEventDestroy(e->scratch_free);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);

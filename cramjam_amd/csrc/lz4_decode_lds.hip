@@ -419,6 +419,284 @@ __global__ __launch_bounds__(kLdsThreads) void lz4_decode_lds_kernel(BatchArgs a
     if (tid == 0 && *s_fail) a.result[c] = CJ_E_CORRUPT;    // cannot happen for a stream the parse kernel accepted
 }
 
+// =====================================================================================================
+// Variant 2: TWO workgroups per CU.  The kernel above keeps the compressed chunk and the record table in LDS next
+// to the output window, which fills the CU's 160 KiB with ONE chunk — and its longest phase (D3) is bound by the
+// latency of the match-dependency chain, not by issue or LDS bandwidth, so most of the CU idles.  Here only what
+// must be in LDS stays there (output window + ready bitmap, 72.4 KiB): the compressed bytes are read straight
+// from global memory (each byte is consumed once, by D1's token walk or D2's literal copy) and the record table
+// lives in a per-workgroup global scratch slot that is written once and read twice with coalesced 16 B accesses
+// (L2-resident: the grid is persistent, 2 slots per CU).  Two chunks per CU then overlap each other's latency.
+// Workgroups are persistent and pull chunk indices from a global counter.
+// =====================================================================================================
+constexpr uint32_t kL2Threads = 512;
+constexpr uint32_t kL2OffBits = 65536;
+constexpr uint32_t kL2OffVars = kL2OffBits + 8192;         // [0] fail flag, [8] current chunk, [64,128) dummy bytes, [128,384) dummy dwords
+constexpr uint32_t kL2Bytes = kL2OffVars + 384;            // 74112 B: two workgroups fit one CU's LDS
+constexpr uint32_t kL2TabRecords = kSyncStride * kSyncEvery;   // the parse kernel routes chunks with more sequences elsewhere
+
+template <int ND>
+__device__ __forceinline__ DW<ND> gl_ld_aligned(const uint8_t* pa, const uint8_t* last) {   // ND aligned dwords, clamped to the last valid one
+    DW<ND> r;
+#pragma unroll
+    for (int i = 0; i < ND; i++) {
+        const uint8_t* q = pa + 4 * i;
+        r.w[i] = *reinterpret_cast<const uint32_t*>(q < last ? q : last);
+    }
+    return r;
+}
+
+// ND dwords (ND = 4k + 2) from the exact, arbitrarily aligned pointer g as k dwordx4 + one dwordx2 load: a scattered
+// wave load costs the texture-address unit about one cycle per lane whatever its width, so 6 dword loads per lane
+// (the aligned form above) take 3x as long as these 2.  May read up to 4*ND bytes from g: the caller checks that
+// this stays inside the chunk's last 16 B granule.
+template <int ND>
+__device__ __forceinline__ DW<ND> gl_ld_vec(const uint8_t* g) {
+    static_assert(ND % 4 == 2, "ND = 4k + 2");
+    DW<ND> r;
+#pragma unroll
+    for (int i = 0; i + 4 <= ND; i += 4) {
+        uint4 v;
+        __builtin_memcpy(&v, g + 4 * i, 16);
+        r.w[i] = v.x; r.w[i + 1] = v.y; r.w[i + 2] = v.z; r.w[i + 3] = v.w;
+    }
+    uint2 t;
+    __builtin_memcpy(&t, g + 4 * (ND - 2), 8);
+    r.w[ND - 2] = t.x; r.w[ND - 1] = t.y;
+    return r;
+}
+
+__global__ __launch_bounds__(kL2Threads) void lz4_decode_lds2_kernel(BatchArgs a, const uint2* sync, const ParseMeta* meta,
+                                                                     uint4* tabs, uint32_t* counter) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t* s_out = smem;
+    uint32_t* s_bits = reinterpret_cast<uint32_t*>(smem + kL2OffBits);
+    uint32_t* s_fail = reinterpret_cast<uint32_t*>(smem + kL2OffVars);
+    uint32_t* s_chunk = reinterpret_cast<uint32_t*>(smem + kL2OffVars + 8u);
+    const uint32_t a_out = (uint32_t)(uintptr_t)s_out;
+    const Dummies dm = {(uint32_t)(uintptr_t)(smem + kL2OffVars + 64u) + (threadIdx.x & 63u),
+                        (uint32_t)(uintptr_t)(smem + kL2OffVars + 128u) + 4u * (threadIdx.x & 63u)};
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint4* table = tabs + (size_t)blockIdx.x * kL2TabRecords;
+    const bool prof = (a.flags & 0x1000u) != 0;
+    unsigned long long t_prev = prof ? __builtin_readcyclecounter() : 0ull;
+
+    for (;;) {
+        if (tid == 0) { *s_chunk = atomicAdd(counter, 1u); *s_fail = 0u; }
+        for (uint32_t i = tid; i < 2048u; i += kL2Threads) s_bits[i] = 0u;
+        __syncthreads();
+        const uint32_t c = *s_chunk;
+        __syncthreads();                                     // everyone has read s_chunk before thread 0 can overwrite it
+        if (c >= a.n_chunks) break;
+        const ParseMeta pm = meta[c];
+        if (pm.nseq == 0u) continue;                         // error, empty, or routed to another kernel
+        const uint32_t nseq = pm.nseq;
+        const uint32_t U = (uint32_t)a.result[c];            // decoded size, 1..65536
+        const uint8_t* in = a.in_base + a.in_off[c] + pm.in_skip;
+        const uint32_t iend = (uint32_t)a.in_len[c] - pm.in_skip;
+        const uint8_t* in_al = in - (reinterpret_cast<uintptr_t>(in) & 3u);
+        const uint8_t* last_dw = in_al + ((((uint32_t)(reinterpret_cast<uintptr_t>(in) & 3u)) + iend - 1u) & ~3u);
+        // offset (relative to in) up to which reads are safe: the end of the 16 B granule holding the last input byte
+        const uint32_t safe_end = ((((uint32_t)(reinterpret_cast<uintptr_t>(in) & 15u)) + iend + 15u) & ~15u) - (uint32_t)(reinterpret_cast<uintptr_t>(in) & 15u);
+        uint8_t* out = a.out_base + a.out_off[c];
+        const uint2* csync = sync + (size_t)c * kSyncStride;
+        const uint32_t nsp = (nseq + kSyncEvery - 1u) / kSyncEvery;
+        // ---- S0: stage the compressed chunk in the (still unused) output window so that D1's dependent token
+        //      reads are LDS reads; D2 re-reads the literal bytes from global memory (L2 hits) because it overwrites
+        //      the window while other lanes still need their sources ----
+        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(in) & 15u);
+        {
+            const uint4* src = reinterpret_cast<const uint4*>(in - mis);
+            uint4* dst = reinterpret_cast<uint4*>(s_out);
+            const uint32_t nvec = (mis + iend + 15u) >> 4;
+            for (uint32_t i = tid; i < nvec; i += kL2Threads) dst[i] = src[i];
+        }
+        __syncthreads();
+        CJ_PHASE_MARK(0);
+
+        // ---- D1: expand sync points into sequence records (LDS -> global table) ----
+        const uint32_t a_in = a_out + mis;
+        for (uint32_t sp = tid; sp < nsp; sp += kL2Threads) {
+            const uint2 p = csync[sp];
+            uint32_t ip = p.x, op = p.y;
+            uint32_t s = sp * kSyncEvery;
+            for (uint32_t j = 0; j < kSyncEvery && s < nseq; j++, s++) {
+                const uint32_t t4 = lds_ld32(a_in + ip);           // token + 3 following bytes (may over-read: harmless)
+                const uint32_t token = t4 & 0xffu;
+                ip += 1;
+                uint32_t lit = token >> 4;
+                if (lit == 15u) {
+                    uint32_t b = (t4 >> 8) & 0xffu;
+                    ip += 1; lit += b;
+                    while (b == 255u) { b = lds_ld8(a_in + ip); ip += 1; lit += b; }
+                }
+                const uint32_t lit_src = ip;
+                ip += lit; op += lit;
+                uint32_t w = 0, mlen = 0;
+                if (s + 1u < nseq) {
+                    const uint32_t o4 = lds_ld32(a_in + ip);
+                    const uint32_t offset = o4 & 0xffffu;
+                    ip += 2;
+                    mlen = token & 15u;
+                    if (mlen == 15u) {
+                        uint32_t b = (o4 >> 16) & 0xffu;
+                        ip += 1; mlen += b;
+                        while (b == 255u) { b = lds_ld8(a_in + ip); ip += 1; mlen += b; }
+                    }
+                    mlen += 4u;
+                    w = offset | (mlen << 16);
+                }
+                table[s] = make_uint4(lit_src, lit, op, w);
+                op += mlen;
+            }
+        }
+        __syncthreads();
+        CJ_PHASE_MARK(1);
+
+        // ---- D2: literals, one lane per sequence: global -> LDS window ----
+        for (uint32_t base = wave * 64u; base < nseq; base += kL2Threads) {
+            const uint32_t r = base + lane;
+            uint4 rec = make_uint4(0, 0, 0, 0);
+            if (r < nseq) rec = table[r];
+            uint32_t n = rec.y, src = rec.x, dst = rec.z - rec.y;
+            uint64_t lm = ballot64(n >= kLongRun);
+            while (lm) {
+                const uint32_t l = ctz64(lm);
+                lm &= lm - 1ull;
+                const uint32_t ln = rdlane(n, l), ls = rdlane(src, l), ld = rdlane(dst, l);
+                for (uint32_t k = lane; k < ln; k += 64u) lds_st8(a_out + ld + k, in[ls + k]);
+                wave_bits_set(s_bits, ld, ld + ln);
+                if (lane == l) n = 0;
+            }
+            while (ballot64(n > 0u)) {                         // <=64 bytes per pass
+                const uint32_t step = n < 64u ? n : 64u;
+                const uint32_t tier = wave_tier(step, step > 0u);
+                if (step > 0u) {
+                    const uint8_t* g = in + src;
+                    if (src + 4u * (tier / 4u + 2u) <= safe_end) {      // the vector loads stay inside the chunk's last granule
+                        if (tier <= 16u) lds_store_tier<16>(gl_ld_vec<6>(g), a_out + dst, 0u, step, dm);
+                        else if (tier <= 32u) lds_store_tier<32>(gl_ld_vec<10>(g), a_out + dst, 0u, step, dm);
+                        else lds_store_tier<64>(gl_ld_vec<18>(g), a_out + dst, 0u, step, dm);
+                    } else {                                            // last few sequences of the chunk: clamped dwords
+                        const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(g) & 3u);
+                        const uint8_t* ga = g - sh;
+                        if (tier <= 16u) lds_store_tier<16>(gl_ld_aligned<6>(ga, last_dw), a_out + dst, sh, step, dm);
+                        else if (tier <= 32u) lds_store_tier<32>(gl_ld_aligned<10>(ga, last_dw), a_out + dst, sh, step, dm);
+                        else lds_store_tier<64>(gl_ld_aligned<18>(ga, last_dw), a_out + dst, sh, step, dm);
+                    }
+                    bits_set(s_bits, dst, dst + step);
+                    n -= step; src += step; dst += step;
+                }
+            }
+        }
+        __syncthreads();
+        CJ_PHASE_MARK(2);
+
+        // ---- D3: matches (same resolver as variant 1) ----
+        for (uint32_t base = wave * 64u; base < nseq; base += kL2Threads) {
+            const uint32_t r = base + lane;
+            uint4 rec = make_uint4(0, 0, 0, 0);
+            if (r < nseq) rec = table[r];
+            const uint32_t dst = rec.z, off = rec.w & 0xffffu, m = rec.w >> 16;
+            const uint32_t src = dst - off;
+            const uint32_t need = off < m ? off : m;
+            bool pending = m > 0u;
+            const bool fast = pending && m <= 32u && off >= m;
+            uint32_t pa = 0, pm0 = 0, pm1 = 0, qa = 0, qm0 = 0, qm1 = 0;
+            if (fast) {
+                const uint32_t sh = src & 31u, e = sh + need;
+                pa = (uint32_t)(uintptr_t)(s_bits + (src >> 5));
+                pm0 = (e >= 32u ? ~0u : ((1u << e) - 1u)) & (~0u << sh);
+                pm1 = e > 32u ? ((1u << (e - 32u)) - 1u) : 0u;
+                const uint32_t dh = dst & 31u, de = dh + m;
+                qa = (uint32_t)(uintptr_t)(s_bits + (dst >> 5));
+                qm0 = (de >= 32u ? ~0u : ((1u << de) - 1u)) & (~0u << dh);
+                qm1 = de > 32u ? ((1u << (de - 32u)) - 1u) : 0u;
+            }
+            const bool any_slow = ballot64(pending && !fast) != 0ull;
+            uint32_t spins = 0;
+            while (ballot64(pending) != 0ull) {
+                bool ready = false;
+                if (pending && fast) {
+                    const uint2 w = lds_ld64(pa);
+                    ready = ((w.x & pm0) == pm0) && ((w.y & pm1) == pm1);
+                }
+                const uint64_t rm = ballot64(ready);
+                if (rm != 0ull) {
+                    const uint32_t tier = ballot64(ready && m > 16u) ? 32u : 16u;
+                    if (ready) {
+                        if (tier == 16u) lds_store_tier<16>(lds_ld_aligned6((a_out + src) & ~3u), a_out + dst, src & 3u, m, dm);
+                        else lds_store_tier<32>(lds_ld_aligned10((a_out + src) & ~3u), a_out + dst, src & 3u, m, dm);
+                        asm volatile("ds_or_b32 %0, %1\n\tds_or_b32 %0, %2 offset:4" :: "v"(qa), "v"(qm0), "v"(qm1) : "memory");
+                        pending = false;
+                    }
+                }
+                if (any_slow) {
+                    bool sready = false;
+                    if (pending && !fast) sready = bits_ready(s_bits, src, src + need);
+                    if (sready && m < kLongRun) {
+                        if (off >= 8u) {
+                            uint32_t k = 0;
+                            for (; k + 8u <= m; k += 8u) {
+                                uint8_t t[8];
+#pragma unroll
+                                for (int q = 0; q < 8; q++) t[q] = s_out[src + k + q];
+#pragma unroll
+                                for (int q = 0; q < 8; q++) s_out[dst + k + q] = t[q];
+                            }
+                            for (; k < m; k++) s_out[dst + k] = s_out[src + k];
+                        } else {
+                            for (uint32_t k = 0; k < m; k++) s_out[dst + k] = s_out[src + k];
+                        }
+                        bits_set(s_bits, dst, dst + m);
+                        pending = false;
+                    }
+                    uint64_t longm = ballot64(sready && m >= kLongRun);
+                    while (longm) {
+                        const uint32_t l = ctz64(longm);
+                        longm &= longm - 1ull;
+                        const uint32_t lmm = rdlane(m, l), lo = rdlane(off, l), ld = rdlane(dst, l);
+                        const uint32_t ls = ld - lo;
+                        uint32_t rr = lane, step = 64u;
+                        if (lo <= 64u) { rr = lane % lo; step = 64u % lo; }
+                        for (uint32_t k = lane; k < lmm; k += 64u) {
+                            s_out[ld + k] = s_out[ls + (lo >= lmm ? k : rr)];
+                            rr += step;
+                            if (rr >= lo) rr -= lo;
+                        }
+                        wave_bits_set(s_bits, ld, ld + lmm);
+                        if (lane == l) pending = false;
+                    }
+                }
+                if (++spins > kSpinLimit) { *s_fail = 1u; break; }
+            }
+        }
+        __syncthreads();
+        CJ_PHASE_MARK(3);
+
+        // ---- D4: stream the window out (16 B per lane), exact tail ----
+        {
+            const uint32_t nvec = U >> 4;
+            const uint4* src = reinterpret_cast<const uint4*>(s_out);
+            for (uint32_t i = tid; i < nvec; i += kL2Threads) st16u(out + 16u * i, src[i]);
+            for (uint32_t i = (nvec << 4) + tid; i < U; i += kL2Threads) out[i] = s_out[i];
+        }
+        if (tid == 0 && *s_fail) a.result[c] = CJ_E_CORRUPT;    // cannot happen for a stream the parse kernel accepted
+        if (prof) { __syncthreads(); CJ_PHASE_MARK(4); if (tid == 0) atomicAdd(&g_lds_phase_cycles[5], 1ull); }
+    }
+}
+
+size_t lz4_lds2_tab_bytes(uint32_t grid) { return (size_t)grid * kL2TabRecords * sizeof(uint4); }
+
+void launch_lz4_decode_lds2(const BatchArgs& a, const void* sync, const void* meta, void* tabs, uint32_t* counter,
+                            uint32_t grid, hipStream_t s) {
+    if (a.n_chunks == 0) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_lds2_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kL2Bytes);
+    hipLaunchKernelGGL(lz4_decode_lds2_kernel, dim3(grid), dim3(kL2Threads), kL2Bytes, s, a,
+                       (const uint2*)sync, (const ParseMeta*)meta, (uint4*)tabs, counter);
+}
+
 void launch_lz4_decode_lds(const BatchArgs& a, const void* sync, const void* meta, hipStream_t s) {
     if (a.n_chunks == 0) return;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_lds_kernel),

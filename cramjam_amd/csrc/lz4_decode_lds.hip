@@ -429,7 +429,10 @@ __global__ __launch_bounds__(kLdsThreads) void lz4_decode_lds_kernel(BatchArgs a
 // (L2-resident: the grid is persistent, 2 slots per CU).  Two chunks per CU then overlap each other's latency.
 // Workgroups are persistent and pull chunk indices from a global counter.
 // =====================================================================================================
-constexpr uint32_t kL2Threads = 512;
+#ifndef CJ_L2_THREADS
+#define CJ_L2_THREADS 512
+#endif
+constexpr uint32_t kL2Threads = CJ_L2_THREADS;
 constexpr uint32_t kL2OffBits = 65536;
 constexpr uint32_t kL2OffVars = kL2OffBits + 8192;         // [0] fail flag, [8] current chunk, [64,128) dummy bytes, [128,384) dummy dwords
 constexpr uint32_t kL2Bytes = kL2OffVars + 384;            // 74112 B: two workgroups fit one CU's LDS
@@ -554,10 +557,14 @@ __global__ __launch_bounds__(kL2Threads) void lz4_decode_lds2_kernel(BatchArgs a
         CJ_PHASE_MARK(1);
 
         // ---- D2: literals, one lane per sequence: global -> LDS window ----
+        // (the next batch's records are requested before the current batch is processed: a coalesced table read is a
+        //  full global round trip and a wave owns only ~5 batches)
+        uint4 rec_nx = make_uint4(0, 0, 0, 0);
+        if (wave * 64u + lane < nseq) rec_nx = table[wave * 64u + lane];
         for (uint32_t base = wave * 64u; base < nseq; base += kL2Threads) {
-            const uint32_t r = base + lane;
-            uint4 rec = make_uint4(0, 0, 0, 0);
-            if (r < nseq) rec = table[r];
+            const uint4 rec = rec_nx;
+            rec_nx = make_uint4(0, 0, 0, 0);
+            if (base + kL2Threads + lane < nseq) rec_nx = table[base + kL2Threads + lane];
             uint32_t n = rec.y, src = rec.x, dst = rec.z - rec.y;
             uint64_t lm = ballot64(n >= kLongRun);
             while (lm) {
@@ -589,14 +596,19 @@ __global__ __launch_bounds__(kL2Threads) void lz4_decode_lds2_kernel(BatchArgs a
                 }
             }
         }
+#ifdef CJ_D23_BARRIER
         __syncthreads();
+#endif
         CJ_PHASE_MARK(2);
 
-        // ---- D3: matches (same resolver as variant 1) ----
+        // ---- D3: matches (same resolver as variant 1).  No barrier after D2: readiness is exact per byte through the
+        //      bitmap, so a wave starts on its matches while other waves are still placing literals ----
+        rec_nx = make_uint4(0, 0, 0, 0);
+        if (wave * 64u + lane < nseq) rec_nx = table[wave * 64u + lane];
         for (uint32_t base = wave * 64u; base < nseq; base += kL2Threads) {
-            const uint32_t r = base + lane;
-            uint4 rec = make_uint4(0, 0, 0, 0);
-            if (r < nseq) rec = table[r];
+            const uint4 rec = rec_nx;
+            rec_nx = make_uint4(0, 0, 0, 0);
+            if (base + kL2Threads + lane < nseq) rec_nx = table[base + kL2Threads + lane];
             const uint32_t dst = rec.z, off = rec.w & 0xffffu, m = rec.w >> 16;
             const uint32_t src = dst - off;
             const uint32_t need = off < m ? off : m;
@@ -678,7 +690,7 @@ __global__ __launch_bounds__(kL2Threads) void lz4_decode_lds2_kernel(BatchArgs a
         {
             const uint32_t nvec = U >> 4;
             const uint4* src = reinterpret_cast<const uint4*>(s_out);
-            for (uint32_t i = tid; i < nvec; i += kL2Threads) st16u(out + 16u * i, src[i]);
+            for (uint32_t i = tid; i < nvec; i += kL2Threads) st16u_nt(out + 16u * i, src[i]);   // streamed out, never re-read: keep L2 for the record tables
             for (uint32_t i = (nvec << 4) + tid; i < U; i += kL2Threads) out[i] = s_out[i];
         }
         if (tid == 0 && *s_fail) a.result[c] = CJ_E_CORRUPT;    // cannot happen for a stream the parse kernel accepted

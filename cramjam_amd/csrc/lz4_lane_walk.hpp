@@ -32,6 +32,7 @@ __device__ __forceinline__ uint4 ld16u(const uint8_t* p) { uint4 v; __builtin_me
 __device__ __forceinline__ void st16u(uint8_t* p, const uint4& v) { __builtin_memcpy(p, &v, 16); }
 #if defined(CJ_HOST_SIM)
 __device__ __forceinline__ uint4 ld16u_nt(const uint8_t* p) { return ld16u(p); }
+__device__ __forceinline__ void st16u_nt(uint8_t* p, const uint4& v) { st16u(p, v); }
 #else
 // Non-temporal 16 B load for the match sources: those reads land anywhere in the last 64 KiB of the chunk's output
 // and are never reused, but through the normal path they evict the partially written output lines of every lane
@@ -40,6 +41,11 @@ typedef uint32_t cj_u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1
 __device__ __forceinline__ uint4 ld16u_nt(const uint8_t* p) {
     const cj_u32x4_unaligned v = __builtin_nontemporal_load(reinterpret_cast<const cj_u32x4_unaligned*>(p));
     return make_uint4(v.x, v.y, v.z, v.w);
+}
+// Non-temporal 16 B store: finished output that this kernel never reads back (keeps L2 for data that is reused)
+__device__ __forceinline__ void st16u_nt(uint8_t* p, const uint4& v) {
+    cj_u32x4_unaligned t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<cj_u32x4_unaligned*>(p));
 }
 #endif
 

@@ -130,7 +130,7 @@ typedef enum { CJ_OP_DECOMPRESS = 0, CJ_OP_COMPRESS = 1 } cj_op;
 #define CJ_LDS_MIN_CHUNKS 8192
 /* share (n/20) of the short-sequence chunks of such a batch that is decoded by the lane-per-chunk kernel on an
  * internal auxiliary stream, concurrently with the LDS workgroup decoder (env CJ_LANE_SHARE overrides; 0 = off) */
-#define CJ_LANE_SHARE_DEFAULT 6
+#define CJ_LANE_SHARE_DEFAULT 0
 /* decode batches larger than this are submitted in slices of this many chunks (env CJ_SLICE_CHUNKS) */
 #define CJ_SLICE_CHUNKS_DEFAULT 131072
 /* Snappy: share (n/20) of the mid-ratio chunks of a large batch decoded by the lane-per-chunk kernel, concurrently

@@ -65,31 +65,208 @@ __device__ __forceinline__ uint32_t wave_extend_back(const uint8_t* in, uint32_t
     return cnt < lim ? cnt : lim;
 }
 
-// One probe round over positions [pos, pos+64).  last_start: last position where a match may start
-// (needs 4 readable bytes).  Returns the ballot of verified lanes; cand (per lane) is the match source,
-// hslot the lane's table slot (kNoSlot when the lane is past last_start).  The table is NOT updated here:
-// the caller inserts, after it has consumed the ballot, only the positions that did not end up inside an
-// emitted match (insert_uncovered).  Positions inside a match repeat content whose source is already
-// indexed; inserting them too evicts distant sources from the small table ~4x faster on match-heavy
-// data (measured on synth-v1: ratio 1.37 with dense insertion vs the CPU encoder's 1.63).
-constexpr uint32_t kNoSlot = 0xffffffffu;
+// ---- per-lane match extension ------------------------------------------------------------------------------
+// Every verified lane measures ITS OWN candidate right after the probe — forward up to kLaneFwdCap bytes, backward
+// up to 16 — with 16 B vector compares, all lanes in parallel.  The greedy selection that follows then runs on
+// registers only (v_readlane), instead of one cooperative extension = several dependent global round trips per
+// selected match: the encoders were bound by exactly those round trips (~13 per 64-position round, ~9k cycles).
+// Matches that hit a cap (long runs) are finished cooperatively by wave_extend / wave_extend_back.
+// (fwd: equal bytes after the 4 verified ones; back: equal bytes before the position / candidate, limited to the
+//  pending literal run and to the candidate's own position.)
+constexpr uint32_t kLaneFwdCap = 64;
 
-__device__ __forceinline__ uint64_t probe_round(const uint8_t* in, const uint16_t* ht, uint32_t pos,
-                                                uint32_t last_start, uint32_t& cand, uint32_t& hslot) {
-    const uint32_t my = pos + lane_id();
-    const bool valid = my <= last_start;
-    uint32_t v = 0, h = kNoSlot, c = 0;
-    bool ok = false;
-    if (valid) {
-        v = ld32u(in + my);
-        h = (v * 2654435761u) >> (32 - kHashBits);
-        c = (my & 0xFFFF0000u) | ht[h];
-        if (c >= my) c -= 65536u;           // slot belongs to the previous 64 KiB lap (or is stale)
-        if (c < my && my - c <= 65535u) ok = ld32u(in + c) == v;
+__device__ __forceinline__ uint4 ld16m(const uint8_t* p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
+
+__device__ __forceinline__ uint32_t first_diff16(const uint4& x, const uint4& y) {     // index of the first differing byte, 16 if none
+    const uint32_t d0 = x.x ^ y.x, d1 = x.y ^ y.y, d2 = x.z ^ y.z, d3 = x.w ^ y.w;
+    if (d0) return (uint32_t)__builtin_ctz(d0) >> 3;
+    if (d1) return 4u + ((uint32_t)__builtin_ctz(d1) >> 3);
+    if (d2) return 8u + ((uint32_t)__builtin_ctz(d2) >> 3);
+    if (d3) return 12u + ((uint32_t)__builtin_ctz(d3) >> 3);
+    return 16u;
+}
+
+__device__ __forceinline__ uint32_t last_same16(const uint4& x, const uint4& y) {      // equal bytes counted from the END of the 16, 16 if all
+    const uint32_t d0 = x.x ^ y.x, d1 = x.y ^ y.y, d2 = x.z ^ y.z, d3 = x.w ^ y.w;
+    if (d3) return (uint32_t)__builtin_clz(d3) >> 3;
+    if (d2) return 4u + ((uint32_t)__builtin_clz(d2) >> 3);
+    if (d1) return 8u + ((uint32_t)__builtin_clz(d1) >> 3);
+    if (d0) return 12u + ((uint32_t)__builtin_clz(d0) >> 3);
+    return 16u;
+}
+
+// One probe ROUND covers kSub x 64 consecutive positions: lane l owns positions pos + 64 j + l, j < kSub.  All kSub
+// sub-rounds are probed against the table as it was at the start of the round, and every kind of memory access is
+// issued for all sub-rounds before the first result is used — the round costs the same ~4 dependent global round
+// trips as a 64-position round did (own dwords, candidate dwords, extension blocks, literal sources of the emitted
+// sequences), which is what bounds these kernels (10 waves per CU: the 16 KiB table per wave fills the LDS).
+// Probing 256 positions against a table that is up to 255 positions stale loses < 1 % of ratio on the benchmark
+// data (simulated: 1.650 -> 1.645) — near repeats are still found through older table entries and the backward
+// extension.  last_start: last position where a match may start (needs 4 readable bytes); limit: a match must end
+// here at the latest; anchor: start of the pending literal run.  The table is NOT updated here: the caller inserts,
+// after it has consumed the ballots, only the positions that did not end up inside an emitted match
+// (insert_uncovered).  Positions inside a match repeat content whose source is already indexed; inserting them
+// too evicts distant sources from the small table ~4x faster on match-heavy data (measured on synth-v1: ratio
+// 1.37 with dense insertion vs the CPU encoder's 1.63).
+constexpr uint32_t kNoSlot = 0xffffffffu;
+constexpr int kSub = 4;
+constexpr uint32_t kRoundPositions = 64u * kSub;
+
+struct Round {
+    uint32_t cand[kSub], hslot[kSub];
+    uint32_t ext[kSub];          // fwd | back << 8 | fwd_more << 14 | back_more << 15 (per lane)
+    uint64_t mask[kSub];         // verified lanes of each sub-round (wave-uniform)
+};
+
+__device__ __forceinline__ void probe_round(const uint8_t* in, const uint16_t* ht, uint32_t pos, uint32_t last_start,
+                                            uint32_t limit, uint32_t anchor, Round& r) {
+    const uint32_t lane = lane_id();
+    uint32_t v[kSub];
+    bool ok[kSub];
+    // own dwords: kSub coalesced loads in flight
+#pragma unroll
+    for (int j = 0; j < kSub; j++) {
+        const uint32_t my = pos + 64u * j + lane;
+        v[j] = 0u;
+        r.hslot[j] = kNoSlot;
+        if (my <= last_start) v[j] = ld32u(in + my);
     }
-    cand = c;
-    hslot = h;
-    return ballot64(ok);
+    // table lookups, then the candidate dwords: kSub divergent loads in flight
+    uint32_t w[kSub];
+#pragma unroll
+    for (int j = 0; j < kSub; j++) {
+        const uint32_t my = pos + 64u * j + lane;
+        uint32_t c = 0;
+        ok[j] = false;
+        if (my <= last_start) {
+            const uint32_t h = (v[j] * 2654435761u) >> (32 - kHashBits);
+            r.hslot[j] = h;
+            c = (my & 0xFFFF0000u) | ht[h];
+            if (c >= my) c -= 65536u;       // slot belongs to the previous 64 KiB lap (or is stale)
+            ok[j] = c < my && my - c <= 65535u;
+        }
+        r.cand[j] = c;
+        w[j] = 0u;
+        if (ok[j]) w[j] = ld32u(in + c);
+    }
+    // first forward block and the backward block of every verified candidate: up to 4 kSub vector loads in flight
+    uint4 fx[kSub], fy[kSub], bx[kSub], by[kSub];
+    bool f16[kSub], b16[kSub];
+    uint32_t blim[kSub];
+#pragma unroll
+    for (int j = 0; j < kSub; j++) {
+        const uint32_t my = pos + 64u * j + lane, c = r.cand[j];
+        ok[j] = ok[j] && w[j] == v[j];
+        const uint32_t room = my > anchor ? my - anchor : 0u;
+        blim[j] = room < c ? room : c;
+        f16[j] = ok[j] && my + 20u <= limit;
+        b16[j] = ok[j] && c >= 16u && blim[j] > 0u;
+        fx[j] = fy[j] = bx[j] = by[j] = make_uint4(0, 0, 0, 0);
+        if (f16[j]) { fx[j] = ld16m(in + my + 4u); fy[j] = ld16m(in + c + 4u); }
+        if (b16[j]) { bx[j] = ld16m(in + my - 16u); by[j] = ld16m(in + c - 16u); }
+    }
+    // first blocks -> lengths; lanes whose first 16 bytes all matched continue, ALL sub-rounds together per extra
+    // round trip (a per-sub-round loop would serialise up to kSub x 3 more round trips)
+    uint32_t fwd[kSub], back[kSub];
+    bool more[kSub], back_more[kSub];
+#pragma unroll
+    for (int j = 0; j < kSub; j++) {
+        const uint32_t my = pos + 64u * j + lane, c = r.cand[j];
+        fwd[j] = 0u; back[j] = 0u; more[j] = false; back_more[j] = false;
+        if (ok[j]) {
+            const uint32_t a = my + 4u, b = c + 4u;
+            if (f16[j]) {
+                fwd[j] = first_diff16(fx[j], fy[j]);
+                more[j] = fwd[j] == 16u;
+            } else {
+                while (a + fwd[j] < limit && in[a + fwd[j]] == in[b + fwd[j]]) fwd[j] += 1u;   // within 16 bytes of the limit: chunk tail only
+            }
+            if (b16[j]) {
+                const uint32_t sm = last_same16(bx[j], by[j]);
+                back[j] = sm < blim[j] ? sm : blim[j];
+                back_more[j] = sm == 16u && blim[j] > 16u;
+            } else {
+                while (back[j] < blim[j] && in[my - 1u - back[j]] == in[c - 1u - back[j]]) back[j] += 1u;   // candidate in the chunk's first 16 bytes
+            }
+        }
+    }
+    for (uint32_t it = 1; it < kLaneFwdCap / 16u; it++) {
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < kSub; j++) any = any || more[j];
+        if (ballot64(any) == 0ull) break;
+#pragma unroll
+        for (int j = 0; j < kSub; j++) {        // loads of all sub-rounds first ...
+            const uint32_t a = pos + 64u * j + lane + 4u + fwd[j];
+            f16[j] = more[j] && a + 16u <= limit;
+            if (f16[j]) { fx[j] = ld16m(in + a); fy[j] = ld16m(in + r.cand[j] + 4u + fwd[j]); }
+        }
+#pragma unroll
+        for (int j = 0; j < kSub; j++) {        // ... then the compares
+            if (!more[j]) continue;
+            const uint32_t a = pos + 64u * j + lane + 4u, b = r.cand[j] + 4u;
+            if (f16[j]) {
+                const uint32_t d = first_diff16(fx[j], fy[j]);
+                fwd[j] += d;
+                more[j] = d == 16u;
+            } else {
+                while (a + fwd[j] < limit && in[a + fwd[j]] == in[b + fwd[j]]) fwd[j] += 1u;
+                more[j] = false;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kSub; j++) {
+        const uint32_t a = pos + 64u * j + lane + 4u;
+        const bool fwd_more = more[j] && a + fwd[j] < limit;
+        r.ext[j] = fwd[j] | (back[j] << 8) | ((uint32_t)fwd_more << 14) | ((uint32_t)back_more[j] << 15);
+        r.mask[j] = ballot64(ok[j]);
+    }
+}
+
+// the selected lane's measurements -> final (mpos, mc, mlen) of the match, finishing capped extensions cooperatively
+__device__ __forceinline__ void finish_match(const uint8_t* in, uint32_t ext_lane, uint32_t first, uint32_t anchor, uint32_t limit,
+                                             uint32_t& mpos, uint32_t& mc, uint32_t& mlen) {
+    const uint32_t e = rdlane(ext_lane, first);
+    mlen = 4u + (e & 0xffu);
+    if (e & (1u << 14)) mlen += wave_extend(in, mpos + mlen, mc + mlen, limit);
+    const uint32_t room = mpos - anchor;
+    uint32_t back = (e >> 8) & 0x3fu;
+    if (back > room) back = room;
+    else if ((e & (1u << 15)) && back == 16u) back += wave_extend_back(in, mpos - 16u, mc - 16u, room - 16u);
+    mpos -= back; mc -= back; mlen += back;
+}
+
+// exact n-byte copy by ONE lane: 64 B batches with the four loads in flight together (a load -> store loop costs one
+// global round trip per 16 bytes), then 16 B blocks and an 8/4/2/1 tail: lane-parallel emission of short literal runs
+__device__ __forceinline__ void lane_copy_exact(uint8_t* dst, const uint8_t* src, uint32_t n) {
+    uint32_t k = 0;
+    for (; k + 64u <= n; k += 64u) {
+        const uint4 t0 = ld16m(src + k), t1 = ld16m(src + k + 16u), t2 = ld16m(src + k + 32u), t3 = ld16m(src + k + 48u);
+        __builtin_memcpy(dst + k, &t0, 16); __builtin_memcpy(dst + k + 16u, &t1, 16);
+        __builtin_memcpy(dst + k + 32u, &t2, 16); __builtin_memcpy(dst + k + 48u, &t3, 16);
+    }
+    const uint32_t rem = n - k;                     // < 64: up to three 16 B blocks + tail, all loads first
+    uint4 t0 = make_uint4(0, 0, 0, 0), t1 = t0, t2 = t0;
+    uint2 t8 = make_uint2(0, 0);
+    uint32_t t4 = 0, t21 = 0;
+    const uint32_t nb = rem >> 4;
+    if (nb > 0u) t0 = ld16m(src + k);
+    if (nb > 1u) t1 = ld16m(src + k + 16u);
+    if (nb > 2u) t2 = ld16m(src + k + 32u);
+    uint32_t q = k + 16u * nb;
+    if (rem & 8u) { __builtin_memcpy(&t8, src + q, 8); q += 8u; }
+    if (rem & 4u) { __builtin_memcpy(&t4, src + q, 4); q += 4u; }
+    if (rem & 2u) { t21 = (uint32_t)src[q] | ((uint32_t)src[q + 1u] << 8); q += 2u; }
+    if (rem & 1u) t21 |= (uint32_t)src[q] << 16;
+    if (nb > 0u) __builtin_memcpy(dst + k, &t0, 16);
+    if (nb > 1u) __builtin_memcpy(dst + k + 16u, &t1, 16);
+    if (nb > 2u) __builtin_memcpy(dst + k + 32u, &t2, 16);
+    q = k + 16u * nb;
+    if (rem & 8u) { __builtin_memcpy(dst + q, &t8, 8); q += 8u; }
+    if (rem & 4u) { __builtin_memcpy(dst + q, &t4, 4); q += 4u; }
+    if (rem & 2u) { dst[q] = (uint8_t)t21; dst[q + 1u] = (uint8_t)(t21 >> 8); q += 2u; }
+    if (rem & 1u) dst[q] = (uint8_t)(t21 >> 16);
 }
 
 // covered: bit l set = position pos + l lies strictly inside an emitted match (not its first byte)

@@ -20,6 +20,32 @@ __device__ __forceinline__ uint32_t emit_len_ext(uint8_t* out, uint32_t op, uint
     return op + full + 1u;
 }
 
+constexpr uint32_t kCoopLit = 256;       // literal runs / match codes at least this long are emitted by the whole wavefront
+constexpr uint32_t kCoopMatch = 2048;
+
+// Lane-parallel emission: lane k < q_n writes sequence k of the round (token, length bytes, literals, offset) at its
+// precomputed output position.  All literal sources are loaded in one round trip instead of one per sequence.
+__device__ __forceinline__ void lz4_emit_queue(const uint8_t* in, uint8_t* out, uint32_t q_n, uint32_t lit0, uint32_t lit,
+                                               uint32_t off, uint32_t mcode, uint32_t qop) {
+    if (lane_id() >= q_n) return;
+    uint8_t* o = out + qop;
+    *o++ = (uint8_t)(((lit < 15u ? lit : 15u) << 4) | (mcode < 15u ? mcode : 15u));
+    if (lit >= 15u) {
+        uint32_t v = lit - 15u;
+        while (v >= 255u) { *o++ = 255u; v -= 255u; }
+        *o++ = (uint8_t)v;
+    }
+    lane_copy_exact(o, in + lit0, lit);
+    o += lit;
+    o[0] = (uint8_t)off; o[1] = (uint8_t)(off >> 8);
+    o += 2;
+    if (mcode >= 15u) {
+        uint32_t v = mcode - 15u;
+        while (v >= 255u) { *o++ = 255u; v -= 255u; }
+        *o++ = (uint8_t)v;
+    }
+}
+
 __global__ __launch_bounds__(kEncThreads) void lz4_encode_kernel(BatchArgs a) {
     __shared__ uint16_t ht_all[kEncWaves][kHashSize];
     const uint32_t wave = uni(threadIdx.x >> 6);
@@ -50,36 +76,55 @@ __global__ __launch_bounds__(kEncThreads) void lz4_encode_kernel(BatchArgs a) {
         const uint32_t matchlimit = n - 5u;     // and must end here at the latest
         uint32_t pos = 0;
         while (pos <= last_start) {
-            uint32_t cand, hslot;
-            uint64_t mask = probe_round(in, ht, pos, last_start, cand, hslot);
-            const uint32_t batch_end = pos + 64u;
-            uint64_t covered = 0ull;
-            while (mask) {
-                const uint32_t first = ctz64(mask);
-                uint32_t mpos = pos + first;
-                uint32_t mc = rdlane(cand, first);
-                uint32_t mlen = 4u + wave_extend(in, mpos + 4u, mc + 4u, matchlimit);
-                const uint32_t back = wave_extend_back(in, mpos, mc, mpos - anchor);
-                mpos -= back; mc -= back; mlen += back;
-                const uint32_t lit = mpos - anchor;
-                const uint32_t mcode = mlen - 4u;
-                // token
-                if (lane == 0) out[op] = (uint8_t)(((lit < 15u ? lit : 15u) << 4) | (mcode < 15u ? mcode : 15u));
-                op += 1;
-                if (lit >= 15u) op = emit_len_ext(out, op, lit - 15u);
-                wave_copy(out + op, in + anchor, lit);
-                op += lit;
-                const uint32_t off = mpos - mc;
-                if (lane < 2) out[op + lane] = (uint8_t)(off >> (8u * lane));
-                op += 2;
-                if (mcode >= 15u) op = emit_len_ext(out, op, mcode - 15u);
-                anchor = mpos + mlen;
-                covered |= covered_bits(pos, mpos, anchor - pos);
-                if (anchor >= batch_end) mask = 0;
-                else mask &= ~0ull << (anchor - pos);
+            Round r;
+            probe_round(in, ht, pos, last_start, matchlimit, anchor, r);
+            const uint32_t round_end = pos + kRoundPositions;
+            uint64_t covered[kSub] = {};
+            // greedy selection on registers; the selected sequences are queued one per lane and emitted together
+            uint32_t q_n = 0, q_lit0 = 0, q_lit = 0, q_off = 0, q_mcode = 0, q_op = 0;
+#pragma unroll
+            for (int j = 0; j < kSub; j++) {
+                const uint32_t pj = pos + 64u * j;
+                uint64_t mask = r.mask[j];
+                if (anchor > pj) mask = anchor - pj >= 64u ? 0ull : mask & (~0ull << (anchor - pj));
+                while (mask) {
+                    const uint32_t first = ctz64(mask);
+                    uint32_t mpos = pj + first;
+                    uint32_t mc = rdlane(r.cand[j], first), mlen;
+                    finish_match(in, r.ext[j], first, anchor, matchlimit, mpos, mc, mlen);
+                    const uint32_t lit = mpos - anchor, mcode = mlen - 4u, off = mpos - mc;
+                    if (lit >= kCoopLit || mcode >= kCoopMatch) {
+                        // long literal run / very long match: whole-wave emission right away (after the queue, to keep op order)
+                        lz4_emit_queue(in, out, q_n, q_lit0, q_lit, q_off, q_mcode, q_op);
+                        q_n = 0;
+                        if (lane == 0) out[op] = (uint8_t)(((lit < 15u ? lit : 15u) << 4) | (mcode < 15u ? mcode : 15u));
+                        op += 1;
+                        if (lit >= 15u) op = emit_len_ext(out, op, lit - 15u);
+                        wave_copy(out + op, in + anchor, lit);
+                        op += lit;
+                        if (lane < 2) out[op + lane] = (uint8_t)(off >> (8u * lane));
+                        op += 2;
+                        if (mcode >= 15u) op = emit_len_ext(out, op, mcode - 15u);
+                    } else {
+                        if (q_n == 64u) { lz4_emit_queue(in, out, q_n, q_lit0, q_lit, q_off, q_mcode, q_op); q_n = 0; }     // cannot happen with >= 4-byte matches; kept as a guard
+                        if (lane == q_n) { q_lit0 = anchor; q_lit = lit; q_off = off; q_mcode = mcode; q_op = op; }
+                        q_n += 1;
+                        op += 1u + (lit >= 15u ? 1u + (lit - 15u) / 255u : 0u) + lit + 2u + (mcode >= 15u ? 1u + (mcode - 15u) / 255u : 0u);
+                    }
+                    anchor = mpos + mlen;
+#pragma unroll
+                    for (int jj = 0; jj < kSub; jj++) {
+                        const uint32_t pjj = pos + 64u * jj;
+                        if (anchor > pjj) covered[jj] |= covered_bits(pjj, mpos, anchor - pjj);
+                    }
+                    if (anchor >= pj + 64u) mask = 0;
+                    else mask &= ~0ull << (anchor - pj);
+                }
             }
-            insert_uncovered(ht, pos, hslot, covered);
-            pos = anchor > batch_end ? anchor : batch_end;
+            lz4_emit_queue(in, out, q_n, q_lit0, q_lit, q_off, q_mcode, q_op);
+#pragma unroll
+            for (int j = 0; j < kSub; j++) insert_uncovered(ht, pos + 64u * j, r.hslot[j], covered[j]);
+            pos = anchor > round_end ? anchor : round_end;
         }
     }
     {   // last literals

@@ -55,6 +55,45 @@ __device__ __forceinline__ uint32_t emit_snappy_copy(uint8_t* out, uint32_t op, 
     return op;
 }
 
+constexpr uint32_t kSnCoopLit = 256;     // literal runs / copies at least this long are emitted by the whole wavefront
+constexpr uint32_t kSnCoopMatch = 1024;
+
+__device__ __forceinline__ uint32_t snappy_literal_size(uint32_t lit) {     // header + data bytes of a literal element (0 for none)
+    if (lit == 0u) return 0u;
+    const uint32_t n1 = lit - 1u;
+    return lit + (n1 < 60u ? 1u : n1 < 256u ? 2u : n1 < 65536u ? 3u : n1 < 16777216u ? 4u : 5u);
+}
+
+__device__ __forceinline__ uint32_t snappy_copy_size(uint32_t off, uint32_t len) {   // mirrors emit_snappy_copy's splitting
+    const uint32_t n64 = len >= 68u ? (len - 4u) / 64u : 0u;
+    uint32_t bytes = 3u * n64;
+    len -= 64u * n64;
+    if (len > 64u) { bytes += 3u; len -= 60u; }
+    return bytes + ((len < 12u && off < 2048u) ? 2u : 3u);
+}
+
+// Lane-parallel emission: lane k < q_n writes literal + copy elements of sequence k at its precomputed output position
+__device__ __forceinline__ void snappy_emit_queue(const uint8_t* in, uint8_t* out, uint32_t q_n, uint32_t lit0, uint32_t lit,
+                                                  uint32_t off, uint32_t len, uint32_t qop) {
+    if (lane_id() >= q_n) return;
+    uint8_t* o = out + qop;
+    if (lit) {
+        const uint32_t n1 = lit - 1u;
+        if (n1 < 60u) *o++ = (uint8_t)(n1 << 2);
+        else {
+            const uint32_t nb = n1 < 256u ? 1u : n1 < 65536u ? 2u : n1 < 16777216u ? 3u : 4u;
+            *o++ = (uint8_t)((59u + nb) << 2);
+            for (uint32_t k = 0; k < nb; k++) *o++ = (uint8_t)(n1 >> (8u * k));
+        }
+        lane_copy_exact(o, in + lit0, lit);
+        o += lit;
+    }
+    while (len >= 68u) { o[0] = (uint8_t)(2u | (63u << 2)); o[1] = (uint8_t)off; o[2] = (uint8_t)(off >> 8); o += 3; len -= 64u; }
+    if (len > 64u) { o[0] = (uint8_t)(2u | (59u << 2)); o[1] = (uint8_t)off; o[2] = (uint8_t)(off >> 8); o += 3; len -= 60u; }
+    if (len < 12u && off < 2048u) { o[0] = (uint8_t)(1u | ((len - 4u) << 2) | ((off >> 8) << 5)); o[1] = (uint8_t)off; }
+    else { o[0] = (uint8_t)(2u | ((len - 1u) << 2)); o[1] = (uint8_t)off; o[2] = (uint8_t)(off >> 8); }
+}
+
 __global__ __launch_bounds__(kEncThreads) void snappy_encode_kernel(BatchArgs a) {
     __shared__ uint16_t ht_all[kEncWaves][kHashSize];
     const uint32_t wave = uni(threadIdx.x >> 6);
@@ -87,26 +126,47 @@ __global__ __launch_bounds__(kEncThreads) void snappy_encode_kernel(BatchArgs a)
         const uint32_t last_start = n - 4u;
         uint32_t pos = 0;
         while (pos <= last_start) {
-            uint32_t cand, hslot;
-            uint64_t mask = probe_round(in, ht, pos, last_start, cand, hslot);
-            const uint32_t batch_end = pos + 64u;
-            uint64_t covered = 0ull;
-            while (mask) {
-                const uint32_t first = ctz64(mask);
-                uint32_t mpos = pos + first;
-                uint32_t mc = rdlane(cand, first);
-                uint32_t mlen = 4u + wave_extend(in, mpos + 4u, mc + 4u, n);
-                const uint32_t back = wave_extend_back(in, mpos, mc, mpos - anchor);
-                mpos -= back; mc -= back; mlen += back;
-                if (mpos > anchor) op = emit_snappy_literal(out, op, in + anchor, mpos - anchor);
-                op = emit_snappy_copy(out, op, mpos - mc, mlen);
-                anchor = mpos + mlen;
-                covered |= covered_bits(pos, mpos, anchor - pos);
-                if (anchor >= batch_end) mask = 0;
-                else mask &= ~0ull << (anchor - pos);
+            Round r;
+            probe_round(in, ht, pos, last_start, n, anchor, r);
+            const uint32_t round_end = pos + kRoundPositions;
+            uint64_t covered[kSub] = {};
+            uint32_t q_n = 0, q_lit0 = 0, q_lit = 0, q_off = 0, q_mlen = 0, q_op = 0;
+#pragma unroll
+            for (int j = 0; j < kSub; j++) {
+                const uint32_t pj = pos + 64u * j;
+                uint64_t mask = r.mask[j];
+                if (anchor > pj) mask = anchor - pj >= 64u ? 0ull : mask & (~0ull << (anchor - pj));
+                while (mask) {
+                    const uint32_t first = ctz64(mask);
+                    uint32_t mpos = pj + first;
+                    uint32_t mc = rdlane(r.cand[j], first), mlen;
+                    finish_match(in, r.ext[j], first, anchor, n, mpos, mc, mlen);
+                    const uint32_t lit = mpos - anchor, off = mpos - mc;
+                    if (lit >= kSnCoopLit || mlen >= kSnCoopMatch) {
+                        snappy_emit_queue(in, out, q_n, q_lit0, q_lit, q_off, q_mlen, q_op);
+                        q_n = 0;
+                        if (lit) op = emit_snappy_literal(out, op, in + anchor, lit);
+                        op = emit_snappy_copy(out, op, off, mlen);
+                    } else {
+                        if (q_n == 64u) { snappy_emit_queue(in, out, q_n, q_lit0, q_lit, q_off, q_mlen, q_op); q_n = 0; }     // cannot happen with >= 4-byte matches; kept as a guard
+                        if (lane == q_n) { q_lit0 = anchor; q_lit = lit; q_off = off; q_mlen = mlen; q_op = op; }
+                        q_n += 1;
+                        op += snappy_literal_size(lit) + snappy_copy_size(off, mlen);
+                    }
+                    anchor = mpos + mlen;
+#pragma unroll
+                    for (int jj = 0; jj < kSub; jj++) {
+                        const uint32_t pjj = pos + 64u * jj;
+                        if (anchor > pjj) covered[jj] |= covered_bits(pjj, mpos, anchor - pjj);
+                    }
+                    if (anchor >= pj + 64u) mask = 0;
+                    else mask &= ~0ull << (anchor - pj);
+                }
             }
-            insert_uncovered(ht, pos, hslot, covered);
-            pos = anchor > batch_end ? anchor : batch_end;
+            snappy_emit_queue(in, out, q_n, q_lit0, q_lit, q_off, q_mlen, q_op);
+#pragma unroll
+            for (int j = 0; j < kSub; j++) insert_uncovered(ht, pos + 64u * j, r.hslot[j], covered[j]);
+            pos = anchor > round_end ? anchor : round_end;
         }
     }
     if (anchor < n) op = emit_snappy_literal(out, op, in + anchor, n - anchor);

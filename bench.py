@@ -260,7 +260,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic,
                          "kernel": {"auto": "lz4_parse_kernel+lz4_decode_lds2_kernel", "lds": "lz4_parse_kernel+lz4_decode_lds2_kernel", "wave": "lz4_decode_kernel",
-                                    "lane": "lz4_decode_lanes_kernel"}[args.lz4_mode] if (dec and args.codec == "lz4") else "%s_%s_kernel" % (args.codec, "decode" if dec else "encode"),
+                                    "lane": "lz4_decode_lanes_kernel"}[args.lz4_mode] if (dec and args.codec == "lz4") else ("snappy_parse_kernel+lz4_decode_lds2_kernel<snappy>" if (dec and args.lz4_mode in ("auto", "lds")) else "%s_%s_kernel" % (args.codec, "decode" if dec else "encode")),
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo},
             "cpu_baseline": cpu,
         }

@@ -33,7 +33,8 @@ void launch_lz4_decode_listed(const BatchArgs& a, const void* lists, uint32_t wa
 void launch_lz4_decode_lds(const BatchArgs& a, const void* sync, const void* meta, hipStream_t s);
 void launch_lz4_decode_routed(const BatchArgs& a, const void* meta, hipStream_t s);   // wave kernel on chunks the parse kernel routed to it
 // variant 2: persistent grid (2 workgroups per CU), record tables in the global scratch `tabs`, chunk indices from *counter
-void launch_lz4_decode_lds2(const BatchArgs& a, const void* sync, const void* meta, void* tabs, uint32_t* counter, uint32_t grid, hipStream_t s);
+// codec: CJ_CODEC_LZ4_BLOCK or CJ_CODEC_SNAPPY_RAW (only the record expansion D1 differs)
+void launch_lz4_decode_lds2(const BatchArgs& a, const void* sync, const void* meta, void* tabs, uint32_t* counter, uint32_t grid, hipStream_t s, int codec = 0);
 size_t lz4_lds2_tab_bytes(uint32_t grid);
 size_t lz4_lds_scratch_sync_bytes(size_t n_chunks);
 size_t lz4_lds_scratch_meta_bytes(size_t n_chunks);
@@ -41,6 +42,8 @@ void launch_lz4_encode(const BatchArgs& a, hipStream_t s);
 void launch_snappy_decode(const BatchArgs& a, hipStream_t s);                                   // one wavefront per chunk
 void launch_snappy_decode_skipping(const BatchArgs& a, const void* meta, hipStream_t s);         // ... except chunks flagged for the lane kernel
 void launch_snappy_decode_lanes(const BatchArgs& a, const void* lists, uint32_t lane_share, hipStream_t s);   // one lane per chunk (all, or the listed share)
+void launch_snappy_parse(const BatchArgs& a, void* sync, void* meta, hipStream_t s);           // parse + LDS pipeline, like launch_lz4_parse
+void launch_snappy_decode_routed(const BatchArgs& a, const void* meta, hipStream_t s);       // wave kernel on chunks the parse kernel routed to it
 void launch_snappy_encode(const BatchArgs& a, hipStream_t s);
 
 #if defined(__HIPCC__)

@@ -105,12 +105,42 @@ int launch_slice(cj_engine* e, cj_codec codec, cj_op op, const cj::BatchArgs& a,
                 long x = v ? std::strtol(v, nullptr, 10) : CJ_SNAPPY_LANE_SHARE_DEFAULT;
                 return (uint32_t)(x < 0 ? 0 : x > 20 ? 20 : x);
             }();
-            int mode = (a.n_chunks >= big_min && sn_share > 0) ? 2 : 0;
+            // large batches: 3 = parse + LDS workgroup decoder (+ wave kernel on routed chunks), the same pipeline as LZ4;
+            // 2 = the earlier classify + lane-kernel pipeline (CJ_SNAPPY_PIPELINE=lanes), kept for comparison
+            static const bool lanes_pipeline = [] { const char* v = std::getenv("CJ_SNAPPY_PIPELINE"); return v && std::string(v) == "lanes"; }();
+            int mode = a.n_chunks >= big_min ? (lanes_pipeline ? (sn_share > 0 ? 2 : 0) : 3) : 0;
             if (a.flags & CJ_FLAG_FORCE_WAVE_PER_CHUNK) mode = 0;
             if (a.flags & CJ_FLAG_FORCE_LANE_PER_CHUNK) mode = 1;
+            if (a.flags & CJ_FLAG_FORCE_LDS_PER_CHUNK) mode = 3;
             if (mode == 0) cj::launch_snappy_decode(a, s);
             else if (mode == 1) cj::launch_snappy_decode_lanes(a, nullptr, 0, s);
-            else {
+            else if (mode == 3) {
+                std::lock_guard<std::mutex> lock(e->scratch_mu);
+                const size_t list_bytes = 16 + (size_t)a.n_chunks * 8;
+                const bool grow = cj::lz4_lds_scratch_sync_bytes(a.n_chunks) > e->d_sync.cap ||
+                                  cj::lz4_lds_scratch_meta_bytes(a.n_chunks) > e->d_pmeta.cap || list_bytes > e->d_lanelist.cap;
+                if (grow && e->scratch_free) HIP_TRY(hipEventSynchronize(e->scratch_free), CJ_E_NO_DEVICE);
+                if (!e->d_sync.reserve(cj::lz4_lds_scratch_sync_bytes(a.n_chunks)) ||
+                    !e->d_pmeta.reserve(cj::lz4_lds_scratch_meta_bytes(a.n_chunks)) || !e->d_lanelist.reserve(list_bytes)) return CJ_E_OOM;
+                if (!e->scratch_free) {
+                    HIP_TRY(hipEventCreateWithFlags(&e->scratch_free, hipEventDisableTiming), CJ_E_NO_DEVICE);
+                    HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming), CJ_E_NO_DEVICE);
+                    HIP_TRY(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming), CJ_E_NO_DEVICE);
+                    HIP_TRY(hipEventCreateWithFlags(&e->ev_join2, hipEventDisableTiming), CJ_E_NO_DEVICE);
+                    HIP_TRY(hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking), CJ_E_NO_DEVICE);
+                    HIP_TRY(hipStreamCreateWithFlags(&e->aux2, hipStreamNonBlocking), CJ_E_NO_DEVICE);
+                } else HIP_TRY(hipStreamWaitEvent(s, e->scratch_free, 0), CJ_E_NO_DEVICE);
+                uint32_t* lists = (uint32_t*)e->d_lanelist.p;
+                HIP_TRY(hipMemsetAsync(lists, 0, 16, s), CJ_E_NO_DEVICE);                                   // [2] = the decoder's chunk counter
+                HIP_TRY(hipMemsetAsync(e->d_pmeta.p, 0, cj::lz4_lds_scratch_meta_bytes(a.n_chunks), s), CJ_E_NO_DEVICE);   // no chunk is pre-routed
+                if (e->n_cu == 0) HIP_TRY(hipDeviceGetAttribute(&e->n_cu, hipDeviceAttributeMultiprocessorCount, e->device), CJ_E_NO_DEVICE);
+                const uint32_t grid = 2u * (uint32_t)e->n_cu;
+                if (!e->d_tab.reserve(cj::lz4_lds2_tab_bytes(grid))) return CJ_E_OOM;
+                cj::launch_snappy_parse(a, e->d_sync.p, e->d_pmeta.p, s);
+                cj::launch_lz4_decode_lds2(a, e->d_sync.p, e->d_pmeta.p, e->d_tab.p, lists + 2, grid, s, CJ_CODEC_SNAPPY_RAW);
+                cj::launch_snappy_decode_routed(a, e->d_pmeta.p, s);
+                HIP_TRY(hipEventRecord(e->scratch_free, s), CJ_E_NO_DEVICE);
+            } else {
                 // large batch: mid-ratio chunks (many short elements) go to the lane kernel on the auxiliary stream, the
                 // rest (and the long-run chunks, which the wave kernel copies 16 B/lane) stay on the wave kernel
                 std::lock_guard<std::mutex> lock(e->scratch_mu);

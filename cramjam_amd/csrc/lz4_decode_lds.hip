@@ -21,6 +21,7 @@
 // D3 is instruction-issue bound (the dependency DAG is ~25 levels x 100-500 matches; only ~4 of 64 lanes
 // are ready per poll); DESIGN.md §5.1 lists the restructurings that were measured and lost.
 #include "lz4_lane_walk.hpp"
+#include "snappy_records.hpp"
 
 namespace cj {
 
@@ -469,6 +470,7 @@ __device__ __forceinline__ DW<ND> gl_ld_vec(const uint8_t* g) {
     return r;
 }
 
+template <int kCodec>
 __global__ __launch_bounds__(kL2Threads) void lz4_decode_lds2_kernel(BatchArgs a, const uint2* sync, const ParseMeta* meta,
                                                                      uint4* tabs, uint32_t* counter) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -519,6 +521,20 @@ __global__ __launch_bounds__(kL2Threads) void lz4_decode_lds2_kernel(BatchArgs a
 
         // ---- D1: expand sync points into sequence records (LDS -> global table) ----
         const uint32_t a_in = a_out + mis;
+        if constexpr (kCodec == CJ_CODEC_SNAPPY_RAW) {
+            // Snappy: a record = optional literal element + optional copy element (snappy_records.hpp)
+            const auto rd = [a_in](uint32_t p) { return lds_ld32(a_in + p); };
+            for (uint32_t sp = tid; sp < nsp; sp += kL2Threads) {
+                const uint2 p = csync[sp];
+                uint32_t ip = p.x, op = p.y;
+                uint32_t s = sp * kSyncEvery;
+                for (uint32_t j = 0; j < kSyncEvery && s < nseq; j++, s++) {
+                    SnRecord rec;
+                    (void)snappy_record_step(rd, ip, op, iend, U, rec);     // the parse kernel accepted this stream
+                    table[s] = make_uint4(rec.lit_src, rec.lit_len, rec.dst, rec.w);
+                }
+            }
+        } else
         for (uint32_t sp = tid; sp < nsp; sp += kL2Threads) {
             const uint2 p = csync[sp];
             uint32_t ip = p.x, op = p.y;
@@ -646,7 +662,11 @@ __global__ __launch_bounds__(kL2Threads) void lz4_decode_lds2_kernel(BatchArgs a
                 if (any_slow) {
                     bool sready = false;
                     if (pending && !fast) sready = bits_ready(s_bits, src, src + need);
-                    if (sready && m < kLongRun) {
+                    if (sready && m <= 64u && off >= m) {        // 33..64 bytes, no self-overlap (Snappy copies reach 64): one tier copy
+                        lds_store_tier<64>(lds_ld_aligned18((a_out + src) & ~3u), a_out + dst, src & 3u, m, dm);
+                        bits_set(s_bits, dst, dst + m);
+                        pending = false;
+                    } else if (sready && m < kLongRun) {
                         if (off >= 8u) {
                             uint32_t k = 0;
                             for (; k + 8u <= m; k += 8u) {
@@ -701,11 +721,18 @@ __global__ __launch_bounds__(kL2Threads) void lz4_decode_lds2_kernel(BatchArgs a
 size_t lz4_lds2_tab_bytes(uint32_t grid) { return (size_t)grid * kL2TabRecords * sizeof(uint4); }
 
 void launch_lz4_decode_lds2(const BatchArgs& a, const void* sync, const void* meta, void* tabs, uint32_t* counter,
-                            uint32_t grid, hipStream_t s) {
+                            uint32_t grid, hipStream_t s, int codec) {
     if (a.n_chunks == 0) return;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_lds2_kernel),
+    if (codec == CJ_CODEC_SNAPPY_RAW) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_lds2_kernel<CJ_CODEC_SNAPPY_RAW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kL2Bytes);
+        hipLaunchKernelGGL(lz4_decode_lds2_kernel<CJ_CODEC_SNAPPY_RAW>, dim3(grid), dim3(kL2Threads), kL2Bytes, s, a,
+                           (const uint2*)sync, (const ParseMeta*)meta, (uint4*)tabs, counter);
+        return;
+    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_lds2_kernel<CJ_CODEC_LZ4_BLOCK>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kL2Bytes);
-    hipLaunchKernelGGL(lz4_decode_lds2_kernel, dim3(grid), dim3(kL2Threads), kL2Bytes, s, a,
+    hipLaunchKernelGGL(lz4_decode_lds2_kernel<CJ_CODEC_LZ4_BLOCK>, dim3(grid), dim3(kL2Threads), kL2Bytes, s, a,
                        (const uint2*)sync, (const ParseMeta*)meta, (uint4*)tabs, counter);
 }
 

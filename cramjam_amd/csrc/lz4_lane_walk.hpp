@@ -14,7 +14,7 @@ namespace cj {
 constexpr uint32_t kSyncEvery = 8;        // sequences per sync point
 constexpr uint32_t kSyncStride = 1024;    // sync points reserved per chunk (=> at most 8192 sequences on the LDS path)
 constexpr uint32_t kLdsOutMax = 65536;    // the LDS decoder holds at most this much output ...
-constexpr uint32_t kLdsInMax = 66560;     // ... and this much compressed input (>= LZ4_compressBound(65536)=65809)
+constexpr uint32_t kLdsInMax = 65504;     // ... and this much compressed input: variant 2 stages it in the 64 KiB output window (<= 15 B misalignment + 15 B round-up)
 
 struct ParseMeta {       // one per chunk, written by lz4_parse_kernel
     uint32_t nseq;       // sequences incl. the final literal-only one; 0 = nothing left for the LDS decoder

@@ -8,14 +8,18 @@
 // Same shape as lz4_decode.hip: tag grammar parsed wave-uniformly from the 512-byte register window,
 // lanes move bytes.
 #include "lz4_lane_walk.hpp"   // lane_copy / lane_match / ParseMeta route flags are codec independent
+#include "lane_stream.hpp"
+#include "snappy_records.hpp"
 
 namespace cj {
 
-// skip: when non-null, chunks flagged kRouteLane there belong to the lane kernel (large-batch pipeline)
-__global__ __launch_bounds__(kBlockThreads) void snappy_decode_kernel(BatchArgs a, const ParseMeta* skip) {
+// skip: when non-null, chunks flagged kRouteLane there belong to the lane kernel (large-batch pipeline);
+// only_routed: decode only the chunks the parse kernel flagged kRouteWave (parse + LDS pipeline)
+__global__ __launch_bounds__(kBlockThreads) void snappy_decode_kernel(BatchArgs a, const ParseMeta* skip, int only_routed) {
     const uint32_t chunk = uni(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
     if (chunk >= a.n_chunks) return;
     if (skip != nullptr && (skip[chunk].in_skip & kRouteLane) != 0u) return;
+    if (only_routed && (skip[chunk].in_skip & kRouteWave) == 0u) return;
     const uint8_t* in = a.in_base + a.in_off[chunk];
     const uint64_t n64 = a.in_len[chunk];
     uint8_t* out = a.out_base + a.out_off[chunk];
@@ -203,13 +207,13 @@ __global__ __launch_bounds__(64) void snappy_decode_lanes_kernel(BatchArgs a, co
 void launch_snappy_decode(const BatchArgs& a, hipStream_t s) {
     if (a.n_chunks == 0) return;
     dim3 grid((a.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlockThreads);
-    hipLaunchKernelGGL(snappy_decode_kernel, grid, block, 0, s, a, (const ParseMeta*)nullptr);
+    hipLaunchKernelGGL(snappy_decode_kernel, grid, block, 0, s, a, (const ParseMeta*)nullptr, 0);
 }
 
 void launch_snappy_decode_skipping(const BatchArgs& a, const void* meta, hipStream_t s) {
     if (a.n_chunks == 0) return;
     dim3 grid((a.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlockThreads);
-    hipLaunchKernelGGL(snappy_decode_kernel, grid, block, 0, s, a, (const ParseMeta*)meta);
+    hipLaunchKernelGGL(snappy_decode_kernel, grid, block, 0, s, a, (const ParseMeta*)meta, 0);
 }
 
 void launch_snappy_decode_lanes(const BatchArgs& a, const void* lists, uint32_t lane_share, hipStream_t s) {
@@ -222,6 +226,107 @@ void launch_snappy_decode_lanes(const BatchArgs& a, const void* lists, uint32_t 
     const uint64_t maxn = ((uint64_t)a.n_chunks + kLaneShareDen - 1u) / kLaneShareDen * lane_share;
     const uint32_t* l = (const uint32_t*)lists;
     hipLaunchKernelGGL(snappy_decode_lanes_kernel, dim3((unsigned)((maxn + 63u) / 64u)), dim3(64), 0, s, a, l + 4, l);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// snappy_parse_kernel — lane-per-chunk walk + validation through the LDS line cache (lane_stream.hpp), the Snappy
+// counterpart of lz4_parse_kernel: emits the decoded size, the record count and an (ip, op) sync point every
+// kSyncEvery records for the workgroup-per-chunk LDS decoder; chunks that decoder cannot take (capacity or input
+// too large, too few / too many records) are flagged kRouteWave for the wave kernel.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * kParseWaves) void snappy_parse_kernel(BatchArgs a, uint2* sync, ParseMeta* meta) {
+    __shared__ __attribute__((aligned(16))) uint8_t rings[kParseWaves * 64 * kRingStride];
+    const uint32_t c = blockIdx.x * (64u * kParseWaves) + threadIdx.x;
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t wave_ring = (uint32_t)(uintptr_t)rings + wave * 64u * kRingStride;
+    const bool exists = c < a.n_chunks && (meta[c < a.n_chunks ? c : 0].in_skip & kRouteLane) == 0u;
+
+    const uint8_t* in = nullptr;
+    uint64_t n64 = 0, cap64 = 0;
+    ParseMeta pm = {0u, 0u};
+    int64_t r = 0;
+    bool done = true;
+    uint32_t dn = 0, hdr = 0;
+    if (exists) {
+        in = a.in_base + a.in_off[c];
+        n64 = a.in_len[c];
+        cap64 = a.out_cap[c];
+        if (n64 == 0) r = CJ_E_SNAPPY_EMPTY;
+        else if (n64 > 0xFFFFFFF0ull) r = CJ_E_SNAPPY_CORRUPT;
+        else {
+            uint64_t ulen = 0;
+            uint32_t shift = 0, i = 0;
+            bool ok = false;
+            while (hdr < (uint32_t)n64 && i < 10u) {
+                const uint32_t b = in[hdr];
+                hdr += 1;
+                if (b < 0x80u) { if (!(i == 9u && b > 1u)) { ulen |= (uint64_t)b << shift; ok = true; } break; }
+                ulen |= (uint64_t)(b & 0x7fu) << shift;
+                shift += 7; i += 1;
+            }
+            if (!ok) r = CJ_E_SNAPPY_HEADER;
+            else if (ulen > 0xFFFFFFFFull) r = CJ_E_SNAPPY_TOO_BIG;
+            else if (ulen > cap64) r = CJ_E_SNAPPY_BUF_SMALL;
+            else if (ulen > kLdsOutMax || n64 - hdr > kLdsInMax || ulen == 0) {
+                if (ulen == 0) r = (hdr == (uint32_t)n64) ? 0 : (int64_t)CJ_E_SNAPPY_CORRUPT;   // nothing to decode: trailing elements are errors
+                else pm.in_skip = kRouteWave;              // too big for the LDS window: the wave kernel decodes + validates
+            } else { dn = (uint32_t)ulen; done = false; }
+        }
+    }
+    LaneStream st;
+    const uint32_t mis = done ? 0u : (uint32_t)(reinterpret_cast<uintptr_t>(in + hdr) & 127u);
+    st.base = done ? nullptr : in + hdr - mis;
+    st.lo = 0; st.hi = 0;
+    st.end = done ? 0u : mis + (uint32_t)n64 - hdr;
+    st.ring = wave_ring + lane * kRingStride;
+    const uint32_t iend = st.end;
+    uint2* csync = sync + (size_t)c * kSyncStride;
+    const auto rd = [&st](uint32_t p) { return st.ld32(p); };
+
+    uint32_t ip = mis, op = 0, nrec = 0;
+    while (ballot64(!done) != 0ull) {
+        if (!done && ip >= st.hi) st.lo = st.hi = ip & ~127u;      // jumped past the window (long literal): re-anchor
+        for (;;) {
+            const bool want = !done && st.hi < iend && (st.hi - st.lo < kRingBytes || ip >= st.lo + 128u);
+            const bool urgent = want && ip + 48u > st.hi;
+            if (ballot64(urgent) == 0ull) break;
+            refill_round(st, want, wave_ring);
+        }
+        if (!done) {
+            if ((nrec % kSyncEvery) == 0u) {
+                const uint32_t slot = nrec / kSyncEvery;
+                if (slot < kSyncStride) csync[slot] = make_uint2(ip - mis, op);
+            }
+            nrec += 1;
+            SnRecord rec;
+            if (snappy_record_step(rd, ip, op, iend, dn, rec) != 0) { r = CJ_E_SNAPPY_CORRUPT; done = true; }
+            else if (ip >= iend) {
+                done = true;
+                if (op != dn) r = CJ_E_SNAPPY_CORRUPT;
+                else {
+                    r = (int64_t)dn;
+                    if ((nrec + kSyncEvery - 1u) / kSyncEvery > kSyncStride || nrec < kLdsMinSeq) pm.in_skip = kRouteWave;
+                    else { pm.nseq = nrec; pm.in_skip = hdr; }
+                }
+            }
+        }
+    }
+    if (exists) {
+        a.result[c] = r;
+        meta[c] = pm;
+    }
+}
+
+void launch_snappy_parse(const BatchArgs& a, void* sync, void* meta, hipStream_t s) {
+    if (a.n_chunks == 0) return;
+    const uint32_t per_block = 64u * kParseWaves;
+    hipLaunchKernelGGL(snappy_parse_kernel, dim3((a.n_chunks + per_block - 1u) / per_block), dim3(per_block), 0, s, a, (uint2*)sync, (ParseMeta*)meta);
+}
+
+void launch_snappy_decode_routed(const BatchArgs& a, const void* meta, hipStream_t s) {
+    if (a.n_chunks == 0) return;
+    dim3 grid((a.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlockThreads);
+    hipLaunchKernelGGL(snappy_decode_kernel, grid, block, 0, s, a, (const ParseMeta*)meta, 1);
 }
 
 }  // namespace cj

@@ -128,3 +128,48 @@ def test_hostsim_lane_parallel_crc32c():
     for o, n in cases:
         assert S.sim_crc32c(addr + o, n) == oracle.crc32c(buf[o:o + n]), (o, n)
     assert S.sim_crc32c_mask(oracle.crc32c(b"abc")) == oracle.crc32c(b"abc", masked=True)
+
+
+def test_hostsim_snappy_records(golden):
+    """The record grammar shared by the GPU Snappy parse kernel and the LDS decoder (snappy_records.hpp), built for the
+    host: same verdicts and bytes as the oracle on the golden vectors, the malformed set and fuzzed blocks."""
+    from conftest import b64d
+    so = os.path.join(ROOT, "tests", "hostsim", "libsim_snappy_records.so")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-shared", "-fPIC",
+                           "-I", os.path.join(ROOT, "cramjam_amd", "csrc"), os.path.join(ROOT, "tests", "hostsim", "sim_snappy_records.cpp"), "-o", so])
+    child = r'''
+import ctypes as C, json, random, sys
+sys.path.insert(0, %r)
+import oracle
+from base64 import b64decode as b64d
+S = C.CDLL(%r); S.sim_snappy_decode.restype = C.c_int64
+S.sim_snappy_decode.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint32)]
+g = json.load(open(%r))
+bad = 0
+def chk(blob, tag):
+    global bad
+    cap = min(max(oracle.snappy_decompress_len(blob), 0), 65536)
+    out = C.create_string_buffer(max(cap, 1)); nr = C.c_uint32(0)
+    r = S.sim_snappy_decode(blob, len(blob), out, cap, C.byref(nr))
+    er, eo = oracle.snappy_decompress(blob, cap)
+    if r != er or (er >= 0 and out.raw[:r] != eo):
+        bad += 1; print("MISMATCH", tag, r, er)
+for v in g["vectors"]:
+    if v["n"] <= 65536: chk(b64d(v["snappy"]), v["name"])
+for m in g["malformed_snappy"]: chk(b64d(m["data"]), (m["src"], m["kind"], m["k"]))
+random.seed(5)
+for t in range(200):
+    n = random.choice([1, 5, 13, 40, 100, 1000, 5000, 65536]); alpha = random.choice([2, 4, 16, 256])
+    raw = bytes(random.randrange(alpha) for _ in range(n))
+    if random.random() < 0.5 and n > 10: raw = (raw[:random.randrange(1, 20)] * n)[:n]
+    _, blob = oracle.snappy_compress(raw)
+    chk(blob, ("fuzz", t))
+    b = bytearray(blob); i = random.randrange(len(b)); b[i] ^= 1 << random.randrange(8); chk(bytes(b), ("fuzzbad", t))
+for i in range(4):
+    _, blob = oracle.snappy_compress(oracle.synth_v1(65536, i)); chk(blob, ("synth", i))
+print("HOSTSIM bad=%%d" %% bad)
+''' % (ROOT, so, os.path.join(GOLDEN_DIR, "golden_vectors.json"))
+    import sys
+    env = dict(os.environ, LD_PRELOAD=subprocess.check_output(["g++", "-print-file-name=libasan.so"]).decode().strip(), ASAN_OPTIONS="detect_leaks=0")
+    r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, env=env)
+    assert "HOSTSIM bad=0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

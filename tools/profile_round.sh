@@ -1,13 +1,23 @@
+# Round-end evidence run (on the GPU box): gpu tests, default bench line, rocprofv3 kernel stats of the same command,
+# FETCH_SIZE / WRITE_SIZE passes (separate, as the MI355X guide prescribes) and the secondary-path bench lines.
+# Outputs land in gpurun_out/<tag>/; copy the summaries into profiles/rNN/.
+TAG=${1:-v7}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
-mkdir -p gpurun_out/v7
-timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-python bench.py > gpurun_out/v7/bench.json 2> gpurun_out/v7/bench.err; tail -c 600 gpurun_out/v7/bench.json
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/v7/stats -- python bench.py --no-cpu-baseline > gpurun_out/v7/stats.log 2>&1
-find gpurun_out/v7/stats -name "*kernel_stats.csv" | head -2
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/v7/fetch -- python bench.py --no-cpu-baseline --steps 3 --warmup 1 > gpurun_out/v7/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/v7/write -- python bench.py --no-cpu-baseline --steps 3 --warmup 1 > gpurun_out/v7/write.log 2>&1
-F=$(find gpurun_out/v7/fetch -name "*counter_collection.csv" | head -1); W=$(find gpurun_out/v7/write -name "*counter_collection.csv" | head -1)
-python tools/pmc_summary.py $F $W gpurun_out/v7/hbm_traffic.json; cat gpurun_out/v7/hbm_traffic.json | head -40
-python bench.py --codec snappy --no-cpu-baseline 2>&1 | tail -1 | cut -c1-220
-CJ_SLICE_CHUNKS=131072 python bench.py --chunks 1000000 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-220
+O=gpurun_out/$TAG; rm -rf $O; mkdir -p $O
+timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 | tee $O/pytest_gpu.txt
+python bench.py > $O/bench.json 2> $O/bench.err; tail -c 700 $O/bench.json; echo
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --no-cpu-baseline > $O/stats.log 2>&1
+cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv; head -8 $O/kernel_stats.csv
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python bench.py --no-cpu-baseline --steps 3 --warmup 1 > $O/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python bench.py --no-cpu-baseline --steps 3 --warmup 1 > $O/write.log 2>&1
+cp $(find $O/fetch -name "*counter_collection.csv" | head -1) $O/fetch_size_counter_collection.csv
+cp $(find $O/write -name "*counter_collection.csv" | head -1) $O/write_size_counter_collection.csv
+python tools/pmc_summary.py $O/fetch_size_counter_collection.csv $O/write_size_counter_collection.csv $O/hbm_traffic.json > /dev/null
+python -c "
+import json; d=json.load(open('$O/hbm_traffic.json')); print({k:(round(v['hbm_read_bytes']/1e9,2),round(v['hbm_write_bytes']/1e9,2)) for k,v in d['kernels'].items()}, d['total_hbm_bytes_per_step']/1e9)"
+for args in "--codec snappy" "--op compress" "--op compress --codec snappy" "--chunks 1000000"; do
+  python bench.py --no-cpu-baseline $args 2>/dev/null | tail -1 >> $O/other_paths.jsonl
+done
+cut -c1-175 $O/other_paths.jsonl
+rm -rf $O/stats $O/fetch $O/write

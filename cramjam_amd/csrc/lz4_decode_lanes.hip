@@ -99,7 +99,7 @@ __global__ __launch_bounds__(64 * kParseWaves) void lz4_parse_kernel(BatchArgs a
             const uint32_t t4 = st.ld32(ip);
             const uint32_t token = t4 & 0xffu;
             ip += 1;
-            uint64_t lit = token >> 4;
+            uint32_t lit = token >> 4;                  // iend <= kLdsInMax here: at most 255 * 65504 + 15, no 64-bit needed
             if (lit == 15u) {
                 if (ip + 15u >= iend) bad = true;
                 else {
@@ -115,15 +115,15 @@ __global__ __launch_bounds__(64 * kParseWaves) void lz4_parse_kernel(BatchArgs a
             }
             if (!bad) {
                 const uint32_t rem_out = cap - op, rem_in = iend - ip;
-                if ((uint64_t)rem_out < lit + 12u || (uint64_t)rem_in < lit + 8u) {
-                    if ((uint64_t)rem_in != lit || (uint64_t)rem_out < lit) bad = true;
-                    else { op += (uint32_t)lit; last = true; }
+                if (rem_out < lit + 12u || rem_in < lit + 8u) {
+                    if (rem_in != lit || rem_out < lit) bad = true;
+                    else { op += lit; last = true; }
                 } else {
-                    ip += (uint32_t)lit; op += (uint32_t)lit;
+                    ip += lit; op += lit;
                     const uint32_t o4 = st.ld32(ip);
                     const uint32_t offset = o4 & 0xffffu;
                     ip += 2;
-                    uint64_t mlen = token & 15u;
+                    uint32_t mlen = token & 15u;
                     if (mlen == 15u) {
                         uint32_t b = (o4 >> 16) & 0xffu;
                         ip += 1; mlen += b;
@@ -137,8 +137,8 @@ __global__ __launch_bounds__(64 * kParseWaves) void lz4_parse_kernel(BatchArgs a
                     mlen += 4u;
                     if (!bad) {
                         if (offset == 0u || offset > op) bad = true;
-                        else if ((uint64_t)(cap - op) < mlen + 5u) bad = true;
-                        else op += (uint32_t)mlen;
+                        else if (cap - op < mlen + 5u) bad = true;
+                        else op += mlen;
                     }
                 }
             }

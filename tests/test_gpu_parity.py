@@ -351,3 +351,60 @@ def test_large_batch_compress_then_decompress_property(eng, codec):
         want = raw_h[(i % U) * S:(i % U + 1) * S].tobytes()
         got = oracle.lz4_decompress_raw(blob, S) if codec == LZ4 else oracle.snappy_decompress(blob)
         assert got == (S, want), i
+
+
+def _shaped_chunks(seed, count, size=65536):
+    """chunks with very different sequence shapes: short/long literals, short/long matches, self-overlapping matches with
+    small periods, near and far offsets, long runs — all with enough sequences to take the LDS workgroup decoder"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(count):
+        kind = i % 6
+        buf = bytearray()
+        while len(buf) < size:
+            r = rng.random()
+            if kind == 0:      # text-like: small alphabet words
+                buf += bytes(rng.integers(97, 101, int(rng.integers(1, 12)), dtype=np.uint8))
+            elif kind == 1:    # periodic runs with tiny periods (offsets 1..8, overlapping matches) between short literals
+                p = bytes(rng.integers(0, 256, int(rng.integers(1, 9)), dtype=np.uint8))
+                buf += p * int(rng.integers(2, 40)) + bytes(rng.integers(0, 256, int(rng.integers(0, 6)), dtype=np.uint8))
+            elif kind == 2:    # far copies of earlier content, lengths 4..300
+                if len(buf) > 64 and r < 0.7:
+                    s = int(rng.integers(0, len(buf) - 4)); ln = int(rng.integers(4, 300))
+                    buf += buf[s:s + ln]
+                else:
+                    buf += bytes(rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8))
+            elif kind == 3:    # long literals (random) alternating with long matches
+                buf += bytes(rng.integers(0, 256, int(rng.integers(30, 700)), dtype=np.uint8))
+                if len(buf) > 1000:
+                    s = int(rng.integers(0, len(buf) - 600)); buf += buf[s:s + int(rng.integers(40, 600))]
+            elif kind == 4:    # mostly short matches from the last 256 bytes (dense dependency chains)
+                if len(buf) > 16 and r < 0.85:
+                    s = len(buf) - int(rng.integers(4, min(len(buf), 256))); ln = int(rng.integers(4, 24))
+                    buf += (bytes(buf[s:]) * (ln // max(1, len(buf) - s) + 1))[:ln]
+                else:
+                    buf += bytes(rng.integers(0, 256, int(rng.integers(1, 8)), dtype=np.uint8))
+            else:              # zero runs and counters
+                buf += bytes(int(rng.integers(1, 400))) if r < 0.3 else bytes((np.arange(int(rng.integers(4, 60))) % 7).astype(np.uint8))
+        out.append(bytes(buf[:size]))
+    return out
+
+
+@pytest.mark.parametrize("codec", [LZ4, SNAPPY])
+def test_lds_decoder_on_shaped_streams(eng, codec):
+    """the parse + LDS workgroup pipeline (forced) on 240 structurally diverse 64 KiB chunks, compressed by the CPU oracle
+    (= liblz4 / libsnappy bytes) and by the GPU encoder: bit-exact, at exact and at loose capacity"""
+    raws = _shaped_chunks(11, 240)
+    comp = oracle.lz4_compress_raw if codec == LZ4 else oracle.snappy_compress
+    blobs = [comp(r)[1] for r in raws]
+    caps = [len(r) + 64 + len(r) // 5 for r in raws]
+    res, gpu_blobs = eng.batch_host(codec, ENC, 0, raws, caps)
+    assert all(r > 0 for r in res)
+    for streams in (blobs, [bytes(b) for b in gpu_blobs]):
+        for extra in (0, 33):
+            res, outs = eng.batch_host(codec, DEC, N.FLAG_FORCE_LDS_PER_CHUNK, streams, [len(r) + extra for r in raws])
+            bad = [i for i, (r, o, raw) in enumerate(zip(res, outs, raws)) if r != len(raw) or o != raw]
+            assert not bad, (codec, extra, bad[:10], [res[i] for i in bad[:10]])
+    # the same streams through the wave kernel give the same bytes (cross-mapping check)
+    res, outs = eng.batch_host(codec, DEC, N.FLAG_FORCE_WAVE_PER_CHUNK, blobs, [len(r) for r in raws])
+    assert all(r == len(raw) and o == raw for r, o, raw in zip(res, outs, raws))

@@ -13,7 +13,7 @@ _SO = os.path.join(_HERE, "libcj_oracle.so")
 
 def build(force=False):
     srcs = [os.path.join(_HERE, f) for f in
-            ("lz4_block_oracle.c", "snappy_raw_oracle.c", "snappy_frame_oracle.c", "synth_batch_oracle.c", "cj_oracle.h")]
+            ("lz4_block_oracle.c", "snappy_raw_oracle.c", "snappy_frame_oracle.c", "lz4_frame_oracle.c", "synth_batch_oracle.c", "cj_oracle.h")]
     if (not force and os.path.exists(_SO)
             and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs)):
         return _SO
@@ -48,6 +48,11 @@ def lib():
             ("cjo_snappy_frame_compress_bs", i64, [u8p, sz, u8p, sz, sz]),
             ("cjo_snappy_frame_decompress_len", i64, [u8p, sz]),
             ("cjo_snappy_frame_decompress", i64, [u8p, sz, u8p, sz]),
+            ("cjo_xxh32", C.c_uint32, [u8p, sz, C.c_uint32]),
+            ("cjo_lz4_frame_compress_bound", sz, [sz, C.c_int]),
+            ("cjo_lz4_frame_compress", i64, [u8p, sz, u8p, sz, C.c_int, C.c_int]),
+            ("cjo_lz4_frame_decompress_bound", i64, [u8p, sz]),
+            ("cjo_lz4_frame_decompress", i64, [u8p, sz, u8p, sz]),
             ("cjo_synth_v1", None, [u8p, sz, C.c_uint64, C.c_uint64]),
             ("cjo_batch_run", C.c_int, [C.c_int, C.c_int, sz, u8p, u8p, u8p, u8p, sz, u8p]),
         ]:
@@ -124,6 +129,30 @@ def snappy_frame_decompress(data, cap=None):
     if cap is None:
         cap = max(snappy_frame_decompress_len(data), 0)
     return _call_out(lib().cjo_snappy_frame_decompress, data, cap)
+
+
+def xxh32(data, seed=0):
+    p, n, keep = _in(data)
+    return lib().cjo_xxh32(p, n, seed)
+
+
+LZ4F_LINKED, LZ4F_BLOCK_CHECKSUM, LZ4F_CONTENT_SIZE, LZ4F_NO_CONTENT_CHECKSUM = 1, 2, 4, 8
+
+
+def lz4_frame_compress(data, bs_code=4, flags=0):
+    cap = lib().cjo_lz4_frame_compress_bound(len(data), bs_code)
+    return _call_out(lib().cjo_lz4_frame_compress, data, cap, bs_code, flags)
+
+
+def lz4_frame_decompress_bound(data):
+    p, n, keep = _in(data)
+    return lib().cjo_lz4_frame_decompress_bound(p, n)
+
+
+def lz4_frame_decompress(data, cap=None):
+    if cap is None:
+        cap = max(lz4_frame_decompress_bound(data), 0)
+    return _call_out(lib().cjo_lz4_frame_decompress, data, cap)
 
 
 def synth_v1(chunk_bytes, index, seed=0x5EED):

@@ -54,6 +54,14 @@ extern "C" {
 #define CJO_E_SNAPPY_CHUNK_TYPE (-16) /* snap Error::UnsupportedChunkType */
 #define CJO_E_SNAPPY_CHUNK_LEN  (-17) /* snap Error::UnsupportedChunkLength */
 #define CJO_E_SNAPPY_CHECKSUM   (-18) /* snap Error::Checksum */
+#define CJO_E_LZ4F_FRAME_TYPE   (-20) /* LZ4F ERROR_frameType_unknown (bad magic) */
+#define CJO_E_LZ4F_HEADER       (-21) /* LZ4F ERROR_headerVersion_wrong / reservedFlag_set / headerChecksum_invalid */
+#define CJO_E_LZ4F_BLOCK_SIZE   (-22) /* LZ4F ERROR_maxBlockSize_invalid */
+#define CJO_E_LZ4F_BLOCK_CHECKSUM (-23) /* LZ4F ERROR_blockChecksum_invalid */
+#define CJO_E_LZ4F_CONTENT_CHECKSUM (-24) /* LZ4F ERROR_contentChecksum_invalid */
+#define CJO_E_LZ4F_CONTENT_SIZE (-25) /* LZ4F ERROR_frameSize_wrong */
+#define CJO_E_LZ4F_INCOMPLETE   (-26) /* lz4 crate: "Finish runned before read end of compressed stream" */
+#define CJO_E_LZ4F_DECOMPRESS   (-27) /* LZ4F ERROR_decompressionFailed (malformed block) */
 
 /* ---- LZ4 block: raw codec (liblz4 semantics) ---- */
 /* LZ4_compressBound: n + n/255 + 16, 0 if n > 0x7E000000 */
@@ -80,6 +88,18 @@ int64_t cjo_snappy_decompress_len(const uint8_t* in, size_t n);
 int64_t cjo_snappy_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap);
 /* src/snappy.rs:57,106 raw::decompress(in,out) */
 int64_t cjo_snappy_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap);
+
+/* ---- LZ4 block with a contiguous history prefix (linked LZ4-frame blocks) ---- */
+int64_t cjo_lz4_decompress_with_prefix(const uint8_t* src, size_t n, uint8_t* buf, size_t hist, size_t cap);
+int64_t cjo_lz4_compress_with_prefix(const uint8_t* base, size_t hist, size_t len, uint8_t* dst, size_t cap);
+
+/* ---- LZ4 frame format (lz4 crate Encoder/Decoder -> LZ4F_*; reference src/lz4.rs:28-66) ---- */
+uint32_t cjo_xxh32(const uint8_t* p, size_t n, uint32_t seed);
+size_t  cjo_lz4_frame_compress_bound(size_t n, int bs_code);
+/* bs_code 4..7 = 64 KiB..4 MiB blocks; flags: 1 linked blocks, 2 block checksums, 4 content size, 8 NO content checksum */
+int64_t cjo_lz4_frame_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap, int bs_code, int flags);
+int64_t cjo_lz4_frame_decompress_bound(const uint8_t* in, size_t n);
+int64_t cjo_lz4_frame_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap);
 
 /* ---- Snappy framing format (snap 1.1.1 read::FrameEncoder/FrameDecoder; reference src/snappy.rs:24,38,82,88) ---- */
 uint32_t cjo_crc32c(const uint8_t* p, size_t n);

@@ -177,7 +177,8 @@ static inline int64_t read_vlen(const uint8_t** ipp, const uint8_t* ilimit, int 
     return len;
 }
 
-int64_t cjo_lz4_decompress_raw(const uint8_t* src, size_t n, uint8_t* dst, size_t cap) {
+/* hist: bytes of valid history directly before dst (LZ4_decompress_safe_usingDict with a contiguous prefix) */
+static int64_t lz4_dec(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t hist) {
     const uint8_t* ip = src;
     const uint8_t* const iend = src + n;
     uint8_t* op = dst;
@@ -212,7 +213,7 @@ int64_t cjo_lz4_decompress_raw(const uint8_t* src, size_t n, uint8_t* dst, size_
             mlen += (size_t)a;
         }
         mlen += MINMATCH;
-        if (offset > (size_t)(op - dst)) return -1;
+        if (offset > (size_t)(op - dst) + hist) return -1;
         /* offset 0 is spec-invalid; liblz4 leaves the output bytes untouched (reads garbage).
          * The build rejects it (documented deviation). */
         if (offset == 0) return -1;
@@ -223,6 +224,62 @@ int64_t cjo_lz4_decompress_raw(const uint8_t* src, size_t n, uint8_t* dst, size_
             op += mlen;
         }
     }
+    return (int64_t)(op - dst);
+}
+
+int64_t cjo_lz4_decompress_raw(const uint8_t* src, size_t n, uint8_t* dst, size_t cap) {
+    return lz4_dec(src, n, dst, cap, 0);
+}
+
+/* linked LZ4-frame blocks: buf[0..hist) is the previous output, the block decodes to buf + hist (capacity cap) */
+int64_t cjo_lz4_decompress_with_prefix(const uint8_t* src, size_t n, uint8_t* buf, size_t hist, size_t cap) {
+    return lz4_dec(src, n, buf + hist, cap, hist);
+}
+
+/* Compress base[hist .. hist+len) as ONE block whose matches may reach into base[0..hist) (hist <= 65536): a plain
+ * greedy single-probe matcher with the history pre-indexed.  Used only to mint linked-block test frames — the bytes are
+ * not meant to equal liblz4's.  Returns 0 when the result does not fit cap; hist == 0 uses the liblz4-identical encoder. */
+int64_t cjo_lz4_compress_with_prefix(const uint8_t* base, size_t hist, size_t len, uint8_t* dst, size_t cap) {
+    if (hist == 0) return cap == 0 ? 0 : cjo_lz4_compress_raw(base, len, dst, cap);
+    enum { HB = 15 };
+    static uint32_t tab[1 << HB];
+    const size_t end = hist + len;
+    memset(tab, 0xff, sizeof tab);
+    for (size_t i = 0; i + 4 <= hist + (len >= 4 ? 0 : 0) && i + 4 <= end; i++) {
+        if (i >= hist) break;
+        tab[(rd32(base + i) * 2654435761u) >> (32 - HB)] = (uint32_t)i;
+    }
+    uint8_t* op = dst; uint8_t* const oend = dst + cap;
+    size_t anchor = hist, ip = hist;
+    const size_t mflimit = end >= MFLIMIT ? end - MFLIMIT : 0, matchlimit = end >= LASTLITERALS ? end - LASTLITERALS : 0;
+    if (len >= LZ4_MIN_LENGTH) {
+        while (ip <= mflimit && ip + 4 <= end) {
+            uint32_t h = (rd32(base + ip) * 2654435761u) >> (32 - HB);
+            uint32_t c = tab[h];
+            tab[h] = (uint32_t)ip;
+            if (c != 0xffffffffu && ip - c <= MAX_DISTANCE && rd32(base + c) == rd32(base + ip)) {
+                size_t ml = 4;
+                while (ip + ml < matchlimit && base[c + ml] == base[ip + ml]) ml++;
+                size_t lit = ip - anchor, mc = ml - 4;
+                if ((size_t)(oend - op) < 1 + lit + lit / 255 + 1 + 2 + mc / 255 + 1) return 0;
+                uint8_t* tok = op++;
+                if (lit >= 15) { size_t v = lit - 15; *tok = 0xF0; while (v >= 255) { *op++ = 255; v -= 255; } *op++ = (uint8_t)v; }
+                else *tok = (uint8_t)(lit << 4);
+                memcpy(op, base + anchor, lit); op += lit;
+                size_t off = ip - c;
+                *op++ = (uint8_t)off; *op++ = (uint8_t)(off >> 8);
+                if (mc >= 15) { size_t v = mc - 15; *tok |= 15; while (v >= 255) { *op++ = 255; v -= 255; } *op++ = (uint8_t)v; }
+                else *tok |= (uint8_t)mc;
+                ip += ml; anchor = ip;
+            } else ip++;
+        }
+    }
+    size_t lit = end - anchor;
+    if ((size_t)(oend - op) < 1 + lit + lit / 255 + 1) return 0;
+    uint8_t* tok = op++;
+    if (lit >= 15) { size_t v = lit - 15; *tok = 0xF0; while (v >= 255) { *op++ = 255; v -= 255; } *op++ = (uint8_t)v; }
+    else *tok = (uint8_t)(lit << 4);
+    memcpy(op, base + anchor, lit); op += lit;
     return (int64_t)(op - dst);
 }
 

@@ -173,3 +173,77 @@ print("HOSTSIM bad=%%d" %% bad)
     env = dict(os.environ, LD_PRELOAD=subprocess.check_output(["g++", "-print-file-name=libasan.so"]).decode().strip(), ASAN_OPTIONS="detect_leaks=0")
     r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, env=env)
     assert "HOSTSIM bad=0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+# ---- LZ4 frame ------------------------------------------------------------------------------------------------
+import base64
+import hashlib
+import json
+
+
+def _frame_vectors():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mgf", os.path.join(GOLDEN_DIR, "make_golden_frames.py"))
+    mgf = importlib.util.module_from_spec(spec); spec.loader.exec_module(mgf)
+    g = json.load(open(os.path.join(GOLDEN_DIR, "golden_frames.json")))
+    for v in g["vectors"]:
+        data = mgf.content(v["kind"], v["n"])
+        assert hashlib.sha256(data).hexdigest() == v["sha256"]
+        yield v, base64.b64decode(v["frame"]), data
+
+
+def test_xxh32_known_answers():
+    assert oracle.xxh32(b"") == 0x02CC5D05 and oracle.xxh32(b"", 1) == 0x0B2CB792
+    assert oracle.xxh32(b"a") == 0x550D7456 and oracle.xxh32(b"abc") == 0x32D153FF
+    assert oracle.xxh32(b"Nobody inspects the spammish repetition") == 0xE2293B2F
+
+
+def test_lz4_frame_fixture_and_golden_frames():
+    """the reference's fixture + 48 frames minted by liblz4's LZ4F (linked/independent, all block sizes, checksums, HC)"""
+    framed, plain = _fx("plaintext.txt.lz4"), _fx("plaintext.txt")
+    assert oracle.lz4_frame_decompress(framed) == (len(plain), plain)
+    n = 0
+    for v, frame, data in _frame_vectors():
+        b = oracle.lz4_frame_decompress_bound(frame)
+        assert b >= len(data) and (not v["content_size"] or b == len(data)), v
+        assert oracle.lz4_frame_decompress(frame) == (len(data), data), {k: v[k] for k in v if k != "frame"}
+        n += 1
+    assert n >= 40
+
+
+@pytest.mark.parametrize("flags", [0, 1, 2, 3, 4, 7, 8, 9])
+@pytest.mark.parametrize("bs", [4, 5, 7])
+def test_lz4_frame_round_trip(flags, bs):
+    random.seed(flags * 8 + bs)
+    data = _fx("plaintext.txt") * 200 + bytes(random.randrange(256) for _ in range(70000)) + bytes(100000)
+    r, fr = oracle.lz4_frame_compress(data, bs, flags)
+    assert r == len(fr) and fr[:4] == b"\x04\x22\x4d\x18"
+    assert fr[4] == 0x40 | (0 if flags & 1 else 0x20) | (0x10 if flags & 2 else 0) | (0x08 if flags & 4 else 0) | (0 if flags & 8 else 0x04)
+    assert oracle.lz4_frame_decompress(fr) == (len(data), data)
+    assert oracle.lz4_frame_compress(b"", bs, flags & ~4)[1][4:6] != b"" and oracle.lz4_frame_decompress(oracle.lz4_frame_compress(b"", bs, flags)[1]) == (0, b"")
+
+
+def test_lz4_frame_malformed():
+    data = _fx("plaintext.txt") * 100
+    r, fr = oracle.lz4_frame_compress(data, 4, 2)            # independent blocks, block + content checksums
+    dec = lambda s, cap=200000: oracle.lz4_frame_decompress(s, cap)[0]
+    assert dec(fr) == len(data)
+    assert dec(b"sknow") == -26 and dec(b"sknowsknow") == -20          # reference tests/test_variants.py:92-96: DecompressionError
+    assert dec(b"") == -26
+    for cut in (3, 6, 8, 12, len(fr) - 5, len(fr) - 1):
+        assert dec(fr[:cut]) == -26, cut
+    assert dec(fr + b"trailing bytes are ignored by the lz4 crate's Decoder") == len(data)
+    b = bytearray(fr); b[4] ^= 0x80; assert dec(bytes(b)) == -21       # version
+    b = bytearray(fr); b[4] |= 0x02; assert dec(bytes(b)) == -21       # reserved flag
+    b = bytearray(fr); b[5] = 0x30; assert dec(bytes(b)) in (-21, -22) # block size code 3
+    b = bytearray(fr); b[6] ^= 1; assert dec(bytes(b)) == -21          # header checksum
+    b = bytearray(fr); b[20] ^= 1; assert dec(bytes(b)) == -23         # block data vs block checksum
+    b = bytearray(fr); b[-1] ^= 1; assert dec(bytes(b)) == -24         # content checksum
+    r2, fr2 = oracle.lz4_frame_compress(data, 4, 8)                    # no checksums at all: damage reaches the block decoder
+    b = bytearray(fr2); b[12] = 0xFF; b[13] = 0xFF; assert dec(bytes(b)) in (-27, len(data))
+    r3, fr3 = oracle.lz4_frame_compress(data, 4, 4 | 8)                # content size stored
+    b = bytearray(fr3); b[6] ^= 1; b[14] = (oracle.xxh32(bytes(b[4:14])) >> 8) & 0xff
+    assert dec(bytes(b)) == -25
+    big = bytearray(fr2); big[7:11] = (70000).to_bytes(4, "little"); assert dec(bytes(big)) in (-22, -26)
+    assert dec(fr, cap=len(data) - 1) == -14
+    assert dec(b"\x50\x2a\x4d\x18\x03\x00\x00\x00abc" + fr) == 0       # skippable frame first: the crate's Decoder stops there

@@ -253,6 +253,14 @@ const char* cj_strerror(int64_t code) {
     case CJ_E_SNAPPY_CHUNK_TYPE: return "snappy: corrupt input (unsupported chunk type)";
     case CJ_E_SNAPPY_CHUNK_LEN: return "snappy: corrupt input (unsupported chunk length)";
     case CJ_E_SNAPPY_CHECKSUM: return "snappy: corrupt input (bad checksum)";
+    case CJ_E_LZ4F_FRAME_TYPE: return "LZ4 error: ERROR_frameType_unknown";
+    case CJ_E_LZ4F_HEADER: return "LZ4 error: ERROR_headerChecksum_invalid";
+    case CJ_E_LZ4F_BLOCK_SIZE: return "LZ4 error: ERROR_maxBlockSize_invalid";
+    case CJ_E_LZ4F_BLOCK_CHECKSUM: return "LZ4 error: ERROR_blockChecksum_invalid";
+    case CJ_E_LZ4F_CONTENT_CHECKSUM: return "LZ4 error: ERROR_contentChecksum_invalid";
+    case CJ_E_LZ4F_CONTENT_SIZE: return "LZ4 error: ERROR_frameSize_wrong";
+    case CJ_E_LZ4F_INCOMPLETE: return "Finish runned before read end of compressed stream";
+    case CJ_E_LZ4F_DECOMPRESS: return "LZ4 error: ERROR_decompressionFailed";
     case CJ_E_NO_DEVICE: return "cramjam_hip: no usable HIP device (no CPU fallback exists)";
     case CJ_E_BAD_ARG: return "cramjam_hip: bad argument";
     case CJ_E_OOM: return "cramjam_hip: out of memory";

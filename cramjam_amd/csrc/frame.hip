@@ -11,7 +11,9 @@
 namespace cj {
 void launch_crc32c_pieces(const uint8_t* base, const uint64_t* off, const uint64_t* len, uint32_t* out, uint32_t n, hipStream_t s);
 void launch_copy_segments(const uint64_t* src, uint8_t* dst_base, const uint64_t* dst_off, const uint64_t* len,
-                          const uint64_t* hdr, uint32_t n, hipStream_t s);
+                          const uint64_t* hdr, uint32_t hdr_len, uint32_t n, hipStream_t s);
+void launch_lz4_frame_chain(const uint8_t* in, const uint64_t* blk_off, const uint32_t* word, uint32_t nblk, uint8_t* out,
+                            uint64_t out_cap, uint32_t block_max, int64_t* result, hipStream_t s);
 }
 
 namespace {
@@ -153,7 +155,7 @@ int64_t cj_snappy_frame_decompress(const uint8_t* in, size_t n, uint8_t* out, si
         const int rc = cj::launch(e, CJ_CODEC_SNAPPY_RAW, CJ_OP_DECOMPRESS, a, s);
         if (rc != 0) return rc;
     }
-    cj::launch_copy_segments(d_meta + r_s, d_out, d_meta + r_s + ns, d_meta + r_s + 2 * ns, nullptr, (uint32_t)ns, s);
+    cj::launch_copy_segments(d_meta + r_s, d_out, d_meta + r_s + ns, d_meta + r_s + 2 * ns, nullptr, 0, (uint32_t)ns, s);
     cj::launch_crc32c_pieces(d_out, d_meta + r_p, d_meta + r_p + np, (uint32_t*)(d_meta + r_crc), (uint32_t)np, s);
     HIP_TRY(hipGetLastError(), CJ_E_NO_DEVICE);
     std::vector<int64_t> res(nc);
@@ -237,11 +239,298 @@ int64_t cj_snappy_frame_compress(const uint8_t* in, size_t n, uint8_t* out, size
     uint8_t* d_frame = (uint8_t*)e->d_frame.p;
     HIP_TRY(hipMemcpyAsync(d_frame, kIdent, 10, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
     HIP_TRY(hipMemcpyAsync(d_meta + 5 * np, m.data() + 5 * np, 4 * np * 8, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
-    cj::launch_copy_segments(d_meta + 5 * np, d_frame, d_meta + 6 * np, d_meta + 7 * np, d_meta + 8 * np, (uint32_t)np, s);
+    cj::launch_copy_segments(d_meta + 5 * np, d_frame, d_meta + 6 * np, d_meta + 7 * np, d_meta + 8 * np, 8, (uint32_t)np, s);
     HIP_TRY(hipGetLastError(), CJ_E_NO_DEVICE);
     HIP_TRY(hipMemcpyAsync(out, d_frame, fpos, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
     HIP_TRY(hipStreamSynchronize(s), CJ_E_NO_DEVICE);
     return (int64_t)fpos;
+}
+
+// =====================================================================================================================
+// LZ4 FRAME format: what the reference reaches at /root/reference/src/lz4.rs:28 (decompress), :43 (compress), :56
+// (compress_into), :63 (decompress_into) through libcramjam::lz4::{compress,decompress} -> lz4 crate Encoder/Decoder ->
+// LZ4F_* (liblz4 1.10.0).  Blocks are de/compressed on the GPU: frames with independent blocks (and single-block
+// frames) as ONE batch through the block engine, frames with linked blocks by the chain kernel (lz4_decode.hip).
+// The frame's XXH32 checksums are the one piece of arithmetic done on the host: XXH32 is a serial recurrence of four
+// 32-bit multiply-rotate accumulators per frame — one CPU core sustains ~6 GB/s on it, one GPU wavefront ~1 GB/s
+// (quarter-rate 32-bit multiplies on a dependent chain) — so it runs on a host thread concurrently with the device batch.
+// =====================================================================================================================
+namespace {
+
+constexpr uint32_t XP1 = 2654435761u, XP2 = 2246822519u, XP3 = 3266489917u, XP4 = 668265263u, XP5 = 374761393u;
+inline uint32_t xrotl(uint32_t v, int r) { return (v << r) | (v >> (32 - r)); }
+inline uint32_t xrd32(const uint8_t* p) { uint32_t v; std::memcpy(&v, p, 4); return v; }
+inline void xwr32(uint8_t* p, uint32_t v) { std::memcpy(p, &v, 4); }
+
+uint32_t xxh32(const uint8_t* p, size_t n, uint32_t seed) {       // published XXH32 algorithm (xxhash spec §"XXH32")
+    const uint8_t* end = p + n;
+    uint32_t h;
+    if (n >= 16) {
+        uint32_t v1 = seed + XP1 + XP2, v2 = seed + XP2, v3 = seed, v4 = seed - XP1;
+        const uint8_t* lim = end - 16;
+        do {
+            v1 = xrotl(v1 + xrd32(p) * XP2, 13) * XP1;
+            v2 = xrotl(v2 + xrd32(p + 4) * XP2, 13) * XP1;
+            v3 = xrotl(v3 + xrd32(p + 8) * XP2, 13) * XP1;
+            v4 = xrotl(v4 + xrd32(p + 12) * XP2, 13) * XP1;
+            p += 16;
+        } while (p <= lim);
+        h = xrotl(v1, 1) + xrotl(v2, 7) + xrotl(v3, 12) + xrotl(v4, 18);
+    } else h = seed + XP5;
+    h += (uint32_t)n;
+    while (p + 4 <= end) { h = xrotl(h + xrd32(p) * XP3, 17) * XP4; p += 4; }
+    while (p < end) { h = xrotl(h + (uint32_t)(*p) * XP5, 11) * XP1; p++; }
+    h ^= h >> 15; h *= XP2; h ^= h >> 13; h *= XP3; h ^= h >> 16;
+    return h;
+}
+
+constexpr size_t kLz4fBlock = 65536;                      // the reference encoder's block size (lz4 crate BlockSize::Default)
+constexpr size_t kLz4fTmpStride = 65824;                  // LZ4_compressBound(65536) = 65809, rounded up to 16
+
+struct Lz4Block { uint64_t src_off; uint32_t word; };     // word = size | bit 31 (stored)
+struct Lz4Frame {
+    bool indep = true, bsum = false, csize = false, csum = false;
+    uint32_t block_max = 0;
+    uint64_t content_size = 0;
+    uint32_t content_sum = 0;
+    std::vector<Lz4Block> blocks;
+    bool skippable = false;
+    bool complete = false;        // the EndMark was reached
+    int64_t late_err = 0;         // error met while walking the blocks (the blocks listed before it are intact)
+};
+
+// header + block walk (LZ4F_decompress's own checks; truncation = the lz4 crate's "Finish runned before read end ...")
+int64_t lz4_frame_walk(const uint8_t* in, size_t n, Lz4Frame& f, bool verify_block_sums) {
+    if (n >= 8 && (xrd32(in) & 0xFFFFFFF0u) == 0x184D2A50u) {
+        f.skippable = true;
+        return n - 8 < xrd32(in + 4) ? (int64_t)CJ_E_LZ4F_INCOMPLETE : 0;
+    }
+    if (n < 7) return CJ_E_LZ4F_INCOMPLETE;
+    if (xrd32(in) != 0x184D2204u) return CJ_E_LZ4F_FRAME_TYPE;
+    const uint8_t flg = in[4], bd = in[5];
+    if ((flg >> 6) != 1 || (flg & 0x02)) return CJ_E_LZ4F_HEADER;
+    if ((bd & 0x8F) != 0) return CJ_E_LZ4F_HEADER;
+    f.indep = (flg >> 5) & 1; f.bsum = (flg >> 4) & 1; f.csize = (flg >> 3) & 1; f.csum = (flg >> 2) & 1;
+    const bool dictid = flg & 1;
+    const uint32_t code = (bd >> 4) & 7;
+    if (code < 4) return CJ_E_LZ4F_BLOCK_SIZE;
+    f.block_max = 1u << (8 + 2 * code);
+    const size_t hl = 6 + (f.csize ? 8 : 0) + (dictid ? 4 : 0);
+    if (n < hl + 1) return CJ_E_LZ4F_INCOMPLETE;
+    if (f.csize) f.content_size = (uint64_t)xrd32(in + 6) | ((uint64_t)xrd32(in + 10) << 32);
+    if (in[hl] != (uint8_t)(xxh32(in + 4, hl - 4, 0) >> 8)) return CJ_E_LZ4F_HEADER;
+    // block walk: an error here is a LATE error — the streaming decoder has already written the blocks before it
+    size_t pos = hl + 1;
+    for (;;) {
+        if (n - pos < 4) { f.late_err = CJ_E_LZ4F_INCOMPLETE; return 0; }
+        const uint32_t w = xrd32(in + pos);
+        pos += 4;
+        if (w == 0) break;
+        const size_t sz = w & 0x7FFFFFFFu;
+        if (sz > f.block_max) { f.late_err = CJ_E_LZ4F_BLOCK_SIZE; return 0; }
+        if (n - pos < sz + (f.bsum ? 4u : 0u)) { f.late_err = CJ_E_LZ4F_INCOMPLETE; return 0; }
+        if (f.bsum && verify_block_sums && xrd32(in + pos + sz) != xxh32(in + pos, sz, 0)) { f.late_err = CJ_E_LZ4F_BLOCK_CHECKSUM; return 0; }
+        f.blocks.push_back({pos, w});
+        pos += sz + (f.bsum ? 4 : 0);
+    }
+    f.complete = true;
+    if (f.csum) {
+        if (n - pos < 4) { f.late_err = CJ_E_LZ4F_INCOMPLETE; return 0; }
+        f.content_sum = xrd32(in + pos);
+    }
+    return 0;
+}
+
+}  // namespace
+
+size_t cj_lz4_frame_compress_bound(size_t n) {
+    return 7 + ((n + kLz4fBlock - 1) / kLz4fBlock) * 4 + n + 4 + 4;
+}
+
+int64_t cj_lz4_frame_decompress_bound(const uint8_t* in, size_t n) {
+    if (n && !in) return CJ_E_BAD_ARG;
+    Lz4Frame f;
+    const int64_t err = lz4_frame_walk(in, n, f, false);
+    if (err) return err;
+    if (f.skippable) return 0;
+    if (f.late_err) return f.late_err;
+    if (f.csize) return (int64_t)f.content_size;
+    uint64_t total = 0;
+    for (const Lz4Block& b : f.blocks) total += (b.word & 0x80000000u) ? (b.word & 0x7FFFFFFFu) : f.block_max;
+    return (int64_t)total;
+}
+
+int64_t cj_lz4_frame_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap, int level) {
+    (void)level;                           // the GPU matcher has one mode; any level yields a valid frame (see header)
+    if ((n && !in) || (cap && !out)) return CJ_E_BAD_ARG;
+    cj_engine* e = cj::default_engine();
+    if (!e) return CJ_E_NO_DEVICE;
+    const size_t np = (n + kLz4fBlock - 1) / kLz4fBlock;
+    if (np > 0xFFFFFFF0ull) return CJ_E_BAD_ARG;
+    if (cap < 7) return CJ_E_FRAME_WRITE;
+    // frame header: version 01, independent blocks, content checksum, 64 KiB blocks (FLG 0x64, BD 0x40)
+    uint8_t hdr[7] = { 0x04, 0x22, 0x4D, 0x18, 0x64, 0x40, 0 };
+    hdr[6] = (uint8_t)(xxh32(hdr + 4, 2, 0) >> 8);
+    std::memcpy(out, hdr, 7);
+    uint64_t fpos = 7;
+    uint32_t content_sum = 0;
+    std::thread summer([&] { content_sum = xxh32(in, n, 0); });          // overlaps the device batch
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{summer};
+    if (np > 0) {
+        std::lock_guard<std::mutex> lock(e->mu);
+        HIP_TRY(hipSetDevice(e->device), CJ_E_NO_DEVICE);
+        // rows: in_off|in_len|tmp_off|tmp_cap|result | src|dst_off|len|hdr (np each)
+        const size_t rows = 9 * np;
+        if (!e->d_in.reserve(n + 16) || !e->d_out.reserve(np * kLz4fTmpStride + 16) || !e->d_meta.reserve(rows * 8)) return CJ_E_OOM;
+        uint8_t* d_in = (uint8_t*)e->d_in.p;
+        uint8_t* d_tmp = (uint8_t*)e->d_out.p;
+        uint64_t* d_meta = (uint64_t*)e->d_meta.p;
+        std::vector<uint64_t>& m = e->h_meta;
+        m.assign(rows, 0);
+        for (size_t i = 0; i < np; i++) {
+            m[i] = i * kLz4fBlock;
+            m[np + i] = std::min(kLz4fBlock, n - i * kLz4fBlock);
+            m[2 * np + i] = i * kLz4fTmpStride;
+            m[3 * np + i] = kLz4fTmpStride;
+        }
+        hipStream_t s = e->stream;
+        HIP_TRY(hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
+        HIP_TRY(hipMemcpyAsync(d_meta, m.data(), 4 * np * 8, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
+        cj::BatchArgs a;
+        cj::fill_args(a, 0, np, d_in, d_meta, d_meta + np, d_tmp, d_meta + 2 * np, d_meta + 3 * np, (int64_t*)(d_meta + 4 * np));
+        const int rc = cj::launch(e, CJ_CODEC_LZ4_BLOCK, CJ_OP_COMPRESS, a, s);
+        if (rc != 0) return rc;
+        std::vector<int64_t> res(np);
+        HIP_TRY(hipMemcpyAsync(res.data(), d_meta + 4 * np, np * 8, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
+        HIP_TRY(hipStreamSynchronize(s), CJ_E_NO_DEVICE);
+        // LZ4F_makeBlock: a block that does not shrink is stored (bit 31 of the size word)
+        for (size_t i = 0; i < np; i++) {
+            if (res[i] < 0) return res[i];
+            const uint64_t len = m[np + i], cl = (uint64_t)res[i];
+            const bool stored = cl >= len;
+            const uint64_t body = stored ? len : cl;
+            m[5 * np + i] = (uint64_t)(uintptr_t)(stored ? d_in + i * kLz4fBlock : d_tmp + i * kLz4fTmpStride);
+            m[6 * np + i] = fpos + 4;
+            m[7 * np + i] = body;
+            m[8 * np + i] = body | (stored ? 0x80000000ull : 0ull);
+            fpos += 4 + body;
+        }
+        if (fpos + 8 > cap) return CJ_E_FRAME_WRITE;
+        if (!e->d_frame.reserve(fpos + 16)) return CJ_E_OOM;
+        uint8_t* d_frame = (uint8_t*)e->d_frame.p;
+        HIP_TRY(hipMemcpyAsync(d_meta + 5 * np, m.data() + 5 * np, 4 * np * 8, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
+        cj::launch_copy_segments(d_meta + 5 * np, d_frame, d_meta + 6 * np, d_meta + 7 * np, d_meta + 8 * np, 4, (uint32_t)np, s);
+        HIP_TRY(hipGetLastError(), CJ_E_NO_DEVICE);
+        HIP_TRY(hipMemcpyAsync(out + 7, d_frame + 7, fpos - 7, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
+        HIP_TRY(hipStreamSynchronize(s), CJ_E_NO_DEVICE);
+    }
+    if (fpos + 8 > cap) return CJ_E_FRAME_WRITE;
+    summer.join();
+    xwr32(out + fpos, 0u);                   // EndMark
+    xwr32(out + fpos + 4, content_sum);
+    return (int64_t)(fpos + 8);
+}
+
+int64_t cj_lz4_frame_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap) {
+    if ((n && !in) || (cap && !out)) return CJ_E_BAD_ARG;
+    cj_engine* e = cj::default_engine();
+    if (!e) return CJ_E_NO_DEVICE;
+    Lz4Frame f;
+    const int64_t werr = lz4_frame_walk(in, n, f, true);
+    if (werr) return werr;
+    if (f.skippable) return 0;
+    const size_t nb = f.blocks.size();
+    if (nb > 0xFFFFFFF0ull) return CJ_E_BAD_ARG;
+    uint64_t total = 0;
+    if (nb > 0) {
+        const uint64_t B = f.block_max;
+        std::lock_guard<std::mutex> lock(e->mu);
+        HIP_TRY(hipSetDevice(e->device), CJ_E_NO_DEVICE);
+        hipStream_t s = e->stream;
+        if (!e->d_frame.reserve(n + 16)) return CJ_E_OOM;
+        uint8_t* d_in = (uint8_t*)e->d_frame.p;
+        HIP_TRY(hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
+        std::vector<int64_t> res(nb);
+        uint8_t* d_final = nullptr;
+        if (f.indep || nb == 1) {
+            // one batch: compressed blocks decode into slots of the maximal block size, then everything is compacted
+            size_t nc = 0;
+            for (const Lz4Block& b : f.blocks) nc += (b.word & 0x80000000u) ? 0 : 1;
+            // rows: in_off|in_len|out_off|out_cap|result (nc each) | src|dst_off|len (nb each)
+            const size_t r_g = 5 * nc, rows = r_g + 3 * nb;
+            if (!e->d_in.reserve(nc * B + 16) || !e->d_meta.reserve(rows * 8)) return CJ_E_OOM;
+            uint8_t* d_tmp = (uint8_t*)e->d_in.p;
+            uint64_t* d_meta = (uint64_t*)e->d_meta.p;
+            std::vector<uint64_t>& m = e->h_meta;
+            m.assign(rows, 0);
+            size_t ci = 0;
+            for (const Lz4Block& b : f.blocks) {
+                if (b.word & 0x80000000u) continue;
+                m[ci] = b.src_off; m[nc + ci] = b.word; m[2 * nc + ci] = ci * B; m[3 * nc + ci] = B;
+                ci++;
+            }
+            std::vector<int64_t> cres(nc);
+            if (nc) {
+                HIP_TRY(hipMemcpyAsync(d_meta, m.data(), 4 * nc * 8, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
+                cj::BatchArgs a;
+                cj::fill_args(a, 0, nc, d_in, d_meta, d_meta + nc, d_tmp, d_meta + 2 * nc, d_meta + 3 * nc, (int64_t*)(d_meta + 4 * nc));
+                const int rc = cj::launch(e, CJ_CODEC_LZ4_BLOCK, CJ_OP_DECOMPRESS, a, s);
+                if (rc != 0) return rc;
+                HIP_TRY(hipMemcpyAsync(cres.data(), d_meta + 4 * nc, nc * 8, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
+            }
+            HIP_TRY(hipStreamSynchronize(s), CJ_E_NO_DEVICE);
+            ci = 0;
+            uint64_t pos = 0;
+            for (size_t i = 0; i < nb; i++) {
+                const Lz4Block& b = f.blocks[i];
+                const bool stored = (b.word & 0x80000000u) != 0;
+                const int64_t r = stored ? (int64_t)(b.word & 0x7FFFFFFFu) : cres[ci];
+                res[i] = r;
+                m[r_g + i] = (uint64_t)(uintptr_t)(stored ? d_in + b.src_off : d_tmp + ci * B);
+                m[r_g + nb + i] = pos;
+                m[r_g + 2 * nb + i] = r > 0 ? (uint64_t)r : 0;
+                if (r > 0) pos += (uint64_t)r;
+                if (!stored) ci++;
+            }
+            if (!e->d_out.reserve(pos + 16)) return CJ_E_OOM;
+            d_final = (uint8_t*)e->d_out.p;
+            HIP_TRY(hipMemcpyAsync(d_meta + r_g, m.data() + r_g, 3 * nb * 8, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
+            cj::launch_copy_segments(d_meta + r_g, d_final, d_meta + r_g + nb, d_meta + r_g + 2 * nb, nullptr, 0, (uint32_t)nb, s);
+            HIP_TRY(hipGetLastError(), CJ_E_NO_DEVICE);
+        } else {
+            // linked blocks: the chain kernel decodes straight into the contiguous output
+            const uint64_t out_cap = nb * B;
+            const size_t words = (nb * 4 + 7) / 8, rows = nb + words + nb;      // blk_off | word (u32) | result
+            if (!e->d_out.reserve(out_cap + 16) || !e->d_meta.reserve(rows * 8)) return CJ_E_OOM;
+            d_final = (uint8_t*)e->d_out.p;
+            uint64_t* d_meta = (uint64_t*)e->d_meta.p;
+            std::vector<uint64_t>& m = e->h_meta;
+            m.assign(rows, 0);
+            uint32_t* wv = reinterpret_cast<uint32_t*>(m.data() + nb);
+            for (size_t i = 0; i < nb; i++) { m[i] = f.blocks[i].src_off; wv[i] = f.blocks[i].word; }
+            HIP_TRY(hipMemcpyAsync(d_meta, m.data(), (nb + words) * 8, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
+            cj::launch_lz4_frame_chain(d_in, d_meta, (const uint32_t*)(d_meta + nb), (uint32_t)nb, d_final, out_cap, (uint32_t)B,
+                                       (int64_t*)(d_meta + nb + words), s);
+            HIP_TRY(hipGetLastError(), CJ_E_NO_DEVICE);
+            HIP_TRY(hipMemcpyAsync(res.data(), d_meta + nb + words, nb * 8, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
+            HIP_TRY(hipStreamSynchronize(s), CJ_E_NO_DEVICE);
+        }
+        // first failure in stream order: malformed block, then the writer running out of room
+        for (size_t i = 0; i < nb; i++) {
+            if (res[i] < 0) return CJ_E_LZ4F_DECOMPRESS;
+            if (out != nullptr && total + (uint64_t)res[i] > cap) return CJ_E_FRAME_WRITE;
+            total += (uint64_t)res[i];
+        }
+        if (out != nullptr && total) {
+            HIP_TRY(hipMemcpyAsync(out, d_final, total, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
+            HIP_TRY(hipStreamSynchronize(s), CJ_E_NO_DEVICE);
+        }
+    }
+    if (f.late_err && !f.complete) return f.late_err;                      // truncated / bad block word or checksum: after the blocks before it
+    if (f.csize && f.content_size != total) return CJ_E_LZ4F_CONTENT_SIZE;
+    if (f.late_err) return f.late_err;                                       // content checksum word missing
+    if (f.csum && out != nullptr && f.content_sum != xxh32(out, total, 0)) return CJ_E_LZ4F_CONTENT_CHECKSUM;
+    return (int64_t)total;
 }
 
 }  // extern "C"

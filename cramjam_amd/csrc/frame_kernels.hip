@@ -24,17 +24,18 @@ __global__ __launch_bounds__(kBlockThreads) void crc32c_pieces_kernel(const uint
     if (lane_id() == 0) out[piece] = crc32c_mask(~c);
 }
 
-// segment i: len[i] bytes from the device address src[i] to dst_base + dst_off[i]; when hdr is non-null the
-// 8 bytes hdr[i] (little endian: chunk type, u24 length, u32 checksum) are written just before the segment.
+// segment i: len[i] bytes from the device address src[i] to dst_base + dst_off[i]; when hdr is non-null the low
+// hdr_len (<= 8) bytes of hdr[i], little endian, are written just before the segment (Snappy: chunk type, u24 length,
+// u32 checksum; LZ4 frame: u32 block size word).
 __global__ __launch_bounds__(kBlockThreads) void copy_segments_kernel(const uint64_t* src, uint8_t* dst_base,
                                                                       const uint64_t* dst_off, const uint64_t* len,
-                                                                      const uint64_t* hdr, uint32_t n) {
+                                                                      const uint64_t* hdr, uint32_t hdr_len, uint32_t n) {
     const uint32_t seg = uni(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
     if (seg >= n) return;
     uint8_t* dst = dst_base + dst_off[seg];
     if (hdr != nullptr) {
         const uint64_t h = hdr[seg];
-        if (lane_id() < 8u) dst[(int)lane_id() - 8] = (uint8_t)(h >> (8u * lane_id()));
+        if (lane_id() < hdr_len) dst[(int)lane_id() - (int)hdr_len] = (uint8_t)(h >> (8u * lane_id()));
     }
     wave_copy(dst, reinterpret_cast<const uint8_t*>(src[seg]), (uint32_t)len[seg]);
 }
@@ -45,9 +46,9 @@ void launch_crc32c_pieces(const uint8_t* base, const uint64_t* off, const uint64
 }
 
 void launch_copy_segments(const uint64_t* src, uint8_t* dst_base, const uint64_t* dst_off, const uint64_t* len,
-                          const uint64_t* hdr, uint32_t n, hipStream_t s) {
+                          const uint64_t* hdr, uint32_t hdr_len, uint32_t n, hipStream_t s) {
     if (n == 0) return;
-    hipLaunchKernelGGL(copy_segments_kernel, dim3((n + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlockThreads), 0, s, src, dst_base, dst_off, len, hdr, n);
+    hipLaunchKernelGGL(copy_segments_kernel, dim3((n + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlockThreads), 0, s, src, dst_base, dst_off, len, hdr, hdr_len, n);
 }
 
 }  // namespace cj

@@ -596,45 +596,69 @@ PyObject* snappy_decompress_raw_len(PyObject*, PyObject* data) {                
 // ------------------------------------------------------------------------------------------
 // cramjam.snappy framed functions (reference src/snappy.rs:22-42,80-91 via the generic! macro, src/lib.rs:211-296)
 // ------------------------------------------------------------------------------------------
-int64_t snappy_frame_need(const Bytes& in, bool compress) {
+// One framed codec: size query (header arithmetic only) + the device call.  `level` is only used by LZ4 compression.
+struct Framed {
+    int64_t (*need)(const Bytes& in, bool compress);
+    int64_t (*run)(const Bytes& in, uint8_t* out, size_t cap, bool compress, int level);
+};
+
+int64_t snappy_need(const Bytes& in, bool compress) {
     if (compress) return (int64_t)cj_snappy_frame_max_compress_len((size_t)in.len);
     int64_t d = cj_snappy_frame_decompress_len(in.ptr, (size_t)in.len);
     // header-level error: let the decoder name the FIRST error in stream order (an earlier piece may be corrupt too)
     if (d < 0) { int64_t r = cj_snappy_frame_decompress(in.ptr, (size_t)in.len, nullptr, 0); return r < 0 ? r : d; }
     return d;
 }
+int64_t snappy_run(const Bytes& in, uint8_t* out, size_t cap, bool compress, int) {
+    return compress ? cj_snappy_frame_compress(in.ptr, (size_t)in.len, out, cap) : cj_snappy_frame_decompress(in.ptr, (size_t)in.len, out, cap);
+}
+int64_t lz4f_need(const Bytes& in, bool compress) {
+    return compress ? (int64_t)cj_lz4_frame_compress_bound((size_t)in.len) : cj_lz4_frame_decompress_bound(in.ptr, (size_t)in.len);
+}
+int64_t lz4f_run(const Bytes& in, uint8_t* out, size_t cap, bool compress, int level) {
+    return compress ? cj_lz4_frame_compress(in.ptr, (size_t)in.len, out, cap, level) : cj_lz4_frame_decompress(in.ptr, (size_t)in.len, out, cap);
+}
+const Framed kSnappyFramed = { snappy_need, snappy_run };
+const Framed kLz4Framed = { lz4f_need, lz4f_run };
 
-PyObject* snappy_framed(PyObject* args, PyObject* kw, bool compress) {
-    static const char* kwl[] = {"data", "output_len", nullptr};
-    PyObject *data, *olen = Py_None;
-    if (!PyArg_ParseTupleAndKeywords(args, kw, "O|O", (char**)kwl, &data, &olen)) return nullptr;
+// (data, [level,] output_len=None) -> Buffer         generic! macro, src/lib.rs:213-235
+PyObject* framed_call(const Framed& fc, PyObject* args, PyObject* kw, bool compress, bool with_level) {
+    static const char* kwl2[] = {"data", "output_len", nullptr};
+    static const char* kwl3[] = {"data", "level", "output_len", nullptr};
+    PyObject *data, *olen = Py_None, *lvl = Py_None;
+    if (with_level) { if (!PyArg_ParseTupleAndKeywords(args, kw, "O|OO", (char**)kwl3, &data, &lvl, &olen)) return nullptr; }
+    else if (!PyArg_ParseTupleAndKeywords(args, kw, "O|O", (char**)kwl2, &data, &olen)) return nullptr;
     bool has; size_t n = 0;
     if (!opt_size(olen, has, n)) return nullptr;
+    const int level = opt_int(lvl, -1);
+    if (level == -2) return nullptr;
     Bytes in;
     if (!get_bytes(data, in)) return nullptr;
     PyObject* exc = compress ? CompressionError : DecompressionError;
     int64_t need, r;
     std::vector<uint8_t> buf;
     Py_BEGIN_ALLOW_THREADS
-    need = snappy_frame_need(in, compress);
+    need = fc.need(in, compress);
     if (need >= 0) {
         // generic!: vec![0; output_len] under a Cursor at 0 -> the result is never shorter than output_len
         buf.assign(std::max((size_t)need, has ? n : (size_t)0), 0);
-        r = compress ? cj_snappy_frame_compress(in.ptr, (size_t)in.len, buf.data(), buf.size())
-                     : cj_snappy_frame_decompress(in.ptr, (size_t)in.len, buf.data(), buf.size());
+        r = fc.run(in, buf.data(), buf.size(), compress, level);
     } else r = need;
     Py_END_ALLOW_THREADS
     if (r < 0) return raise_code(exc, r);
     buf.resize(std::max((size_t)r, has ? n : (size_t)0));
     return buffer_from_vec(std::move(buf));
 }
-PyObject* snappy_compress(PyObject*, PyObject* a, PyObject* k) { return snappy_framed(a, k, true); }
-PyObject* snappy_decompress(PyObject*, PyObject* a, PyObject* k) { return snappy_framed(a, k, false); }
 
-PyObject* snappy_framed_into(PyObject* args, PyObject* kw, bool compress) {
-    static const char* kwl[] = {"input", "output", nullptr};
-    PyObject *input, *output;
-    if (!PyArg_ParseTupleAndKeywords(args, kw, "OO", (char**)kwl, &input, &output)) return nullptr;
+// (input, output[, level]) -> int                    generic! macro, src/lib.rs:237-296
+PyObject* framed_into(const Framed& fc, PyObject* args, PyObject* kw, bool compress, bool with_level) {
+    static const char* kwl2[] = {"input", "output", nullptr};
+    static const char* kwl3[] = {"input", "output", "level", nullptr};
+    PyObject *input, *output, *lvl = Py_None;
+    if (with_level) { if (!PyArg_ParseTupleAndKeywords(args, kw, "OO|O", (char**)kwl3, &input, &output, &lvl)) return nullptr; }
+    else if (!PyArg_ParseTupleAndKeywords(args, kw, "OO", (char**)kwl2, &input, &output)) return nullptr;
+    const int level = opt_int(lvl, -1);
+    if (level == -2) return nullptr;
     Bytes in, out;
     if (!get_bytes(input, in) || !get_bytes(output, out)) return nullptr;
     PyObject* exc = compress ? CompressionError : DecompressionError;
@@ -643,11 +667,10 @@ PyObject* snappy_framed_into(PyObject* args, PyObject* kw, bool compress) {
         // Buffer output: a Cursor<Vec<u8>> written at its position, growing as needed (views cannot grow)
         std::vector<uint8_t> tmp;
         Py_BEGIN_ALLOW_THREADS
-        r = snappy_frame_need(in, compress);
+        r = fc.need(in, compress);
         if (r >= 0) {
             tmp.assign((size_t)r, 0);
-            r = compress ? cj_snappy_frame_compress(in.ptr, (size_t)in.len, tmp.data(), tmp.size())
-                         : cj_snappy_frame_decompress(in.ptr, (size_t)in.len, tmp.data(), tmp.size());
+            r = fc.run(in, tmp.data(), tmp.size(), compress, level);
         }
         Py_END_ALLOW_THREADS
         if (r < 0) return raise_code(exc, r);
@@ -663,16 +686,28 @@ PyObject* snappy_framed_into(PyObject* args, PyObject* kw, bool compress) {
         return PyLong_FromLongLong(r);
     }
     Py_BEGIN_ALLOW_THREADS
-    r = compress ? cj_snappy_frame_compress(in.ptr, (size_t)in.len, out.ptr, (size_t)out.len)
-                 : cj_snappy_frame_decompress(in.ptr, (size_t)in.len, out.ptr, (size_t)out.len);
+    r = fc.run(in, out.ptr, (size_t)out.len, compress, level);
     Py_END_ALLOW_THREADS
     if (r < 0) return raise_code(exc, r);
     return PyLong_FromLongLong(r);
 }
-PyObject* snappy_compress_into(PyObject*, PyObject* a, PyObject* k) { return snappy_framed_into(a, k, true); }
-PyObject* snappy_decompress_into(PyObject*, PyObject* a, PyObject* k) { return snappy_framed_into(a, k, false); }
+
+// cramjam.snappy framed functions (reference src/snappy.rs:22-42,80-91)
+PyObject* snappy_compress(PyObject*, PyObject* a, PyObject* k) { return framed_call(kSnappyFramed, a, k, true, false); }
+PyObject* snappy_decompress(PyObject*, PyObject* a, PyObject* k) { return framed_call(kSnappyFramed, a, k, false, false); }
+PyObject* snappy_compress_into(PyObject*, PyObject* a, PyObject* k) { return framed_into(kSnappyFramed, a, k, true, false); }
+PyObject* snappy_decompress_into(PyObject*, PyObject* a, PyObject* k) { return framed_into(kSnappyFramed, a, k, false, false); }
+// cramjam.lz4 frame functions (reference src/lz4.rs:18-66)
+PyObject* lz4_compress(PyObject*, PyObject* a, PyObject* k) { return framed_call(kLz4Framed, a, k, true, true); }
+PyObject* lz4_decompress(PyObject*, PyObject* a, PyObject* k) { return framed_call(kLz4Framed, a, k, false, false); }
+PyObject* lz4_compress_into(PyObject*, PyObject* a, PyObject* k) { return framed_into(kLz4Framed, a, k, true, true); }
+PyObject* lz4_decompress_into(PyObject*, PyObject* a, PyObject* k) { return framed_into(kLz4Framed, a, k, false, false); }
 
 PyMethodDef lz4_methods[] = {
+    {"compress", (PyCFunction)lz4_compress, METH_VARARGS | METH_KEYWORDS, "LZ4 (frame) compression (data, level=None, output_len=None)"},
+    {"decompress", (PyCFunction)lz4_decompress, METH_VARARGS | METH_KEYWORDS, "LZ4 (frame) decompression (data, output_len=None)"},
+    {"compress_into", (PyCFunction)lz4_compress_into, METH_VARARGS | METH_KEYWORDS, "Compress (frame) directly into an output buffer (input, output, level=None)"},
+    {"decompress_into", (PyCFunction)lz4_decompress_into, METH_VARARGS | METH_KEYWORDS, "Decompress (frame) directly into an output buffer (input, output)"},
     {"decompress_block", (PyCFunction)lz4_decompress_block, METH_VARARGS | METH_KEYWORDS, "LZ4 block decompression (data, output_len=None)"},
     {"compress_block", (PyCFunction)lz4_compress_block, METH_VARARGS | METH_KEYWORDS, "LZ4 block compression (data, output_len=None, mode=None, acceleration=None, compression=None, store_size=None)"},
     {"decompress_block_into", (PyCFunction)lz4_decompress_block_into, METH_VARARGS | METH_KEYWORDS, "LZ4 block decompression into a pre-allocated buffer (input, output, output_len=None)"},

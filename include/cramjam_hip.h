@@ -48,6 +48,14 @@ extern "C" {
 #define CJ_E_SNAPPY_CHUNK_TYPE (-16) /* snap::Error::UnsupportedChunkType */
 #define CJ_E_SNAPPY_CHUNK_LEN  (-17) /* snap::Error::UnsupportedChunkLength */
 #define CJ_E_SNAPPY_CHECKSUM   (-18) /* snap::Error::Checksum */
+#define CJ_E_LZ4F_FRAME_TYPE    (-20) /* LZ4F ERROR_frameType_unknown (bad magic number) */
+#define CJ_E_LZ4F_HEADER        (-21) /* LZ4F ERROR_headerVersion_wrong / reservedFlag_set / headerChecksum_invalid */
+#define CJ_E_LZ4F_BLOCK_SIZE    (-22) /* LZ4F ERROR_maxBlockSize_invalid */
+#define CJ_E_LZ4F_BLOCK_CHECKSUM (-23) /* LZ4F ERROR_blockChecksum_invalid */
+#define CJ_E_LZ4F_CONTENT_CHECKSUM (-24) /* LZ4F ERROR_contentChecksum_invalid */
+#define CJ_E_LZ4F_CONTENT_SIZE  (-25) /* LZ4F ERROR_frameSize_wrong */
+#define CJ_E_LZ4F_INCOMPLETE    (-26) /* lz4 crate Decoder::finish: "Finish runned before read end of compressed stream" */
+#define CJ_E_LZ4F_DECOMPRESS    (-27) /* LZ4F ERROR_decompressionFailed (malformed block) */
 #define CJ_E_NO_DEVICE         (-100) /* no HIP device / HIP runtime failure (see cj_last_hip_error) */
 #define CJ_E_BAD_ARG           (-101)
 #define CJ_E_OOM               (-102) /* device or pinned-host allocation failed */
@@ -107,6 +115,22 @@ int64_t cj_snappy_frame_decompress_len(const uint8_t* in, size_t n);
  * order like the sequential decoder would (block error, checksum, output full, then header errors).
  * out == NULL: validate only — decode and checksum on the device, return the decoded length or the first error. */
 int64_t cj_snappy_frame_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap);
+
+/* ---- LZ4 FRAME format: blocks de/compressed on the GPU — independent-block and single-block
+ * frames as one batch, linked-block frames by a chain kernel; XXH32 frame checksums on a concurrent host thread. ---- */
+/* upper bound of cj_lz4_frame_compress's output: 15 + 4 * ceil(n / 65536) + n. No device. */
+size_t cj_lz4_frame_compress_bound(size_t n);
+/* src/lz4.rs:43,56  libcramjam::lz4::compress(input, output, level) (lz4 crate EncoderBuilder -> LZ4F): 64 KiB blocks,
+ * content checksum, no content size — like the reference — but INDEPENDENT blocks (the reference links them) and one
+ * matcher for every `level` (the reference's default level 4 is LZ4HC): any LZ4F decoder reads the result. */
+int64_t cj_lz4_frame_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap, int level);
+/* upper bound of the decoded size from the headers alone (content size if stored, else blocks x max block size), or the
+ * first header-level error. No device. */
+int64_t cj_lz4_frame_decompress_bound(const uint8_t* in, size_t n);
+/* src/lz4.rs:28,63  libcramjam::lz4::decompress (lz4 crate Decoder -> LZ4F_decompress): all block sizes, linked and
+ * independent blocks, block / content checksums, content size; stops after the first frame like the crate's Decoder.
+ * out == NULL: validate only (block structure and block decode; the content checksum needs the bytes on the host). */
+int64_t cj_lz4_frame_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap);
 
 /* =====================================================================================
  * Batch extension (no reference equivalent: the reference API is one buffer per call; a GPU only

@@ -155,48 +155,61 @@ def test_large_stream_round_trip():
     assert abi_decompress(bytes(dmg), cap=len(data))[0] == oracle.snappy_frame_decompress(bytes(dmg), len(data))[0] < 0
 
 
-# ---- the reference's generic variant tests, restated for cramjam.snappy (tests/test_variants.py:48-245) ----
+# ---- the reference's generic variant tests, restated for cramjam.snappy and cramjam.lz4 (tests/test_variants.py:48-245) ----
+VARIANTS = ("snappy", "lz4")
+
+
+def _oracle_decode(variant_str, framed):
+    return (oracle.snappy_frame_decompress if variant_str == "snappy" else oracle.lz4_frame_decompress)(framed)[1]
+
 
 def same_same(a, b):
     return bytes(a) == bytes(b)
 
 
+@pytest.mark.parametrize("variant_str", VARIANTS)
 @FAST
 @given(arr=st_np.arrays(st_np.scalar_dtypes(), shape=st.integers(0, int(1e4))))
-def test_variants_different_dtypes(arr):
-    compressed = cramjam.snappy.compress(arr)
-    assert same_same(cramjam.snappy.decompress(compressed), arr.tobytes())
+def test_variants_different_dtypes(variant_str, arr):
+    variant = getattr(cramjam, variant_str)
+    compressed = variant.compress(arr)
+    assert same_same(variant.decompress(compressed), arr.tobytes())
     if arr.shape[0] % 2 == 0:
         arr = arr.reshape((2, -1))
-        assert same_same(cramjam.snappy.decompress(cramjam.snappy.compress(arr)), arr.tobytes())
+        assert same_same(variant.decompress(variant.compress(arr)), arr.tobytes())
 
 
 @pytest.mark.parametrize("is_bytearray", (True, False))
+@pytest.mark.parametrize("variant_str", VARIANTS)
 @FAST
 @given(uncompressed=st.binary(min_size=1))
-def test_variants_simple(is_bytearray, uncompressed):
+def test_variants_simple(variant_str, is_bytearray, uncompressed):
+    variant = getattr(cramjam, variant_str)
     if is_bytearray:
         uncompressed = bytearray(uncompressed)
-    compressed = cramjam.snappy.compress(uncompressed)
+    compressed = variant.compress(uncompressed)
     assert compressed.read() != uncompressed
     compressed.seek(0)
     assert isinstance(compressed, cramjam.Buffer)
-    assert oracle.snappy_frame_decompress(bytes(compressed))[1] == bytes(uncompressed)
-    decompressed = cramjam.snappy.decompress(compressed, output_len=len(uncompressed))
+    assert _oracle_decode(variant_str, bytes(compressed)) == bytes(uncompressed)     # the CPU decoder reads the GPU's container
+    decompressed = variant.decompress(compressed, output_len=len(uncompressed))
     assert same_same(decompressed.read(), uncompressed)
     assert isinstance(decompressed, cramjam.Buffer)
 
 
-def test_variants_raise_exception():
+@pytest.mark.parametrize("variant_str", VARIANTS)
+def test_variants_raise_exception(variant_str):
     with pytest.raises(cramjam.DecompressionError):
-        cramjam.snappy.decompress(b"sknow")
+        getattr(cramjam, variant_str).decompress(b"sknow")
 
 
-def test_output_len_is_a_floor():
+@pytest.mark.parametrize("variant_str", VARIANTS)
+def test_output_len_is_a_floor(variant_str):
     # generic!: vec![0; output_len] under a Cursor -> never shorter than output_len (src/lib.rs:216-219)
-    out = cramjam.snappy.decompress(cramjam.snappy.compress(b"abc" * 10), output_len=100)
+    variant = getattr(cramjam, variant_str)
+    out = variant.decompress(variant.compress(b"abc" * 10), output_len=100)
     assert len(out) == 100 and bytes(out)[:30] == b"abc" * 10 and bytes(out)[30:] == bytes(70)
-    out = cramjam.snappy.decompress(cramjam.snappy.compress(b"abc" * 10), output_len=5)
+    out = variant.decompress(variant.compress(b"abc" * 10), output_len=5)
     assert bytes(out) == b"abc" * 10
 
 
@@ -221,33 +234,153 @@ TYPES = (bytes, bytearray, "numpy", cramjam.Buffer, memoryview)     # cramjam.Fi
 
 @pytest.mark.parametrize("input_type", TYPES)
 @pytest.mark.parametrize("output_type", TYPES)
-@settings(max_examples=8, deadline=None)
+@pytest.mark.parametrize("variant_str", VARIANTS)
+@settings(max_examples=6, deadline=None)
 @given(raw_data=st.binary())
-def test_variants_compress_into(input_type, output_type, raw_data):
+def test_variants_compress_into(variant_str, input_type, output_type, raw_data):
+    variant = getattr(cramjam, variant_str)
     inp = _make(input_type, raw_data)
-    compressed_len = len(cramjam.snappy.compress(raw_data))
+    compressed_len = len(variant.compress(raw_data))
     output = cramjam.Buffer() if output_type is cramjam.Buffer else _make(output_type, b"0" * compressed_len)
-    n_bytes = cramjam.snappy.compress_into(inp, output)
+    n_bytes = variant.compress_into(inp, output)
     assert n_bytes == compressed_len
-    assert same_same(raw_data, cramjam.snappy.decompress(_collect(output)[:n_bytes]))
+    assert same_same(raw_data, variant.decompress(_collect(output)[:n_bytes]))
 
 
 @pytest.mark.parametrize("input_type", TYPES)
 @pytest.mark.parametrize("output_type", TYPES)
-@settings(max_examples=8, deadline=None)
+@pytest.mark.parametrize("variant_str", VARIANTS)
+@settings(max_examples=6, deadline=None)
 @given(raw_data=st.binary())
-def test_variants_decompress_into(input_type, output_type, raw_data):
-    compressed = bytes(cramjam.snappy.compress(raw_data))
+def test_variants_decompress_into(variant_str, input_type, output_type, raw_data):
+    variant = getattr(cramjam, variant_str)
+    compressed = bytes(variant.compress(raw_data))
     inp = _make(input_type, compressed)
     output = cramjam.Buffer() if output_type is cramjam.Buffer else _make(output_type, b"0" * len(raw_data))
-    n_bytes = cramjam.snappy.decompress_into(inp, output)
+    n_bytes = variant.decompress_into(inp, output)
     assert n_bytes == len(raw_data)
     assert same_same(_collect(output), raw_data)
 
 
-def test_into_output_too_small():
+@pytest.mark.parametrize("variant_str", VARIANTS)
+def test_into_output_too_small(variant_str):
+    variant = getattr(cramjam, variant_str)
     data = b"some bytes here" * 100
     with pytest.raises(cramjam.CompressionError):
-        cramjam.snappy.compress_into(data, bytearray(10))
+        variant.compress_into(data, bytearray(10))
     with pytest.raises(cramjam.DecompressionError):
-        cramjam.snappy.decompress_into(cramjam.snappy.compress(data), bytearray(len(data) - 1))
+        variant.decompress_into(variant.compress(data), bytearray(len(data) - 1))
+
+
+# ---- LZ4 frame through the C-ABI ----------------------------------------------------------------------------------
+
+def lz4f_decompress(framed, cap=None):
+    L = N.lib()
+    framed = bytes(framed)
+    if cap is None:
+        cap = max(L.cj_lz4_frame_decompress_bound(framed, len(framed)), 0)
+    out = C.create_string_buffer(max(cap, 1))
+    r = L.cj_lz4_frame_decompress(framed, len(framed), out, cap)
+    return r, out.raw[:max(r, 0)]
+
+
+def lz4f_compress(data, cap=None, level=-1):
+    L = N.lib()
+    data = bytes(data)
+    cap = L.cj_lz4_frame_compress_bound(len(data)) if cap is None else cap
+    out = C.create_string_buffer(max(cap, 1))
+    r = L.cj_lz4_frame_compress(data, len(data), out, cap, level)
+    return r, out.raw[:max(r, 0)]
+
+
+def test_lz4_frame_fixture_and_golden_frames():
+    """reference fixture + 50 frames minted by liblz4's LZ4F: linked and independent blocks, all block sizes, checksums"""
+    import base64, hashlib, importlib.util, json
+    framed, plain = _fx("plaintext.txt.lz4"), _fx("plaintext.txt")
+    assert lz4f_decompress(framed) == (len(plain), plain)
+    assert bytes(cramjam.lz4.decompress(framed)) == plain
+    spec = importlib.util.spec_from_file_location("mgf", os.path.join(GOLDEN_DIR, "make_golden_frames.py"))
+    mgf = importlib.util.module_from_spec(spec); spec.loader.exec_module(mgf)
+    g = json.load(open(os.path.join(GOLDEN_DIR, "golden_frames.json")))
+    kinds = set()
+    for v in g["vectors"]:
+        data = mgf.content(v["kind"], v["n"])
+        frame = base64.b64decode(v["frame"])
+        assert hashlib.sha256(data).hexdigest() == v["sha256"]
+        assert N.lib().cj_lz4_frame_decompress_bound(frame, len(frame)) == oracle.lz4_frame_decompress_bound(frame)
+        r, out = lz4f_decompress(frame)
+        assert r == len(data) and out == data, {k: v[k] for k in v if k != "frame"}
+        kinds.add((frame[4] >> 5) & 1)
+    assert kinds == {0, 1}                      # both linked (chain kernel) and independent (batch) frames were exercised
+
+
+@pytest.mark.parametrize("flags", [0, 1, 2, 3, 7, 9])
+@pytest.mark.parametrize("bs", [4, 5, 7])
+def test_lz4_frame_decode_oracle_frames(flags, bs):
+    data = mixed_data(7 + flags, 200, 70000, 100000)
+    r, frame = oracle.lz4_frame_compress(data, bs, flags)
+    assert lz4f_decompress(frame) == (len(data), data)
+
+
+def test_lz4_frame_encode_layout_and_round_trip():
+    data = mixed_data(8)
+    r, frame = lz4f_compress(data)
+    assert r == len(frame) <= N.lib().cj_lz4_frame_compress_bound(len(data))
+    assert frame[:6] == b"\x04\x22\x4d\x18\x64\x40" and frame[6] == (oracle.xxh32(frame[4:6]) >> 8) & 0xff
+    pos, off, kinds = 7, 0, set()
+    while True:                                   # 64 KiB independent blocks; stored iff the block did not shrink
+        w = int.from_bytes(frame[pos:pos + 4], "little"); pos += 4
+        if w == 0:
+            break
+        sz, stored = w & 0x7FFFFFFF, w >> 31
+        piece = data[off:off + 65536]
+        if stored:
+            assert frame[pos:pos + sz] == piece
+        else:
+            assert sz < len(piece) and oracle.lz4_decompress_raw(frame[pos:pos + sz], len(piece)) == (len(piece), piece)
+        kinds.add(stored); pos += sz; off += len(piece)
+    assert off == len(data) and kinds == {0, 1}
+    assert int.from_bytes(frame[pos:pos + 4], "little") == oracle.xxh32(data) and pos + 4 == len(frame)
+    assert oracle.lz4_frame_decompress(frame) == (len(data), data)           # the CPU decoder accepts the GPU's frame
+    assert lz4f_decompress(frame) == (len(data), data)
+    assert lz4f_compress(data, cap=len(frame) - 1)[0] == E_WRITE and lz4f_compress(data, cap=len(frame))[0] == len(frame)
+    assert lz4f_compress(b"") == (15, bytes.fromhex("04224d186440a700000000055dcc02"))       # = liblz4's empty frame
+    assert lz4f_decompress(lz4f_compress(b"")[1]) == (0, b"")
+    for level in (0, 4, 12):
+        assert lz4f_decompress(lz4f_compress(data[:100000], level=level)[1])[1] == data[:100000]
+
+
+def test_lz4_frame_malformed_matches_oracle():
+    data = _fx("plaintext.txt") * 100
+    cases = []
+    for flags in (2, 8, 4 | 8, 1 | 2):
+        r, fr = oracle.lz4_frame_compress(data, 4, flags)
+        cases += [fr, fr[:3], fr[:6], fr[:8], fr[:12], fr[:len(fr) - 5], fr[:len(fr) - 1], fr + b"trailing"]
+        for pos, mask in ((4, 0x80), (4, 0x02), (5, 0x70), (6, 1), (12, 0xFF), (13, 0xFF), (20, 1), (len(fr) - 1, 1), (len(fr) - 6, 0x40), (7, 0x10), (9, 0x01)):
+            b = bytearray(fr); b[pos] ^= mask
+            cases.append(bytes(b))
+    cases += [b"sknow", b"sknowsknow", b"", b"\x50\x2a\x4d\x18\x03\x00\x00\x00abc" + cases[0], b"\x50\x2a\x4d\x18\x09\x00\x00\x00abc"]
+    random.seed(13)
+    r, fr = oracle.lz4_frame_compress(data + bytes(random.randrange(256) for _ in range(3000)), 4, 1)      # linked, 2 blocks
+    for _ in range(40):
+        b = bytearray(fr); b[random.randrange(len(b))] ^= 1 << random.randrange(8)
+        cases.append(bytes(b))
+    for s in cases:
+        for cap in (200000, 100):
+            want = oracle.lz4_frame_decompress(s, cap)
+            got = lz4f_decompress(s, cap)
+            assert got[0] == want[0], (s[:24].hex(), len(s), cap, got[0], want[0])
+            if want[0] >= 0:
+                assert got[1] == want[1]
+
+
+def test_lz4_frame_large_round_trip():
+    """64 MiB: 1024 independent 64 KiB blocks through the batch engine, host XXH32 overlapped"""
+    rng = np.random.default_rng(5)
+    pieces = [oracle.synth_v1(65536, i) for i in range(64)]
+    data = b"".join(pieces[i % 64] for i in range(1016)) + rng.integers(0, 256, 8 * 65536 - 777, dtype=np.uint8).tobytes()
+    r, frame = lz4f_compress(data)
+    assert 0 < r < len(data)
+    assert lz4f_decompress(frame) == (len(data), data)
+    dmg = bytearray(frame); dmg[len(frame) // 3] ^= 0x04
+    assert lz4f_decompress(bytes(dmg), cap=len(data))[0] == oracle.lz4_frame_decompress(bytes(dmg), len(data))[0] < 0

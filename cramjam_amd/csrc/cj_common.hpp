@@ -18,7 +18,12 @@ struct BatchArgs {
     int64_t* result;
     uint32_t n_chunks;
     uint32_t flags;
+    const uint32_t* hist;       // linked LZ4-frame blocks only (frame.hip): bytes of history before out_off[i]; nullptr = none
 };
+
+// internal flag bits (never part of the C-ABI): 0x1000 = LDS decoder phase profile, 0x2000 = linked-frame parse
+// (bit 63 of in_len marks a STORED block; no minimum sequence count for the LDS decoder)
+constexpr uint32_t kFlagLinkedFrame = 0x2000u;
 
 constexpr int kWavesPerBlock = 4;
 constexpr int kBlockThreads = 64 * kWavesPerBlock;
@@ -35,6 +40,9 @@ void launch_lz4_decode_routed(const BatchArgs& a, const void* meta, hipStream_t 
 // variant 2: persistent grid (2 workgroups per CU), record tables in the global scratch `tabs`, chunk indices from *counter
 // codec: CJ_CODEC_LZ4_BLOCK or CJ_CODEC_SNAPPY_RAW (only the record expansion D1 differs)
 void launch_lz4_decode_lds2(const BatchArgs& a, const void* sync, const void* meta, void* tabs, uint32_t* counter, uint32_t grid, hipStream_t s, int codec = 0);
+// linked LZ4-frame blocks: one workgroup walks the blocks of a frame in order, previous block kept as a second LDS window
+void launch_lz4_decode_lds2_linked(const BatchArgs& a, const void* sync, const void* meta, void* tabs, uint32_t* counter,
+                                   const void* frames, uint32_t n_frames, uint32_t grid, hipStream_t s);
 size_t lz4_lds2_tab_bytes(uint32_t grid);
 size_t lz4_lds_scratch_sync_bytes(size_t n_chunks);
 size_t lz4_lds_scratch_meta_bytes(size_t n_chunks);

@@ -17,7 +17,7 @@ void cj::fill_args(cj::BatchArgs& a, uint32_t flags, size_t n, const uint8_t* in
                int64_t* result) {
     a.in_base = in_base; a.in_off = in_off; a.in_len = in_len;
     a.out_base = out_base; a.out_off = out_off; a.out_cap = out_cap;
-    a.result = result; a.n_chunks = (uint32_t)n; a.flags = flags;
+    a.result = result; a.n_chunks = (uint32_t)n; a.flags = flags; a.hist = nullptr;
 }
 
 namespace {

@@ -8,6 +8,8 @@
 // assembles the stream (copy_segments).  No codec or checksum arithmetic runs on the host.
 #include "cj_engine.hpp"
 
+#include <atomic>
+
 namespace cj {
 void launch_crc32c_pieces(const uint8_t* base, const uint64_t* off, const uint64_t* len, uint32_t* out, uint32_t n, hipStream_t s);
 void launch_copy_segments(const uint64_t* src, uint8_t* dst_base, const uint64_t* dst_off, const uint64_t* len,
@@ -343,6 +345,73 @@ int64_t lz4_frame_walk(const uint8_t* in, size_t n, Lz4Frame& f, bool verify_blo
 
 }  // namespace
 
+namespace {
+
+std::atomic<unsigned long long> g_linked_lds_frames{0};
+
+// Linked 64 KiB blocks through parse + lz4_decode_lds2_kernel<LZ4, linked>: ~100x the chain kernel on short-sequence data.
+// Needs every non-last block to decode to exactly 64 KiB (block k then starts at k * 64 KiB and its history is the whole
+// previous block) and every block to fit the LDS decoder (<= 8192 sequences, <= 65 504 input bytes); the parse kernel
+// establishes both.  Returns 0 when the frame was decoded this way, 1 when the caller must fall back to the chain
+// kernel, < 0 on a device error.
+int lz4_frame_linked_lds(cj_engine* e, const Lz4Frame& f, const uint8_t* d_in, std::vector<int64_t>& res, uint8_t** d_final) {
+    const size_t nb = f.blocks.size();
+    const uint64_t B = 65536;
+    hipStream_t s = e->stream;
+    std::lock_guard<std::mutex> lock(e->scratch_mu);
+    // rows: in_off | in_len | out_off | out_cap | result | hist(u32) | frames(uint2)
+    const size_t hw = (nb * 4 + 7) / 8, rows = 5 * nb + hw + 1;
+    const size_t list_bytes = 16;
+    if (e->scratch_free) HIP_TRY(hipEventSynchronize(e->scratch_free), CJ_E_NO_DEVICE);
+    if (!e->d_out.reserve(nb * B + 16) || !e->d_meta.reserve(rows * 8) || !e->d_sync.reserve(cj::lz4_lds_scratch_sync_bytes(nb)) ||
+        !e->d_pmeta.reserve(cj::lz4_lds_scratch_meta_bytes(nb)) || !e->d_lanelist.reserve(list_bytes) ||
+        !e->d_tab.reserve(cj::lz4_lds2_tab_bytes(1))) return CJ_E_OOM;
+    uint64_t* d_meta = (uint64_t*)e->d_meta.p;
+    std::vector<uint64_t>& m = e->h_meta;
+    m.assign(rows, 0);
+    uint32_t* hist = reinterpret_cast<uint32_t*>(m.data() + 5 * nb);
+    for (size_t i = 0; i < nb; i++) {
+        const Lz4Block& b = f.blocks[i];
+        m[i] = b.src_off;
+        m[nb + i] = (uint64_t)(b.word & 0x7FFFFFFFu) | ((b.word & 0x80000000u) ? (1ull << 63) : 0ull);
+        m[2 * nb + i] = i * B;
+        m[3 * nb + i] = B;
+        hist[i] = i ? 65536u : 0u;
+    }
+    uint32_t* fr = reinterpret_cast<uint32_t*>(m.data() + 5 * nb + hw);
+    fr[0] = 0u; fr[1] = (uint32_t)nb;
+    HIP_TRY(hipMemcpyAsync(d_meta, m.data(), rows * 8, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
+    HIP_TRY(hipMemsetAsync(e->d_pmeta.p, 0, cj::lz4_lds_scratch_meta_bytes(nb), s), CJ_E_NO_DEVICE);
+    HIP_TRY(hipMemsetAsync(e->d_lanelist.p, 0, 16, s), CJ_E_NO_DEVICE);
+    cj::BatchArgs a;
+    cj::fill_args(a, cj::kFlagLinkedFrame, nb, d_in, d_meta, d_meta + nb, (uint8_t*)e->d_out.p, d_meta + 2 * nb, d_meta + 3 * nb,
+                  (int64_t*)(d_meta + 4 * nb));
+    a.hist = reinterpret_cast<const uint32_t*>(d_meta + 5 * nb);
+    cj::launch_lz4_parse(a, e->d_sync.p, e->d_pmeta.p, s);
+    HIP_TRY(hipGetLastError(), CJ_E_NO_DEVICE);
+    std::vector<uint64_t> pmeta(nb);
+    HIP_TRY(hipMemcpyAsync(res.data(), d_meta + 4 * nb, nb * 8, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
+    HIP_TRY(hipMemcpyAsync(pmeta.data(), e->d_pmeta.p, nb * 8, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
+    HIP_TRY(hipStreamSynchronize(s), CJ_E_NO_DEVICE);
+    for (size_t i = 0; i < nb; i++) {
+        const uint32_t in_skip = (uint32_t)(pmeta[i] >> 32);          // ParseMeta {nseq, in_skip}
+        if (res[i] < 0 || (in_skip & 0x80000000u)) return 1;          // malformed (the chain kernel names the block) or not LDS-capable
+        if (i + 1 < nb && (uint64_t)res[i] != B) return 1;            // a short block in the middle: positions are not k * 64 KiB
+        if (res[i] == 0 && !(in_skip & 0x20000000u)) return 1;
+    }
+    cj::launch_lz4_decode_lds2_linked(a, e->d_sync.p, e->d_pmeta.p, e->d_tab.p, (uint32_t*)e->d_lanelist.p + 2,
+                                      d_meta + 5 * nb + hw, 1u, 1u, s);
+    HIP_TRY(hipGetLastError(), CJ_E_NO_DEVICE);
+    *d_final = (uint8_t*)e->d_out.p;
+    g_linked_lds_frames.fetch_add(1);
+    return 0;
+}
+
+}  // namespace
+
+// debug aid (tests): number of linked-block frames decoded by the two-window LDS decoder in this process
+extern "C" unsigned long long cj_debug_linked_lds_frames(void) { return g_linked_lds_frames.load(); }
+
 size_t cj_lz4_frame_compress_bound(size_t n) {
     return 7 + ((n + kLz4fBlock - 1) / kLz4fBlock) * 4 + n + 4 + 4;
 }
@@ -497,6 +566,8 @@ int64_t cj_lz4_frame_decompress(const uint8_t* in, size_t n, uint8_t* out, size_
             HIP_TRY(hipMemcpyAsync(d_meta + r_g, m.data() + r_g, 3 * nb * 8, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
             cj::launch_copy_segments(d_meta + r_g, d_final, d_meta + r_g + nb, d_meta + r_g + 2 * nb, nullptr, 0, (uint32_t)nb, s);
             HIP_TRY(hipGetLastError(), CJ_E_NO_DEVICE);
+        } else if (B == 65536 && !std::getenv("CJ_LZ4F_CHAIN_ONLY") && lz4_frame_linked_lds(e, f, d_in, res, &d_final) == 0) {
+            // linked 64 KiB blocks, decoded by the two-window LDS workgroup decoder (results in res, bytes at d_final)
         } else {
             // linked blocks: the chain kernel decodes straight into the contiguous output
             const uint64_t out_cap = nb * B;

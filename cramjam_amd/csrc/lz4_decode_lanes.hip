@@ -52,12 +52,20 @@ __global__ __launch_bounds__(64 * kParseWaves) void lz4_parse_kernel(BatchArgs a
     ParseMeta pm = {0u, 0u};
     int64_t r = 0;
     bool done = true;
+    const bool linked = (a.flags & kFlagLinkedFrame) != 0u;
+    uint32_t hist = 0;
     if (exists) {
         in0 = in = a.in_base + a.in_off[c];
         n64 = a.in_len[c];
         cap64 = a.out_cap[c];
+        if (linked && a.hist != nullptr) hist = a.hist[c];
+        if (linked && (n64 >> 63)) {                       // stored block: nothing to parse
+            n64 &= 0x7FFFFFFFFFFFFFFFull;
+            r = n64 <= cap64 ? (int64_t)n64 : (int64_t)CJ_E_CORRUPT;
+            pm.in_skip = kRouteStored;
+        } else
         r = lz4_block_prologue(a.flags, in, n64, cap64);
-        if (r == 0) {
+        if (r == 0 && pm.in_skip == 0u) {
             const uint32_t cap0 = (uint32_t)cap64, iend0 = (uint32_t)n64;
             if (cap0 == 0) r = (iend0 == 1 && in[0] == 0) ? 0 : (int64_t)CJ_E_CORRUPT;
             else if (iend0 == 0) r = CJ_E_CORRUPT;
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(64 * kParseWaves) void lz4_parse_kernel(BatchArgs a
                     }
                     mlen += 4u;
                     if (!bad) {
-                        if (offset == 0u || offset > op) bad = true;
+                        if (offset == 0u || offset > op + hist) bad = true;
                         else if (cap - op < mlen + 5u) bad = true;
                         else op += mlen;
                     }
@@ -147,7 +155,7 @@ __global__ __launch_bounds__(64 * kParseWaves) void lz4_parse_kernel(BatchArgs a
                 r = (int64_t)op;
                 done = true;
                 if (r > 0) {
-                    if ((nseq + kSyncEvery - 1u) / kSyncEvery > kSyncStride || nseq < kLdsMinSeq) pm.in_skip = kRouteWave;
+                    if ((nseq + kSyncEvery - 1u) / kSyncEvery > kSyncStride || (nseq < kLdsMinSeq && !linked)) pm.in_skip = kRouteWave;
                     else { pm.nseq = nseq; pm.in_skip = (uint32_t)(in - in0); }
                 }
             }

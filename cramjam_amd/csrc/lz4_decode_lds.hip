@@ -470,30 +470,78 @@ __device__ __forceinline__ DW<ND> gl_ld_vec(const uint8_t* g) {
     return r;
 }
 
-template <int kCodec>
+// kLinked (LZ4 frames with linked blocks, frame.hip): the workgroup takes a whole FRAME (frames[f] = first block index,
+// block count) and walks its blocks in order; the LDS holds TWO 64 KiB windows, the block being decoded and the previous
+// block (every non-last block of such a frame decodes to exactly 64 KiB — the host checks that before it launches this
+// path), so a match that reaches back past the start of its block reads final bytes from the other window.
+constexpr uint32_t kL2LinkedBytes = 2u * 65536u + 8192u + 384u;        // 139 648 B: one workgroup per CU
+
+template <int kCodec, bool kLinked = false>
 __global__ __launch_bounds__(kL2Threads) void lz4_decode_lds2_kernel(BatchArgs a, const uint2* sync, const ParseMeta* meta,
-                                                                     uint4* tabs, uint32_t* counter) {
+                                                                     uint4* tabs, uint32_t* counter,
+                                                                     const uint2* frames, uint32_t n_frames) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr uint32_t kOffBits = kLinked ? 131072u : kL2OffBits, kOffVars = kOffBits + 8192u;
     uint8_t* s_out = smem;
-    uint32_t* s_bits = reinterpret_cast<uint32_t*>(smem + kL2OffBits);
-    uint32_t* s_fail = reinterpret_cast<uint32_t*>(smem + kL2OffVars);
-    uint32_t* s_chunk = reinterpret_cast<uint32_t*>(smem + kL2OffVars + 8u);
-    const uint32_t a_out = (uint32_t)(uintptr_t)s_out;
-    const Dummies dm = {(uint32_t)(uintptr_t)(smem + kL2OffVars + 64u) + (threadIdx.x & 63u),
-                        (uint32_t)(uintptr_t)(smem + kL2OffVars + 128u) + 4u * (threadIdx.x & 63u)};
+    uint32_t* s_bits = reinterpret_cast<uint32_t*>(smem + kOffBits);
+    uint32_t* s_fail = reinterpret_cast<uint32_t*>(smem + kOffVars);
+    uint32_t* s_chunk = reinterpret_cast<uint32_t*>(smem + kOffVars + 8u);
+    uint32_t a_out = (uint32_t)(uintptr_t)s_out;
+    uint32_t a_prev = a_out;                                 // kLinked: LDS address of the previous block's window
+    const Dummies dm = {(uint32_t)(uintptr_t)(smem + kOffVars + 64u) + (threadIdx.x & 63u),
+                        (uint32_t)(uintptr_t)(smem + kOffVars + 128u) + 4u * (threadIdx.x & 63u)};
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     uint4* table = tabs + (size_t)blockIdx.x * kL2TabRecords;
     const bool prof = (a.flags & 0x1000u) != 0;
     unsigned long long t_prev = prof ? __builtin_readcyclecounter() : 0ull;
+    uint32_t fr_first = 0, fr_n = 0, fr_k = 0;               // kLinked: current frame and position in it
 
     for (;;) {
-        if (tid == 0) { *s_chunk = atomicAdd(counter, 1u); *s_fail = 0u; }
-        for (uint32_t i = tid; i < 2048u; i += kL2Threads) s_bits[i] = 0u;
-        __syncthreads();
-        const uint32_t c = *s_chunk;
-        __syncthreads();                                     // everyone has read s_chunk before thread 0 can overwrite it
-        if (c >= a.n_chunks) break;
+        uint32_t c;
+        if constexpr (kLinked) {
+            if (fr_k == fr_n) {                              // next frame
+                if (tid == 0) *s_chunk = atomicAdd(counter, 1u);
+                __syncthreads();
+                const uint32_t f = *s_chunk;
+                __syncthreads();
+                if (f >= n_frames) break;
+                fr_first = frames[f].x; fr_n = frames[f].y; fr_k = 0;
+                if (fr_n == 0u) continue;
+            }
+            c = fr_first + fr_k;
+            s_out = smem + ((fr_k & 1u) ? 65536u : 0u);
+            a_out = (uint32_t)(uintptr_t)s_out;
+            a_prev = (uint32_t)(uintptr_t)(smem + ((fr_k & 1u) ? 0u : 65536u));
+            fr_k += 1;
+            if (tid == 0) *s_fail = 0u;
+            for (uint32_t i = tid; i < 2048u; i += kL2Threads) s_bits[i] = 0u;
+            __syncthreads();                                 // also: the previous block's D4 has finished reading its window
+        } else {
+            if (tid == 0) { *s_chunk = atomicAdd(counter, 1u); *s_fail = 0u; }
+            for (uint32_t i = tid; i < 2048u; i += kL2Threads) s_bits[i] = 0u;
+            __syncthreads();
+            c = *s_chunk;
+            __syncthreads();                                 // everyone has read s_chunk before thread 0 can overwrite it
+            if (c >= a.n_chunks) break;
+        }
         const ParseMeta pm = meta[c];
+        if constexpr (kLinked) {
+            if (pm.in_skip & kRouteStored) {                 // stored block: its bytes ARE the window (history for the next block)
+                const uint32_t len = (uint32_t)a.result[c];
+                const uint8_t* src = a.in_base + a.in_off[c];
+                uint8_t* dsto = a.out_base + a.out_off[c];
+                for (uint32_t i = tid * 16u; i < len; i += kL2Threads * 16u) {
+                    if (i + 16u <= len) {
+                        const uint4 v = ld16u(src + i);
+                        *reinterpret_cast<uint4*>(s_out + i) = v;
+                        st16u_nt(dsto + i, v);
+                    } else {
+                        for (uint32_t q = i; q < len; q++) { const uint8_t b = src[q]; s_out[q] = b; dsto[q] = b; }
+                    }
+                }
+                continue;                                    // the barrier at the top of the next block orders these LDS writes
+            }
+        }
         if (pm.nseq == 0u) continue;                         // error, empty, or routed to another kernel
         const uint32_t nseq = pm.nseq;
         const uint32_t U = (uint32_t)a.result[c];            // decoded size, 1..65536
@@ -626,16 +674,20 @@ __global__ __launch_bounds__(kL2Threads) void lz4_decode_lds2_kernel(BatchArgs a
             rec_nx = make_uint4(0, 0, 0, 0);
             if (base + kL2Threads + lane < nseq) rec_nx = table[base + kL2Threads + lane];
             const uint32_t dst = rec.z, off = rec.w & 0xffffu, m = rec.w >> 16;
-            const uint32_t src = dst - off;
+            const uint32_t src = dst - off;                   // kLinked: "negative" (wraps) when the source starts in the previous block
             const uint32_t need = off < m ? off : m;
             bool pending = m > 0u;
-            const bool fast = pending && m <= 32u && off >= m;
+            // kLinked: cross = source starts in the previous window; cross_full = it also ends there (final bytes, no polling)
+            const bool cross = kLinked && off > dst;
+            const bool cross_full = cross && off - dst >= m;
+            const uint32_t asrc = cross ? a_prev + 65536u - (off - dst) : a_out + src;      // LDS address of the first source byte
+            const bool fast = pending && m <= 32u && off >= m && (!cross || cross_full);
             uint32_t pa = 0, pm0 = 0, pm1 = 0, qa = 0, qm0 = 0, qm1 = 0;
             if (fast) {
                 const uint32_t sh = src & 31u, e = sh + need;
-                pa = (uint32_t)(uintptr_t)(s_bits + (src >> 5));
-                pm0 = (e >= 32u ? ~0u : ((1u << e) - 1u)) & (~0u << sh);
-                pm1 = e > 32u ? ((1u << (e - 32u)) - 1u) : 0u;
+                pa = (uint32_t)(uintptr_t)(s_bits + (cross ? 0u : (src >> 5)));
+                pm0 = cross ? 0u : (e >= 32u ? ~0u : ((1u << e) - 1u)) & (~0u << sh);
+                pm1 = cross ? 0u : (e > 32u ? ((1u << (e - 32u)) - 1u) : 0u);
                 const uint32_t dh = dst & 31u, de = dh + m;
                 qa = (uint32_t)(uintptr_t)(s_bits + (dst >> 5));
                 qm0 = (de >= 32u ? ~0u : ((1u << de) - 1u)) & (~0u << dh);
@@ -653,46 +705,75 @@ __global__ __launch_bounds__(kL2Threads) void lz4_decode_lds2_kernel(BatchArgs a
                 if (rm != 0ull) {
                     const uint32_t tier = ballot64(ready && m > 16u) ? 32u : 16u;
                     if (ready) {
-                        if (tier == 16u) lds_store_tier<16>(lds_ld_aligned6((a_out + src) & ~3u), a_out + dst, src & 3u, m, dm);
-                        else lds_store_tier<32>(lds_ld_aligned10((a_out + src) & ~3u), a_out + dst, src & 3u, m, dm);
+                        if (tier == 16u) lds_store_tier<16>(lds_ld_aligned6(asrc & ~3u), a_out + dst, asrc & 3u, m, dm);
+                        else lds_store_tier<32>(lds_ld_aligned10(asrc & ~3u), a_out + dst, asrc & 3u, m, dm);
                         asm volatile("ds_or_b32 %0, %1\n\tds_or_b32 %0, %2 offset:4" :: "v"(qa), "v"(qm0), "v"(qm1) : "memory");
                         pending = false;
                     }
                 }
                 if (any_slow) {
                     bool sready = false;
-                    if (pending && !fast) sready = bits_ready(s_bits, src, src + need);
-                    if (sready && m <= 64u && off >= m) {        // 33..64 bytes, no self-overlap (Snappy copies reach 64): one tier copy
-                        lds_store_tier<64>(lds_ld_aligned18((a_out + src) & ~3u), a_out + dst, src & 3u, m, dm);
+                    if (pending && !fast) {
+                        if (!cross) sready = bits_ready(s_bits, src, src + need);
+                        else {                                   // bytes in the previous window are final; the part in this window must be ready
+                            const uint32_t own = off - dst >= need ? 0u : need - (off - dst);
+                            sready = own == 0u || bits_ready(s_bits, 0u, own);
+                        }
+                    }
+                    // a match that straddles the block start (a handful per block at most) = its first `back` bytes from the
+                    // previous window + an ordinary, possibly self-overlapping, match whose source starts at window offset 0:
+                    // the whole wavefront copies both parts
+                    uint64_t strad = ballot64(sready && cross && !cross_full);
+                    while (strad) {
+                        const uint32_t l = ctz64(strad);
+                        strad &= strad - 1ull;
+                        const uint32_t lmm = rdlane(m, l), lo = rdlane(off, l), ld = rdlane(dst, l);
+                        const uint32_t back = lo - ld, rem = lmm - back, d2 = ld + back;
+                        for (uint32_t q = lane; q < back; q += 64u) lds_st8(a_out + ld + q, lds_ld8(a_prev + 65536u - back + q));
+                        uint32_t rr = lane, step = 64u;
+                        if (lo <= 64u) { rr = lane % lo; step = 64u % lo; }
+                        for (uint32_t q = lane; q < rem; q += 64u) {           // periodic read of the lo bytes that start the window
+                            s_out[d2 + q] = s_out[lo >= rem ? q : rr];
+                            rr += step;
+                            if (rr >= lo) rr -= lo;
+                        }
+                        wave_bits_set(s_bits, ld, ld + lmm);
+                        if (lane == l) pending = false;
+                    }
+                    if (sready && cross && !cross_full) {
+                        // done above
+                    } else if (sready && m <= 64u && off >= m) {        // 33..64 bytes, no self-overlap (Snappy copies reach 64): one tier copy
+                        lds_store_tier<64>(lds_ld_aligned18(asrc & ~3u), a_out + dst, asrc & 3u, m, dm);
                         bits_set(s_bits, dst, dst + m);
                         pending = false;
                     } else if (sready && m < kLongRun) {
+                        const uint8_t* sp = cross ? smem + (a_prev - (uint32_t)(uintptr_t)smem) + 65536u - (off - dst) : s_out + src;
                         if (off >= 8u) {
                             uint32_t k = 0;
                             for (; k + 8u <= m; k += 8u) {
                                 uint8_t t[8];
 #pragma unroll
-                                for (int q = 0; q < 8; q++) t[q] = s_out[src + k + q];
+                                for (int q = 0; q < 8; q++) t[q] = sp[k + q];
 #pragma unroll
                                 for (int q = 0; q < 8; q++) s_out[dst + k + q] = t[q];
                             }
-                            for (; k < m; k++) s_out[dst + k] = s_out[src + k];
+                            for (; k < m; k++) s_out[dst + k] = sp[k];
                         } else {
-                            for (uint32_t k = 0; k < m; k++) s_out[dst + k] = s_out[src + k];
+                            for (uint32_t k = 0; k < m; k++) s_out[dst + k] = sp[k];
                         }
                         bits_set(s_bits, dst, dst + m);
                         pending = false;
                     }
-                    uint64_t longm = ballot64(sready && m >= kLongRun);
+                    uint64_t longm = ballot64(sready && m >= kLongRun && !(cross && !cross_full));
                     while (longm) {
                         const uint32_t l = ctz64(longm);
                         longm &= longm - 1ull;
                         const uint32_t lmm = rdlane(m, l), lo = rdlane(off, l), ld = rdlane(dst, l);
-                        const uint32_t ls = ld - lo;
+                        const uint8_t* sb = (kLinked && lo > ld) ? smem + (a_prev - (uint32_t)(uintptr_t)smem) + 65536u - (lo - ld) : s_out + (ld - lo);
                         uint32_t rr = lane, step = 64u;
                         if (lo <= 64u) { rr = lane % lo; step = 64u % lo; }
                         for (uint32_t k = lane; k < lmm; k += 64u) {
-                            s_out[ld + k] = s_out[ls + (lo >= lmm ? k : rr)];
+                            s_out[ld + k] = sb[lo >= lmm ? k : rr];
                             rr += step;
                             if (rr >= lo) rr -= lo;
                         }
@@ -724,16 +805,25 @@ void launch_lz4_decode_lds2(const BatchArgs& a, const void* sync, const void* me
                             uint32_t grid, hipStream_t s, int codec) {
     if (a.n_chunks == 0) return;
     if (codec == CJ_CODEC_SNAPPY_RAW) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_lds2_kernel<CJ_CODEC_SNAPPY_RAW>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_lds2_kernel<CJ_CODEC_SNAPPY_RAW, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kL2Bytes);
-        hipLaunchKernelGGL(lz4_decode_lds2_kernel<CJ_CODEC_SNAPPY_RAW>, dim3(grid), dim3(kL2Threads), kL2Bytes, s, a,
-                           (const uint2*)sync, (const ParseMeta*)meta, (uint4*)tabs, counter);
+        hipLaunchKernelGGL((lz4_decode_lds2_kernel<CJ_CODEC_SNAPPY_RAW, false>), dim3(grid), dim3(kL2Threads), kL2Bytes, s, a,
+                           (const uint2*)sync, (const ParseMeta*)meta, (uint4*)tabs, counter, (const uint2*)nullptr, 0u);
         return;
     }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_lds2_kernel<CJ_CODEC_LZ4_BLOCK>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_lds2_kernel<CJ_CODEC_LZ4_BLOCK, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kL2Bytes);
-    hipLaunchKernelGGL(lz4_decode_lds2_kernel<CJ_CODEC_LZ4_BLOCK>, dim3(grid), dim3(kL2Threads), kL2Bytes, s, a,
-                       (const uint2*)sync, (const ParseMeta*)meta, (uint4*)tabs, counter);
+    hipLaunchKernelGGL((lz4_decode_lds2_kernel<CJ_CODEC_LZ4_BLOCK, false>), dim3(grid), dim3(kL2Threads), kL2Bytes, s, a,
+                       (const uint2*)sync, (const ParseMeta*)meta, (uint4*)tabs, counter, (const uint2*)nullptr, 0u);
+}
+
+void launch_lz4_decode_lds2_linked(const BatchArgs& a, const void* sync, const void* meta, void* tabs, uint32_t* counter,
+                                   const void* frames, uint32_t n_frames, uint32_t grid, hipStream_t s) {
+    if (a.n_chunks == 0 || n_frames == 0) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_lds2_kernel<CJ_CODEC_LZ4_BLOCK, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kL2LinkedBytes);
+    hipLaunchKernelGGL((lz4_decode_lds2_kernel<CJ_CODEC_LZ4_BLOCK, true>), dim3(grid), dim3(kL2Threads), kL2LinkedBytes, s, a,
+                       (const uint2*)sync, (const ParseMeta*)meta, (uint4*)tabs, counter, (const uint2*)frames, n_frames);
 }
 
 void launch_lz4_decode_lds(const BatchArgs& a, const void* sync, const void* meta, hipStream_t s) {

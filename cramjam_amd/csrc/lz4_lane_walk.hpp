@@ -27,6 +27,7 @@ constexpr uint32_t kLaneShareDen = 20;         // lane_share/20 of the LDS-class
 // 2.2-2.6 TB/s with the wave-per-chunk kernel (16 B/lane cooperative copies) but crawl through the LDS path;
 // chunks with many short sequences are ~2x faster through parse + LDS.  The parse kernel knows the count.
 constexpr uint32_t kLdsMinSeq = 256;
+constexpr uint32_t kRouteStored = 0x20000000u;   // linked-frame parse: the block is stored uncompressed (copied, not decoded)
 
 __device__ __forceinline__ uint4 ld16u(const uint8_t* p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
 __device__ __forceinline__ void st16u(uint8_t* p, const uint4& v) { __builtin_memcpy(p, &v, 16); }

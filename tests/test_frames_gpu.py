@@ -303,6 +303,7 @@ def test_lz4_frame_fixture_and_golden_frames():
     mgf = importlib.util.module_from_spec(spec); spec.loader.exec_module(mgf)
     g = json.load(open(os.path.join(GOLDEN_DIR, "golden_frames.json")))
     kinds = set()
+    lds0 = N.lib().cj_debug_linked_lds_frames()
     for v in g["vectors"]:
         data = mgf.content(v["kind"], v["n"])
         frame = base64.b64decode(v["frame"])
@@ -311,7 +312,37 @@ def test_lz4_frame_fixture_and_golden_frames():
         r, out = lz4f_decompress(frame)
         assert r == len(data) and out == data, {k: v[k] for k in v if k != "frame"}
         kinds.add((frame[4] >> 5) & 1)
-    assert kinds == {0, 1}                      # both linked (chain kernel) and independent (batch) frames were exercised
+    assert kinds == {0, 1}                      # both linked and independent (batch) frames were exercised
+    # linked frames with 64 KiB blocks took the two-window LDS decoder, the other linked ones the chain kernel
+    assert N.lib().cj_debug_linked_lds_frames() - lds0 >= 6
+
+
+def test_lz4_frame_linked_blocks_at_scale():
+    """8 MiB linked-block frame (128 blocks) with matches reaching across block boundaries, long runs straddling block
+    starts, stored blocks in the middle: the two-window LDS decoder against the CPU oracle's bytes"""
+    rng = np.random.default_rng(9)
+    parts = [oracle.synth_v1(65536, i) for i in range(24)]
+    body = bytearray()
+    for i in range(128):
+        kind = i % 8
+        if kind == 5:
+            body += bytes(65536)                               # zero run: every block starts with a match that straddles the boundary
+        elif kind == 6:
+            body += rng.integers(0, 256, 65536, dtype=np.uint8).tobytes()      # incompressible: stored block
+        elif kind == 7:
+            body += bytes(body[-70000:-70000 + 65536]) if len(body) > 70000 else parts[0]    # far copies of the previous block
+        else:
+            body += parts[int(rng.integers(0, 24))]
+    data = bytes(body[:128 * 65536 - 4321])
+    r, frame = oracle.lz4_frame_compress(data, 4, 1)          # linked, 64 KiB blocks
+    assert r > 0 and (frame[4] >> 5) & 1 == 0
+    lds0 = N.lib().cj_debug_linked_lds_frames()
+    got = lz4f_decompress(frame)
+    assert got[0] == len(data) and got[1] == data
+    assert N.lib().cj_debug_linked_lds_frames() == lds0 + 1
+    assert bytes(cramjam.lz4.decompress(frame)) == data
+    dmg = bytearray(frame); dmg[len(frame) // 2] ^= 0x08     # damage -> same verdict as the oracle (falls back to the chain kernel)
+    assert lz4f_decompress(bytes(dmg), cap=len(data))[0] == oracle.lz4_frame_decompress(bytes(dmg), len(data))[0]
 
 
 @pytest.mark.parametrize("flags", [0, 1, 2, 3, 7, 9])

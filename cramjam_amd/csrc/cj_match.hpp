@@ -269,19 +269,11 @@ __device__ __forceinline__ void lane_copy_exact(uint8_t* dst, const uint8_t* src
     if (rem & 1u) dst[q] = (uint8_t)(t21 >> 16);
 }
 
-// covered: bit l set = position pos + l lies strictly inside an emitted match (not its first byte)
-__device__ __forceinline__ void insert_uncovered(uint16_t* ht, uint32_t pos, uint32_t hslot, uint64_t covered) {
-    const uint32_t lane = lane_id();
-    if (hslot != kNoSlot && ((covered >> lane) & 1ull) == 0ull) ht[hslot] = (uint16_t)(pos + lane);
-}
-
-// lanes of a round strictly inside a match that starts at position mstart (possibly before the round, after a
-// backward extension) and ends before lane `end_lane`
-__device__ __forceinline__ uint64_t covered_bits(uint32_t pos, uint32_t mstart, uint32_t end_lane) {
-    const uint32_t lo = mstart >= pos ? mstart - pos + 1u : 0u, hi = end_lane < 64u ? end_lane : 64u;
-    if (hi <= lo) return 0ull;
-    const uint64_t upto_hi = hi >= 64u ? ~0ull : ((1ull << hi) - 1ull);
-    return upto_hi & ~((1ull << lo) - 1ull);
+// covered (per lane): the lane's position lies strictly inside an emitted match (not its first byte).  Tracked with
+// two VALU compares per sub-round and match — the scalar unit is the busiest pipe of these kernels (one per CU,
+// shared by all waves), 64-bit mask arithmetic there cost ~60 scalar instructions per match.
+__device__ __forceinline__ void insert_uncovered(uint16_t* ht, uint32_t pos, uint32_t hslot, bool covered) {
+    if (hslot != kNoSlot && !covered) ht[hslot] = (uint16_t)(pos + lane_id());
 }
 
 #endif

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(kEncThreads) void lz4_encode_kernel(BatchArgs a) {
             Round r;
             probe_round(in, ht, pos, last_start, matchlimit, anchor, r);
             const uint32_t round_end = pos + kRoundPositions;
-            uint64_t covered[kSub] = {};
+            bool covered[kSub] = {};
             // greedy selection on registers; the selected sequences are queued one per lane and emitted together
             uint32_t q_n = 0, q_lit0 = 0, q_lit = 0, q_off = 0, q_mcode = 0, q_op = 0;
 #pragma unroll
@@ -114,8 +114,8 @@ __global__ __launch_bounds__(kEncThreads) void lz4_encode_kernel(BatchArgs a) {
                     anchor = mpos + mlen;
 #pragma unroll
                     for (int jj = 0; jj < kSub; jj++) {
-                        const uint32_t pjj = pos + 64u * jj;
-                        if (anchor > pjj) covered[jj] |= covered_bits(pjj, mpos, anchor - pjj);
+                        const uint32_t my = pos + 64u * jj + lane;
+                        covered[jj] = covered[jj] || (my > mpos && my < anchor);
                     }
                     if (anchor >= pj + 64u) mask = 0;
                     else mask &= ~0ull << (anchor - pj);

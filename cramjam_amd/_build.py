@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libcramjam_hip.so")
 SOURCES = ["engine.hip", "lz4_decode.hip", "lz4_decode_lanes.hip", "lz4_decode_lds.hip", "lz4_encode.hip", "snappy_decode.hip", "snappy_encode.hip", "frame_kernels.hip", "frame.hip", "bench_util.hip"]
-HEADERS = ["cj_common.hpp", "cj_engine.hpp", "cj_match.hpp", "crc32c_lanes.hpp", "lz4_lane_walk.hpp", os.path.join("..", "..", "include", "cramjam_hip.h")]
+HEADERS = ["cj_common.hpp", "cj_engine.hpp", "cj_match.hpp", "crc32c_lanes.hpp", "lane_stream.hpp", "snappy_records.hpp", "xxh32_host.hpp", "lz4_lane_walk.hpp", os.path.join("..", "..", "include", "cramjam_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + os.environ.get("CJ_EXTRA_HIPCC_FLAGS", "").split()
 
@@ -59,10 +59,10 @@ def build_pymod(force=False, verbose=False):
     import sysconfig
     src = os.path.join(CSRC, "pymod.cpp")
     out = pymod_path()
-    if not force and not _newer(out, [src, os.path.join(HERE, "..", "include", "cramjam_hip.h"), LIB]):
+    if not force and not _newer(out, [src, os.path.join(CSRC, "xxh32_host.hpp"), os.path.join(HERE, "..", "include", "cramjam_hip.h"), LIB]):
         return out
     cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-missing-field-initializers",
-           "-I" + sysconfig.get_paths()["include"], src, "-o", out,
+           "-I" + sysconfig.get_paths()["include"], "-I" + CSRC, src, "-o", out,
            "-L" + HERE, "-lcramjam_hip", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -36,6 +36,7 @@ SYMBOLS = {
     "cj_snappy_frame_decompress": (_i64, [_vp, _sz, _vp, _sz]),
     "cj_lz4_frame_compress_bound": (_sz, [_sz]),
     "cj_lz4_frame_compress": (_i64, [_vp, _sz, _vp, _sz, C.c_int]),
+    "cj_lz4_frame_compress_blocks": (_i64, [_vp, _sz, _vp, _sz]),
     "cj_lz4_frame_decompress_bound": (_i64, [_vp, _sz]),
     "cj_lz4_frame_decompress": (_i64, [_vp, _sz, _vp, _sz]),
     "cj_engine_create": (_int, [_int, C.POINTER(_vp)]),

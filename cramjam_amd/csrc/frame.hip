@@ -7,6 +7,7 @@
 // but trivial scan), the GPU decodes/encodes every piece in one batch, checksums every piece (crc32c_pieces) and
 // assembles the stream (copy_segments).  No codec or checksum arithmetic runs on the host.
 #include "cj_engine.hpp"
+#include "xxh32_host.hpp"
 
 #include <atomic>
 
@@ -259,32 +260,9 @@ int64_t cj_snappy_frame_compress(const uint8_t* in, size_t n, uint8_t* out, size
 // =====================================================================================================================
 namespace {
 
-constexpr uint32_t XP1 = 2654435761u, XP2 = 2246822519u, XP3 = 3266489917u, XP4 = 668265263u, XP5 = 374761393u;
-inline uint32_t xrotl(uint32_t v, int r) { return (v << r) | (v >> (32 - r)); }
+using cj::xxh32;
 inline uint32_t xrd32(const uint8_t* p) { uint32_t v; std::memcpy(&v, p, 4); return v; }
 inline void xwr32(uint8_t* p, uint32_t v) { std::memcpy(p, &v, 4); }
-
-uint32_t xxh32(const uint8_t* p, size_t n, uint32_t seed) {       // published XXH32 algorithm (xxhash spec §"XXH32")
-    const uint8_t* end = p + n;
-    uint32_t h;
-    if (n >= 16) {
-        uint32_t v1 = seed + XP1 + XP2, v2 = seed + XP2, v3 = seed, v4 = seed - XP1;
-        const uint8_t* lim = end - 16;
-        do {
-            v1 = xrotl(v1 + xrd32(p) * XP2, 13) * XP1;
-            v2 = xrotl(v2 + xrd32(p + 4) * XP2, 13) * XP1;
-            v3 = xrotl(v3 + xrd32(p + 8) * XP2, 13) * XP1;
-            v4 = xrotl(v4 + xrd32(p + 12) * XP2, 13) * XP1;
-            p += 16;
-        } while (p <= lim);
-        h = xrotl(v1, 1) + xrotl(v2, 7) + xrotl(v3, 12) + xrotl(v4, 18);
-    } else h = seed + XP5;
-    h += (uint32_t)n;
-    while (p + 4 <= end) { h = xrotl(h + xrd32(p) * XP3, 17) * XP4; p += 4; }
-    while (p < end) { h = xrotl(h + (uint32_t)(*p) * XP5, 11) * XP1; p++; }
-    h ^= h >> 15; h *= XP2; h ^= h >> 13; h *= XP3; h ^= h >> 16;
-    return h;
-}
 
 constexpr size_t kLz4fBlock = 65536;                      // the reference encoder's block size (lz4 crate BlockSize::Default)
 constexpr size_t kLz4fTmpStride = 65824;                  // LZ4_compressBound(65536) = 65809, rounded up to 16
@@ -429,75 +407,81 @@ int64_t cj_lz4_frame_decompress_bound(const uint8_t* in, size_t n) {
     return (int64_t)total;
 }
 
-int64_t cj_lz4_frame_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap, int level) {
-    (void)level;                           // the GPU matcher has one mode; any level yields a valid frame (see header)
+// the block sequence of a frame (u32 size word + data per 64 KiB of input, no header, no EndMark) written to out
+int64_t cj_lz4_frame_compress_blocks(const uint8_t* in, size_t n, uint8_t* out, size_t cap) {
     if ((n && !in) || (cap && !out)) return CJ_E_BAD_ARG;
     cj_engine* e = cj::default_engine();
     if (!e) return CJ_E_NO_DEVICE;
     const size_t np = (n + kLz4fBlock - 1) / kLz4fBlock;
     if (np > 0xFFFFFFF0ull) return CJ_E_BAD_ARG;
-    if (cap < 7) return CJ_E_FRAME_WRITE;
+    if (np == 0) return 0;
+    uint64_t fpos = 0;
+    std::lock_guard<std::mutex> lock(e->mu);
+    HIP_TRY(hipSetDevice(e->device), CJ_E_NO_DEVICE);
+    // rows: in_off|in_len|tmp_off|tmp_cap|result | src|dst_off|len|hdr (np each)
+    const size_t rows = 9 * np;
+    if (!e->d_in.reserve(n + 16) || !e->d_out.reserve(np * kLz4fTmpStride + 16) || !e->d_meta.reserve(rows * 8)) return CJ_E_OOM;
+    uint8_t* d_in = (uint8_t*)e->d_in.p;
+    uint8_t* d_tmp = (uint8_t*)e->d_out.p;
+    uint64_t* d_meta = (uint64_t*)e->d_meta.p;
+    std::vector<uint64_t>& m = e->h_meta;
+    m.assign(rows, 0);
+    for (size_t i = 0; i < np; i++) {
+        m[i] = i * kLz4fBlock;
+        m[np + i] = std::min(kLz4fBlock, n - i * kLz4fBlock);
+        m[2 * np + i] = i * kLz4fTmpStride;
+        m[3 * np + i] = kLz4fTmpStride;
+    }
+    hipStream_t s = e->stream;
+    HIP_TRY(hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
+    HIP_TRY(hipMemcpyAsync(d_meta, m.data(), 4 * np * 8, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
+    cj::BatchArgs a;
+    cj::fill_args(a, 0, np, d_in, d_meta, d_meta + np, d_tmp, d_meta + 2 * np, d_meta + 3 * np, (int64_t*)(d_meta + 4 * np));
+    const int rc = cj::launch(e, CJ_CODEC_LZ4_BLOCK, CJ_OP_COMPRESS, a, s);
+    if (rc != 0) return rc;
+    std::vector<int64_t> res(np);
+    HIP_TRY(hipMemcpyAsync(res.data(), d_meta + 4 * np, np * 8, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
+    HIP_TRY(hipStreamSynchronize(s), CJ_E_NO_DEVICE);
+    // LZ4F_makeBlock: a block that does not shrink is stored (bit 31 of the size word)
+    for (size_t i = 0; i < np; i++) {
+        if (res[i] < 0) return res[i];
+        const uint64_t len = m[np + i], cl = (uint64_t)res[i];
+        const bool stored = cl >= len;
+        const uint64_t body = stored ? len : cl;
+        m[5 * np + i] = (uint64_t)(uintptr_t)(stored ? d_in + i * kLz4fBlock : d_tmp + i * kLz4fTmpStride);
+        m[6 * np + i] = fpos + 4;
+        m[7 * np + i] = body;
+        m[8 * np + i] = body | (stored ? 0x80000000ull : 0ull);
+        fpos += 4 + body;
+    }
+    if (fpos > cap) return CJ_E_FRAME_WRITE;
+    if (!e->d_frame.reserve(fpos + 16)) return CJ_E_OOM;
+    uint8_t* d_frame = (uint8_t*)e->d_frame.p;
+    HIP_TRY(hipMemcpyAsync(d_meta + 5 * np, m.data() + 5 * np, 4 * np * 8, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
+    cj::launch_copy_segments(d_meta + 5 * np, d_frame, d_meta + 6 * np, d_meta + 7 * np, d_meta + 8 * np, 4, (uint32_t)np, s);
+    HIP_TRY(hipGetLastError(), CJ_E_NO_DEVICE);
+    HIP_TRY(hipMemcpyAsync(out, d_frame, fpos, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
+    HIP_TRY(hipStreamSynchronize(s), CJ_E_NO_DEVICE);
+    return (int64_t)fpos;
+}
+
+int64_t cj_lz4_frame_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap, int level) {
+    (void)level;                           // the GPU matcher has one mode; any level yields a valid frame (see header)
+    if ((n && !in) || (cap && !out)) return CJ_E_BAD_ARG;
+    if (!cj::default_engine()) return CJ_E_NO_DEVICE;
+    if (cap < 15) return CJ_E_FRAME_WRITE;
     // frame header: version 01, independent blocks, content checksum, 64 KiB blocks (FLG 0x64, BD 0x40)
     uint8_t hdr[7] = { 0x04, 0x22, 0x4D, 0x18, 0x64, 0x40, 0 };
     hdr[6] = (uint8_t)(xxh32(hdr + 4, 2, 0) >> 8);
     std::memcpy(out, hdr, 7);
-    uint64_t fpos = 7;
     uint32_t content_sum = 0;
     std::thread summer([&] { content_sum = xxh32(in, n, 0); });          // overlaps the device batch
-    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{summer};
-    if (np > 0) {
-        std::lock_guard<std::mutex> lock(e->mu);
-        HIP_TRY(hipSetDevice(e->device), CJ_E_NO_DEVICE);
-        // rows: in_off|in_len|tmp_off|tmp_cap|result | src|dst_off|len|hdr (np each)
-        const size_t rows = 9 * np;
-        if (!e->d_in.reserve(n + 16) || !e->d_out.reserve(np * kLz4fTmpStride + 16) || !e->d_meta.reserve(rows * 8)) return CJ_E_OOM;
-        uint8_t* d_in = (uint8_t*)e->d_in.p;
-        uint8_t* d_tmp = (uint8_t*)e->d_out.p;
-        uint64_t* d_meta = (uint64_t*)e->d_meta.p;
-        std::vector<uint64_t>& m = e->h_meta;
-        m.assign(rows, 0);
-        for (size_t i = 0; i < np; i++) {
-            m[i] = i * kLz4fBlock;
-            m[np + i] = std::min(kLz4fBlock, n - i * kLz4fBlock);
-            m[2 * np + i] = i * kLz4fTmpStride;
-            m[3 * np + i] = kLz4fTmpStride;
-        }
-        hipStream_t s = e->stream;
-        HIP_TRY(hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
-        HIP_TRY(hipMemcpyAsync(d_meta, m.data(), 4 * np * 8, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
-        cj::BatchArgs a;
-        cj::fill_args(a, 0, np, d_in, d_meta, d_meta + np, d_tmp, d_meta + 2 * np, d_meta + 3 * np, (int64_t*)(d_meta + 4 * np));
-        const int rc = cj::launch(e, CJ_CODEC_LZ4_BLOCK, CJ_OP_COMPRESS, a, s);
-        if (rc != 0) return rc;
-        std::vector<int64_t> res(np);
-        HIP_TRY(hipMemcpyAsync(res.data(), d_meta + 4 * np, np * 8, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
-        HIP_TRY(hipStreamSynchronize(s), CJ_E_NO_DEVICE);
-        // LZ4F_makeBlock: a block that does not shrink is stored (bit 31 of the size word)
-        for (size_t i = 0; i < np; i++) {
-            if (res[i] < 0) return res[i];
-            const uint64_t len = m[np + i], cl = (uint64_t)res[i];
-            const bool stored = cl >= len;
-            const uint64_t body = stored ? len : cl;
-            m[5 * np + i] = (uint64_t)(uintptr_t)(stored ? d_in + i * kLz4fBlock : d_tmp + i * kLz4fTmpStride);
-            m[6 * np + i] = fpos + 4;
-            m[7 * np + i] = body;
-            m[8 * np + i] = body | (stored ? 0x80000000ull : 0ull);
-            fpos += 4 + body;
-        }
-        if (fpos + 8 > cap) return CJ_E_FRAME_WRITE;
-        if (!e->d_frame.reserve(fpos + 16)) return CJ_E_OOM;
-        uint8_t* d_frame = (uint8_t*)e->d_frame.p;
-        HIP_TRY(hipMemcpyAsync(d_meta + 5 * np, m.data() + 5 * np, 4 * np * 8, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
-        cj::launch_copy_segments(d_meta + 5 * np, d_frame, d_meta + 6 * np, d_meta + 7 * np, d_meta + 8 * np, 4, (uint32_t)np, s);
-        HIP_TRY(hipGetLastError(), CJ_E_NO_DEVICE);
-        HIP_TRY(hipMemcpyAsync(out + 7, d_frame + 7, fpos - 7, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
-        HIP_TRY(hipStreamSynchronize(s), CJ_E_NO_DEVICE);
-    }
-    if (fpos + 8 > cap) return CJ_E_FRAME_WRITE;
+    const int64_t r = cj_lz4_frame_compress_blocks(in, n, out + 7, cap - 15);
     summer.join();
-    xwr32(out + fpos, 0u);                   // EndMark
-    xwr32(out + fpos + 4, content_sum);
-    return (int64_t)(fpos + 8);
+    if (r < 0) return r;
+    xwr32(out + 7 + r, 0u);                  // EndMark
+    xwr32(out + 11 + r, content_sum);
+    return r + 15;
 }
 
 int64_t cj_lz4_frame_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap) {

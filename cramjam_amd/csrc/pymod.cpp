@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "../../include/cramjam_hip.h"
+#include "xxh32_host.hpp"
 
 namespace {
 
@@ -790,6 +791,239 @@ PyObject* lz4_decompress(PyObject*, PyObject* a, PyObject* k) { return framed_ca
 PyObject* lz4_compress_into(PyObject*, PyObject* a, PyObject* k) { return framed_into(kLz4Framed, a, k, true, true); }
 PyObject* lz4_decompress_into(PyObject*, PyObject* a, PyObject* k) { return framed_into(kLz4Framed, a, k, false, false); }
 
+// ------------------------------------------------------------------------------------------
+// Streaming objects (reference src/snappy.rs:124-161, src/lz4.rs:231-294, src/lib.rs:298-394, src/io.rs:761-814).
+// The reference's encoders compress as blocks fill; here input is collected and every flush()/finish() compresses what
+// is pending as ONE device batch — the bytes returned by the flushes concatenate to one valid framed stream.
+// ------------------------------------------------------------------------------------------
+struct CompressorObject {
+    PyObject_HEAD
+    int codec;                   // 0 snappy, 1 lz4
+    bool finished, started, content_checksum;
+    int level;
+    ByteVec* pending;
+    cj::Xxh32* hash;
+};
+
+extern PyTypeObject SnappyCompressorType, Lz4CompressorType, SnappyDecompressorType, Lz4DecompressorType;
+
+PyObject* Compressor_new_common(PyTypeObject* type, int codec) {
+    CompressorObject* self = (CompressorObject*)type->tp_alloc(type, 0);
+    if (!self) return nullptr;
+    self->codec = codec; self->finished = false; self->started = false; self->content_checksum = true; self->level = -1;
+    self->pending = new ByteVec();
+    self->hash = new cj::Xxh32(0);
+    return (PyObject*)self;
+}
+PyObject* SnappyCompressor_new(PyTypeObject* t, PyObject*, PyObject*) { return Compressor_new_common(t, 0); }
+PyObject* Lz4Compressor_new(PyTypeObject* t, PyObject*, PyObject*) { return Compressor_new_common(t, 1); }
+
+int SnappyCompressor_init(CompressorObject*, PyObject* args, PyObject* kw) {
+    static const char* kwl[] = {nullptr};
+    return PyArg_ParseTupleAndKeywords(args, kw, "", (char**)kwl) ? 0 : -1;
+}
+int Lz4Compressor_init(CompressorObject* self, PyObject* args, PyObject* kw) {       // src/lz4.rs:240-262
+    static const char* kwl[] = {"level", "content_checksum", "block_linked", nullptr};
+    PyObject *lvl = Py_None, *cs = Py_None, *bl = Py_None;
+    if (!PyArg_ParseTupleAndKeywords(args, kw, "|OOO", (char**)kwl, &lvl, &cs, &bl)) return -1;
+    self->level = opt_int(lvl, -1);
+    if (self->level == -2) return -1;
+    if (cs != Py_None) { int t = PyObject_IsTrue(cs); if (t < 0) return -1; self->content_checksum = t != 0; }
+    if (bl != Py_None && PyObject_IsTrue(bl) < 0) return -1;     // accepted; blocks are always independent here
+    return 0;
+}
+void Compressor_dealloc(CompressorObject* self) {
+    delete self->pending; delete self->hash;
+    Py_TYPE(self)->tp_free((PyObject*)self);
+}
+
+PyObject* Compressor_compress(CompressorObject* self, PyObject* input) {               // src/io.rs:761-771
+    if (self->finished) {
+        PyErr_SetString(CompressionError, "Compressor looks to have been consumed via `finish()`. please create a new compressor instance.");
+        return nullptr;
+    }
+    Bytes in;
+    if (!get_bytes(input, in)) return nullptr;
+    self->pending->insert(self->pending->end(), in.ptr, in.ptr + in.len);
+    return PyLong_FromSsize_t(in.len);
+}
+
+// compress what is pending and append it to `out`; 0 or a CJ_E_* code
+int64_t compressor_emit(CompressorObject* self, ByteVec& out, bool finish) {
+    ByteVec& pend = *self->pending;
+    if (self->codec == 0) {
+        // snap write::FrameEncoder: the stream identifier goes out with the first chunk; nothing at all for no input
+        if (!pend.empty()) {
+            ByteVec tmp(cj_snappy_frame_max_compress_len(pend.size()));
+            const int64_t r = cj_snappy_frame_compress(pend.data(), pend.size(), tmp.data(), tmp.size());
+            if (r < 0) return r;
+            const size_t skip = self->started ? 10 : 0;
+            out.insert(out.end(), tmp.begin() + (long)skip, tmp.begin() + (long)r);
+            self->started = true;
+        }
+    } else {
+        if (!self->started) {                  // LZ4F_compressBegin: the header exists before any data
+            uint8_t hdr[7] = { 0x04, 0x22, 0x4D, 0x18, (uint8_t)(0x60 | (self->content_checksum ? 0x04 : 0)), 0x40, 0 };
+            hdr[6] = (uint8_t)(cj::xxh32(hdr + 4, 2, 0) >> 8);
+            out.insert(out.end(), hdr, hdr + 7);
+            self->started = true;
+        }
+        if (!pend.empty()) {
+            if (self->content_checksum) self->hash->update(pend.data(), pend.size());
+            ByteVec tmp(pend.size() + 4 * ((pend.size() + 65535) / 65536));
+            const int64_t r = cj_lz4_frame_compress_blocks(pend.data(), pend.size(), tmp.data(), tmp.size());
+            if (r < 0) return r;
+            out.insert(out.end(), tmp.begin(), tmp.begin() + (long)r);
+        }
+        if (finish) {
+            uint8_t tail[8] = {0};
+            const uint32_t d = self->hash->digest();
+            std::memcpy(tail + 4, &d, 4);
+            out.insert(out.end(), tail, tail + (self->content_checksum ? 8 : 4));
+        }
+    }
+    pend.clear();
+    return 0;
+}
+
+PyObject* Compressor_flush(CompressorObject* self, PyObject*) {                        // src/io.rs:796-814
+    ByteVec out;
+    if (!self->finished) {
+        int64_t r;
+        Py_BEGIN_ALLOW_THREADS
+        r = compressor_emit(self, out, false);
+        Py_END_ALLOW_THREADS
+        if (r < 0) return raise_code(CompressionError, r);
+    }
+    return buffer_from_vec(std::move(out));
+}
+
+PyObject* Compressor_finish(CompressorObject* self, PyObject*) {                       // src/io.rs:773-794
+    ByteVec out;
+    if (!self->finished) {
+        int64_t r;
+        Py_BEGIN_ALLOW_THREADS
+        r = compressor_emit(self, out, true);
+        Py_END_ALLOW_THREADS
+        if (r < 0) return raise_code(CompressionError, r);
+        self->finished = true;
+    }
+    return buffer_from_vec(std::move(out));
+}
+
+PyMethodDef Compressor_methods[] = {
+    {"compress", (PyCFunction)Compressor_compress, METH_O, "Compress input into the current compressor's stream."},
+    {"flush", (PyCFunction)Compressor_flush, METH_NOARGS, "Flush and return current compressed stream"},
+    {"finish", (PyCFunction)Compressor_finish, METH_NOARGS, "Consume the current compressor state and return the compressed stream"},
+    {nullptr, nullptr, 0, nullptr}};
+
+struct DecompressorObject {                                                            // src/lib.rs:298-394
+    PyObject_HEAD
+    int codec;
+    bool finished;
+    ByteVec* inner;
+};
+
+PyObject* Decompressor_new_common(PyTypeObject* type, int codec) {
+    DecompressorObject* self = (DecompressorObject*)type->tp_alloc(type, 0);
+    if (!self) return nullptr;
+    self->codec = codec; self->finished = false; self->inner = new ByteVec();
+    return (PyObject*)self;
+}
+PyObject* SnappyDecompressor_new(PyTypeObject* t, PyObject*, PyObject*) { return Decompressor_new_common(t, 0); }
+PyObject* Lz4Decompressor_new(PyTypeObject* t, PyObject*, PyObject*) { return Decompressor_new_common(t, 1); }
+void Decompressor_dealloc(DecompressorObject* self) { delete self->inner; Py_TYPE(self)->tp_free((PyObject*)self); }
+
+PyObject* decompressor_gone() {
+    PyErr_SetString(DecompressionError, "Appears `finish()` was called on this instance");
+    return nullptr;
+}
+
+PyObject* Decompressor_decompress(DecompressorObject* self, PyObject* input) {
+    if (self->finished) return decompressor_gone();
+    Bytes in;
+    if (!get_bytes(input, in)) return nullptr;
+    const Framed& fc = self->codec == 0 ? kSnappyFramed : kLz4Framed;
+    int64_t r;
+    ByteVec tmp;
+    Py_BEGIN_ALLOW_THREADS
+    r = fc.need(in, false);
+    if (r >= 0) {
+        tmp = make_result((size_t)r);
+        r = fc.run(in, tmp.data(), tmp.size(), false, -1);
+    }
+    Py_END_ALLOW_THREADS
+    if (r < 0) return raise_code(DecompressionError, r);
+    self->inner->insert(self->inner->end(), tmp.begin(), tmp.begin() + (long)r);
+    return PyLong_FromLongLong(r);
+}
+PyObject* Decompressor_flush(DecompressorObject* self, PyObject*) {
+    if (self->finished) return decompressor_gone();
+    ByteVec out;
+    out.swap(*self->inner);
+    return buffer_from_vec(std::move(out));
+}
+PyObject* Decompressor_finish(DecompressorObject* self, PyObject*) {
+    if (self->finished) return decompressor_gone();
+    self->finished = true;
+    ByteVec out;
+    out.swap(*self->inner);
+    return buffer_from_vec(std::move(out));
+}
+PyObject* Decompressor_len(DecompressorObject* self, PyObject*) { return PyLong_FromSize_t(self->finished ? 0 : self->inner->size()); }
+Py_ssize_t Decompressor_sq_len(DecompressorObject* self) { return self->finished ? 0 : (Py_ssize_t)self->inner->size(); }
+int Decompressor_contains(DecompressorObject* self, PyObject* x) {
+    Bytes b;
+    if (!get_bytes(x, b)) return -1;
+    if (self->finished) return 0;
+    const ByteVec& v = *self->inner;
+    if (b.len == 0) return 1;
+    return std::search(v.begin(), v.end(), b.ptr, b.ptr + b.len) != v.end();
+}
+int Decompressor_bool(DecompressorObject* self) { return !self->finished && !self->inner->empty(); }
+PyObject* Decompressor_repr(DecompressorObject* self) { return PyUnicode_FromFormat("Decompressor<len=%zu>", self->finished ? (size_t)0 : self->inner->size()); }
+
+PyMethodDef Decompressor_methods[] = {
+    {"decompress", (PyCFunction)Decompressor_decompress, METH_O, "Decompress this input into the inner buffer."},
+    {"flush", (PyCFunction)Decompressor_flush, METH_NOARGS, "Flush and return current decompressed stream."},
+    {"finish", (PyCFunction)Decompressor_finish, METH_NOARGS, "Consume the current Decompressor state and return the decompressed stream"},
+    {"len", (PyCFunction)Decompressor_len, METH_NOARGS, "Length of internal buffer containing decompressed data."},
+    {nullptr, nullptr, 0, nullptr}};
+PySequenceMethods Decompressor_as_sequence = {};
+PyNumberMethods Decompressor_as_number = {};
+
+PyTypeObject SnappyCompressorType = { PyVarObject_HEAD_INIT(nullptr, 0) };
+PyTypeObject Lz4CompressorType = { PyVarObject_HEAD_INIT(nullptr, 0) };
+PyTypeObject SnappyDecompressorType = { PyVarObject_HEAD_INIT(nullptr, 0) };
+PyTypeObject Lz4DecompressorType = { PyVarObject_HEAD_INIT(nullptr, 0) };
+
+bool ready_stream_types() {
+    struct { PyTypeObject* t; const char* name; newfunc nw; initproc in; } cs[] = {
+        { &SnappyCompressorType, "cramjam_amd.snappy.Compressor", SnappyCompressor_new, (initproc)SnappyCompressor_init },
+        { &Lz4CompressorType, "cramjam_amd.lz4.Compressor", Lz4Compressor_new, (initproc)Lz4Compressor_init } };
+    for (auto& c : cs) {
+        c.t->tp_name = c.name; c.t->tp_basicsize = sizeof(CompressorObject); c.t->tp_flags = Py_TPFLAGS_DEFAULT;
+        c.t->tp_doc = "Compressor object for streaming compression"; c.t->tp_new = c.nw; c.t->tp_init = c.in;
+        c.t->tp_dealloc = (destructor)Compressor_dealloc; c.t->tp_methods = Compressor_methods;
+        if (PyType_Ready(c.t) < 0) return false;
+    }
+    Decompressor_as_sequence.sq_length = (lenfunc)Decompressor_sq_len;
+    Decompressor_as_sequence.sq_contains = (objobjproc)Decompressor_contains;
+    Decompressor_as_number.nb_bool = (inquiry)Decompressor_bool;
+    struct { PyTypeObject* t; const char* name; newfunc nw; } ds[] = {
+        { &SnappyDecompressorType, "cramjam_amd.snappy.Decompressor", SnappyDecompressor_new },
+        { &Lz4DecompressorType, "cramjam_amd.lz4.Decompressor", Lz4Decompressor_new } };
+    for (auto& d : ds) {
+        d.t->tp_name = d.name; d.t->tp_basicsize = sizeof(DecompressorObject); d.t->tp_flags = Py_TPFLAGS_DEFAULT;
+        d.t->tp_doc = "Decompressor object for streaming decompression"; d.t->tp_new = d.nw;
+        d.t->tp_dealloc = (destructor)Decompressor_dealloc; d.t->tp_methods = Decompressor_methods;
+        d.t->tp_as_sequence = &Decompressor_as_sequence; d.t->tp_as_number = &Decompressor_as_number;
+        d.t->tp_repr = (reprfunc)Decompressor_repr;
+        if (PyType_Ready(d.t) < 0) return false;
+    }
+    return true;
+}
+
 PyMethodDef lz4_methods[] = {
     {"compress", (PyCFunction)lz4_compress, METH_VARARGS | METH_KEYWORDS, "LZ4 (frame) compression (data, level=None, output_len=None)"},
     {"decompress", (PyCFunction)lz4_decompress, METH_VARARGS | METH_KEYWORDS, "LZ4 (frame) decompression (data, output_len=None)"},
@@ -849,6 +1083,11 @@ PyMODINIT_FUNC PyInit__cramjam(void) {
     PyObject* lz4 = PyModule_Create(&lz4_def);
     PyObject* snappy = PyModule_Create(&snappy_def);
     if (!lz4 || !snappy) return nullptr;
+    if (!ready_stream_types()) return nullptr;
+    Py_INCREF(&Lz4CompressorType); PyModule_AddObject(lz4, "Compressor", (PyObject*)&Lz4CompressorType);
+    Py_INCREF(&Lz4DecompressorType); PyModule_AddObject(lz4, "Decompressor", (PyObject*)&Lz4DecompressorType);
+    Py_INCREF(&SnappyCompressorType); PyModule_AddObject(snappy, "Compressor", (PyObject*)&SnappyCompressorType);
+    Py_INCREF(&SnappyDecompressorType); PyModule_AddObject(snappy, "Decompressor", (PyObject*)&SnappyDecompressorType);
     PyModule_AddObject(m, "lz4", lz4);
     PyModule_AddObject(m, "snappy", snappy);
     PyModule_AddIntConstant(m, "abi_version", cj_abi_version());

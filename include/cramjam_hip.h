@@ -124,6 +124,9 @@ size_t cj_lz4_frame_compress_bound(size_t n);
  * content checksum, no content size — like the reference — but INDEPENDENT blocks (the reference links them) and one
  * matcher for every `level` (the reference's default level 4 is LZ4HC): any LZ4F decoder reads the result. */
 int64_t cj_lz4_frame_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap, int level);
+/* only the block sequence of such a frame (u32 size word + data per 64 KiB of input; no header, EndMark or checksum):
+ * what a streaming encoder (reference src/lz4.rs:231-292 `Compressor`) emits per flush.  cap >= n + 4 * ceil(n / 65536). */
+int64_t cj_lz4_frame_compress_blocks(const uint8_t* in, size_t n, uint8_t* out, size_t cap);
 /* upper bound of the decoded size from the headers alone (content size if stored, else blocks x max block size), or the
  * first header-level error. No device. */
 int64_t cj_lz4_frame_decompress_bound(const uint8_t* in, size_t n);

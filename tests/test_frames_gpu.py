@@ -415,3 +415,59 @@ def test_lz4_frame_large_round_trip():
     assert lz4f_decompress(frame) == (len(data), data)
     dmg = bytearray(frame); dmg[len(frame) // 3] ^= 0x04
     assert lz4f_decompress(bytes(dmg), cap=len(data))[0] == oracle.lz4_frame_decompress(bytes(dmg), len(data))[0] < 0
+
+
+# ---- streaming objects (reference tests/test_variants.py:361-417, restated for snappy + lz4) ------------------------
+
+@pytest.mark.parametrize("variant_str", VARIANTS)
+@FAST
+@given(first=st.binary(), second=st.binary())
+def test_streams_compressor(variant_str, first, second):
+    mod = getattr(cramjam, variant_str)
+    compressor = mod.Compressor()
+    compressor.compress(first)
+    out = bytes(compressor.flush())
+    compressor.compress(second)
+    out += bytes(compressor.flush())
+    out += bytes(compressor.finish())
+    assert same_same(bytes(mod.decompress(out)), first + second)
+    assert _oracle_decode(variant_str, out) == first + second             # the CPU decoder reads the concatenated flushes
+    assert bytes(compressor.finish()) == b""                               # just empty bytes after the first .finish()
+    with pytest.raises(cramjam.CompressionError):
+        compressor.compress(b"data")
+
+
+@pytest.mark.parametrize("variant_str", VARIANTS)
+def test_variants_stream_decompressors(variant_str):
+    variant = getattr(cramjam, variant_str)
+    decompressor = variant.Decompressor()
+    compressed = variant.compress(b"bytes")
+    for _ in range(2):
+        assert decompressor.decompress(bytes(compressed)) == 5
+    assert len(decompressor) == 10 and decompressor.len() == 10 and b"sby" in decompressor and bool(decompressor)
+    assert repr(decompressor) == "Decompressor<len=10>"
+    assert bytes(decompressor.flush()) == b"bytesbytes"
+    assert bytes(decompressor.flush()) == b""
+    decompressor.decompress(bytes(compressed))
+    assert bytes(decompressor.finish()) == b"bytes"
+    with pytest.raises(cramjam.DecompressionError):
+        decompressor.finish()
+    with pytest.raises(cramjam.DecompressionError):
+        decompressor.decompress(bytes(compressed))
+
+
+def test_stream_compressor_large_and_options():
+    data = mixed_data(21)
+    for mod, kw in ((cramjam.snappy, {}), (cramjam.lz4, {}), (cramjam.lz4, dict(level=9, content_checksum=False, block_linked=False))):
+        c = mod.Compressor(**kw)
+        out = b""
+        for i in range(0, len(data), 100_000):                   # pieces that do not line up with the 64 KiB blocks
+            assert c.compress(data[i:i + 100_000]) == len(data[i:i + 100_000])
+            if (i // 100_000) % 2:
+                out += bytes(c.flush())
+        out += bytes(c.finish())
+        assert bytes(mod.decompress(out)) == data
+        assert _oracle_decode("snappy" if mod is cramjam.snappy else "lz4", out) == data
+    empty = cramjam.lz4.Compressor()
+    assert bytes(empty.finish()) == bytes.fromhex("04224d186440a700000000055dcc02")      # liblz4's empty frame
+    assert bytes(cramjam.snappy.Compressor().finish()) == b""

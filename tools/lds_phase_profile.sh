@@ -1,6 +1,7 @@
-# one-off A/B harness (kept for the record)
+# A/B harness for compile-time variants: rebuild with CJ_EXTRA_HIPCC_FLAGS and print the LDS decoder's
+# per-phase cycle counters.  usage on the GPU box: bash tools/lds_phase_profile.sh "-DSOME_FLAG" "-DCJ_NONE"
 cd $GRAFT_REPO_ROOT
-for cfg in "-DCJ_D3_SLEEP=1" "-DCJ_D3_SLEEP=2" "-DCJ_D3_SLEEP=4" "-DCJ_NONE"; do
+for cfg in "$@"; do
   CJ_EXTRA_HIPCC_FLAGS="$cfg" python -c "
 from cramjam_amd import _build; _build.build(force=True)" 2>&1 | tail -3
   echo "CFG $cfg"

@@ -18,6 +18,8 @@ except ImportError as _exc:          # not built yet: keep `cramjam_amd._build` 
     _missing = _exc
 
     def __getattr__(name):
+        if name not in ("Buffer", "CompressionError", "DecompressionError", "lz4", "snappy", "batch"):
+            raise AttributeError(name)          # lets `from cramjam_amd import _build` fall through to the submodule import
         raise ImportError("cramjam_amd: the native module is not built (%s) — run `python -c 'import __graft_entry__ as g; "
                           "g.build()'` (hipcc --offload-arch=gfx950 + g++). There is no CPU fallback." % _missing) from _missing
 else:

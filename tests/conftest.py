@@ -20,6 +20,8 @@ def pytest_configure(config):
     from cramjam_amd import _build
     if not (os.path.exists(_build.LIB) and os.path.exists(_build.pymod_path())):
         _build.build()
+        for name in [k for k in sys.modules if k == "cramjam_amd" or k.startswith("cramjam_amd.")]:
+            del sys.modules[name]          # the package was imported before its native module existed: import it afresh
     import oracle
     oracle.build()
 

@@ -237,6 +237,79 @@ __device__ __forceinline__ void finish_match(const uint8_t* in, uint32_t ext_lan
     mpos -= back; mc -= back; mlen += back;
 }
 
+// ---- lane-parallel greedy selection ---------------------------------------------------------------------------
+// The greedy leftmost rule is a serial chain over the selected matches, but only ONE thing has to be carried along
+// it: where the previous selected match ended.  select_walk does exactly that (≈12 instructions per match: ctz,
+// one v_readlane, a predicated move); everything that used to ride on the chain (backward clamp, literal length,
+// encoded size, output position, queue slot, coverage) is computed afterwards for all candidates at once — sizes
+// and coverage through wave prefix scans, the queue through ds_permute.  Rounds that contain a capped extension
+// (very long match) or need whole-wave emission (long literal run) fall back to the serial loop.
+struct Selection {
+    uint64_t sel[kSub];          // selected lanes per sub-round (wave-uniform)
+    uint32_t prev_end[kSub];     // per lane: end of the previous selected match (start of this sequence's literals)
+    uint32_t out_pos[kSub];      // per lane: output position of this sequence
+    bool covered[kSub];          // per lane: position lies inside a selected match (not its first byte)
+    uint32_t anchor;             // end of the last selected match (wave-uniform)
+    uint32_t op;                 // output position after the last selected sequence (wave-uniform)
+    uint32_t count;
+    bool coop;                   // a selected sequence needs whole-wave handling: the caller redoes the round serially
+};
+
+// size_fn(lit, mcode, off) = encoded bytes of one sequence; coop_fn(lit, mcode) = needs whole-wave emission
+template <class SizeFn, class CoopFn>
+__device__ __forceinline__ void select_walk(const Round& r, uint32_t pos, uint32_t anchor, uint32_t op, Selection& s,
+                                            SizeFn size_fn, CoopFn coop_fn) {
+    const uint32_t lane = lane_id();
+    uint32_t cur = anchor, cur_op = op, cnt = 0;
+    bool coop = false;
+#pragma unroll
+    for (int j = 0; j < kSub; j++) s.covered[j] = pos + 64u * j + lane < anchor;     // inside a match of an earlier round
+#pragma unroll
+    for (int j = 0; j < kSub; j++) {
+        const uint32_t pj = pos + 64u * j;
+        uint64_t mask = r.mask[j], sel = 0ull;
+        uint32_t pe = 0, po = 0;
+        if (cur > pj) mask = cur - pj >= 64u ? 0ull : mask & (~0ull << (cur - pj));
+        while (mask) {
+            const uint32_t first = ctz64(mask);
+            const uint32_t ext = rdlane(r.ext[j], first), p = pj + first;
+            const uint32_t room = p - cur;
+            uint32_t bk = (ext >> 8) & 0x3fu;
+            bk = bk < room ? bk : room;
+            const uint32_t lit = room - bk, mcode = (ext & 0xffu) + bk, e = p + 4u + (ext & 0xffu);
+            // capped extensions: forward -> the match end above is too short; backward -> only if the literal run leaves room
+            coop = coop || coop_fn(lit, mcode) || (ext & 0x4000u) != 0u || ((ext & 0x8000u) != 0u && room > 16u);
+            sel |= 1ull << first;
+            pe = lane == first ? cur : pe;
+            po = lane == first ? cur_op : po;
+            cur_op += size_fn(lit, mcode, p - rdlane(r.cand[j], first));
+#pragma unroll
+            for (int jj = 0; jj < kSub; jj++) {
+                const uint32_t my = pos + 64u * jj + lane;
+                s.covered[jj] = s.covered[jj] || (my > p - bk && my < e);
+            }
+            cur = e; cnt += 1;
+            mask = e - pj >= 64u ? 0ull : mask & (~0ull << (e - pj));
+        }
+        s.sel[j] = sel;
+        s.prev_end[j] = pe;
+        s.out_pos[j] = po;
+    }
+    s.anchor = cur; s.op = cur_op; s.count = cnt; s.coop = coop;
+}
+
+// number of set bits of m below this lane
+__device__ __forceinline__ uint32_t bits_below_lane(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+// push `v` of the selected lanes of a sub-round to queue lanes base + rank; the other lanes push to the remaining lanes
+// (a permutation, so nothing collides); lanes whose queue slot belongs to this sub-round take the received value
+__device__ __forceinline__ uint32_t queue_push(uint32_t q, uint32_t v, uint32_t dest, uint32_t base, uint32_t cnt) {
+    const uint32_t t = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest << 2), (int)v);
+    const uint32_t lane = lane_id();
+    return (lane >= base && lane < base + cnt) ? t : q;
+}
+
 // exact n-byte copy by ONE lane: 64 B batches with the four loads in flight together (a load -> store loop costs one
 // global round trip per 16 bytes), then 16 B blocks and an 8/4/2/1 tail: lane-parallel emission of short literal runs
 __device__ __forceinline__ void lane_copy_exact(uint8_t* dst, const uint8_t* src, uint32_t n) {

@@ -80,10 +80,44 @@ __global__ __launch_bounds__(kEncThreads) void lz4_encode_kernel(BatchArgs a) {
             probe_round(in, ht, pos, last_start, matchlimit, anchor, r);
             const uint32_t round_end = pos + kRoundPositions;
             bool covered[kSub] = {};
-            // greedy selection on registers; the selected sequences are queued one per lane and emitted together
             uint32_t q_n = 0, q_lit0 = 0, q_lit = 0, q_off = 0, q_mcode = 0, q_op = 0;
+            // ---- fast path: minimal serial walk, then everything else for all candidates at once (cj_match.hpp) ----
+            bool fast_round = false;
+            {
+                Selection sl;
+                select_walk(r, pos, anchor, op, sl,
+                            [](uint32_t lit, uint32_t mc, uint32_t) { return 1u + (lit >= 15u ? 1u + (lit - 15u) / 255u : 0u) + lit + 2u + (mc >= 15u ? 1u + (mc - 15u) / 255u : 0u); },
+                            [](uint32_t lit, uint32_t mc) { return lit >= kCoopLit || mc >= kCoopMatch; });
+                if (!sl.coop && sl.count <= 64u) {
+                    fast_round = true;
+                    uint32_t base = 0;
+#pragma unroll
+                    for (int j = 0; j < kSub; j++) {
+                        const uint32_t p = pos + 64u * j + lane, ext = r.ext[j];
+                        const bool sel = ((sl.sel[j] >> lane) & 1ull) != 0ull;
+                        const uint32_t room = p - sl.prev_end[j];
+                        uint32_t bk = (ext >> 8) & 0x3fu;
+                        bk = bk < room ? bk : room;
+                        const uint32_t cnt = (uint32_t)__builtin_popcountll(sl.sel[j]);
+                        const uint32_t below = bits_below_lane(sl.sel[j]);
+                        // selected lanes -> queue lanes base + rank; the rest -> the other lanes, in order
+                        const uint32_t dest = sel ? base + below : (base + cnt + (lane - below)) & 63u;
+                        q_lit0 = queue_push(q_lit0, sl.prev_end[j], dest, base, cnt);
+                        q_lit = queue_push(q_lit, room - bk, dest, base, cnt);
+                        q_off = queue_push(q_off, p - r.cand[j], dest, base, cnt);
+                        q_mcode = queue_push(q_mcode, (ext & 0xffu) + bk, dest, base, cnt);
+                        q_op = queue_push(q_op, sl.out_pos[j], dest, base, cnt);
+                        base += cnt;
+                        covered[j] = sl.covered[j];
+                    }
+                    q_n = base;
+                    op = sl.op;
+                    anchor = sl.anchor;
+                }
+            }
 #pragma unroll
             for (int j = 0; j < kSub; j++) {
+                if (fast_round) break;
                 const uint32_t pj = pos + 64u * j;
                 uint64_t mask = r.mask[j];
                 if (anchor > pj) mask = anchor - pj >= 64u ? 0ull : mask & (~0ull << (anchor - pj));

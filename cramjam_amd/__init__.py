@@ -13,16 +13,16 @@ There is no CPU fallback: importing works without a GPU, computing without one r
 from ._native import Engine, EngineError  # noqa: F401
 
 try:
-    from ._cramjam import Buffer, CompressionError, DecompressionError, lz4, snappy  # noqa: F401
+    from ._cramjam import Buffer, CompressionError, DecompressionError, File, lz4, snappy  # noqa: F401
 except ImportError as _exc:          # not built yet: keep `cramjam_amd._build` importable, fail loudly on everything else
     _missing = _exc
 
     def __getattr__(name):
-        if name not in ("Buffer", "CompressionError", "DecompressionError", "lz4", "snappy", "batch"):
+        if name not in ("Buffer", "File", "CompressionError", "DecompressionError", "lz4", "snappy", "batch"):
             raise AttributeError(name)          # lets `from cramjam_amd import _build` fall through to the submodule import
         raise ImportError("cramjam_amd: the native module is not built (%s) — run `python -c 'import __graft_entry__ as g; "
                           "g.build()'` (hipcc --offload-arch=gfx950 + g++). There is no CPU fallback." % _missing) from _missing
 else:
     from . import batch  # noqa: F401
 
-__all__ = ["Buffer", "CompressionError", "DecompressionError", "lz4", "snappy", "Engine", "EngineError", "batch"]
+__all__ = ["Buffer", "File", "CompressionError", "DecompressionError", "lz4", "snappy", "Engine", "EngineError", "batch"]

@@ -20,7 +20,11 @@
 #include <cstdint>
 #include <cstring>
 #include <string>
+#include <cerrno>
 #include <cstdlib>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -131,6 +135,17 @@ extern PyTypeObject BufferType;
 
 inline bool Buffer_Check(PyObject* o) { return PyObject_TypeCheck(o, &BufferType); }
 
+// cramjam.File (reference src/io.rs:30-172): a plain read/write file handle usable wherever a BytesType is streamed
+struct FileObject {
+    PyObject_HEAD
+    int fd;
+    std::string* path;
+};
+extern PyTypeObject FileType;
+inline bool File_Check(PyObject* o) { return PyObject_TypeCheck(o, &FileType); }
+bool file_read_to_end(FileObject* f, std::vector<uint8_t>& out);
+bool file_write_all(FileObject* f, const uint8_t* p, size_t n);
+
 // borrowed bytes of any BytesType-like object: Buffer, or anything with the buffer protocol
 struct Bytes {
     uint8_t* ptr = nullptr;
@@ -138,6 +153,8 @@ struct Bytes {
     Py_buffer pb{};
     bool have_pb = false;
     BufferObject* buf = nullptr;
+    FileObject* file = nullptr;          // set when the object is a File and the caller allowed it
+    std::vector<uint8_t> filedata;       // a File INPUT is read (from its position to the end) into here
     ~Bytes() { if (have_pb) PyBuffer_Release(&pb); }
     Bytes() = default;
     Bytes(const Bytes&) = delete;
@@ -150,7 +167,20 @@ uint8_t* buffer_data(BufferObject* b) { return b->view ? b->vptr : b->vec->data(
 Py_ssize_t buffer_len(BufferObject* b) { return b->view ? b->vlen : (Py_ssize_t)b->vec->size(); }
 
 // reference src/io.rs:273-298 (PythonBuffer::try_from) + src/lib.rs:104-115 (BytesType extraction)
-bool get_bytes(PyObject* obj, Bytes& out) {
+bool get_bytes(PyObject* obj, Bytes& out, int file_mode = 0) {      // file_mode: 0 refuse Files, 1 File input (read now), 2 File output
+    if (File_Check(obj)) {
+        if (file_mode == 0) {
+            PyErr_SetString(PyExc_TypeError, "Converting a File to bytes is not supported, as it'd require reading the entire file "
+                                             "into memory; consider using cramjam.Buffer");
+            return false;
+        }
+        out.file = (FileObject*)obj;
+        if (file_mode == 1) {
+            if (!file_read_to_end(out.file, out.filedata)) return false;
+            out.ptr = out.filedata.data(); out.len = (Py_ssize_t)out.filedata.size();
+        }
+        return true;
+    }
     if (Buffer_Check(obj)) {
         BufferObject* b = (BufferObject*)obj;
         if (buffer_sync_view(b) < 0) return false;
@@ -258,7 +288,7 @@ void owned_write(BufferObject* self, const uint8_t* p, size_t n) {
 PyObject* Buffer_write(BufferObject* self, PyObject* input) {
     if (buffer_sync_view(self) < 0) return nullptr;
     Bytes in;
-    if (!get_bytes(input, in)) return nullptr;
+    if (!get_bytes(input, in, 1)) return nullptr;
     if (self->view) {
         Py_ssize_t room = self->vlen - (Py_ssize_t)std::min<uint64_t>(self->pos, (uint64_t)self->vlen);
         if (in.len > room) { PyErr_SetString(PyExc_OSError, "Too much to write on view"); return nullptr; }
@@ -316,6 +346,8 @@ PyObject* Buffer_readinto(BufferObject* self, PyObject* output) {
             if (n) std::memcpy(o->vptr + o->pos, src, (size_t)n);
             o->pos += (uint64_t)n;
         } else owned_write(o, src, (size_t)n);
+    } else if (File_Check(output)) {
+        if (!file_write_all((FileObject*)output, src, (size_t)n)) return nullptr;
     } else {
         Bytes out;
         if (!get_bytes(output, out)) return nullptr;
@@ -720,7 +752,7 @@ PyObject* framed_call(const Framed& fc, PyObject* args, PyObject* kw, bool compr
     const int level = opt_int(lvl, -1);
     if (level == -2) return nullptr;
     Bytes in;
-    if (!get_bytes(data, in)) return nullptr;
+    if (!get_bytes(data, in, 1)) return nullptr;
     PyObject* exc = compress ? CompressionError : DecompressionError;
     int64_t need, r;
     ByteVec buf;
@@ -748,11 +780,12 @@ PyObject* framed_into(const Framed& fc, PyObject* args, PyObject* kw, bool compr
     const int level = opt_int(lvl, -1);
     if (level == -2) return nullptr;
     Bytes in, out;
-    if (!get_bytes(input, in) || !get_bytes(output, out)) return nullptr;
+    if (!get_bytes(input, in, 1) || !get_bytes(output, out, 2)) return nullptr;
     PyObject* exc = compress ? CompressionError : DecompressionError;
     int64_t r;
-    if (out.buf) {
-        // Buffer output: a Cursor<Vec<u8>> written at its position, growing as needed (views cannot grow)
+    if (out.buf || out.file) {
+        // Buffer output: a Cursor<Vec<u8>> written at its position, growing as needed (views cannot grow); File output:
+        // written at the file's position
         ByteVec tmp;
         Py_BEGIN_ALLOW_THREADS
         r = fc.need(in, compress);
@@ -762,6 +795,10 @@ PyObject* framed_into(const Framed& fc, PyObject* args, PyObject* kw, bool compr
         }
         Py_END_ALLOW_THREADS
         if (r < 0) return raise_code(exc, r);
+        if (out.file) {
+            if (!file_write_all(out.file, tmp.data(), (size_t)r)) return nullptr;
+            return PyLong_FromLongLong(r);
+        }
         BufferObject* b = out.buf;
         if (b->view) {
             const uint64_t pos = std::min<uint64_t>(b->pos, (uint64_t)b->vlen);
@@ -790,6 +827,181 @@ PyObject* lz4_compress(PyObject*, PyObject* a, PyObject* k) { return framed_call
 PyObject* lz4_decompress(PyObject*, PyObject* a, PyObject* k) { return framed_call(kLz4Framed, a, k, false, false); }
 PyObject* lz4_compress_into(PyObject*, PyObject* a, PyObject* k) { return framed_into(kLz4Framed, a, k, true, true); }
 PyObject* lz4_decompress_into(PyObject*, PyObject* a, PyObject* k) { return framed_into(kLz4Framed, a, k, false, false); }
+
+// ------------------------------------------------------------------------------------------
+// cramjam.File (reference src/io.rs:30-172)
+// ------------------------------------------------------------------------------------------
+PyObject* os_error(const char* what) { return PyErr_Format(PyExc_OSError, "%s: %s", what, std::strerror(errno)); }
+
+bool file_read_to_end(FileObject* f, std::vector<uint8_t>& out) {
+    out.clear();
+    uint8_t chunk[1 << 16];
+    for (;;) {
+        const ssize_t r = ::read(f->fd, chunk, sizeof chunk);
+        if (r < 0) { if (errno == EINTR) continue; os_error("read"); return false; }
+        if (r == 0) return true;
+        out.insert(out.end(), chunk, chunk + r);
+    }
+}
+bool file_write_all(FileObject* f, const uint8_t* p, size_t n) {
+    while (n) {
+        const ssize_t r = ::write(f->fd, p, n);
+        if (r < 0) { if (errno == EINTR) continue; os_error("write"); return false; }
+        p += r; n -= (size_t)r;
+    }
+    return true;
+}
+
+PyObject* File_new(PyTypeObject* type, PyObject*, PyObject*) {
+    FileObject* self = (FileObject*)type->tp_alloc(type, 0);
+    if (!self) return nullptr;
+    self->fd = -1; self->path = new std::string();
+    return (PyObject*)self;
+}
+int File_init(FileObject* self, PyObject* args, PyObject* kw) {
+    static const char* kwl[] = {"path", "read", "write", "truncate", "append", nullptr};
+    const char* path; PyObject *rd = Py_None, *wr = Py_None, *tr = Py_None, *ap = Py_None;
+    if (!PyArg_ParseTupleAndKeywords(args, kw, "s|OOOO", (char**)kwl, &path, &rd, &wr, &tr, &ap)) return -1;
+    auto flag = [](PyObject* o, bool dflt, bool& ok) { if (o == Py_None) return dflt; int t = PyObject_IsTrue(o); if (t < 0) ok = false; return t > 0; };
+    bool ok = true;
+    const bool r = flag(rd, true, ok), w = flag(wr, true, ok), t = flag(tr, false, ok), a = flag(ap, false, ok);
+    if (!ok) return -1;
+    int fl = (r && (w || a)) ? O_RDWR : (w || a) ? O_WRONLY : O_RDONLY;
+    fl |= O_CREAT | O_CLOEXEC;            // create if it doesn't exist, but open if it does
+    if (t) fl |= O_TRUNC;
+    if (a) fl |= O_APPEND;
+    if (self->fd >= 0) ::close(self->fd);
+    self->fd = ::open(path, fl, 0666);
+    if (self->fd < 0) { PyErr_SetFromErrnoWithFilename(PyExc_OSError, path); return -1; }
+    *self->path = path;
+    return 0;
+}
+void File_dealloc(FileObject* self) {
+    if (self->fd >= 0) ::close(self->fd);
+    delete self->path;
+    Py_TYPE(self)->tp_free((PyObject*)self);
+}
+PyObject* File_write(FileObject* self, PyObject* input) {
+    Bytes in;
+    if ((PyObject*)self == input) { PyErr_SetString(PyExc_OSError, "cannot write a file into itself"); return nullptr; }
+    if (!get_bytes(input, in, 1)) return nullptr;
+    const uint8_t* p; Py_ssize_t n;
+    read_to_end(in, p, n);                // Buffer inputs are consumed from their position
+    if (!file_write_all(self, p, (size_t)n)) return nullptr;
+    return PyLong_FromSsize_t(n);
+}
+PyObject* File_read(FileObject* self, PyObject* args, PyObject* kw) {
+    static const char* kwl[] = {"n_bytes", nullptr};
+    PyObject* nobj = Py_None;
+    if (!PyArg_ParseTupleAndKeywords(args, kw, "|O", (char**)kwl, &nobj)) return nullptr;
+    if (nobj == Py_None) {
+        std::vector<uint8_t> all;
+        if (!file_read_to_end(self, all)) return nullptr;
+        return PyBytes_FromStringAndSize((const char*)all.data(), (Py_ssize_t)all.size());
+    }
+    const Py_ssize_t want = PyLong_AsSsize_t(nobj);
+    if (want == -1 && PyErr_Occurred()) return nullptr;
+    std::vector<uint8_t> b((size_t)std::max<Py_ssize_t>(want, 0));
+    size_t got = 0;
+    while (got < b.size()) {
+        const ssize_t r = ::read(self->fd, b.data() + got, b.size() - got);
+        if (r < 0) { if (errno == EINTR) continue; return os_error("read"); }
+        if (r == 0) break;
+        got += (size_t)r;
+    }
+    return PyBytes_FromStringAndSize((const char*)b.data(), (Py_ssize_t)got);
+}
+PyObject* File_readinto(FileObject* self, PyObject* output) {       // std::io::copy(file -> output)
+    std::vector<uint8_t> all;
+    if (File_Check(output)) {
+        if ((PyObject*)self == output) { PyErr_SetString(PyExc_OSError, "cannot readinto self"); return nullptr; }
+        if (!file_read_to_end(self, all) || !file_write_all((FileObject*)output, all.data(), all.size())) return nullptr;
+        return PyLong_FromSize_t(all.size());
+    }
+    if (Buffer_Check(output)) {
+        BufferObject* o = (BufferObject*)output;
+        if (buffer_sync_view(o) < 0 || !file_read_to_end(self, all)) return nullptr;
+        if (o->view) {
+            const Py_ssize_t room = o->vlen - (Py_ssize_t)std::min<uint64_t>(o->pos, (uint64_t)o->vlen);
+            if ((Py_ssize_t)all.size() > room) { PyErr_SetString(PyExc_OSError, "failed to write whole buffer"); return nullptr; }
+            if (!all.empty()) std::memcpy(o->vptr + o->pos, all.data(), all.size());
+            o->pos += all.size();
+        } else owned_write(o, all.data(), all.size());
+        return PyLong_FromSize_t(all.size());
+    }
+    Bytes out;
+    if (!get_bytes(output, out)) return nullptr;
+    size_t got = 0;
+    while (got < (size_t)out.len) {
+        const ssize_t r = ::read(self->fd, out.ptr + got, (size_t)out.len - got);
+        if (r < 0) { if (errno == EINTR) continue; return os_error("read"); }
+        if (r == 0) break;
+        got += (size_t)r;
+    }
+    if (got == (size_t)out.len) {         // more data left than the output can take -> write_all fails (WriteZero)
+        uint8_t probe;
+        const ssize_t r = ::read(self->fd, &probe, 1);
+        if (r > 0) { (void)::lseek(self->fd, -1, SEEK_CUR); PyErr_SetString(PyExc_OSError, "failed to write whole buffer"); return nullptr; }
+    }
+    return PyLong_FromSize_t(got);
+}
+PyObject* File_seek(FileObject* self, PyObject* args, PyObject* kw) {
+    static const char* kwl[] = {"position", "whence", nullptr};
+    Py_ssize_t position; PyObject* wobj = Py_None;
+    if (!PyArg_ParseTupleAndKeywords(args, kw, "n|O", (char**)kwl, &position, &wobj)) return nullptr;
+    long whence = 0;
+    if (wobj != Py_None) { whence = PyLong_AsLong(wobj); if (whence == -1 && PyErr_Occurred()) return nullptr; }
+    if (whence < 0 || whence > 2) {
+        PyErr_SetString(PyExc_ValueError, "whence should be one of 0: seek from start, 1: seek from current, or 2: seek from end");
+        return nullptr;
+    }
+    const off_t r = ::lseek(self->fd, (off_t)position, whence == 0 ? SEEK_SET : whence == 1 ? SEEK_CUR : SEEK_END);
+    if (r < 0) return os_error("seek");
+    return PyLong_FromLongLong((long long)r);
+}
+PyObject* File_seekable(FileObject*, PyObject*) { Py_RETURN_TRUE; }
+PyObject* File_tell(FileObject* self, PyObject*) {
+    const off_t r = ::lseek(self->fd, 0, SEEK_CUR);
+    if (r < 0) return os_error("seek");
+    return PyLong_FromLongLong((long long)r);
+}
+PyObject* File_set_len(FileObject* self, PyObject* arg) {
+    const size_t n = PyLong_AsSize_t(arg);
+    if (n == (size_t)-1 && PyErr_Occurred()) return nullptr;
+    if (::ftruncate(self->fd, (off_t)n) != 0) return os_error("set_len");
+    Py_RETURN_NONE;
+}
+PyObject* File_truncate(FileObject* self, PyObject*) {
+    if (::ftruncate(self->fd, 0) != 0) return os_error("set_len");
+    Py_RETURN_NONE;
+}
+Py_ssize_t file_len(FileObject* self) {
+    struct stat st;
+    if (::fstat(self->fd, &st) != 0) { os_error("metadata"); return -1; }
+    return (Py_ssize_t)st.st_size;
+}
+PyObject* File_len(FileObject* self, PyObject*) { const Py_ssize_t n = file_len(self); return n < 0 ? nullptr : PyLong_FromSsize_t(n); }
+Py_ssize_t File_sq_len(FileObject* self) { return file_len(self); }
+int File_bool(FileObject* self) { const Py_ssize_t n = file_len(self); return n < 0 ? -1 : n > 0; }
+PyObject* File_repr(FileObject* self) {
+    const Py_ssize_t n = file_len(self);
+    if (n < 0) return nullptr;
+    return PyUnicode_FromFormat("cramjam.File<path=%s, len=%zd>", self->path->c_str(), n);
+}
+PyMethodDef File_methods[] = {
+    {"write", (PyCFunction)File_write, METH_O, "Write some bytes to the file, where input data can be anything in BytesType"},
+    {"read", (PyCFunction)File_read, METH_VARARGS | METH_KEYWORDS, "Read from the file in its current position, returns bytes (n_bytes=None)"},
+    {"readinto", (PyCFunction)File_readinto, METH_O, "Read from the file in its current position, into a BytesType object."},
+    {"seek", (PyCFunction)File_seek, METH_VARARGS | METH_KEYWORDS, "Seek to a position within the file (position, whence=None)"},
+    {"seekable", (PyCFunction)File_seekable, METH_NOARGS, "Whether the file is seekable; always True."},
+    {"tell", (PyCFunction)File_tell, METH_NOARGS, "Give the current position of the file."},
+    {"set_len", (PyCFunction)File_set_len, METH_O, "Set the length of the file (truncates or null-byte fills)."},
+    {"truncate", (PyCFunction)File_truncate, METH_NOARGS, "Truncate the file."},
+    {"len", (PyCFunction)File_len, METH_NOARGS, "Length of the file in bytes"},
+    {nullptr, nullptr, 0, nullptr}};
+PySequenceMethods File_as_sequence = {};
+PyNumberMethods File_as_number = {};
+PyTypeObject FileType = { PyVarObject_HEAD_INIT(nullptr, 0) };
 
 // ------------------------------------------------------------------------------------------
 // Streaming objects (reference src/snappy.rs:124-161, src/lz4.rs:231-294, src/lib.rs:298-394, src/io.rs:761-814).
@@ -1083,6 +1295,22 @@ PyMODINIT_FUNC PyInit__cramjam(void) {
     PyObject* lz4 = PyModule_Create(&lz4_def);
     PyObject* snappy = PyModule_Create(&snappy_def);
     if (!lz4 || !snappy) return nullptr;
+    FileType.tp_name = "cramjam_amd.File";
+    FileType.tp_basicsize = sizeof(FileObject);
+    FileType.tp_flags = Py_TPFLAGS_DEFAULT;
+    FileType.tp_doc = "A native file object (cramjam.File)";
+    FileType.tp_new = File_new;
+    FileType.tp_init = (initproc)File_init;
+    FileType.tp_dealloc = (destructor)File_dealloc;
+    FileType.tp_methods = File_methods;
+    File_as_sequence.sq_length = (lenfunc)File_sq_len;
+    File_as_number.nb_bool = (inquiry)File_bool;
+    FileType.tp_as_sequence = &File_as_sequence;
+    FileType.tp_as_number = &File_as_number;
+    FileType.tp_repr = (reprfunc)File_repr;
+    if (PyType_Ready(&FileType) < 0) return nullptr;
+    Py_INCREF(&FileType);
+    PyModule_AddObject(m, "File", (PyObject*)&FileType);
     if (!ready_stream_types()) return nullptr;
     Py_INCREF(&Lz4CompressorType); PyModule_AddObject(lz4, "Compressor", (PyObject*)&Lz4CompressorType);
     Py_INCREF(&Lz4DecompressorType); PyModule_AddObject(lz4, "Decompressor", (PyObject*)&Lz4DecompressorType);

@@ -193,3 +193,65 @@ def test_errors_are_exception_subclasses_and_no_cpu_fallback():
     assert cramjam.snappy.decompress_raw_len(b"") == 0
     with pytest.raises(cramjam.DecompressionError):
         cramjam.snappy.decompress_raw_len(b"\xff\xff\xff\xff\xff\xff\xff\xff\xff\xff\xff")
+
+
+# ---- cramjam.File (reference src/io.rs:30-172; tests/test_rust_io.py:8-66, tests/test_variants.py:292-311) --------------
+def test_file_obj_api(tmp_path):
+    File, Buffer = cramjam.File, cramjam.Buffer
+    buf = File(str(tmp_path / "file.txt"))
+    assert buf.write(b"bytes") == 5
+    assert buf.tell() == 5
+    assert buf.seek(0) == 0
+    assert buf.read() == b"bytes"
+    assert buf.seek(-1, 2) == 4
+    assert buf.read() == b"s"
+    assert buf.seek(-2, whence=1) == 3
+    assert buf.read() == b"es"
+    with pytest.raises(ValueError):
+        buf.seek(1, 3)
+    for out in (bytearray(b"12345"), File(str(tmp_path / "test.txt")), Buffer()):
+        buf.seek(0)
+        assert buf.readinto(out) == 5
+        if isinstance(out, (File, Buffer)):
+            out.seek(0)
+            assert out.read() == b"bytes"
+        else:
+            assert out == bytearray(b"bytes")
+    buf.seek(0)
+    with pytest.raises(OSError):
+        buf.readinto(bytearray(3))                        # output smaller than what is left: "failed to write whole buffer"
+    buf.set_len(2)
+    buf.seek(0)
+    assert buf.read() == b"by"
+    buf.set_len(10)
+    buf.seek(0)
+    assert buf.read() == b"by" + bytes(8)
+    assert buf.seekable() and len(buf) == 10 and buf.len() == 10 and bool(buf)
+    assert repr(buf) == "cramjam.File<path=%s, len=10>" % (tmp_path / "file.txt")
+    buf.truncate()
+    assert len(buf) == 0 and not buf
+    assert buf.tell() == 10 and buf.seek(0) == 0          # set_len does not move the cursor (std::fs::File::set_len)
+    # BytesType inputs of write(): Buffer is consumed from its position, another File from its position
+    b = Buffer(b"0123456789"); b.seek(4)
+    assert buf.write(b) == 6 and b.tell() == 10
+    other = File(str(tmp_path / "other.txt")); other.write(b"abc"); other.seek(1)
+    assert buf.write(other) == 2
+    buf.seek(0)
+    assert buf.read(3) == b"456" and buf.read() == b"789bc"
+    # Buffer <-> File
+    bb = Buffer()
+    buf.seek(0)
+    assert bb.write(buf) == 8 and bytes(bb) == b"456789bc"
+    bb.seek(0)
+    sink = File(str(tmp_path / "sink.txt"), truncate=True)
+    assert bb.readinto(sink) == 8 and sink.seek(0) == 0 and sink.read() == b"456789bc"
+    # modes
+    ro = File(str(tmp_path / "sink.txt"), write=False)
+    assert ro.read() == b"456789bc"
+    with pytest.raises(OSError):
+        ro.write(b"x")
+    ap = File(str(tmp_path / "sink.txt"), append=True)
+    ap.write(b"!!")
+    assert File(str(tmp_path / "sink.txt")).read() == b"456789bc!!"
+    with pytest.raises(TypeError):
+        cramjam.lz4.compress_block(ap)                    # block functions need bytes in memory (the reference panics here)

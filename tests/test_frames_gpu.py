@@ -204,6 +204,21 @@ def test_variants_raise_exception(variant_str):
 
 
 @pytest.mark.parametrize("variant_str", VARIANTS)
+def test_file_in_file_out(variant_str, tmp_path):
+    """compress a File into a File and back (reference generic! macro, src/lib.rs:237-265): both are streamed at their positions"""
+    variant = getattr(cramjam, variant_str)
+    data = mixed_data(31, 40, 30000, 5000)
+    src = cramjam.File(str(tmp_path / "plain.bin")); src.write(data); src.seek(0)
+    dst = cramjam.File(str(tmp_path / "packed.bin"))
+    n = variant.compress_into(src, dst)
+    assert n == len(dst) and dst.seek(0) == 0
+    assert bytes(variant.decompress(dst)) == data          # File as `data`: read from its position to the end
+    dst.seek(0)
+    back = cramjam.File(str(tmp_path / "back.bin"))
+    assert variant.decompress_into(dst, back) == len(data) and back.seek(0) == 0 and back.read() == data
+
+
+@pytest.mark.parametrize("variant_str", VARIANTS)
 def test_output_len_is_a_floor(variant_str):
     # generic!: vec![0; output_len] under a Cursor -> never shorter than output_len (src/lib.rs:216-219)
     variant = getattr(cramjam, variant_str)
@@ -213,7 +228,11 @@ def test_output_len_is_a_floor(variant_str):
     assert bytes(out) == b"abc" * 10
 
 
-def _make(kind, payload):
+def _make(kind, payload, tmp=None):
+    if kind is cramjam.File:
+        f = cramjam.File(str(tmp.mktemp("f").joinpath("data.bin")))
+        f.write(payload); f.seek(0)
+        return f
     if kind == "numpy":
         return np.frombuffer(payload, dtype=np.uint8).copy()
     if kind is cramjam.Buffer:
@@ -223,13 +242,13 @@ def _make(kind, payload):
 
 
 def _collect(obj):
-    if isinstance(obj, cramjam.Buffer):
+    if isinstance(obj, (cramjam.Buffer, cramjam.File)):
         obj.seek(0)
         return obj.read()
     return obj.tobytes() if hasattr(obj, "tobytes") else bytes(obj)
 
 
-TYPES = (bytes, bytearray, "numpy", cramjam.Buffer, memoryview)     # cramjam.File is outside the hot path
+TYPES = (bytes, bytearray, "numpy", cramjam.Buffer, cramjam.File, memoryview)
 
 
 @pytest.mark.parametrize("input_type", TYPES)
@@ -237,11 +256,12 @@ TYPES = (bytes, bytearray, "numpy", cramjam.Buffer, memoryview)     # cramjam.Fi
 @pytest.mark.parametrize("variant_str", VARIANTS)
 @settings(max_examples=6, deadline=None)
 @given(raw_data=st.binary())
-def test_variants_compress_into(variant_str, input_type, output_type, raw_data):
+def test_variants_compress_into(variant_str, input_type, output_type, raw_data, tmp_path_factory):
     variant = getattr(cramjam, variant_str)
-    inp = _make(input_type, raw_data)
+    inp = _make(input_type, raw_data, tmp_path_factory)
     compressed_len = len(variant.compress(raw_data))
-    output = cramjam.Buffer() if output_type is cramjam.Buffer else _make(output_type, b"0" * compressed_len)
+    output = (cramjam.Buffer() if output_type is cramjam.Buffer else _make(cramjam.File, b"", tmp_path_factory) if output_type is cramjam.File
+              else _make(output_type, b"0" * compressed_len))
     n_bytes = variant.compress_into(inp, output)
     assert n_bytes == compressed_len
     assert same_same(raw_data, variant.decompress(_collect(output)[:n_bytes]))
@@ -252,11 +272,12 @@ def test_variants_compress_into(variant_str, input_type, output_type, raw_data):
 @pytest.mark.parametrize("variant_str", VARIANTS)
 @settings(max_examples=6, deadline=None)
 @given(raw_data=st.binary())
-def test_variants_decompress_into(variant_str, input_type, output_type, raw_data):
+def test_variants_decompress_into(variant_str, input_type, output_type, raw_data, tmp_path_factory):
     variant = getattr(cramjam, variant_str)
     compressed = bytes(variant.compress(raw_data))
-    inp = _make(input_type, compressed)
-    output = cramjam.Buffer() if output_type is cramjam.Buffer else _make(output_type, b"0" * len(raw_data))
+    inp = _make(input_type, compressed, tmp_path_factory)
+    output = (cramjam.Buffer() if output_type is cramjam.Buffer else _make(cramjam.File, b"", tmp_path_factory) if output_type is cramjam.File
+              else _make(output_type, b"0" * len(raw_data)))
     n_bytes = variant.decompress_into(inp, output)
     assert n_bytes == len(raw_data)
     assert same_same(_collect(output), raw_data)

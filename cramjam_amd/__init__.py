@@ -12,6 +12,8 @@ There is no CPU fallback: importing works without a GPU, computing without one r
 """
 from ._native import Engine, EngineError  # noqa: F401
 
+__version__ = "0.1.0"          # reference: cramjam.__version__ (tests/test_variants.py:43-46)
+
 try:
     from ._cramjam import Buffer, CompressionError, DecompressionError, File, lz4, snappy  # noqa: F401
 except ImportError as _exc:          # not built yet: keep `cramjam_amd._build` importable, fail loudly on everything else

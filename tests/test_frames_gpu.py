@@ -492,3 +492,30 @@ def test_stream_compressor_large_and_options():
     empty = cramjam.lz4.Compressor()
     assert bytes(empty.finish()) == bytes.fromhex("04224d186440a700000000055dcc02")      # liblz4's empty frame
     assert bytes(cramjam.snappy.Compressor().finish()) == b""
+
+
+def test_concurrent_calls_from_python_threads():
+    """every hot call releases the GIL (src/lib.rs allow_threads), so Python may enter the exports from many threads at once
+    (SURVEY.md §8b "Threading"): results must be the same as when called alone"""
+    import threading
+    datas = [mixed_data(40 + i, 20 + i, 40000 + 1000 * i, 3000) for i in range(6)]
+    errors = []
+
+    def worker(i):
+        try:
+            d = datas[i % len(datas)]
+            for _ in range(4):
+                assert bytes(cramjam.snappy.decompress(cramjam.snappy.compress(d))) == d
+                assert bytes(cramjam.lz4.decompress(cramjam.lz4.compress(d))) == d
+                blk = cramjam.lz4.compress_block(d[:200000])
+                assert bytes(cramjam.lz4.decompress_block(blk)) == d[:200000]
+                raw = cramjam.snappy.compress_raw(d[:150000])
+                assert bytes(cramjam.snappy.decompress_raw(raw)) == d[:150000]
+                assert bytes(cramjam.lz4.decompress(oracle.lz4_frame_compress(d, 4, 1)[1])) == d      # linked path (own scratch lock)
+        except Exception as exc:                      # noqa: BLE001
+            errors.append((i, repr(exc)))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(8)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert not errors, errors

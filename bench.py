@@ -245,7 +245,7 @@ def main():
         algo = bytes_in + (bytes_out if bytes_out is not None else 0)
         achieved = algo / (kernel_ms * 1e-3)
         line = {
-            "metric": "uncompressed GB/s (LZ4-block decomp, 64 KiB chunks)" if (dec and args.codec == "lz4")
+            "metric": "uncompressed GB/s (LZ4-block decomp, 64 KiB chunks)" if (dec and args.codec == "lz4" and S == 65536)
                       else "uncompressed GB/s (%s %s, %d B chunks)" % (args.codec, args.op, S),
             "value": total_unc / (wall_max / args.steps) / 1e9,
             "unit": "GB/s",

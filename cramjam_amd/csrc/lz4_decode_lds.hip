@@ -476,8 +476,13 @@ __device__ __forceinline__ DW<ND> gl_ld_vec(const uint8_t* g) {
 // path), so a match that reaches back past the start of its block reads final bytes from the other window.
 constexpr uint32_t kL2LinkedBytes = 2u * 65536u + 8192u + 384u;        // 139 648 B: one workgroup per CU
 
+#ifdef CJ_L2_WAVES_PER_EU
+#define CJ_L2_ATTR __attribute__((amdgpu_waves_per_eu(CJ_L2_WAVES_PER_EU, CJ_L2_WAVES_PER_EU)))
+#else
+#define CJ_L2_ATTR
+#endif
 template <int kCodec, bool kLinked = false>
-__global__ __launch_bounds__(kL2Threads) void lz4_decode_lds2_kernel(BatchArgs a, const uint2* sync, const ParseMeta* meta,
+__global__ __launch_bounds__(kL2Threads) CJ_L2_ATTR void lz4_decode_lds2_kernel(BatchArgs a, const uint2* sync, const ParseMeta* meta,
                                                                      uint4* tabs, uint32_t* counter,
                                                                      const uint2* frames, uint32_t n_frames) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];

@@ -131,8 +131,42 @@ __global__ __launch_bounds__(kEncThreads) void snappy_encode_kernel(BatchArgs a)
             const uint32_t round_end = pos + kRoundPositions;
             bool covered[kSub] = {};
             uint32_t q_n = 0, q_lit0 = 0, q_lit = 0, q_off = 0, q_mlen = 0, q_op = 0;
+            // fast path: minimal serial walk, sequence fields for all candidates at once, ds_permute push into the queue
+            bool fast_round = false;
+            {
+                Selection sl;
+                select_walk(r, pos, anchor, op, sl,
+                            [](uint32_t lit, uint32_t mc, uint32_t off) { return snappy_literal_size(lit) + snappy_copy_size(off, mc + 4u); },
+                            [](uint32_t lit, uint32_t mc) { return lit >= kSnCoopLit || mc + 4u >= kSnCoopMatch; });
+                if (!sl.coop && sl.count <= 64u) {
+                    fast_round = true;
+                    uint32_t base = 0;
+#pragma unroll
+                    for (int j = 0; j < kSub; j++) {
+                        const uint32_t p = pos + 64u * j + lane, ext = r.ext[j];
+                        const bool sel = ((sl.sel[j] >> lane) & 1ull) != 0ull;
+                        const uint32_t room = p - sl.prev_end[j];
+                        uint32_t bk = (ext >> 8) & 0x3fu;
+                        bk = bk < room ? bk : room;
+                        const uint32_t cnt = (uint32_t)__builtin_popcountll(sl.sel[j]);
+                        const uint32_t below = bits_below_lane(sl.sel[j]);
+                        const uint32_t dest = sel ? base + below : (base + cnt + (lane - below)) & 63u;
+                        q_lit0 = queue_push(q_lit0, sl.prev_end[j], dest, base, cnt);
+                        q_lit = queue_push(q_lit, room - bk, dest, base, cnt);
+                        q_off = queue_push(q_off, p - r.cand[j], dest, base, cnt);
+                        q_mlen = queue_push(q_mlen, 4u + (ext & 0xffu) + bk, dest, base, cnt);
+                        q_op = queue_push(q_op, sl.out_pos[j], dest, base, cnt);
+                        base += cnt;
+                        covered[j] = sl.covered[j];
+                    }
+                    q_n = base;
+                    op = sl.op;
+                    anchor = sl.anchor;
+                }
+            }
 #pragma unroll
             for (int j = 0; j < kSub; j++) {
+                if (fast_round) break;
                 const uint32_t pj = pos + 64u * j;
                 uint64_t mask = r.mask[j];
                 if (anchor > pj) mask = anchor - pj >= 64u ? 0ull : mask & (~0ull << (anchor - pj));

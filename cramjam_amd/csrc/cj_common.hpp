@@ -33,6 +33,7 @@ void launch_lz4_decode_lanes(const BatchArgs& a, hipStream_t s);  // one lane pe
 // parse (lane per chunk) + decode (workgroup per chunk, LDS-resident window); sync/meta are engine scratch
 void launch_lz4_classify(const BatchArgs& a, void* meta, void* lists, uint32_t lane_share, uint32_t wave_share, hipStream_t s);
 void launch_lz4_parse(const BatchArgs& a, void* sync, void* meta, hipStream_t s);
+void launch_lz4_parse_wave(const BatchArgs& a, void* sync, void* meta, hipStream_t s);      // wavefront per chunk: small / medium batches
 void launch_lz4_decode_lanes_listed(const BatchArgs& a, const void* lists, uint32_t lane_share, hipStream_t s);
 void launch_lz4_decode_listed(const BatchArgs& a, const void* lists, uint32_t wave_share, hipStream_t s);   // wave kernel on the classify kernel's early wave share
 void launch_lz4_decode_lds(const BatchArgs& a, const void* sync, const void* meta, hipStream_t s);
@@ -50,7 +51,8 @@ void launch_lz4_encode(const BatchArgs& a, hipStream_t s);
 void launch_snappy_decode(const BatchArgs& a, hipStream_t s);                                   // one wavefront per chunk
 void launch_snappy_decode_skipping(const BatchArgs& a, const void* meta, hipStream_t s);         // ... except chunks flagged for the lane kernel
 void launch_snappy_decode_lanes(const BatchArgs& a, const void* lists, uint32_t lane_share, hipStream_t s);   // one lane per chunk (all, or the listed share)
-void launch_snappy_parse(const BatchArgs& a, void* sync, void* meta, hipStream_t s);           // parse + LDS pipeline, like launch_lz4_parse
+void launch_snappy_parse(const BatchArgs& a, void* sync, void* meta, hipStream_t s);
+void launch_snappy_parse_wave(const BatchArgs& a, void* sync, void* meta, hipStream_t s);  // wavefront per chunk: small / medium batches           // parse + LDS pipeline, like launch_lz4_parse
 void launch_snappy_decode_routed(const BatchArgs& a, const void* meta, hipStream_t s);       // wave kernel on chunks the parse kernel routed to it
 void launch_snappy_encode(const BatchArgs& a, hipStream_t s);
 

@@ -147,14 +147,17 @@ typedef enum { CJ_OP_DECOMPRESS = 0, CJ_OP_COMPRESS = 1 } cj_op;
 
 /* flags */
 #define CJ_FLAG_LZ4_SIZE_PREFIX 1u   /* lz4: blocks carry / get the u32-LE length prefix (store_size) */
-/* LZ4-decode kernel-mapping overrides (tuning/testing; results are identical).  Default: batches of at
- * least CJ_LDS_MIN_CHUNKS chunks (env CJ_LDS_MIN_CHUNKS overrides) run "lane-per-chunk parse, then per chunk
- * either the workgroup-per-chunk decoder with the 64 KiB window in LDS (many short sequences) or the
- * wavefront-per-chunk decoder (few long runs)"; smaller batches map one wavefront per chunk directly. */
+/* Decode kernel-mapping overrides (tuning/testing; results are identical).  Default (batches of at least
+ * CJ_LDS_MIN_CHUNKS chunks, env override): "parse, then per chunk either the workgroup decoder with the 64 KiB output
+ * window resident in LDS (many short sequences) or the wavefront-per-chunk decoder (few long runs, chunks > 64 KiB)". */
 #define CJ_FLAG_FORCE_WAVE_PER_CHUNK 0x100u
 #define CJ_FLAG_FORCE_LANE_PER_CHUNK 0x200u
 #define CJ_FLAG_FORCE_LDS_PER_CHUNK  0x400u
-#define CJ_LDS_MIN_CHUNKS 8192
+#define CJ_LDS_MIN_CHUNKS 1
+/* below this many chunks the parse stage runs one WAVEFRONT per chunk (≈0.9 ms per 64 KiB chunk, independent of the
+ * batch size but one chunk per wave: 2.2 ms for 4 096 chunks), above it one LANE per chunk (3.5 ms flat, 64 chunks per
+ * wave: 3.2 ms for 4 096, 4.5 ms for 16 384); env CJ_WAVE_PARSE_MAX overrides */
+#define CJ_WAVE_PARSE_MAX_DEFAULT 6144
 /* share (n/20) of the short-sequence chunks of such a batch that is decoded by the lane-per-chunk kernel on an
  * internal auxiliary stream, concurrently with the LDS workgroup decoder (env CJ_LANE_SHARE overrides; 0 = off) */
 #define CJ_LANE_SHARE_DEFAULT 0

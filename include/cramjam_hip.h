@@ -16,8 +16,10 @@
  *     written into caller memory (the host layer allocates with the bound/len helpers and truncates).
  *   - every export is thread-safe and re-entrant (the reference calls with the GIL released,
  *     src/lz4.rs:84,126,163,205; src/snappy.rs:57,75,97,106).
- *   - all codec arithmetic runs in HIP kernels on the GPU.  There is NO CPU fallback: without a
- *     usable HIP device every compute entry point returns CJ_E_NO_DEVICE.
+ *   - all codec arithmetic (and the Snappy framing CRC-32C) runs in HIP kernels on the GPU.  There is NO CPU
+ *     fallback: without a usable HIP device every compute entry point returns CJ_E_NO_DEVICE.  The one
+ *     piece of checksum arithmetic on the host is the LZ4 frame format's XXH32 (a serial recurrence per frame;
+ *     it runs on a thread concurrently with the device batch — see DESIGN.md §5.5).
  */
 #ifndef CRAMJAM_HIP_H
 #define CRAMJAM_HIP_H

@@ -33,7 +33,8 @@ void launch_lz4_decode_lanes(const BatchArgs& a, hipStream_t s);  // one lane pe
 // parse (lane per chunk) + decode (workgroup per chunk, LDS-resident window); sync/meta are engine scratch
 void launch_lz4_classify(const BatchArgs& a, void* meta, void* lists, uint32_t lane_share, uint32_t wave_share, hipStream_t s);
 void launch_lz4_parse(const BatchArgs& a, void* sync, void* meta, hipStream_t s);
-void launch_lz4_parse_wave(const BatchArgs& a, void* sync, void* meta, hipStream_t s);      // wavefront per chunk: small / medium batches
+void launch_lz4_parse_wave(const BatchArgs& a, void* sync, void* meta, hipStream_t s);
+void launch_lz4_parse_spec(const BatchArgs& a, void* sync, void* meta, hipStream_t s);      // wavefront per chunk, 64 segments parsed at once      // wavefront per chunk: small / medium batches
 void launch_lz4_decode_lanes_listed(const BatchArgs& a, const void* lists, uint32_t lane_share, hipStream_t s);
 void launch_lz4_decode_listed(const BatchArgs& a, const void* lists, uint32_t wave_share, hipStream_t s);   // wave kernel on the classify kernel's early wave share
 void launch_lz4_decode_lds(const BatchArgs& a, const void* sync, const void* meta, hipStream_t s);

@@ -85,7 +85,12 @@ int launch_slice(cj_engine* e, cj_codec codec, cj_op op, const cj::BatchArgs& a,
                     const char* v = std::getenv("CJ_WAVE_PARSE_MAX");
                     return v ? (size_t)std::strtoull(v, nullptr, 10) : (size_t)CJ_WAVE_PARSE_MAX_DEFAULT;
                 }();
-                if (a.n_chunks < wave_parse_max) cj::launch_lz4_parse_wave(a, e->d_sync.p, e->d_pmeta.p, s);
+                static const size_t spec_parse_max = [] {
+                    const char* v = std::getenv("CJ_SPEC_PARSE_MAX");
+                    return v ? (size_t)std::strtoull(v, nullptr, 10) : (size_t)CJ_SPEC_PARSE_MAX_DEFAULT;
+                }();
+                if (a.n_chunks < spec_parse_max) cj::launch_lz4_parse_spec(a, e->d_sync.p, e->d_pmeta.p, s);
+                else if (a.n_chunks < wave_parse_max) cj::launch_lz4_parse_wave(a, e->d_sync.p, e->d_pmeta.p, s);
                 else cj::launch_lz4_parse(a, e->d_sync.p, e->d_pmeta.p, s);
                 static const int lds_variant = [] { const char* v = std::getenv("CJ_LDS_VARIANT"); return v ? std::atoi(v) : 2; }();
                 if (lds_variant == 2) {

@@ -53,6 +53,7 @@ void launch_snappy_decode(const BatchArgs& a, hipStream_t s);                   
 void launch_snappy_decode_skipping(const BatchArgs& a, const void* meta, hipStream_t s);         // ... except chunks flagged for the lane kernel
 void launch_snappy_decode_lanes(const BatchArgs& a, const void* lists, uint32_t lane_share, hipStream_t s);   // one lane per chunk (all, or the listed share)
 void launch_snappy_parse(const BatchArgs& a, void* sync, void* meta, hipStream_t s);
+void launch_snappy_parse_spec(const BatchArgs& a, void* sync, void* meta, hipStream_t s);  // wavefront per chunk, 64 segments parsed at once
 void launch_snappy_parse_wave(const BatchArgs& a, void* sync, void* meta, hipStream_t s);  // wavefront per chunk: small / medium batches           // parse + LDS pipeline, like launch_lz4_parse
 void launch_snappy_decode_routed(const BatchArgs& a, const void* meta, hipStream_t s);       // wave kernel on chunks the parse kernel routed to it
 void launch_snappy_encode(const BatchArgs& a, hipStream_t s);

@@ -152,7 +152,12 @@ int launch_slice(cj_engine* e, cj_codec codec, cj_op op, const cj::BatchArgs& a,
                     const char* v = std::getenv("CJ_WAVE_PARSE_MAX");
                     return v ? (size_t)std::strtoull(v, nullptr, 10) : (size_t)CJ_WAVE_PARSE_MAX_DEFAULT;
                 }();
-                if (a.n_chunks < sn_wave_parse_max) cj::launch_snappy_parse_wave(a, e->d_sync.p, e->d_pmeta.p, s);
+                static const size_t sn_spec_parse_max = [] {
+                    const char* v = std::getenv("CJ_SPEC_PARSE_MAX");
+                    return v ? (size_t)std::strtoull(v, nullptr, 10) : (size_t)CJ_SPEC_PARSE_MAX_DEFAULT;
+                }();
+                if (a.n_chunks < sn_spec_parse_max) cj::launch_snappy_parse_spec(a, e->d_sync.p, e->d_pmeta.p, s);
+                else if (a.n_chunks < sn_wave_parse_max) cj::launch_snappy_parse_wave(a, e->d_sync.p, e->d_pmeta.p, s);
                 else cj::launch_snappy_parse(a, e->d_sync.p, e->d_pmeta.p, s);
                 cj::launch_lz4_decode_lds2(a, e->d_sync.p, e->d_pmeta.p, e->d_tab.p, lists + 2, grid, s, CJ_CODEC_SNAPPY_RAW);
                 cj::launch_snappy_decode_routed(a, e->d_pmeta.p, s);

@@ -44,53 +44,135 @@ __device__ __forceinline__ uint32_t sp_ld32(uint32_t a_in, uint32_t p) {
     return __builtin_amdgcn_alignbyte(w1, w0, p & 3u);
 }
 
-// One sequence at position ip (relative to the block start).  Computes the literal length, the match length (0 for
-// the final, literal-only sequence), the offset and the position of the next sequence — from the input bytes only.
-// Returns false when a length field or the sequence itself runs past the input (malformed on whatever path it lies).
+// One sequence / record at position ip (relative to the start of the element stream).  `at` computes, FROM THE INPUT
+// BYTES ONLY, the literal length, the match length (0 = none), the offset and the position of the next one; it returns
+// false when a field or the item itself runs past the input (malformed on whatever path it lies).  `check` applies the
+// decoder's rules that need the output position (phase 4).
 struct Seq { uint32_t lit, mlen, offset, next; bool last; };
 
-__device__ __forceinline__ bool seq_at(uint32_t a_in, uint32_t ip, uint32_t iend, Seq& s) {
-    const uint32_t t4 = sp_ld32(a_in, ip);
-    const uint32_t token = t4 & 0xffu;
-    ip += 1;
-    uint32_t lit = token >> 4;
-    if (lit == 15u) {
-        if (ip + 15u >= iend) return false;
-        uint32_t b = (t4 >> 8) & 0xffu;
-        ip += 1; lit += b;
-        if (ip + 15u > iend) return false;
-        while (b == 255u) {
-            b = sp_ld32(a_in, ip) & 0xffu;
+struct Lz4Grammar {
+    static __device__ __forceinline__ bool at(uint32_t a_in, uint32_t ip, uint32_t iend, Seq& s) {
+        const uint32_t t4 = sp_ld32(a_in, ip);
+        const uint32_t token = t4 & 0xffu;
+        ip += 1;
+        uint32_t lit = token >> 4;
+        if (lit == 15u) {
+            if (ip + 15u >= iend) return false;
+            uint32_t b = (t4 >> 8) & 0xffu;
             ip += 1; lit += b;
             if (ip + 15u > iend) return false;
+            while (b == 255u) {
+                b = sp_ld32(a_in, ip) & 0xffu;
+                ip += 1; lit += b;
+                if (ip + 15u > iend) return false;
+            }
         }
-    }
-    s.lit = lit;
-    const uint32_t rem_in = iend - ip;
-    if (rem_in < lit + 8u) {                     // can only be the final sequence: it must consume the input exactly
-        s.last = true; s.mlen = 0; s.offset = 0; s.next = kPosEnd;
-        return rem_in == lit;
-    }
-    s.last = false;
-    ip += lit;
-    const uint32_t o4 = sp_ld32(a_in, ip);
-    s.offset = o4 & 0xffffu;
-    ip += 2;
-    uint32_t mlen = token & 15u;
-    if (mlen == 15u) {
-        uint32_t b = (o4 >> 16) & 0xffu;
-        ip += 1; mlen += b;
-        if (ip + 4u > iend) return false;
-        while (b == 255u) {
-            b = sp_ld32(a_in, ip) & 0xffu;
+        s.lit = lit;
+        const uint32_t rem_in = iend - ip;
+        if (rem_in < lit + 8u) {                     // can only be the final sequence: it must consume the input exactly
+            s.last = true; s.mlen = 0; s.offset = 0; s.next = kPosEnd;
+            return rem_in == lit;
+        }
+        s.last = false;
+        ip += lit;
+        const uint32_t o4 = sp_ld32(a_in, ip);
+        s.offset = o4 & 0xffffu;
+        ip += 2;
+        uint32_t mlen = token & 15u;
+        if (mlen == 15u) {
+            uint32_t b = (o4 >> 16) & 0xffu;
             ip += 1; mlen += b;
             if (ip + 4u > iend) return false;
+            while (b == 255u) {
+                b = sp_ld32(a_in, ip) & 0xffu;
+                ip += 1; mlen += b;
+                if (ip + 4u > iend) return false;
+            }
         }
+        s.mlen = mlen + 4u;
+        s.next = ip;
+        return true;
     }
-    s.mlen = mlen + 4u;
-    s.next = ip;
-    return true;
-}
+    // LZ4_decompress_safe's rules with the output capacity (same as lz4_parse_kernel).  Returns false = malformed;
+    // `fin` is set when this was the final sequence.
+    static __device__ __forceinline__ bool check(const Seq& s, uint32_t& op, uint32_t cap, bool& fin) {
+        const uint32_t rem_out = cap - op;
+        fin = false;
+        if (s.last || rem_out < s.lit + 12u) {
+            // must be the final sequence: consumes the input exactly (`at` checked that when s.last), fits the output
+            if (!s.last || rem_out < s.lit) return false;
+            op += s.lit; fin = true;
+            return true;
+        }
+        op += s.lit;
+        if (s.offset == 0u || s.offset > op) return false;
+        if (cap - op < s.mlen + 5u) return false;
+        op += s.mlen;
+        return true;
+    }
+    static __device__ __forceinline__ bool result_ok(uint32_t, uint32_t) { return true; }
+};
+
+// Snappy: a record = optional literal element + optional copy element (snappy_records.hpp); cap = the decoded length dn
+struct SnappyGrammar {
+    static __device__ __forceinline__ bool at(uint32_t a_in, uint32_t ip, uint32_t iend, Seq& s) {
+        uint32_t t4 = sp_ld32(a_in, ip);
+        uint32_t tag = t4 & 0xffu;
+        s.lit = 0; s.mlen = 0; s.offset = 0; s.last = false;
+        if ((tag & 3u) == 0u) {
+            ip += 1;
+            uint64_t len = (tag >> 2) + 1u;
+            if (len > 60u) {
+                const uint32_t nb = (uint32_t)len - 60u;
+                if (iend - ip < nb) return false;
+                uint32_t v = sp_ld32(a_in, ip);
+                if (nb < 4u) v &= (1u << (8u * nb)) - 1u;
+                ip += nb;
+                len = (uint64_t)v + 1u;
+            }
+            if (len > (uint64_t)(iend - ip)) return false;
+            s.lit = (uint32_t)len;
+            ip += (uint32_t)len;
+            if (ip >= iend) { s.last = true; s.next = kPosEnd; return true; }
+            t4 = sp_ld32(a_in, ip);
+            tag = t4 & 0xffu;
+            if ((tag & 3u) == 0u) { s.next = ip; return true; }       // another literal follows: it starts the next record
+        }
+        const uint32_t kind = tag & 3u;
+        ip += 1;
+        if (kind == 1u) {
+            if (iend - ip < 1u) return false;
+            s.mlen = 4u + ((tag >> 2) & 7u);
+            s.offset = ((tag >> 5) << 8) | ((t4 >> 8) & 0xffu);
+            ip += 1;
+        } else if (kind == 2u) {
+            if (iend - ip < 2u) return false;
+            s.mlen = 1u + (tag >> 2);
+            s.offset = (t4 >> 8) & 0xffffu;
+            ip += 2;
+        } else {
+            if (iend - ip < 4u) return false;
+            s.mlen = 1u + (tag >> 2);
+            s.offset = sp_ld32(a_in, ip);
+            ip += 4;
+        }
+        if (ip >= iend) { s.last = true; s.next = kPosEnd; }
+        else s.next = ip;
+        return true;
+    }
+    static __device__ __forceinline__ bool check(const Seq& s, uint32_t& op, uint32_t dn, bool& fin) {
+        fin = s.last;
+        if (s.lit > dn - op) return false;
+        op += s.lit;
+        if (s.mlen) {
+            if (s.offset == 0u || s.offset > op) return false;
+            if (s.mlen > dn - op) return false;
+            op += s.mlen;
+        }
+        return true;
+    }
+    static __device__ __forceinline__ bool result_ok(uint32_t op_end, uint32_t dn) { return op_end == dn; }
+};
 
 __device__ __forceinline__ uint32_t wave_excl_scan_add(uint32_t v, uint32_t& total) {
     const uint32_t lane = lane_id();
@@ -106,30 +188,11 @@ __device__ __forceinline__ uint32_t wave_excl_scan_add(uint32_t v, uint32_t& tot
 
 }  // namespace
 
-__global__ __launch_bounds__(64) void lz4_parse_spec_kernel(BatchArgs a, uint2* sync, ParseMeta* meta) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t c = blockIdx.x;
-    if (c >= a.n_chunks) return;
-    if ((meta[c].in_skip & kRouteLane) != 0u) return;
+// The segmented walk over the staged element stream in[0, iend) (global pointer `in`, any alignment).  cap = output
+// capacity (LZ4) / decoded length (Snappy).  Returns the decoded size or -1 (malformed); nseq_out = number of sequences.
+template <class G>
+__device__ __forceinline__ int64_t spec_walk(const uint8_t* in, uint32_t iend, uint32_t cap, uint2* csync, uint8_t* smem, uint32_t& nseq_out) {
     const uint32_t lane = lane_id();
-    const uint8_t* in = a.in_base + a.in_off[c];
-    const uint8_t* const in0 = in;
-    uint64_t n64 = a.in_len[c], cap64 = a.out_cap[c];
-    ParseMeta pm = {0u, 0u};
-    int64_t r = lz4_block_prologue(a.flags, in, n64, cap64);
-    bool walk = false;
-    if (r == 0) {
-        const uint32_t cap0 = (uint32_t)cap64, iend0 = (uint32_t)n64;
-        if (cap0 == 0) r = (iend0 == 1 && in[0] == 0) ? 0 : (int64_t)CJ_E_CORRUPT;
-        else if (iend0 == 0) r = CJ_E_CORRUPT;
-        else if (cap0 > kLdsOutMax || iend0 > kLdsInMax) pm.in_skip = kRouteWave;      // too big for the LDS window
-        else walk = true;
-    }
-    if (!walk) {
-        if (lane == 0) { a.result[c] = r; meta[c] = pm; }
-        return;
-    }
-    const uint32_t iend = (uint32_t)n64, cap = (uint32_t)cap64;
     uint32_t* s_bits = reinterpret_cast<uint32_t*>(smem + kSpecLdsIn);
     const uint32_t a_bits = (uint32_t)(uintptr_t)s_bits;
 
@@ -165,7 +228,7 @@ __global__ __launch_bounds__(64) void lz4_parse_spec_kernel(BatchArgs a, uint2* 
         if (p < seg_end && p < iend) {
             asm volatile("ds_or_b32 %0, %1" :: "v"(a_bits + 4u * (p >> 5)), "v"(1u << (p & 31u)) : "memory");
             Seq s;
-            p = seq_at(a_in, p, iend, s) ? s.next : kPosErr;
+            p = G::at(a_in, p, iend, s) ? s.next : kPosErr;
         }
     }
     __syncthreads();                                      // all marks are in place
@@ -181,7 +244,7 @@ __global__ __launch_bounds__(64) void lz4_parse_spec_kernel(BatchArgs a, uint2* 
                 if ((w >> (p & 31u)) & 1u) { merge_pos = p; going = false; }
                 else {
                     Seq s;
-                    p = seq_at(a_in, p, iend, s) ? s.next : kPosErr;
+                    p = G::at(a_in, p, iend, s) ? s.next : kPosErr;
                     if (p >= iend) { merge_pos = p; going = false; }      // kPosEnd, kPosErr (or a position past the input: malformed)
                 }
             }
@@ -213,7 +276,7 @@ __global__ __launch_bounds__(64) void lz4_parse_spec_kernel(BatchArgs a, uint2* 
         while (ballot64(q < iend && q != piece_end) != 0ull) {
             if (q < iend && q != piece_end) {
                 Seq s;
-                if (seq_at(a_in, q, iend, s)) { cnt += 1; outb += s.lit + s.mlen; q = s.next; }
+                if (G::at(a_in, q, iend, s)) { cnt += 1; outb += s.lit + s.mlen; q = s.next; }
                 else q = kPosErr;
             }
         }
@@ -223,7 +286,6 @@ __global__ __launch_bounds__(64) void lz4_parse_spec_kernel(BatchArgs a, uint2* 
     const uint32_t base_op = wave_excl_scan_add(outb, total_out);
 
     // ---- 4: walk the pieces with the true sequence index and output position: validation + sync points ----
-    uint2* csync = sync + (size_t)c * kSyncStride;
     bool bad = false;
     uint32_t final_op = 0;                                // set by the lane that meets the last sequence
     bool saw_last = false;
@@ -236,48 +298,110 @@ __global__ __launch_bounds__(64) void lz4_parse_spec_kernel(BatchArgs a, uint2* 
                     if (slot < kSyncStride) csync[slot] = make_uint2(q, op);
                 }
                 Seq s;
-                if (!seq_at(a_in, q, iend, s)) { bad = true; }
-                else {
-                    // LZ4_decompress_safe's rules with the output capacity (same as lz4_parse_kernel)
-                    const uint32_t rem_out = cap - op;
-                    if (s.last || rem_out < s.lit + 12u) {
-                        // must be the final sequence: consumes the input exactly (seq_at checked that when s.last), fits the output
-                        if (!s.last || rem_out < s.lit) bad = true;
-                        else { op += s.lit; final_op = op; saw_last = true; q = kPosEnd; }
-                    } else {
-                        op += s.lit;
-                        if (s.offset == 0u || s.offset > op) bad = true;
-                        else if (cap - op < s.mlen + 5u) bad = true;
-                        else { op += s.mlen; q = s.next; idx += 1; }
-                    }
-                }
+                bool fin = false;
+                if (!G::at(a_in, q, iend, s) || !G::check(s, op, cap, fin)) bad = true;
+                else if (fin) { final_op = op; saw_last = true; q = kPosEnd; }
+                else { q = s.next; idx += 1; }
             }
         }
     }
     // the chain must end in a last sequence and nothing on it may be malformed
     const bool any_bad = ballot64(on_chain && (bad || piece_end == kPosErr)) != 0ull;
     const uint64_t last_lanes = ballot64(on_chain && saw_last);
-    if (any_bad || last_lanes == 0ull) r = CJ_E_CORRUPT;
-    else {
-        const uint32_t ll = ctz64(last_lanes);
-        const uint32_t op_end = rdlane(final_op, ll);
-        const uint32_t nseq = total_seq;
-        r = (int64_t)op_end;
-        if (r > 0) {
+    nseq_out = total_seq;
+    if (any_bad || last_lanes == 0ull) return -1;
+    const uint32_t op_end = rdlane(final_op, ctz64(last_lanes));
+    if (!G::result_ok(op_end, cap)) return -1;
+    return (int64_t)op_end;
+}
+
+__global__ __launch_bounds__(64) void lz4_parse_spec_kernel(BatchArgs a, uint2* sync, ParseMeta* meta) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t c = blockIdx.x;
+    if (c >= a.n_chunks) return;
+    if ((meta[c].in_skip & kRouteLane) != 0u) return;
+    const uint32_t lane = lane_id();
+    const uint8_t* in = a.in_base + a.in_off[c];
+    const uint8_t* const in0 = in;
+    uint64_t n64 = a.in_len[c], cap64 = a.out_cap[c];
+    ParseMeta pm = {0u, 0u};
+    int64_t r = lz4_block_prologue(a.flags, in, n64, cap64);
+    bool walk = false;
+    if (r == 0) {
+        const uint32_t cap0 = (uint32_t)cap64, iend0 = (uint32_t)n64;
+        if (cap0 == 0) r = (iend0 == 1 && in[0] == 0) ? 0 : (int64_t)CJ_E_CORRUPT;
+        else if (iend0 == 0) r = CJ_E_CORRUPT;
+        else if (cap0 > kLdsOutMax || iend0 > kLdsInMax) pm.in_skip = kRouteWave;      // too big for the LDS window
+        else walk = true;
+    }
+    if (walk) {
+        uint32_t nseq = 0;
+        r = spec_walk<Lz4Grammar>(in, (uint32_t)n64, (uint32_t)cap64, sync + (size_t)c * kSyncStride, smem, nseq);
+        if (r < 0) r = CJ_E_CORRUPT;
+        else if (r > 0) {
             if ((nseq + kSyncEvery - 1u) / kSyncEvery > kSyncStride || nseq < kLdsMinSeq) pm.in_skip = kRouteWave;
             else { pm.nseq = nseq; pm.in_skip = (uint32_t)(in - in0); }
         }
     }
-    if (lane == 0) {
-        a.result[c] = r;
-        meta[c] = pm;
+    if (lane == 0) { a.result[c] = r; meta[c] = pm; }
+}
+
+__global__ __launch_bounds__(64) void snappy_parse_spec_kernel(BatchArgs a, uint2* sync, ParseMeta* meta) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t c = blockIdx.x;
+    if (c >= a.n_chunks) return;
+    if ((meta[c].in_skip & kRouteLane) != 0u) return;
+    const uint32_t lane = lane_id();
+    const uint8_t* in = a.in_base + a.in_off[c];
+    const uint64_t n64 = a.in_len[c], cap64 = a.out_cap[c];
+    ParseMeta pm = {0u, 0u};
+    int64_t r = 0;
+    uint32_t dn = 0, hdr = 0;
+    bool walk = false;
+    if (n64 == 0) r = CJ_E_SNAPPY_EMPTY;
+    else if (n64 > 0xFFFFFFF0ull) r = CJ_E_SNAPPY_CORRUPT;
+    else {
+        uint64_t ulen = 0;
+        uint32_t shift = 0, i = 0;
+        bool ok = false;
+        while (hdr < (uint32_t)n64 && i < 10u) {
+            const uint32_t b = in[hdr];
+            hdr += 1;
+            if (b < 0x80u) { if (!(i == 9u && b > 1u)) { ulen |= (uint64_t)b << shift; ok = true; } break; }
+            ulen |= (uint64_t)(b & 0x7fu) << shift;
+            shift += 7; i += 1;
+        }
+        if (!ok) r = CJ_E_SNAPPY_HEADER;
+        else if (ulen > 0xFFFFFFFFull) r = CJ_E_SNAPPY_TOO_BIG;
+        else if (ulen > cap64) r = CJ_E_SNAPPY_BUF_SMALL;
+        else if (ulen == 0) r = (hdr == (uint32_t)n64) ? 0 : (int64_t)CJ_E_SNAPPY_CORRUPT;
+        else if (ulen > kLdsOutMax || n64 - hdr > kLdsInMax) pm.in_skip = kRouteWave;
+        else if (hdr == (uint32_t)n64) r = CJ_E_SNAPPY_CORRUPT;                 // a length but no elements
+        else { dn = (uint32_t)ulen; walk = true; }
     }
+    if (walk) {
+        uint32_t nrec = 0;
+        r = spec_walk<SnappyGrammar>(in + hdr, (uint32_t)n64 - hdr, dn, sync + (size_t)c * kSyncStride, smem, nrec);
+        if (r < 0) r = CJ_E_SNAPPY_CORRUPT;
+        else {
+            if ((nrec + kSyncEvery - 1u) / kSyncEvery > kSyncStride || nrec < kLdsMinSeq) pm.in_skip = kRouteWave;
+            else { pm.nseq = nrec; pm.in_skip = hdr; }
+        }
+    }
+    if (lane == 0) { a.result[c] = r; meta[c] = pm; }
 }
 
 void launch_lz4_parse_spec(const BatchArgs& a, void* sync, void* meta, hipStream_t s) {
     if (a.n_chunks == 0) return;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_parse_spec_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSpecLdsBytes);
     hipLaunchKernelGGL(lz4_parse_spec_kernel, dim3(a.n_chunks), dim3(64), kSpecLdsBytes, s, a, (uint2*)sync, (ParseMeta*)meta);
+}
+
+
+void launch_snappy_parse_spec(const BatchArgs& a, void* sync, void* meta, hipStream_t s) {
+    if (a.n_chunks == 0) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(snappy_parse_spec_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSpecLdsBytes);
+    hipLaunchKernelGGL(snappy_parse_spec_kernel, dim3(a.n_chunks), dim3(64), kSpecLdsBytes, s, a, (uint2*)sync, (ParseMeta*)meta);
 }
 
 }  // namespace cj

@@ -202,13 +202,17 @@ __device__ __forceinline__ int64_t spec_walk(const uint8_t* in, uint32_t iend, u
         const uint4* src = reinterpret_cast<const uint4*>(in - mis);
         uint4* dst = reinterpret_cast<uint4*>(smem);
         const uint32_t nvec = (mis + iend + 15u) >> 4;
-        for (uint32_t i0 = 0; i0 < nvec; i0 += 64u * 16u) {       // 16 loads in flight per lane: one wave must not pay a round trip per KiB
-            uint4 v[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) { const uint32_t i = i0 + 64u * k + lane; if (i < nvec) v[k] = src[i]; }
-#pragma unroll
-            for (int k = 0; k < 16; k++) { const uint32_t i = i0 + 64u * k + lane; if (i < nvec) dst[i] = v[k]; }
+        // 8 loads in flight per lane (one wave must not pay a round trip per KiB).  Named scalars and clamped indices —
+        // lanes past the end repeat the last vector: with an array or a predicated access the compiler keeps the
+        // values in scratch memory.
+#define CJ_SP_LD(k) const uint32_t j##k = b0 + 64u * k##u + lane; const uint32_t x##k = j##k < nvec ? j##k : nvec - 1u; const uint4 v##k = src[x##k];
+#define CJ_SP_ST(k) dst[x##k] = v##k;
+        for (uint32_t b0 = 0; b0 < nvec; b0 += 64u * 8u) {
+            CJ_SP_LD(0) CJ_SP_LD(1) CJ_SP_LD(2) CJ_SP_LD(3) CJ_SP_LD(4) CJ_SP_LD(5) CJ_SP_LD(6) CJ_SP_LD(7)
+            CJ_SP_ST(0) CJ_SP_ST(1) CJ_SP_ST(2) CJ_SP_ST(3) CJ_SP_ST(4) CJ_SP_ST(5) CJ_SP_ST(6) CJ_SP_ST(7)
         }
+#undef CJ_SP_LD
+#undef CJ_SP_ST
         for (uint32_t i = lane; i < 2048u; i += 64u) s_bits[i] = 0u;
     }
     __syncthreads();

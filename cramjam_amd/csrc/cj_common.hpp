@@ -24,6 +24,7 @@ struct BatchArgs {
 // internal flag bits (never part of the C-ABI): 0x1000 = LDS decoder phase profile, 0x2000 = linked-frame parse
 // (bit 63 of in_len marks a STORED block; no minimum sequence count for the LDS decoder)
 constexpr uint32_t kFlagLinkedFrame = 0x2000u;
+constexpr uint32_t kFlagReportTail = 0x4000u;      // LZ4 encoder (large.hip): result = size | length of the final literal run << 32
 
 constexpr int kWavesPerBlock = 4;
 constexpr int kBlockThreads = 64 * kWavesPerBlock;
@@ -53,6 +54,9 @@ void launch_snappy_decode(const BatchArgs& a, hipStream_t s);                   
 void launch_snappy_decode_skipping(const BatchArgs& a, const void* meta, hipStream_t s);         // ... except chunks flagged for the lane kernel
 void launch_snappy_decode_lanes(const BatchArgs& a, const void* lists, uint32_t lane_share, hipStream_t s);   // one lane per chunk (all, or the listed share)
 void launch_snappy_parse(const BatchArgs& a, void* sync, void* meta, hipStream_t s);
+// large.hip: one large buffer cut into pieces that are compressed as a batch and joined into one stream
+int64_t large_snappy_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap);
+int64_t large_lz4_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap, bool prefix);
 void launch_snappy_parse_spec(const BatchArgs& a, void* sync, void* meta, hipStream_t s);  // wavefront per chunk, 64 segments parsed at once
 void launch_snappy_parse_wave(const BatchArgs& a, void* sync, void* meta, hipStream_t s);  // wavefront per chunk: small / medium batches           // parse + LDS pipeline, like launch_lz4_parse
 void launch_snappy_decode_routed(const BatchArgs& a, const void* meta, hipStream_t s);       // wave kernel on chunks the parse kernel routed to it

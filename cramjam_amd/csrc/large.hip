@@ -1,0 +1,204 @@
+// large.hip — ONE large buffer through the single-buffer C-ABI (cj_lz4_block_compress, cj_snappy_raw_compress: what the
+// reference reaches at /root/reference/src/lz4.rs:168 compress_block and /root/reference/src/snappy.rs:57 compress_raw).
+// A batch gives the GPU one independent stream per wavefront; a single 100 MB buffer handed to compress_block would be
+// ONE stream on ONE wavefront (0.04 GB/s measured).  Both raw formats allow cutting the INPUT into pieces that are
+// compressed independently and joined into one valid stream:
+//   * Snappy raw = varint(total length) + elements.  Elements never refer to anything but earlier output, so the element
+//     streams of consecutive 64 KiB pieces (each compressed with its own hash table — which is also how snap's own
+//     encoder works through a large input, 64 KiB block by block) simply concatenate.
+//   * LZ4 block = sequences (literal run + match), the last one literal-only.  The pieces' streams are stitched: the
+//     trailing literal-only sequence of piece k is dropped and its bytes are prepended to the literal run of the first
+//     sequence of the next piece that has a match (literals are copies of the INPUT, so the merged run is one contiguous
+//     input range); only that one token and its length bytes are rewritten.  Every piece obeys LZ4's end-of-block rules
+//     on its own, so the joined stream does too.
+// The result is a stream any LZ4 / Snappy decoder accepts (round trip through the oracle decoders: tests/test_large_gpu.py);
+// like all compressed output of this library it is not byte-identical to liblz4's / snap's.
+#include "cj_engine.hpp"
+
+namespace cj {
+
+void launch_copy_segments(const uint64_t* src, uint8_t* dst_base, const uint64_t* dst_off, const uint64_t* len,
+                          const uint64_t* hdr, uint32_t hdr_len, uint32_t n, hipStream_t s);      // frame_kernels.hip
+
+namespace {
+
+constexpr size_t kPiece = 65536;
+constexpr size_t kLz4Stride = 65824;          // LZ4_compressBound(65536) = 65809, rounded up to 16
+constexpr size_t kSnStride = 76512;           // snap max_compress_len(65536) = 76490, rounded up to 16
+
+__host__ __device__ inline uint32_t lz4_len_ext(uint32_t len) { return len < 15u ? 0u : (len - 15u) / 255u + 1u; }
+
+// first_lit[i] = literal length of the first sequence of piece i's stream
+__global__ __launch_bounds__(256) void lz4_stitch_plan_kernel(const uint8_t* tmp, uint32_t* first_lit, uint32_t np) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= np) return;
+    const uint8_t* p = tmp + (size_t)i * kLz4Stride;
+    uint32_t lit = p[0] >> 4, q = 1;
+    if (lit == 15u) {
+        uint32_t b;
+        do { b = p[q++]; lit += b; } while (b == 255u);
+    }
+    first_lit[i] = lit;
+}
+
+// One wavefront per descriptor: token + length bytes of the merged literal run, the run itself (from the input), then the
+// rest of the piece's stream.  d = {dst offset, run start (input offset), run length, body source (device address), body
+// length, address of the piece's first token (its low nibble = the match length code; 0 = literal-only sequence)};
+// run length 0 and body length 0 = nothing to write.
+struct Stitch { uint64_t dst, run_start, run, body_src, body_len, tok_src; };
+
+__global__ __launch_bounds__(kBlockThreads) void lz4_stitch_kernel(const Stitch* d, const uint8_t* in, uint8_t* out, uint32_t n) {
+    const uint32_t k = uni(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+    if (k >= n) return;
+    const Stitch s = d[k];
+    const uint32_t run = (uint32_t)s.run;
+    if (run == 0u && s.body_len == 0ull) return;
+    const uint32_t nib = s.tok_src ? (uint32_t)(*reinterpret_cast<const uint8_t*>(s.tok_src)) & 15u : 0u;
+    uint8_t* o = out + s.dst;
+    const uint32_t lane = lane_id();
+    if (lane == 0) o[0] = (uint8_t)(((run < 15u ? run : 15u) << 4) | nib);
+    const uint32_t ext = lz4_len_ext(run);
+    if (ext) {
+        const uint32_t rem = run - 15u;
+        for (uint32_t q = lane; q < ext; q += 64u) o[1u + q] = (uint8_t)(q + 1u < ext ? 255u : rem - 255u * (ext - 1u));
+    }
+    wave_copy(o + 1u + ext, in + s.run_start, run);
+    if (s.body_len) wave_copy(o + 1u + ext + run, reinterpret_cast<const uint8_t*>(s.body_src), (uint32_t)s.body_len);
+}
+
+inline uint32_t varint_len(uint64_t v) { uint32_t k = 1; while (v >= 0x80u) { v >>= 7; k++; } return k; }
+
+}  // namespace
+
+// compress the np pieces of d_in as one batch into d_tmp (stride bytes apart); results -> res
+static int compress_pieces(cj_engine* e, cj_codec codec, uint32_t flags, const uint8_t* in, size_t n, size_t np, size_t stride,
+                           std::vector<int64_t>& res) {
+    hipStream_t s = e->stream;
+    if (!e->d_in.reserve(n + 16) || !e->d_out.reserve(np * stride + 16) || !e->d_meta.reserve(12 * np * 8)) return CJ_E_OOM;
+    uint8_t* d_in = (uint8_t*)e->d_in.p;
+    uint64_t* d_meta = (uint64_t*)e->d_meta.p;
+    std::vector<uint64_t>& m = e->h_meta;
+    m.assign(12 * np, 0);
+    for (size_t i = 0; i < np; i++) {
+        m[i] = i * kPiece;
+        m[np + i] = std::min(kPiece, n - i * kPiece);
+        m[2 * np + i] = i * stride;
+        m[3 * np + i] = stride;
+    }
+    HIP_TRY(hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
+    HIP_TRY(hipMemcpyAsync(d_meta, m.data(), 4 * np * 8, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
+    BatchArgs a;
+    fill_args(a, flags, np, d_in, d_meta, d_meta + np, (uint8_t*)e->d_out.p, d_meta + 2 * np, d_meta + 3 * np, (int64_t*)(d_meta + 4 * np));
+    const int rc = launch(e, codec, CJ_OP_COMPRESS, a, s);
+    if (rc != 0) return rc;
+    res.resize(np);
+    HIP_TRY(hipMemcpyAsync(res.data(), d_meta + 4 * np, np * 8, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
+    return 0;
+}
+
+int64_t large_snappy_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap) {
+    cj_engine* e = default_engine();
+    if (!e) return CJ_E_NO_DEVICE;
+    if (n > 0xFFFFFFFFull) return CJ_E_SNAPPY_TOO_BIG;
+    const size_t np = (n + kPiece - 1) / kPiece;
+    std::lock_guard<std::mutex> lock(e->mu);
+    HIP_TRY(hipSetDevice(e->device), CJ_E_NO_DEVICE);
+    hipStream_t s = e->stream;
+    std::vector<int64_t> res;
+    int rc = compress_pieces(e, CJ_CODEC_SNAPPY_RAW, 0u, in, n, np, kSnStride, res);
+    if (rc != 0) return rc;
+    HIP_TRY(hipStreamSynchronize(s), CJ_E_NO_DEVICE);
+
+    std::vector<uint64_t>& m = e->h_meta;
+    uint8_t hdr[10];
+    uint32_t hl = 0;
+    for (uint64_t v = n;; ) { if (v < 0x80u) { hdr[hl++] = (uint8_t)v; break; } hdr[hl++] = (uint8_t)(v | 0x80u); v >>= 7; }
+    uint64_t pos = hl;
+    uint8_t* d_tmp = (uint8_t*)e->d_out.p;
+    for (size_t i = 0; i < np; i++) {
+        if (res[i] < 0) return res[i];
+        const uint32_t ph = varint_len(m[np + i]);             // the piece's own length header is dropped
+        const uint64_t body = (uint64_t)res[i] - ph;
+        m[5 * np + i] = (uint64_t)(uintptr_t)(d_tmp + i * kSnStride + ph);
+        m[6 * np + i] = pos;
+        m[7 * np + i] = body;
+        pos += body;
+    }
+    if (pos > cap) return CJ_E_SNAPPY_BUF_SMALL;
+    if (!e->d_frame.reserve(pos + 16)) return CJ_E_OOM;
+    uint8_t* d_frame = (uint8_t*)e->d_frame.p;
+    uint64_t* d_meta = (uint64_t*)e->d_meta.p;
+    HIP_TRY(hipMemcpyAsync(d_frame, hdr, hl, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
+    HIP_TRY(hipMemcpyAsync(d_meta + 5 * np, m.data() + 5 * np, 3 * np * 8, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
+    launch_copy_segments(d_meta + 5 * np, d_frame, d_meta + 6 * np, d_meta + 7 * np, nullptr, 0, (uint32_t)np, s);
+    HIP_TRY(hipGetLastError(), CJ_E_NO_DEVICE);
+    HIP_TRY(hipMemcpyAsync(out, d_frame, pos, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
+    HIP_TRY(hipStreamSynchronize(s), CJ_E_NO_DEVICE);
+    return (int64_t)pos;
+}
+
+int64_t large_lz4_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap, bool prefix) {
+    cj_engine* e = default_engine();
+    if (!e) return CJ_E_NO_DEVICE;
+    const size_t np = (n + kPiece - 1) / kPiece;
+    const size_t pre = prefix ? 4 : 0;
+    if (cap < pre) return CJ_E_COMPRESS_FAILED;
+    std::lock_guard<std::mutex> lock(e->mu);
+    HIP_TRY(hipSetDevice(e->device), CJ_E_NO_DEVICE);
+    hipStream_t s = e->stream;
+    std::vector<int64_t> res;
+    int rc = compress_pieces(e, CJ_CODEC_LZ4_BLOCK, kFlagReportTail, in, n, np, kLz4Stride, res);
+    if (rc != 0) return rc;
+    uint64_t* d_meta = (uint64_t*)e->d_meta.p;
+    uint8_t* d_tmp = (uint8_t*)e->d_out.p;
+    uint32_t* d_first = (uint32_t*)(d_meta + 5 * np);
+    hipLaunchKernelGGL(lz4_stitch_plan_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, d_tmp, d_first, (uint32_t)np);
+    HIP_TRY(hipGetLastError(), CJ_E_NO_DEVICE);
+    std::vector<uint32_t> first(np);
+    HIP_TRY(hipMemcpyAsync(first.data(), d_first, np * 4, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
+    HIP_TRY(hipStreamSynchronize(s), CJ_E_NO_DEVICE);
+
+    std::vector<Stitch> plan(np);
+    uint64_t pos = 0, pending = 0;                 // pending = literal bytes before this piece that no sequence carries yet
+    for (size_t i = 0; i < np; i++) {
+        if (res[i] < 0) return res[i];
+        const uint64_t len = std::min(kPiece, n - i * kPiece);
+        const uint32_t r = (uint32_t)((uint64_t)res[i] & 0xFFFFFFFFull), tail = (uint32_t)((uint64_t)res[i] >> 32);
+        const uint32_t l2 = first[i];
+        const bool last = i + 1 == np, has_match = l2 < len;
+        Stitch d = {pos, i * kPiece - pending, 0, 0, 0, 0};
+        if (has_match) {
+            const uint32_t skip = 1u + lz4_len_ext(l2) + l2;                         // token, length bytes and literals of the first sequence
+            const uint32_t end = last ? r : r - (1u + lz4_len_ext(tail) + tail);     // non-final pieces lose their literal-only last sequence
+            const uint64_t run = pending + l2;
+            d.run = run;
+            d.tok_src = (uint64_t)(uintptr_t)(d_tmp + i * kLz4Stride);
+            d.body_src = d.tok_src + skip;
+            d.body_len = end - skip;
+            pos += 1u + lz4_len_ext((uint32_t)run) + run + d.body_len;
+            pending = last ? 0 : tail;
+        } else {
+            pending += len;
+            if (last) {                                                               // the block ends with one literal-only sequence
+                d.run = pending;
+                pos += 1u + lz4_len_ext((uint32_t)pending) + pending;
+                pending = 0;
+            }
+        }
+        plan[i] = d;
+    }
+    if (pos + pre > cap) return CJ_E_COMPRESS_FAILED;
+    if (!e->d_frame.reserve(pos + np * sizeof(Stitch) + 64)) return CJ_E_OOM;
+    uint8_t* d_frame = (uint8_t*)e->d_frame.p;
+    Stitch* d_plan = reinterpret_cast<Stitch*>(d_frame + ((pos + 15u) & ~(uint64_t)15u));
+    HIP_TRY(hipMemcpyAsync(d_plan, plan.data(), np * sizeof(Stitch), hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
+    hipLaunchKernelGGL(lz4_stitch_kernel, dim3((unsigned)((np + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlockThreads), 0, s,
+                       d_plan, (const uint8_t*)e->d_in.p, d_frame, (uint32_t)np);
+    HIP_TRY(hipGetLastError(), CJ_E_NO_DEVICE);
+    if (prefix) { const uint32_t v = (uint32_t)n; std::memcpy(out, &v, 4); }
+    HIP_TRY(hipMemcpyAsync(out + pre, d_frame, pos, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
+    HIP_TRY(hipStreamSynchronize(s), CJ_E_NO_DEVICE);
+    return (int64_t)(pos + pre);
+}
+
+}  // namespace cj

@@ -161,15 +161,17 @@ __global__ __launch_bounds__(kEncThreads) void lz4_encode_kernel(BatchArgs a) {
             pos = anchor > round_end ? anchor : round_end;
         }
     }
+    uint64_t tail_report = 0;
     {   // last literals
         const uint32_t lit = n - anchor;
+        if (a.flags & kFlagReportTail) tail_report = (uint64_t)lit << 32;
         if (lane == 0) out[op] = (uint8_t)((lit < 15u ? lit : 15u) << 4);
         op += 1;
         if (lit >= 15u) op = emit_len_ext(out, op, lit - 15u);
         wave_copy(out + op, in + anchor, lit);
         op += lit;
     }
-    if (lane == 0) a.result[chunk] = (int64_t)op + (prefix ? 4 : 0);
+    if (lane == 0) a.result[chunk] = (int64_t)(((uint64_t)op + (prefix ? 4u : 0u)) | tail_report);
 }
 
 void launch_lz4_encode(const BatchArgs& a, hipStream_t s) {

@@ -1,0 +1,43 @@
+// big_parse.hpp — argument blocks of the large-stream parse (big_parse.hip) shared with its host side (large.hip).
+#pragma once
+#include "cj_common.hpp"
+
+namespace cj {
+
+constexpr uint32_t kBigPiece = 16384;          // input bytes per parse piece (one wavefront)
+
+struct BigParse {
+    const uint8_t* in;       // stream position 0 (device; padded by >= 16 readable bytes)
+    uint32_t iend;           // stream length
+    uint32_t start;          // position of the first element (Snappy: after the length header)
+    uint32_t np;             // pieces of kBigPiece bytes covering [start, iend)
+    uint64_t cap;            // LZ4: output capacity; Snappy: the decoded length the header announces
+    uint32_t* bits;          // np * kBigPiece / 32 words: positions visited by the lanes' own walks
+    uint32_t* merge;         // np * 64
+    uint32_t* exitp;         // np * 64
+    uint2* entry;            // np
+    uint32_t* lane_idx;      // np * 64
+    uint64_t* lane_op;       // np * 64
+    uint64_t* totals;        // np * 2 (count, bytes) -> exclusive prefix after the scan
+    uint2* sync;             // absolute (ip, op) of every 8th sequence; iend / 16 + 2 entries cover any stream
+    uint32_t* status;        // 16 words, zeroed: [0] chain did not end at the input's end, [1] violation, [2,3] sequences,
+                             // [4,5] output bytes counted, [6,7] decoded size, [8] last sequence seen
+};
+
+struct BigSlabs {
+    const uint2* sync;
+    uint32_t n_sync;
+    uint64_t n_seq, total;   // sequences, decoded bytes
+    uint32_t iend;
+    uint64_t in_base_off;    // offset of stream position 0 from the batch's in_base
+    uint32_t n_slabs;
+    uint64_t* in_off; uint64_t* in_len; uint64_t* out_off; uint64_t* out_cap; int64_t* result;
+    uint2* meta;             // ParseMeta {records, 0}
+    uint2* first;            // {first sync index, stream position of that sync point}
+    uint32_t* max_rec;       // atomicMax of the slabs' record counts
+};
+
+void launch_big_parse(const BigParse& a, int codec, hipStream_t s);
+void launch_big_slabs(const BigSlabs& d, hipStream_t s);
+
+}  // namespace cj

@@ -85,6 +85,7 @@ struct cj_engine {
     std::vector<uint64_t> h_meta;
     cj::DevBuf d_frame;            // frame.hip: assembled / staged framed stream
     cj::DevBuf d_tab;              // LDS decoder variant 2: per-workgroup record tables
+    cj::DevBuf d_big, d_bigtab;    // large.hip: parse scratch / record tables of one large stream (under `mu`)
     int n_cu = 0;
 };
 

@@ -352,7 +352,7 @@ int cj_engine_create(int device, cj_engine** out) {
 void cj_engine_destroy(cj_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
-    e->d_in.release(); e->d_out.release(); e->d_meta.release(); e->d_sync.release(); e->d_pmeta.release(); e->d_lanelist.release(); e->d_frame.release(); e->d_tab.release();
+    e->d_in.release(); e->d_out.release(); e->d_meta.release(); e->d_sync.release(); e->d_pmeta.release(); e->d_lanelist.release(); e->d_frame.release(); e->d_tab.release(); e->d_big.release(); e->d_bigtab.release();
     e->h_in.release(); e->h_out.release();
     if (e->scratch_free) (void)hipEventDestroy(e->scratch_free);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
@@ -492,6 +492,11 @@ int64_t cj_lz4_block_compress(const uint8_t* in, size_t n, uint8_t* out, size_t 
 }
 
 int64_t cj_lz4_block_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap, int size_prepended) {
+    // one large stream (by its input, or by the output size it announces): parsed and decoded slab-parallel (large.hip)
+    uint64_t announced = cap;
+    if (size_prepended && in && n >= 4) { uint32_t u; std::memcpy(&u, in, 4); if ((int32_t)u >= 0 && u <= cap) announced = u; }
+    if ((n > kLargeMin || announced > kLargeMin) && in && out)
+        return cj::large_decompress(CJ_CODEC_LZ4_BLOCK, size_prepended ? CJ_FLAG_LZ4_SIZE_PREFIX : 0u, in, n, out, cap);
     return single(CJ_CODEC_LZ4_BLOCK, CJ_OP_DECOMPRESS, size_prepended ? CJ_FLAG_LZ4_SIZE_PREFIX : 0u, in, n, out, cap);
 }
 
@@ -501,6 +506,8 @@ int64_t cj_snappy_raw_compress(const uint8_t* in, size_t n, uint8_t* out, size_t
 }
 
 int64_t cj_snappy_raw_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap) {
+    if (in && out && (n > kLargeMin || (n > 0 && cj_snappy_raw_decompress_len(in, n) > (int64_t)kLargeMin)))
+        return cj::large_decompress(CJ_CODEC_SNAPPY_RAW, 0u, in, n, out, cap);
     return single(CJ_CODEC_SNAPPY_RAW, CJ_OP_DECOMPRESS, 0u, in, n, out, cap);
 }
 

@@ -14,6 +14,8 @@
 // The result is a stream any LZ4 / Snappy decoder accepts (round trip through the oracle decoders: tests/test_large_gpu.py);
 // like all compressed output of this library it is not byte-identical to liblz4's / snap's.
 #include "cj_engine.hpp"
+#include "lz4_lane_walk.hpp"
+#include "big_parse.hpp"
 
 namespace cj {
 
@@ -199,6 +201,116 @@ int64_t large_lz4_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap
     HIP_TRY(hipMemcpyAsync(out + pre, d_frame, pos, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
     HIP_TRY(hipStreamSynchronize(s), CJ_E_NO_DEVICE);
     return (int64_t)(pos + pre);
+}
+
+
+// =====================================================================================================================
+// decompress ONE large stream: parallel parse (big_parse.hip) -> one decoder workgroup per 64 KiB slab of output
+// (lz4_decode_lds.hip, kSlab).  Error codes and capacity rules are those of the single-chunk kernels (lz4_block_prologue,
+// snappy_parse_kernel's header checks), applied here on the host.
+// =====================================================================================================================
+int64_t large_decompress(int codec, uint32_t flags, const uint8_t* in, size_t n, uint8_t* out, size_t cap) {
+    cj_engine* e = default_engine();
+    if (!e) return CJ_E_NO_DEVICE;
+    const bool snappy = codec == CJ_CODEC_SNAPPY_RAW;
+    const int64_t corrupt = snappy ? CJ_E_SNAPPY_CORRUPT : CJ_E_CORRUPT;
+    uint64_t skip = 0, start = 0, cap64 = cap;
+    if (!snappy) {
+        if (flags & CJ_FLAG_LZ4_SIZE_PREFIX) {
+            if (n < 4) return CJ_E_NO_PREFIX;
+            uint32_t u; std::memcpy(&u, in, 4);
+            const int32_t size = (int32_t)u;
+            if (size < 0) return CJ_E_NEG_PREFIX;
+            if ((uint32_t)size > 0x7E000000u) return CJ_E_PREFIX_TOO_BIG;
+            if ((uint64_t)size > cap64) return CJ_E_OUT_TOO_SMALL;
+            skip = 4; cap64 = (uint64_t)size;
+        } else {
+            if (cap64 > 0xFFFFFFFFull || (int32_t)(uint32_t)cap64 < 0) return CJ_E_NEG_PREFIX;
+            if ((uint32_t)cap64 > 0x7E000000u) return CJ_E_PREFIX_TOO_BIG;
+        }
+        if (n - skip > 0x7FFFFFF0ull) return CJ_E_CORRUPT;
+        if (cap64 == 0) return (n - skip == 1 && in[skip] == 0) ? 0 : (int64_t)CJ_E_CORRUPT;
+        if (n - skip == 0) return CJ_E_CORRUPT;
+    } else {
+        if (n == 0) return CJ_E_SNAPPY_EMPTY;
+        if (n > 0x7FFFFFF0ull) return CJ_E_SNAPPY_CORRUPT;
+        uint64_t ulen = 0; uint32_t shift = 0, i = 0, hdr = 0; bool ok = false;
+        while (hdr < n && i < 10u) {
+            const uint32_t b = in[hdr++];
+            if (b < 0x80u) { if (!(i == 9u && b > 1u)) { ulen |= (uint64_t)b << shift; ok = true; } break; }
+            ulen |= (uint64_t)(b & 0x7fu) << shift;
+            shift += 7; i += 1;
+        }
+        if (!ok) return CJ_E_SNAPPY_HEADER;
+        if (ulen > 0xFFFFFFFFull) return CJ_E_SNAPPY_TOO_BIG;
+        if (ulen > cap64) return CJ_E_SNAPPY_BUF_SMALL;
+        if (ulen == 0) return hdr == n ? 0 : (int64_t)CJ_E_SNAPPY_CORRUPT;
+        if (hdr == n) return CJ_E_SNAPPY_CORRUPT;
+        start = hdr; cap64 = ulen;
+    }
+    const uint32_t iend = (uint32_t)(n - skip);
+    const uint32_t np = (uint32_t)((iend - start + kBigPiece - 1) / kBigPiece);
+
+    std::lock_guard<std::mutex> lock(e->mu);
+    HIP_TRY(hipSetDevice(e->device), CJ_E_NO_DEVICE);
+    hipStream_t s = e->stream;
+    // parse scratch, 256 B aligned regions
+    size_t off = 0;
+    const auto region = [&off](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_status = region(64), o_bits = region((size_t)np * (kBigPiece / 8)), o_merge = region((size_t)np * 256),
+                 o_exit = region((size_t)np * 256), o_entry = region((size_t)np * 8), o_lidx = region((size_t)np * 256),
+                 o_lop = region((size_t)np * 512), o_tot = region((size_t)np * 16), o_sync = region(((size_t)iend / 16 + 2) * 8);
+    if (!e->d_in.reserve(n + 64) || !e->d_big.reserve(off)) return CJ_E_OOM;
+    uint8_t* d_in = (uint8_t*)e->d_in.p;
+    uint8_t* b = (uint8_t*)e->d_big.p;
+    HIP_TRY(hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
+    HIP_TRY(hipMemsetAsync(b + o_status, 0, 64, s), CJ_E_NO_DEVICE);
+    BigParse bp;
+    bp.in = d_in + skip; bp.iend = iend; bp.start = (uint32_t)start; bp.np = np; bp.cap = cap64;
+    bp.bits = (uint32_t*)(b + o_bits); bp.merge = (uint32_t*)(b + o_merge); bp.exitp = (uint32_t*)(b + o_exit);
+    bp.entry = (uint2*)(b + o_entry); bp.lane_idx = (uint32_t*)(b + o_lidx); bp.lane_op = (uint64_t*)(b + o_lop);
+    bp.totals = (uint64_t*)(b + o_tot); bp.sync = (uint2*)(b + o_sync); bp.status = (uint32_t*)(b + o_status);
+    launch_big_parse(bp, codec, s);
+    HIP_TRY(hipGetLastError(), CJ_E_NO_DEVICE);
+    uint32_t st[16];
+    HIP_TRY(hipMemcpyAsync(st, b + o_status, 64, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
+    HIP_TRY(hipStreamSynchronize(s), CJ_E_NO_DEVICE);
+    if (st[0] != 0 || st[1] != 0 || st[8] != 1) return corrupt;
+    const uint64_t n_seq = ((uint64_t)st[3] << 32) | st[2], total = ((uint64_t)st[7] << 32) | st[6];
+    if (total == 0) return 0;
+    const uint32_t n_sync = (uint32_t)((n_seq + kSyncEvery - 1) / kSyncEvery);
+    const uint32_t n_slabs = (uint32_t)((total + 65535) / 65536);
+
+    // slab descriptors: 5 u64 rows | meta | first | max_rec, counter | done flags
+    const size_t r_meta = 5 * (size_t)n_slabs, r_first = r_meta + n_slabs, r_misc = r_first + n_slabs, r_done = r_misc + 2,
+                 rows = r_done + (n_slabs + 1) / 2 + 1;
+    if (!e->d_meta.reserve(rows * 8)) return CJ_E_OOM;
+    uint64_t* d_meta = (uint64_t*)e->d_meta.p;
+    HIP_TRY(hipMemsetAsync(d_meta + r_misc, 0, (rows - r_misc) * 8, s), CJ_E_NO_DEVICE);
+    BigSlabs sd;
+    sd.sync = bp.sync; sd.n_sync = n_sync; sd.n_seq = n_seq; sd.total = total; sd.iend = iend; sd.in_base_off = skip; sd.n_slabs = n_slabs;
+    sd.in_off = d_meta; sd.in_len = d_meta + n_slabs; sd.out_off = d_meta + 2 * (size_t)n_slabs; sd.out_cap = d_meta + 3 * (size_t)n_slabs;
+    sd.result = (int64_t*)(d_meta + 4 * (size_t)n_slabs); sd.meta = (uint2*)(d_meta + r_meta); sd.first = (uint2*)(d_meta + r_first);
+    sd.max_rec = (uint32_t*)(d_meta + r_misc);
+    launch_big_slabs(sd, s);
+    HIP_TRY(hipGetLastError(), CJ_E_NO_DEVICE);
+    uint32_t max_rec = 0;
+    HIP_TRY(hipMemcpyAsync(&max_rec, sd.max_rec, 4, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
+    HIP_TRY(hipStreamSynchronize(s), CJ_E_NO_DEVICE);
+
+    if (e->n_cu == 0) HIP_TRY(hipDeviceGetAttribute(&e->n_cu, hipDeviceAttributeMultiprocessorCount, e->device), CJ_E_NO_DEVICE);
+    const uint32_t grid = std::min<uint32_t>(2u * (uint32_t)e->n_cu, n_slabs);
+    const uint32_t cross_stride = (max_rec + 63u) & ~63u, tab_stride = 2u * cross_stride;
+    const size_t tab_bytes = (size_t)grid * tab_stride * 16, cross_bytes = (size_t)grid * cross_stride * 16;
+    if (!e->d_bigtab.reserve(tab_bytes + cross_bytes) || !e->d_out.reserve(total + 256)) return CJ_E_OOM;
+    BatchArgs a;
+    fill_args(a, 0u, n_slabs, d_in, sd.in_off, sd.in_len, (uint8_t*)e->d_out.p, sd.out_off, sd.out_cap, sd.result);
+    launch_lz4_decode_lds2_slabs(a, bp.sync, sd.meta, e->d_bigtab.p, (uint32_t*)(d_meta + r_misc) + 1, sd.first, iend,
+                                 (uint32_t*)(d_meta + r_done), (uint8_t*)e->d_bigtab.p + tab_bytes, tab_stride, cross_stride, grid, s, codec);
+    HIP_TRY(hipGetLastError(), CJ_E_NO_DEVICE);
+    HIP_TRY(hipMemcpyAsync(out, e->d_out.p, total, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
+    HIP_TRY(hipStreamSynchronize(s), CJ_E_NO_DEVICE);
+    return (int64_t)total;
 }
 
 }  // namespace cj

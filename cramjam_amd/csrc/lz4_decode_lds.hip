@@ -22,6 +22,8 @@
 // are ready per poll); DESIGN.md §5.1 lists the restructurings that were measured and lost.
 #include "lz4_lane_walk.hpp"
 #include "snappy_records.hpp"
+#include "parse_grammar.hpp"
+#include <type_traits>
 
 namespace cj {
 
@@ -481,10 +483,17 @@ constexpr uint32_t kL2LinkedBytes = 2u * 65536u + 8192u + 384u;        // 139 64
 #else
 #define CJ_L2_ATTR
 #endif
-template <int kCodec, bool kLinked = false>
+// kSlab (large.hip: ONE large stream): chunk c is the 64 KiB slab c of the stream's OUTPUT.  Its records are cut from the
+// stream's absolute sync points (frames[c] = {first sync index, stream position of that sync point}; n_frames = stream
+// length): sequences that begin before the slab or end after it are clipped, and the part of a match whose source lies
+// before the slab ("cross") is copied from the finished output of the earlier slabs in global memory once slab c-1 has
+// published its completion flag.  Slabs are claimed in order, so the slab a workgroup waits for is always running.
+struct SlabArgs { uint32_t* done; uint4* cross; uint32_t tab_stride, cross_stride; };
+
+template <int kCodec, bool kLinked = false, bool kSlab = false>
 __global__ __launch_bounds__(kL2Threads) CJ_L2_ATTR void lz4_decode_lds2_kernel(BatchArgs a, const uint2* sync, const ParseMeta* meta,
                                                                      uint4* tabs, uint32_t* counter,
-                                                                     const uint2* frames, uint32_t n_frames) {
+                                                                     const uint2* frames, uint32_t n_frames, SlabArgs sl) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr uint32_t kOffBits = kLinked ? 131072u : kL2OffBits, kOffVars = kOffBits + 8192u;
     uint8_t* s_out = smem;
@@ -496,7 +505,9 @@ __global__ __launch_bounds__(kL2Threads) CJ_L2_ATTR void lz4_decode_lds2_kernel(
     const Dummies dm = {(uint32_t)(uintptr_t)(smem + kOffVars + 64u) + (threadIdx.x & 63u),
                         (uint32_t)(uintptr_t)(smem + kOffVars + 128u) + 4u * (threadIdx.x & 63u)};
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    uint4* table = tabs + (size_t)blockIdx.x * kL2TabRecords;
+    uint4* table = tabs + (size_t)blockIdx.x * (kSlab ? sl.tab_stride : kL2TabRecords);
+    uint32_t* s_ncross = reinterpret_cast<uint32_t*>(smem + kOffVars + 16u);     // kSlab: entries in the cross list / extra records
+    uint32_t* s_nextra = reinterpret_cast<uint32_t*>(smem + kOffVars + 20u);
     const bool prof = (a.flags & 0x1000u) != 0;
     unsigned long long t_prev = prof ? __builtin_readcyclecounter() : 0ull;
     uint32_t fr_first = 0, fr_n = 0, fr_k = 0;               // kLinked: current frame and position in it
@@ -522,7 +533,7 @@ __global__ __launch_bounds__(kL2Threads) CJ_L2_ATTR void lz4_decode_lds2_kernel(
             for (uint32_t i = tid; i < 2048u; i += kL2Threads) s_bits[i] = 0u;
             __syncthreads();                                 // also: the previous block's D4 has finished reading its window
         } else {
-            if (tid == 0) { *s_chunk = atomicAdd(counter, 1u); *s_fail = 0u; }
+            if (tid == 0) { *s_chunk = atomicAdd(counter, 1u); *s_fail = 0u; *s_ncross = 0u; *s_nextra = 0u; }
             for (uint32_t i = tid; i < 2048u; i += kL2Threads) s_bits[i] = 0u;
             __syncthreads();
             c = *s_chunk;
@@ -557,8 +568,9 @@ __global__ __launch_bounds__(kL2Threads) CJ_L2_ATTR void lz4_decode_lds2_kernel(
         // offset (relative to in) up to which reads are safe: the end of the 16 B granule holding the last input byte
         const uint32_t safe_end = ((((uint32_t)(reinterpret_cast<uintptr_t>(in) & 15u)) + iend + 15u) & ~15u) - (uint32_t)(reinterpret_cast<uintptr_t>(in) & 15u);
         uint8_t* out = a.out_base + a.out_off[c];
-        const uint2* csync = sync + (size_t)c * kSyncStride;
+        const uint2* csync = kSlab ? sync + frames[c].x : sync + (size_t)c * kSyncStride;
         const uint32_t nsp = (nseq + kSyncEvery - 1u) / kSyncEvery;
+        const bool staged = !kSlab || iend <= kLdsInMax;   // kSlab: a slab inside a long literal run may span more input than the window holds
         // ---- S0: stage the compressed chunk in the (still unused) output window so that D1's dependent token
         //      reads are LDS reads; D2 re-reads the literal bytes from global memory (L2 hits) because it overwrites
         //      the window while other lanes still need their sources ----
@@ -566,7 +578,7 @@ __global__ __launch_bounds__(kL2Threads) CJ_L2_ATTR void lz4_decode_lds2_kernel(
         {
             const uint4* src = reinterpret_cast<const uint4*>(in - mis);
             uint4* dst = reinterpret_cast<uint4*>(s_out);
-            const uint32_t nvec = (mis + iend + 15u) >> 4;
+            const uint32_t nvec = staged ? (mis + iend + 15u) >> 4 : 0u;
             for (uint32_t i = tid; i < nvec; i += kL2Threads) dst[i] = src[i];
         }
         __syncthreads();
@@ -574,6 +586,57 @@ __global__ __launch_bounds__(kL2Threads) CJ_L2_ATTR void lz4_decode_lds2_kernel(
 
         // ---- D1: expand sync points into sequence records (LDS -> global table) ----
         const uint32_t a_in = a_out + mis;
+        uint32_t nrec_all = nseq;                            // kSlab: + the internal remainders of cross matches (extra records)
+        if constexpr (kSlab) {
+            using G = typename std::conditional<kCodec == CJ_CODEC_SNAPPY_RAW, SnappyGrammar, Lz4Grammar>::type;
+            const uint32_t in_lo = frames[c].y;
+            const uint32_t s_iend = n_frames - in_lo;        // the stream's end, relative to this slab's input
+            const uint64_t S = a.out_off[c];
+            const auto rd = [&](uint32_t p) { return staged ? lds_ld32(a_in + p) : ld32u(in + p); };
+            uint4* cross = sl.cross + (size_t)blockIdx.x * sl.cross_stride;
+            for (uint32_t sp = tid; sp < nsp; sp += kL2Threads) {
+                const uint2 p = csync[sp];
+                uint32_t ip = p.x - in_lo;
+                int64_t op = (int64_t)(uint64_t)p.y - (int64_t)S;       // may be negative: the group starts before the slab
+                uint32_t sq = sp * kSyncEvery;
+                for (uint32_t j = 0; j < kSyncEvery && sq < nseq; j++, sq++) {
+                    Seq q;
+                    (void)G::at(rd, ip, s_iend, q);                      // the parse stage accepted this stream
+                    uint32_t lit = q.lit, src = q.lit_at, mlen = q.mlen;
+                    int64_t o0 = op;
+                    if (o0 < 0) { const uint32_t cut = (uint64_t)(-o0) < lit ? (uint32_t)(-o0) : lit; src += cut; lit -= cut; o0 += cut; }
+                    int64_t d0 = o0 + lit;
+                    if (d0 < 0) { const uint32_t cut = (uint64_t)(-d0) < mlen ? (uint32_t)(-d0) : mlen; mlen -= cut; d0 += cut; }
+                    if (d0 < 0) { d0 = 0; o0 = 0; }                      // entirely before the slab (lit = mlen = 0 now)
+                    if (o0 < 0) o0 = 0;
+                    if (o0 >= (int64_t)U) { lit = 0; mlen = 0; d0 = U; }
+                    else {
+                        if (o0 + lit > (int64_t)U) { lit = U - (uint32_t)o0; mlen = 0; }
+                        d0 = o0 + lit;
+                        if (d0 + mlen > (int64_t)U) mlen = U - (uint32_t)d0;
+                    }
+                    const uint32_t dst = (uint32_t)d0, off = q.offset;
+                    uint32_t w = 0;
+                    if (mlen > 0u) {
+                        if (off > dst) {                                  // source starts before the slab
+                            const uint32_t back = off - dst, n1 = mlen < back ? mlen : back;
+                            const uint64_t src_abs = S + dst - off;
+                            const uint32_t k = atomicAdd(s_ncross, 1u);
+                            cross[k] = make_uint4((uint32_t)src_abs, (uint32_t)(src_abs >> 32), dst, n1);
+                            if (mlen > n1) {                              // the rest repeats bytes of this slab: an ordinary match
+                                const uint32_t e = atomicAdd(s_nextra, 1u);
+                                table[nseq + e] = make_uint4(0u, 0u, dst + n1, off | ((mlen - n1) << 16));
+                            }
+                        } else w = off | (mlen << 16);
+                    }
+                    table[sq] = make_uint4(src, lit, dst, w);
+                    ip = q.next;
+                    op += (int64_t)q.lit + q.mlen;
+                }
+            }
+            __syncthreads();
+            nrec_all = nseq + *s_nextra;
+        } else
         if constexpr (kCodec == CJ_CODEC_SNAPPY_RAW) {
             // Snappy: a record = optional literal element + optional copy element (snappy_records.hpp)
             const auto rd = [a_in](uint32_t p) { return lds_ld32(a_in + p); };
@@ -629,11 +692,11 @@ __global__ __launch_bounds__(kL2Threads) CJ_L2_ATTR void lz4_decode_lds2_kernel(
         // (the next batch's records are requested before the current batch is processed: a coalesced table read is a
         //  full global round trip and a wave owns only ~5 batches)
         uint4 rec_nx = make_uint4(0, 0, 0, 0);
-        if (wave * 64u + lane < nseq) rec_nx = table[wave * 64u + lane];
-        for (uint32_t base = wave * 64u; base < nseq; base += kL2Threads) {
+        if (wave * 64u + lane < nrec_all) rec_nx = table[wave * 64u + lane];
+        for (uint32_t base = wave * 64u; base < nrec_all; base += kL2Threads) {
             const uint4 rec = rec_nx;
             rec_nx = make_uint4(0, 0, 0, 0);
-            if (base + kL2Threads + lane < nseq) rec_nx = table[base + kL2Threads + lane];
+            if (base + kL2Threads + lane < nrec_all) rec_nx = table[base + kL2Threads + lane];
             uint32_t n = rec.y, src = rec.x, dst = rec.z - rec.y;
             uint64_t lm = ballot64(n >= kLongRun);
             while (lm) {
@@ -665,6 +728,52 @@ __global__ __launch_bounds__(kL2Threads) CJ_L2_ATTR void lz4_decode_lds2_kernel(
                 }
             }
         }
+        // kSlab — D2b: the parts of matches whose source lies before this slab come from the finished output of the earlier
+        // slabs in global memory.  Each wave copies its share of the cross list as soon as it sees slab c-1's flag: from
+        // inside D3's wait loop (non-blocking poll while none of its matches is ready) or, blocking, after its last batch —
+        // so everything that does not depend on earlier slabs is resolved while the predecessor is still running.
+        bool cross_done = true;
+        uint32_t ncross = 0;
+        if constexpr (kSlab) { ncross = *s_ncross; cross_done = ncross <= wave * 64u; }      // complete since the barrier after D1
+        const auto try_cross = [&](bool block) {
+            if constexpr (kSlab) {
+                uint32_t f = 0;
+                for (;;) {
+                    if (lane == 0) f = __hip_atomic_load(&sl.done[c - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    f = rdlane(f, 0);
+                    if (f != 0u || !block) break;
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                if (f == 0u) return;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                const uint4* cross = sl.cross + (size_t)blockIdx.x * sl.cross_stride;
+                for (uint32_t base = wave * 64u; base < ncross; base += kL2Threads) {
+                    uint4 e = make_uint4(0, 0, 0, 0);
+                    if (base + lane < ncross) e = cross[base + lane];
+                    const uint8_t* g = a.out_base + (((uint64_t)e.y << 32) | e.x);
+                    uint32_t n = e.w, dst = e.z;
+                    uint64_t lm = ballot64(n >= kLongRun);
+                    while (lm) {
+                        const uint32_t l = ctz64(lm);
+                        lm &= lm - 1ull;
+                        const uint32_t ln = rdlane(n, l), ld = rdlane(dst, l);
+                        const uint8_t* lg = reinterpret_cast<const uint8_t*>(((uint64_t)rdlane((uint32_t)((uintptr_t)g >> 32), l) << 32) | rdlane((uint32_t)(uintptr_t)g, l));
+                        for (uint32_t k = lane; k < ln; k += 64u) lds_st8(a_out + ld + k, lg[k]);
+                        wave_bits_set(s_bits, ld, ld + ln);
+                        if (lane == l) n = 0;
+                    }
+                    while (ballot64(n > 0u)) {                 // <=16 bytes per pass (register budget: this sits inside D3's loop); the
+                        const uint32_t step = n < 16u ? n : 16u;   // output buffer is padded, over-reads are harmless
+                        if (step > 0u) {
+                            lds_store_tier<16>(gl_ld_vec<6>(g), a_out + dst, 0u, step, dm);
+                            bits_set(s_bits, dst, dst + step);
+                            n -= step; g += step; dst += step;
+                        }
+                    }
+                }
+                cross_done = true;
+            }
+        };
 #ifdef CJ_D23_BARRIER
         __syncthreads();
 #endif
@@ -673,11 +782,11 @@ __global__ __launch_bounds__(kL2Threads) CJ_L2_ATTR void lz4_decode_lds2_kernel(
         // ---- D3: matches (same resolver as variant 1).  No barrier after D2: readiness is exact per byte through the
         //      bitmap, so a wave starts on its matches while other waves are still placing literals ----
         rec_nx = make_uint4(0, 0, 0, 0);
-        if (wave * 64u + lane < nseq) rec_nx = table[wave * 64u + lane];
-        for (uint32_t base = wave * 64u; base < nseq; base += kL2Threads) {
+        if (wave * 64u + lane < nrec_all) rec_nx = table[wave * 64u + lane];
+        for (uint32_t base = wave * 64u; base < nrec_all; base += kL2Threads) {
             const uint4 rec = rec_nx;
             rec_nx = make_uint4(0, 0, 0, 0);
-            if (base + kL2Threads + lane < nseq) rec_nx = table[base + kL2Threads + lane];
+            if (base + kL2Threads + lane < nrec_all) rec_nx = table[base + kL2Threads + lane];
             const uint32_t dst = rec.z, off = rec.w & 0xffffu, m = rec.w >> 16;
             const uint32_t src = dst - off;                   // kLinked: "negative" (wraps) when the source starts in the previous block
             const uint32_t need = off < m ? off : m;
@@ -699,7 +808,7 @@ __global__ __launch_bounds__(kL2Threads) CJ_L2_ATTR void lz4_decode_lds2_kernel(
                 qm1 = de > 32u ? ((1u << (de - 32u)) - 1u) : 0u;
             }
             const bool any_slow = ballot64(pending && !fast) != 0ull;
-            uint32_t spins = 0;
+            uint32_t spins = 0, idle = 0;
             while (ballot64(pending) != 0ull) {
                 bool ready = false;
                 if (pending && fast) {
@@ -786,9 +895,16 @@ __global__ __launch_bounds__(kL2Threads) CJ_L2_ATTR void lz4_decode_lds2_kernel(
                         if (lane == l) pending = false;
                     }
                 }
+                if constexpr (kSlab) {
+                    if (!cross_done) {                             // waiting on an earlier slab is not a stall of this one
+                        spins = 0;
+                        if (rm == 0ull && (++idle & 7u) == 0u) try_cross(false);
+                    }
+                }
                 if (++spins > kSpinLimit) { *s_fail = 1u; break; }
             }
         }
+        if constexpr (kSlab) { if (!cross_done) try_cross(true); }
         __syncthreads();
         CJ_PHASE_MARK(3);
 
@@ -800,6 +916,11 @@ __global__ __launch_bounds__(kL2Threads) CJ_L2_ATTR void lz4_decode_lds2_kernel(
             for (uint32_t i = (nvec << 4) + tid; i < U; i += kL2Threads) out[i] = s_out[i];
         }
         if (tid == 0 && *s_fail) a.result[c] = CJ_E_CORRUPT;    // cannot happen for a stream the parse kernel accepted
+        if constexpr (kSlab) {                               // publish: every wave's stores are out before the flag is
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(&sl.done[c], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (prof) { __syncthreads(); CJ_PHASE_MARK(4); if (tid == 0) atomicAdd(&g_lds_phase_cycles[5], 1ull); }
     }
 }
@@ -813,13 +934,13 @@ void launch_lz4_decode_lds2(const BatchArgs& a, const void* sync, const void* me
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_lds2_kernel<CJ_CODEC_SNAPPY_RAW, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kL2Bytes);
         hipLaunchKernelGGL((lz4_decode_lds2_kernel<CJ_CODEC_SNAPPY_RAW, false>), dim3(grid), dim3(kL2Threads), kL2Bytes, s, a,
-                           (const uint2*)sync, (const ParseMeta*)meta, (uint4*)tabs, counter, (const uint2*)nullptr, 0u);
+                           (const uint2*)sync, (const ParseMeta*)meta, (uint4*)tabs, counter, (const uint2*)nullptr, 0u, SlabArgs{nullptr, nullptr, 0u, 0u});
         return;
     }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_lds2_kernel<CJ_CODEC_LZ4_BLOCK, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kL2Bytes);
     hipLaunchKernelGGL((lz4_decode_lds2_kernel<CJ_CODEC_LZ4_BLOCK, false>), dim3(grid), dim3(kL2Threads), kL2Bytes, s, a,
-                       (const uint2*)sync, (const ParseMeta*)meta, (uint4*)tabs, counter, (const uint2*)nullptr, 0u);
+                       (const uint2*)sync, (const ParseMeta*)meta, (uint4*)tabs, counter, (const uint2*)nullptr, 0u, SlabArgs{nullptr, nullptr, 0u, 0u});
 }
 
 void launch_lz4_decode_lds2_linked(const BatchArgs& a, const void* sync, const void* meta, void* tabs, uint32_t* counter,
@@ -828,7 +949,27 @@ void launch_lz4_decode_lds2_linked(const BatchArgs& a, const void* sync, const v
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_lds2_kernel<CJ_CODEC_LZ4_BLOCK, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kL2LinkedBytes);
     hipLaunchKernelGGL((lz4_decode_lds2_kernel<CJ_CODEC_LZ4_BLOCK, true>), dim3(grid), dim3(kL2Threads), kL2LinkedBytes, s, a,
-                       (const uint2*)sync, (const ParseMeta*)meta, (uint4*)tabs, counter, (const uint2*)frames, n_frames);
+                       (const uint2*)sync, (const ParseMeta*)meta, (uint4*)tabs, counter, (const uint2*)frames, n_frames, SlabArgs{nullptr, nullptr, 0u, 0u});
+}
+
+// large.hip: the slabs of one large stream.  tabs: grid * tab_stride records; cross: grid * cross_stride entries; done: one
+// zeroed word per slab
+void launch_lz4_decode_lds2_slabs(const BatchArgs& a, const void* sync, const void* meta, void* tabs, uint32_t* counter,
+                                  const void* first, uint32_t stream_len, uint32_t* done, void* cross, uint32_t tab_stride,
+                                  uint32_t cross_stride, uint32_t grid, hipStream_t s, int codec) {
+    if (a.n_chunks == 0) return;
+    const SlabArgs sl = {done, (uint4*)cross, tab_stride, cross_stride};
+    if (codec == CJ_CODEC_SNAPPY_RAW) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_lds2_kernel<CJ_CODEC_SNAPPY_RAW, false, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kL2Bytes);
+        hipLaunchKernelGGL((lz4_decode_lds2_kernel<CJ_CODEC_SNAPPY_RAW, false, true>), dim3(grid), dim3(kL2Threads), kL2Bytes, s, a,
+                           (const uint2*)sync, (const ParseMeta*)meta, (uint4*)tabs, counter, (const uint2*)first, stream_len, sl);
+        return;
+    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_lds2_kernel<CJ_CODEC_LZ4_BLOCK, false, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kL2Bytes);
+    hipLaunchKernelGGL((lz4_decode_lds2_kernel<CJ_CODEC_LZ4_BLOCK, false, true>), dim3(grid), dim3(kL2Threads), kL2Bytes, s, a,
+                       (const uint2*)sync, (const ParseMeta*)meta, (uint4*)tabs, counter, (const uint2*)first, stream_len, sl);
 }
 
 void launch_lz4_decode_lds(const BatchArgs& a, const void* sync, const void* meta, hipStream_t s) {

@@ -24,6 +24,7 @@
 // Outputs are exactly those of the other parse kernels (result, ParseMeta, sync points), so the decode stage and every
 // parity test are unchanged.
 #include "lz4_lane_walk.hpp"
+#include "parse_grammar.hpp"
 
 namespace cj {
 
@@ -31,8 +32,6 @@ namespace {
 
 constexpr uint32_t kSpecLdsIn = 65536;                   // staged compressed chunk (<= kLdsInMax + alignment slack)
 constexpr uint32_t kSpecLdsBytes = kSpecLdsIn + 8192;    // + 1 bit per input byte
-constexpr uint32_t kPosEnd = 0xFFFFFFFEu;                // the walk consumed the input exactly (last sequence)
-constexpr uint32_t kPosErr = 0xFFFFFFFFu;                // the walk ran into a malformed field
 
 // 4 bytes at byte offset p of the staged chunk (LDS address a_in + p), any alignment; bytes past the staged data are
 // whatever the LDS holds — callers never let such bytes decide anything (every length is bounds-checked against iend)
@@ -43,136 +42,6 @@ __device__ __forceinline__ uint32_t sp_ld32(uint32_t a_in, uint32_t p) {
                  : "=&v"(w0), "=&v"(w1) : "v"(a) : "memory");
     return __builtin_amdgcn_alignbyte(w1, w0, p & 3u);
 }
-
-// One sequence / record at position ip (relative to the start of the element stream).  `at` computes, FROM THE INPUT
-// BYTES ONLY, the literal length, the match length (0 = none), the offset and the position of the next one; it returns
-// false when a field or the item itself runs past the input (malformed on whatever path it lies).  `check` applies the
-// decoder's rules that need the output position (phase 4).
-struct Seq { uint32_t lit, mlen, offset, next; bool last; };
-
-struct Lz4Grammar {
-    static __device__ __forceinline__ bool at(uint32_t a_in, uint32_t ip, uint32_t iend, Seq& s) {
-        const uint32_t t4 = sp_ld32(a_in, ip);
-        const uint32_t token = t4 & 0xffu;
-        ip += 1;
-        uint32_t lit = token >> 4;
-        if (lit == 15u) {
-            if (ip + 15u >= iend) return false;
-            uint32_t b = (t4 >> 8) & 0xffu;
-            ip += 1; lit += b;
-            if (ip + 15u > iend) return false;
-            while (b == 255u) {
-                b = sp_ld32(a_in, ip) & 0xffu;
-                ip += 1; lit += b;
-                if (ip + 15u > iend) return false;
-            }
-        }
-        s.lit = lit;
-        const uint32_t rem_in = iend - ip;
-        if (rem_in < lit + 8u) {                     // can only be the final sequence: it must consume the input exactly
-            s.last = true; s.mlen = 0; s.offset = 0; s.next = kPosEnd;
-            return rem_in == lit;
-        }
-        s.last = false;
-        ip += lit;
-        const uint32_t o4 = sp_ld32(a_in, ip);
-        s.offset = o4 & 0xffffu;
-        ip += 2;
-        uint32_t mlen = token & 15u;
-        if (mlen == 15u) {
-            uint32_t b = (o4 >> 16) & 0xffu;
-            ip += 1; mlen += b;
-            if (ip + 4u > iend) return false;
-            while (b == 255u) {
-                b = sp_ld32(a_in, ip) & 0xffu;
-                ip += 1; mlen += b;
-                if (ip + 4u > iend) return false;
-            }
-        }
-        s.mlen = mlen + 4u;
-        s.next = ip;
-        return true;
-    }
-    // LZ4_decompress_safe's rules with the output capacity (same as lz4_parse_kernel).  Returns false = malformed;
-    // `fin` is set when this was the final sequence.
-    static __device__ __forceinline__ bool check(const Seq& s, uint32_t& op, uint32_t cap, bool& fin) {
-        const uint32_t rem_out = cap - op;
-        fin = false;
-        if (s.last || rem_out < s.lit + 12u) {
-            // must be the final sequence: consumes the input exactly (`at` checked that when s.last), fits the output
-            if (!s.last || rem_out < s.lit) return false;
-            op += s.lit; fin = true;
-            return true;
-        }
-        op += s.lit;
-        if (s.offset == 0u || s.offset > op) return false;
-        if (cap - op < s.mlen + 5u) return false;
-        op += s.mlen;
-        return true;
-    }
-    static __device__ __forceinline__ bool result_ok(uint32_t, uint32_t) { return true; }
-};
-
-// Snappy: a record = optional literal element + optional copy element (snappy_records.hpp); cap = the decoded length dn
-struct SnappyGrammar {
-    static __device__ __forceinline__ bool at(uint32_t a_in, uint32_t ip, uint32_t iend, Seq& s) {
-        uint32_t t4 = sp_ld32(a_in, ip);
-        uint32_t tag = t4 & 0xffu;
-        s.lit = 0; s.mlen = 0; s.offset = 0; s.last = false;
-        if ((tag & 3u) == 0u) {
-            ip += 1;
-            uint64_t len = (tag >> 2) + 1u;
-            if (len > 60u) {
-                const uint32_t nb = (uint32_t)len - 60u;
-                if (iend - ip < nb) return false;
-                uint32_t v = sp_ld32(a_in, ip);
-                if (nb < 4u) v &= (1u << (8u * nb)) - 1u;
-                ip += nb;
-                len = (uint64_t)v + 1u;
-            }
-            if (len > (uint64_t)(iend - ip)) return false;
-            s.lit = (uint32_t)len;
-            ip += (uint32_t)len;
-            if (ip >= iend) { s.last = true; s.next = kPosEnd; return true; }
-            t4 = sp_ld32(a_in, ip);
-            tag = t4 & 0xffu;
-            if ((tag & 3u) == 0u) { s.next = ip; return true; }       // another literal follows: it starts the next record
-        }
-        const uint32_t kind = tag & 3u;
-        ip += 1;
-        if (kind == 1u) {
-            if (iend - ip < 1u) return false;
-            s.mlen = 4u + ((tag >> 2) & 7u);
-            s.offset = ((tag >> 5) << 8) | ((t4 >> 8) & 0xffu);
-            ip += 1;
-        } else if (kind == 2u) {
-            if (iend - ip < 2u) return false;
-            s.mlen = 1u + (tag >> 2);
-            s.offset = (t4 >> 8) & 0xffffu;
-            ip += 2;
-        } else {
-            if (iend - ip < 4u) return false;
-            s.mlen = 1u + (tag >> 2);
-            s.offset = sp_ld32(a_in, ip);
-            ip += 4;
-        }
-        if (ip >= iend) { s.last = true; s.next = kPosEnd; }
-        else s.next = ip;
-        return true;
-    }
-    static __device__ __forceinline__ bool check(const Seq& s, uint32_t& op, uint32_t dn, bool& fin) {
-        fin = s.last;
-        if (s.lit > dn - op) return false;
-        op += s.lit;
-        if (s.mlen) {
-            if (s.offset == 0u || s.offset > op) return false;
-            if (s.mlen > dn - op) return false;
-            op += s.mlen;
-        }
-        return true;
-    }
-    static __device__ __forceinline__ bool result_ok(uint32_t op_end, uint32_t dn) { return op_end == dn; }
-};
 
 __device__ __forceinline__ uint32_t wave_excl_scan_add(uint32_t v, uint32_t& total) {
     const uint32_t lane = lane_id();
@@ -217,6 +86,7 @@ __device__ __forceinline__ int64_t spec_walk(const uint8_t* in, uint32_t iend, u
     }
     __syncthreads();
     const uint32_t a_in = (uint32_t)(uintptr_t)smem + mis;
+    const auto rd = [a_in](uint32_t q) { return sp_ld32(a_in, q); };
 
     // ---- segments: SEG = 4 x (odd number) bytes, so that the lanes' start positions fall into 64 different LDS banks
     //      (a stride of 32 k bytes would put all lanes on at most 8 banks) ----
@@ -232,7 +102,7 @@ __device__ __forceinline__ int64_t spec_walk(const uint8_t* in, uint32_t iend, u
         if (p < seg_end && p < iend) {
             asm volatile("ds_or_b32 %0, %1" :: "v"(a_bits + 4u * (p >> 5)), "v"(1u << (p & 31u)) : "memory");
             Seq s;
-            p = G::at(a_in, p, iend, s) ? s.next : kPosErr;
+            p = G::at(rd, p, iend, s) ? s.next : kPosErr;
         }
     }
     __syncthreads();                                      // all marks are in place
@@ -248,7 +118,7 @@ __device__ __forceinline__ int64_t spec_walk(const uint8_t* in, uint32_t iend, u
                 if ((w >> (p & 31u)) & 1u) { merge_pos = p; going = false; }
                 else {
                     Seq s;
-                    p = G::at(a_in, p, iend, s) ? s.next : kPosErr;
+                    p = G::at(rd, p, iend, s) ? s.next : kPosErr;
                     if (p >= iend) { merge_pos = p; going = false; }      // kPosEnd, kPosErr (or a position past the input: malformed)
                 }
             }
@@ -280,7 +150,7 @@ __device__ __forceinline__ int64_t spec_walk(const uint8_t* in, uint32_t iend, u
         while (ballot64(q < iend && q != piece_end) != 0ull) {
             if (q < iend && q != piece_end) {
                 Seq s;
-                if (G::at(a_in, q, iend, s)) { cnt += 1; outb += s.lit + s.mlen; q = s.next; }
+                if (G::at(rd, q, iend, s)) { cnt += 1; outb += s.lit + s.mlen; q = s.next; }
                 else q = kPosErr;
             }
         }
@@ -303,7 +173,7 @@ __device__ __forceinline__ int64_t spec_walk(const uint8_t* in, uint32_t iend, u
                 }
                 Seq s;
                 bool fin = false;
-                if (!G::at(a_in, q, iend, s) || !G::check(s, op, cap, fin)) bad = true;
+                if (!G::at(rd, q, iend, s) || !G::check(s, op, cap, fin)) bad = true;
                 else if (fin) { final_op = op; saw_last = true; q = kPosEnd; }
                 else { q = s.next; idx += 1; }
             }

@@ -1,0 +1,150 @@
+// parse_grammar.hpp — the two element grammars of the parallel parse kernels (lz4_parse_spec.hip: one chunk per
+// wavefront; big_parse.hip: one large stream cut into pieces).  `at` reads the stream through rd(p) = the 4 bytes at
+// stream offset p (little endian; bytes past the end may be anything — every length is bounds-checked against iend).
+#pragma once
+#include "cj_common.hpp"
+
+namespace cj {
+
+constexpr uint32_t kPosEnd = 0xFFFFFFFEu;                // the walk consumed the input exactly (last sequence)
+constexpr uint32_t kPosErr = 0xFFFFFFFFu;                // the walk ran into a malformed field
+
+// One sequence / record at position ip (relative to the start of the element stream).  `at` computes, FROM THE INPUT
+// BYTES ONLY, the literal length, the match length (0 = none), the offset and the position of the next one; it returns
+// false when a field or the item itself runs past the input (malformed on whatever path it lies).  `check` applies the
+// decoder's rules that need the output position (phase 4).
+struct Seq { uint32_t lit, mlen, offset, next, lit_at; bool last; };      // lit_at = position of the literal bytes
+
+struct Lz4Grammar {
+    template <class Rd>
+    static __device__ __forceinline__ bool at(const Rd& rd, uint32_t ip, uint32_t iend, Seq& s) {
+        const uint32_t t4 = rd(ip);
+        const uint32_t token = t4 & 0xffu;
+        ip += 1;
+        uint32_t lit = token >> 4;
+        if (lit == 15u) {
+            if (ip + 15u >= iend) return false;
+            uint32_t b = (t4 >> 8) & 0xffu;
+            ip += 1; lit += b;
+            if (ip + 15u > iend) return false;
+            while (b == 255u) {
+                b = rd(ip) & 0xffu;
+                ip += 1; lit += b;
+                if (ip + 15u > iend) return false;
+            }
+        }
+        s.lit = lit;
+        s.lit_at = ip;
+        const uint32_t rem_in = iend - ip;
+        if (rem_in < lit + 8u) {                     // can only be the final sequence: it must consume the input exactly
+            s.last = true; s.mlen = 0; s.offset = 0; s.next = kPosEnd;
+            return rem_in == lit;
+        }
+        s.last = false;
+        ip += lit;
+        const uint32_t o4 = rd(ip);
+        s.offset = o4 & 0xffffu;
+        ip += 2;
+        uint32_t mlen = token & 15u;
+        if (mlen == 15u) {
+            uint32_t b = (o4 >> 16) & 0xffu;
+            ip += 1; mlen += b;
+            if (ip + 4u > iend) return false;
+            while (b == 255u) {
+                b = rd(ip) & 0xffu;
+                ip += 1; mlen += b;
+                if (ip + 4u > iend) return false;
+            }
+        }
+        s.mlen = mlen + 4u;
+        s.next = ip;
+        return true;
+    }
+    // LZ4_decompress_safe's rules with the output capacity (same as lz4_parse_kernel).  Returns false = malformed;
+    // `fin` is set when this was the final sequence.
+    template <class T>
+    static __device__ __forceinline__ bool check(const Seq& s, T& op, T cap, bool& fin) {
+        const T rem_out = cap - op;
+        fin = false;
+        if (s.last || rem_out < s.lit + 12u) {
+            // must be the final sequence: consumes the input exactly (`at` checked that when s.last), fits the output
+            if (!s.last || rem_out < s.lit) return false;
+            op += s.lit; fin = true;
+            return true;
+        }
+        op += s.lit;
+        if (s.offset == 0u || s.offset > op) return false;
+        if (cap - op < s.mlen + 5u) return false;
+        op += s.mlen;
+        return true;
+    }
+    template <class T>
+    static __device__ __forceinline__ bool result_ok(T, T) { return true; }
+};
+
+// Snappy: a record = optional literal element + optional copy element (snappy_records.hpp); cap = the decoded length dn
+struct SnappyGrammar {
+    template <class Rd>
+    static __device__ __forceinline__ bool at(const Rd& rd, uint32_t ip, uint32_t iend, Seq& s) {
+        uint32_t t4 = rd(ip);
+        uint32_t tag = t4 & 0xffu;
+        s.lit = 0; s.mlen = 0; s.offset = 0; s.last = false; s.lit_at = ip;
+        if ((tag & 3u) == 0u) {
+            ip += 1;
+            uint64_t len = (tag >> 2) + 1u;
+            if (len > 60u) {
+                const uint32_t nb = (uint32_t)len - 60u;
+                if (iend - ip < nb) return false;
+                uint32_t v = rd(ip);
+                if (nb < 4u) v &= (1u << (8u * nb)) - 1u;
+                ip += nb;
+                len = (uint64_t)v + 1u;
+            }
+            if (len > (uint64_t)(iend - ip)) return false;
+            s.lit = (uint32_t)len;
+            s.lit_at = ip;
+            ip += (uint32_t)len;
+            if (ip >= iend) { s.last = true; s.next = kPosEnd; return true; }
+            t4 = rd(ip);
+            tag = t4 & 0xffu;
+            if ((tag & 3u) == 0u) { s.next = ip; return true; }       // another literal follows: it starts the next record
+        }
+        const uint32_t kind = tag & 3u;
+        ip += 1;
+        if (kind == 1u) {
+            if (iend - ip < 1u) return false;
+            s.mlen = 4u + ((tag >> 2) & 7u);
+            s.offset = ((tag >> 5) << 8) | ((t4 >> 8) & 0xffu);
+            ip += 1;
+        } else if (kind == 2u) {
+            if (iend - ip < 2u) return false;
+            s.mlen = 1u + (tag >> 2);
+            s.offset = (t4 >> 8) & 0xffffu;
+            ip += 2;
+        } else {
+            if (iend - ip < 4u) return false;
+            s.mlen = 1u + (tag >> 2);
+            s.offset = rd(ip);
+            ip += 4;
+        }
+        if (ip >= iend) { s.last = true; s.next = kPosEnd; }
+        else s.next = ip;
+        return true;
+    }
+    template <class T>
+    static __device__ __forceinline__ bool check(const Seq& s, T& op, T dn, bool& fin) {
+        fin = s.last;
+        if (s.lit > dn - op) return false;
+        op += s.lit;
+        if (s.mlen) {
+            if (s.offset == 0u || s.offset > op) return false;
+            if (s.mlen > dn - op) return false;
+            op += s.mlen;
+        }
+        return true;
+    }
+    template <class T>
+    static __device__ __forceinline__ bool result_ok(T op_end, T dn) { return op_end == dn; }
+};
+
+}  // namespace cj

@@ -76,3 +76,67 @@ def test_into_variants_and_small_outputs():
         cramjam.lz4.compress_block_into(data, small)
     with pytest.raises(cramjam.CompressionError):
         cramjam.snappy.compress_raw_into(data, small)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# decompress: ONE large stream (big_parse.hip + the slab mode of the LDS decoder).  Streams come from the oracle's
+# encoders (liblz4-style: matches reach back across every 64 KiB boundary) and from the GPU's own piece-wise encoder.
+
+def lz4_streams(data):
+    yield "oracle", oracle.lz4_compress_raw(data)[1]
+    yield "gpu", bytes(cramjam.lz4.compress_block(data, store_size=False))
+
+
+@pytest.mark.parametrize("name,data", CASES, ids=IDS)
+def test_lz4_decompress_block_large(name, data):
+    for src, blob in lz4_streams(data):
+        if len(blob) <= PIECE:
+            continue                                      # small stream: the ordinary single-chunk path
+        assert bytes(cramjam.lz4.decompress_block(blob, output_len=len(data))) == data, src
+        pre = len(data).to_bytes(4, "little") + blob
+        assert bytes(cramjam.lz4.decompress_block(pre)) == data, src
+        out = np.zeros(len(data) + 100, dtype=np.uint8)
+        n = cramjam.lz4.decompress_block_into(pre, out)
+        assert n == len(data) and out[:n].tobytes() == data, src
+
+
+@pytest.mark.parametrize("name,data", CASES, ids=IDS)
+def test_snappy_decompress_raw_large(name, data):
+    for src, blob in (("oracle", oracle.snappy_compress(data)[1]), ("gpu", bytes(cramjam.snappy.compress_raw(data)))):
+        if len(blob) <= PIECE:
+            continue
+        assert bytes(cramjam.snappy.decompress_raw(blob)) == data, src
+        out = np.zeros(len(data), dtype=np.uint8)
+        assert cramjam.snappy.decompress_raw_into(blob, out) == len(data) and out.tobytes() == data, src
+
+
+def test_large_decompress_verdicts_match_the_oracle():
+    rnd = random.Random(77)
+    data = b"".join(oracle.synth_v1(PIECE, i) for i in range(5)) + bytes(70000) + rnd.randbytes(90000)
+    n = len(data)
+    lz = oracle.lz4_compress_raw(data)[1]
+    sn = oracle.snappy_compress(data)[1]
+    for t in range(40):
+        b = bytearray(lz); i = rnd.randrange(len(b)); b[i] ^= 1 << rnd.randrange(8)
+        if t % 5 == 0: b = b[:rnd.randrange(PIECE + 1, len(b))]
+        er, eo = oracle.lz4_decompress_raw(bytes(b), n)
+        try:
+            got = bytes(cramjam.lz4.decompress_block(bytes(b), output_len=n))      # Some(n): length n, zero tail (src/lz4.rs:78-95)
+            assert er >= 0 and got[:er] == eo[:er] and got[er:] == bytes(n - er), ("lz4", t, er)
+        except cramjam.DecompressionError:
+            assert er < 0, ("lz4", t, er)
+    for t in range(40):
+        b = bytearray(sn); i = rnd.randrange(len(b)); b[i] ^= 1 << rnd.randrange(8)
+        if t % 5 == 0: b = b[:rnd.randrange(PIECE + 1, len(b))]
+        er, eo = oracle.snappy_decompress(bytes(b), n + 64)
+        try:
+            got = bytes(cramjam.snappy.decompress_raw(bytes(b)))
+            assert er >= 0 and got == eo[:er], ("snappy", t, er)
+        except cramjam.DecompressionError:
+            assert er < 0, ("snappy", t, er)
+    # capacity rules
+    assert bytes(cramjam.lz4.decompress_block(lz, output_len=n + 1000)) == data + bytes(1000)
+    with pytest.raises(cramjam.DecompressionError):
+        cramjam.lz4.decompress_block(lz, output_len=n - 1)
+    with pytest.raises(cramjam.DecompressionError):
+        cramjam.snappy.decompress_raw_into(sn, np.zeros(n - 1, dtype=np.uint8))

@@ -24,9 +24,8 @@ namespace cj {
 namespace {
 
 constexpr uint32_t kBpSlack = 1024;                       // staged bytes past the piece's end (sequences that cross it)
-constexpr uint32_t kBpSub = kBigPiece / 64u;              // sub-segment per lane
-constexpr uint32_t kBpLdsIn = kBigPiece + kBpSlack + 32u;
-constexpr uint32_t kBpLdsBytes = kBpLdsIn + kBigPiece / 8u + 64u * 4u;
+__host__ __device__ inline uint32_t bp_lds_in(uint32_t piece) { return piece + kBpSlack + 32u; }              // staged window
+__host__ __device__ inline uint32_t bp_lds_all(uint32_t piece) { return bp_lds_in(piece) + piece / 8u + 64u * 4u; } // + bitmap + links
 
 // the stream through a staged window: positions [lo, hi) come from LDS, anything else from global memory
 struct WinReader {
@@ -96,23 +95,24 @@ __device__ __forceinline__ uint64_t bp_scan64(uint64_t v, uint64_t& total) {
 // K1
 template <class G>
 __global__ __launch_bounds__(64) void big_mark_kernel(BigParse a) {
+    const uint32_t P = a.piece, sub = P / 64u;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t p = blockIdx.x, lane = lane_id();
-    const uint32_t B = a.start + p * kBigPiece;
-    const uint32_t E = a.iend - B > kBigPiece ? B + kBigPiece : a.iend;         // piece = [B, E)
-    uint32_t* s_bits = reinterpret_cast<uint32_t*>(smem + kBpLdsIn);
-    uint32_t* s_link = s_bits + kBigPiece / 32u;
+    const uint32_t B = a.start + p * P;
+    const uint32_t E = a.iend - B > P ? B + P : a.iend;         // piece = [B, E)
+    uint32_t* s_bits = reinterpret_cast<uint32_t*>(smem + bp_lds_in(P));
+    uint32_t* s_link = s_bits + P / 32u;
     const uint32_t a_bits = (uint32_t)(uintptr_t)s_bits;
-    const uint32_t whi = a.iend - B > kBigPiece + kBpSlack ? B + kBigPiece + kBpSlack : a.iend;
+    const uint32_t whi = a.iend - B > P + kBpSlack ? B + P + kBpSlack : a.iend;
     WinReader rd;
     rd.a_win = bp_stage(a.in, B, whi, smem, lane);
     rd.lo = B; rd.hi = whi; rd.g = a.in;
-    for (uint32_t i = lane; i < kBigPiece / 32u; i += 64u) s_bits[i] = 0u;
+    for (uint32_t i = lane; i < P / 32u; i += 64u) s_bits[i] = 0u;
     __syncthreads();
 
     // 1a: own sub-segment, marking
-    const uint32_t s0 = B + lane * kBpSub;
-    const uint32_t s1 = s0 + kBpSub < E ? s0 + kBpSub : E;
+    const uint32_t s0 = B + lane * sub;
+    const uint32_t s1 = s0 + sub < E ? s0 + sub : E;
     uint32_t pos = s0 < E ? s0 : kPosEnd;
     while (ballot64(pos < s1) != 0ull) {
         if (pos < s1) {
@@ -146,13 +146,13 @@ __global__ __launch_bounds__(64) void big_mark_kernel(BigParse a) {
     for (int round = 0; round < 6; round++) {
         s_link[lane] = ex;
         __syncthreads();
-        if (ex < E) ex = s_link[(ex - B) / kBpSub];
+        if (ex < E) ex = s_link[(ex - B) / sub];
         __syncthreads();
     }
     a.merge[(size_t)p * 64u + lane] = merge;
     a.exitp[(size_t)p * 64u + lane] = ex;
-    uint32_t* gb = a.bits + (size_t)p * (kBigPiece / 32u);
-    for (uint32_t i = lane; i < kBigPiece / 32u; i += 64u) gb[i] = s_bits[i];
+    uint32_t* gb = a.bits + (size_t)p * (P / 32u);
+    for (uint32_t i = lane; i < P / 32u; i += 64u) gb[i] = s_bits[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -161,14 +161,15 @@ __global__ __launch_bounds__(64) void big_mark_kernel(BigParse a) {
 template <class G>
 __global__ __launch_bounds__(64) void big_thread_kernel(BigParse a) {
     if (threadIdx.x != 0) return;
+    const uint32_t P = a.piece, sub = P / 64u;
     GlobalReader rd = {a.in};
     uint32_t e = a.start;
     for (uint32_t p = 0; p < a.np; p++) {
-        const uint32_t B = a.start + p * kBigPiece;
-        const uint32_t E = a.iend - B > kBigPiece ? B + kBigPiece : a.iend;
+        const uint32_t B = a.start + p * P;
+        const uint32_t E = a.iend - B > P ? B + P : a.iend;
         if (e >= E) { a.entry[p] = make_uint2(kPosEnd, kPosEnd); continue; }      // a long sequence spans the piece, or the chain is over
-        const uint32_t* gb = a.bits + (size_t)p * (kBigPiece / 32u);
-        const uint32_t lx = (e - B) / kBpSub;
+        const uint32_t* gb = a.bits + (size_t)p * (P / 32u);
+        const uint32_t lx = (e - B) / sub;
         uint32_t q = e;
         while (q < E) {
             const uint32_t r = q - B;
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(64) void big_thread_kernel(BigParse a) {
         }
         uint32_t first_end, nxt;
         if (q < E) {
-            const uint32_t o = (q - B) / kBpSub;
+            const uint32_t o = (q - B) / sub;
             first_end = o == lx ? a.merge[(size_t)p * 64u + lx] : q;
             nxt = a.exitp[(size_t)p * 64u + o];
         } else { first_end = q; nxt = q; }
@@ -190,15 +191,16 @@ __global__ __launch_bounds__(64) void big_thread_kernel(BigParse a) {
 
 // the chain inside one piece: per lane (entry, end); end < E = the next lane's entry, else the piece's exit / kPosEnd / kPosErr
 __device__ __forceinline__ void bp_chain(const BigParse& a, uint32_t p, uint32_t B, uint32_t E, uint32_t lane, uint32_t& entry, uint32_t& end, bool& on) {
+    const uint32_t sub = a.piece / 64u;
     const uint2 en = a.entry[p];
     const uint32_t merge = a.merge[(size_t)p * 64u + lane];
     entry = kPosEnd; end = kPosEnd; on = false;
     if (en.x == kPosEnd) return;
-    uint32_t cur = (en.x - B) / kBpSub, ent = en.x, fin = en.y;
+    uint32_t cur = (en.x - B) / sub, ent = en.x, fin = en.y;
     for (uint32_t hop = 0; hop < 64u; hop++) {
         if (lane == cur) { entry = ent; end = fin; on = true; }
         if (fin >= E) break;
-        cur = (fin - B) / kBpSub;
+        cur = (fin - B) / sub;
         ent = fin;
         fin = rdlane(merge, cur);
     }
@@ -208,11 +210,12 @@ __device__ __forceinline__ void bp_chain(const BigParse& a, uint32_t p, uint32_t
 // K3
 template <class G>
 __global__ __launch_bounds__(64) void big_count_kernel(BigParse a) {
+    const uint32_t P = a.piece, sub = P / 64u;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t p = blockIdx.x, lane = lane_id();
-    const uint32_t B = a.start + p * kBigPiece;
-    const uint32_t E = a.iend - B > kBigPiece ? B + kBigPiece : a.iend;
-    const uint32_t whi = a.iend - B > kBigPiece + kBpSlack ? B + kBigPiece + kBpSlack : a.iend;
+    const uint32_t B = a.start + p * P;
+    const uint32_t E = a.iend - B > P ? B + P : a.iend;
+    const uint32_t whi = a.iend - B > P + kBpSlack ? B + P + kBpSlack : a.iend;
     uint32_t entry, end; bool on;
     bp_chain(a, p, B, E, lane, entry, end, on);
     if (a.entry[p].x == kPosEnd) {
@@ -263,11 +266,12 @@ __global__ __launch_bounds__(64) void big_scan_kernel(BigParse a) {
 // that meets the last sequence)
 template <class G>
 __global__ __launch_bounds__(64) void big_emit_kernel(BigParse a) {
+    const uint32_t P = a.piece, sub = P / 64u;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t p = blockIdx.x, lane = lane_id();
-    const uint32_t B = a.start + p * kBigPiece;
-    const uint32_t E = a.iend - B > kBigPiece ? B + kBigPiece : a.iend;
-    const uint32_t whi = a.iend - B > kBigPiece + kBpSlack ? B + kBigPiece + kBpSlack : a.iend;
+    const uint32_t B = a.start + p * P;
+    const uint32_t E = a.iend - B > P ? B + P : a.iend;
+    const uint32_t whi = a.iend - B > P + kBpSlack ? B + P + kBpSlack : a.iend;
     if (a.entry[p].x == kPosEnd) return;
     uint32_t entry, end; bool on;
     bp_chain(a, p, B, E, lane, entry, end, on);
@@ -330,14 +334,15 @@ __global__ __launch_bounds__(256) void big_slab_kernel(BigSlabs d) {
 
 template <class G>
 void run(const BigParse& a, hipStream_t s) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(big_mark_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBpLdsBytes);
-    hipLaunchKernelGGL(big_mark_kernel<G>, dim3(a.np), dim3(64), kBpLdsBytes, s, a);
+    const uint32_t P = a.piece;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(big_mark_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bp_lds_all(kBigPieceLarge));
+    hipLaunchKernelGGL(big_mark_kernel<G>, dim3(a.np), dim3(64), bp_lds_all(P), s, a);
     hipLaunchKernelGGL(big_thread_kernel<G>, dim3(1), dim3(64), 0, s, a);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(big_count_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBpLdsIn);
-    hipLaunchKernelGGL(big_count_kernel<G>, dim3(a.np), dim3(64), kBpLdsIn, s, a);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(big_count_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bp_lds_in(kBigPieceLarge));
+    hipLaunchKernelGGL(big_count_kernel<G>, dim3(a.np), dim3(64), bp_lds_in(P), s, a);
     hipLaunchKernelGGL(big_scan_kernel, dim3(1), dim3(64), 0, s, a);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(big_emit_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBpLdsIn);
-    hipLaunchKernelGGL(big_emit_kernel<G>, dim3(a.np), dim3(64), kBpLdsIn, s, a);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(big_emit_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bp_lds_in(kBigPieceLarge));
+    hipLaunchKernelGGL(big_emit_kernel<G>, dim3(a.np), dim3(64), bp_lds_in(P), s, a);
 }
 
 }  // namespace

@@ -4,15 +4,18 @@
 
 namespace cj {
 
-constexpr uint32_t kBigPiece = 16384;          // input bytes per parse piece (one wavefront)
+constexpr uint32_t kBigPieceSmall = 16384, kBigPieceLarge = 65536;   // input bytes per parse piece (one wavefront): streams
+                                                                      // below / from kBigPieceSwitch bytes (fewer serial steps in K2)
+constexpr uint32_t kBigPieceSwitch = 4u << 20;
 
 struct BigParse {
     const uint8_t* in;       // stream position 0 (device; padded by >= 16 readable bytes)
     uint32_t iend;           // stream length
     uint32_t start;          // position of the first element (Snappy: after the length header)
-    uint32_t np;             // pieces of kBigPiece bytes covering [start, iend)
+    uint32_t piece;          // bytes per piece (a multiple of 2048)
+    uint32_t np;             // pieces covering [start, iend)
     uint64_t cap;            // LZ4: output capacity; Snappy: the decoded length the header announces
-    uint32_t* bits;          // np * kBigPiece / 32 words: positions visited by the lanes' own walks
+    uint32_t* bits;          // np * piece / 32 words: positions visited by the lanes' own walks
     uint32_t* merge;         // np * 64
     uint32_t* exitp;         // np * 64
     uint2* entry;            // np

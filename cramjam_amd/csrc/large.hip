@@ -209,6 +209,9 @@ int64_t large_lz4_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap
 // (lz4_decode_lds.hip, kSlab).  Error codes and capacity rules are those of the single-chunk kernels (lz4_block_prologue,
 // snappy_parse_kernel's header checks), applied here on the host.
 // =====================================================================================================================
+static std::vector<uint32_t>* g_dbg_sync = nullptr;       // set by cj_debug_big_parse only (single-threaded test hook)
+static uint64_t g_dbg_nseq = 0;
+
 int64_t large_decompress(int codec, uint32_t flags, const uint8_t* in, size_t n, uint8_t* out, size_t cap) {
     cj_engine* e = default_engine();
     if (!e) return CJ_E_NO_DEVICE;
@@ -249,7 +252,8 @@ int64_t large_decompress(int codec, uint32_t flags, const uint8_t* in, size_t n,
         start = hdr; cap64 = ulen;
     }
     const uint32_t iend = (uint32_t)(n - skip);
-    const uint32_t np = (uint32_t)((iend - start + kBigPiece - 1) / kBigPiece);
+    const uint32_t piece = iend < kBigPieceSwitch ? kBigPieceSmall : kBigPieceLarge;
+    const uint32_t np = (uint32_t)((iend - start + piece - 1) / piece);
 
     std::lock_guard<std::mutex> lock(e->mu);
     HIP_TRY(hipSetDevice(e->device), CJ_E_NO_DEVICE);
@@ -257,7 +261,7 @@ int64_t large_decompress(int codec, uint32_t flags, const uint8_t* in, size_t n,
     // parse scratch, 256 B aligned regions
     size_t off = 0;
     const auto region = [&off](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    const size_t o_status = region(64), o_bits = region((size_t)np * (kBigPiece / 8)), o_merge = region((size_t)np * 256),
+    const size_t o_status = region(64), o_bits = region((size_t)np * (piece / 8)), o_merge = region((size_t)np * 256),
                  o_exit = region((size_t)np * 256), o_entry = region((size_t)np * 8), o_lidx = region((size_t)np * 256),
                  o_lop = region((size_t)np * 512), o_tot = region((size_t)np * 16), o_sync = region(((size_t)iend / 16 + 2) * 8);
     if (!e->d_in.reserve(n + 64) || !e->d_big.reserve(off)) return CJ_E_OOM;
@@ -266,7 +270,7 @@ int64_t large_decompress(int codec, uint32_t flags, const uint8_t* in, size_t n,
     HIP_TRY(hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
     HIP_TRY(hipMemsetAsync(b + o_status, 0, 64, s), CJ_E_NO_DEVICE);
     BigParse bp;
-    bp.in = d_in + skip; bp.iend = iend; bp.start = (uint32_t)start; bp.np = np; bp.cap = cap64;
+    bp.in = d_in + skip; bp.iend = iend; bp.start = (uint32_t)start; bp.piece = piece; bp.np = np; bp.cap = cap64;
     bp.bits = (uint32_t*)(b + o_bits); bp.merge = (uint32_t*)(b + o_merge); bp.exitp = (uint32_t*)(b + o_exit);
     bp.entry = (uint2*)(b + o_entry); bp.lane_idx = (uint32_t*)(b + o_lidx); bp.lane_op = (uint64_t*)(b + o_lop);
     bp.totals = (uint64_t*)(b + o_tot); bp.sync = (uint2*)(b + o_sync); bp.status = (uint32_t*)(b + o_status);
@@ -280,6 +284,11 @@ int64_t large_decompress(int codec, uint32_t flags, const uint8_t* in, size_t n,
     if (total == 0) return 0;
     const uint32_t n_sync = (uint32_t)((n_seq + kSyncEvery - 1) / kSyncEvery);
     const uint32_t n_slabs = (uint32_t)((total + 65535) / 65536);
+    if (g_dbg_sync) {                                       // test hook (cj_debug_big_parse): hand the sync points to the host
+        g_dbg_nseq = n_seq;
+        g_dbg_sync->resize((size_t)n_sync * 2);
+        HIP_TRY(hipMemcpy(g_dbg_sync->data(), bp.sync, (size_t)n_sync * 8, hipMemcpyDeviceToHost), CJ_E_NO_DEVICE);
+    }
 
     // slab descriptors: 5 u64 rows | meta | first | max_rec, counter | done flags
     const size_t r_meta = 5 * (size_t)n_slabs, r_first = r_meta + n_slabs, r_misc = r_first + n_slabs, r_done = r_misc + 2,
@@ -308,9 +317,27 @@ int64_t large_decompress(int codec, uint32_t flags, const uint8_t* in, size_t n,
     launch_lz4_decode_lds2_slabs(a, bp.sync, sd.meta, e->d_bigtab.p, (uint32_t*)(d_meta + r_misc) + 1, sd.first, iend,
                                  (uint32_t*)(d_meta + r_done), (uint8_t*)e->d_bigtab.p + tab_bytes, tab_stride, cross_stride, grid, s, codec);
     HIP_TRY(hipGetLastError(), CJ_E_NO_DEVICE);
+    std::vector<int64_t> res(n_slabs);
+    HIP_TRY(hipMemcpyAsync(res.data(), sd.result, (size_t)n_slabs * 8, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
     HIP_TRY(hipMemcpyAsync(out, e->d_out.p, total, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
     HIP_TRY(hipStreamSynchronize(s), CJ_E_NO_DEVICE);
+    for (uint32_t i = 0; i < n_slabs; i++)
+        if (res[i] < 0) return corrupt;                     // the decoder's stall guard: cannot happen for a stream the parse accepted
     return (int64_t)total;
 }
 
 }  // namespace cj
+
+// Test hook: decompress one stream through the large path and return the parse stage's absolute sync points
+// ((ip, op) of every 8th sequence, as pairs of u32) and the sequence count.  Returns the decoded size or CJ_E_*.
+extern "C" int64_t cj_debug_big_parse(int codec, uint32_t flags, const uint8_t* in, size_t n, uint8_t* out, size_t cap,
+                                      uint32_t* sync_pairs, size_t max_pairs, uint64_t* n_seq) {
+    std::vector<uint32_t> v;
+    cj::g_dbg_sync = &v;
+    const int64_t r = cj::large_decompress(codec, flags, in, n, out, cap);
+    cj::g_dbg_sync = nullptr;
+    if (n_seq) *n_seq = cj::g_dbg_nseq;
+    if (r >= 0 && sync_pairs) std::memcpy(sync_pairs, v.data(), std::min(v.size() / 2, max_pairs) * 8);
+    return r;
+}
+

@@ -616,20 +616,24 @@ __global__ __launch_bounds__(kL2Threads) CJ_L2_ATTR void lz4_decode_lds2_kernel(
                         if (d0 + mlen > (int64_t)U) mlen = U - (uint32_t)d0;
                     }
                     const uint32_t dst = (uint32_t)d0, off = q.offset;
-                    uint32_t w = 0;
+                    uint4 rec = make_uint4(src, lit, dst, 0u);
                     if (mlen > 0u) {
                         if (off > dst) {                                  // source starts before the slab
                             const uint32_t back = off - dst, n1 = mlen < back ? mlen : back;
                             const uint64_t src_abs = S + dst - off;
                             const uint32_t k = atomicAdd(s_ncross, 1u);
                             cross[k] = make_uint4((uint32_t)src_abs, (uint32_t)(src_abs >> 32), dst, n1);
-                            if (mlen > n1) {                              // the rest repeats bytes of this slab: an ordinary match
-                                const uint32_t e = atomicAdd(s_nextra, 1u);
-                                table[nseq + e] = make_uint4(0u, 0u, dst + n1, off | ((mlen - n1) << 16));
+                            if (mlen > n1) {
+                                // the rest of the match repeats bytes from the start of THIS slab: an ordinary match at dst + n1.
+                                // It keeps the sequence's place in the record order (D3's progress argument: a record waits
+                                // only for records before it), so the sequence's literals move to an extra record instead —
+                                // literals depend on nothing and may sit anywhere.
+                                if (lit > 0u) table[nseq + atomicAdd(s_nextra, 1u)] = rec;
+                                rec = make_uint4(0u, 0u, dst + n1, off | ((mlen - n1) << 16));
                             }
-                        } else w = off | (mlen << 16);
+                        } else rec.w = off | (mlen << 16);
                     }
-                    table[sq] = make_uint4(src, lit, dst, w);
+                    table[sq] = rec;
                     ip = q.next;
                     op += (int64_t)q.lit + q.mlen;
                 }
@@ -732,7 +736,7 @@ __global__ __launch_bounds__(kL2Threads) CJ_L2_ATTR void lz4_decode_lds2_kernel(
         // slabs in global memory.  Each wave copies its share of the cross list as soon as it sees slab c-1's flag: from
         // inside D3's wait loop (non-blocking poll while none of its matches is ready) or, blocking, after its last batch —
         // so everything that does not depend on earlier slabs is resolved while the predecessor is still running.
-        bool cross_done = true;
+        bool cross_done = true, prev_seen = false;
         uint32_t ncross = 0;
         if constexpr (kSlab) { ncross = *s_ncross; cross_done = ncross <= wave * 64u; }      // complete since the barrier after D1
         const auto try_cross = [&](bool block) {
@@ -901,7 +905,18 @@ __global__ __launch_bounds__(kL2Threads) CJ_L2_ATTR void lz4_decode_lds2_kernel(
                         if (rm == 0ull && (++idle & 7u) == 0u) try_cross(false);
                     }
                 }
-                if (++spins > kSpinLimit) { *s_fail = 1u; break; }
+                if (++spins > kSpinLimit) {
+                    if constexpr (kSlab) {                         // a long wait is legitimate while the previous slab is still running
+                        if (c > 0u && !prev_seen) {
+                            uint32_t f = 0;
+                            if (lane == 0) f = __hip_atomic_load(&sl.done[c - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            prev_seen = rdlane(f, 0) != 0u;
+                            spins = 0;
+                            continue;
+                        }
+                    }
+                    *s_fail = 1u; break;
+                }
             }
         }
         if constexpr (kSlab) { if (!cross_done) try_cross(true); }

@@ -140,3 +140,127 @@ def test_large_decompress_verdicts_match_the_oracle():
         cramjam.lz4.decompress_block(lz, output_len=n - 1)
     with pytest.raises(cramjam.DecompressionError):
         cramjam.snappy.decompress_raw_into(sn, np.zeros(n - 1, dtype=np.uint8))
+
+
+def _snappy_varint(n):
+    out = bytearray()
+    while n >= 0x80:
+        out.append((n & 0x7f) | 0x80); n >>= 7
+    out.append(n)
+    return bytes(out)
+
+
+def _snappy_literal(b):
+    n = len(b) - 1
+    if n < 60: return bytes([n << 2]) + b
+    if n < 256: return bytes([60 << 2, n]) + b
+    if n < 65536: return bytes([61 << 2]) + n.to_bytes(2, "little") + b
+    return bytes([62 << 2]) + n.to_bytes(3, "little") + b
+
+
+def test_snappy_hand_made_streams_far_offsets_and_tiny_copies():
+    """shapes no 64 KiB-block encoder emits, but the format allows: copies with 4-byte offsets reaching far back across
+    many slabs, and hundreds of thousands of 1-byte copies (65 536 records in one slab)"""
+    rnd = random.Random(3)
+    base = rnd.randbytes(150000)
+    elems = [_snappy_literal(base)]
+    plain = bytearray(base)
+    for k in range(3000):
+        off = rnd.randrange(70000, len(plain)) if k % 3 else rnd.randrange(1, 60)
+        ln = rnd.randrange(1, 65)
+        elems.append(bytes([((ln - 1) << 2) | 3]) + off.to_bytes(4, "little"))          # copy with a 4-byte offset
+        for _ in range(ln): plain.append(plain[-off])
+        if k % 7 == 0:
+            lit = rnd.randbytes(rnd.randrange(1, 80)); elems.append(_snappy_literal(lit)); plain += lit
+    blob = _snappy_varint(len(plain)) + b"".join(elems)
+    r, out = oracle.snappy_decompress(blob, len(plain))
+    assert r == len(plain) and out == bytes(plain)
+    assert bytes(cramjam.snappy.decompress_raw(blob)) == bytes(plain)
+
+    n_copies = 200000
+    blob = _snappy_varint(1 + n_copies) + _snappy_literal(b"a") + (bytes([(0 << 2) | 2]) + (1).to_bytes(2, "little")) * n_copies
+    assert bytes(cramjam.snappy.decompress_raw(blob)) == b"a" * (1 + n_copies)
+
+
+def test_many_slabs_with_matches_across_every_boundary():
+    """more slabs than decoder workgroups (2 per CU), every slab waiting for bytes of its predecessor"""
+    parts = [oracle.synth_v1(PIECE, i) for i in range(32)]
+    data = bytes(777) + b"".join(parts[i % 32] for i in range(700))       # ~44 MiB, chunk boundaries off the slab grid
+    lz = oracle.lz4_compress_raw(data)[1]
+    assert bytes(cramjam.lz4.decompress_block(lz, output_len=len(data))) == data
+    sn = oracle.snappy_compress(data)[1]
+    assert bytes(cramjam.snappy.decompress_raw(sn)) == data
+    text = b"".join(b"%d bottles of beer on the wall, %d bottles of beer\n" % (i % 977, i % 1013) for i in range(600000))
+    lz = oracle.lz4_compress_raw(text)[1]
+    assert bytes(cramjam.lz4.decompress_block(lz, output_len=len(text))) == text
+    big_run = bytes(40 << 20)                                             # one match of 40 MiB: every slab is a piece of it
+    lz = oracle.lz4_compress_raw(big_run)[1]
+    assert bytes(cramjam.lz4.decompress_block(lz, output_len=len(big_run))) == big_run
+
+
+def _serial_sync_lz4(b):
+    pts = []; ip = op = k = 0; n = len(b)
+    while ip < n:
+        if k % 8 == 0: pts.append((ip, op))
+        k += 1
+        tok = b[ip]; ip += 1
+        lit = tok >> 4
+        if lit == 15:
+            while True:
+                x = b[ip]; ip += 1; lit += x
+                if x != 255: break
+        ip += lit; op += lit
+        if ip >= n: break
+        ip += 2; ml = tok & 15
+        if ml == 15:
+            while True:
+                x = b[ip]; ip += 1; ml += x
+                if x != 255: break
+        op += ml + 4
+    return k, pts
+
+
+def _serial_sync_snappy(b):
+    ip = 0
+    while b[ip] & 0x80: ip += 1
+    ip += 1
+    pts = []; op = k = 0; n = len(b); start = ip
+    while ip < n:
+        if k % 8 == 0: pts.append((ip, op))
+        k += 1
+        tag = b[ip]
+        if tag & 3 == 0:
+            ip += 1; ln = (tag >> 2) + 1
+            if ln > 60:
+                nb = ln - 60; ln = int.from_bytes(b[ip:ip + nb], "little") + 1; ip += nb
+            ip += ln; op += ln
+            if ip >= n: break
+            tag = b[ip]
+            if tag & 3 == 0: continue
+        kind = tag & 3
+        if kind == 1: op += 4 + ((tag >> 2) & 7); ip += 2
+        elif kind == 2: op += 1 + (tag >> 2); ip += 3
+        else: op += 1 + (tag >> 2); ip += 5
+    return k, pts
+
+
+@pytest.mark.parametrize("name,data", CASES, ids=IDS)
+def test_big_parse_sync_points_equal_a_serial_walk(name, data):
+    """the parse stage alone: sequence count and the absolute (ip, op) of every 8th sequence"""
+    import ctypes as C
+    from cramjam_amd import _native as N
+    L = N.lib()
+    for codec, blob, walk in ((N.CODEC_LZ4_BLOCK, oracle.lz4_compress_raw(data)[1], _serial_sync_lz4),
+                              (N.CODEC_SNAPPY_RAW, oracle.snappy_compress(data)[1], _serial_sync_snappy)):
+        k, pts = walk(blob)
+        out = np.zeros(len(data), dtype=np.uint8)
+        sync = np.zeros(2 * (len(pts) + 8), dtype=np.uint32)
+        nseq = C.c_uint64(0)
+        r = L.cj_debug_big_parse(codec, 0, blob, len(blob), out.ctypes.data, len(data), sync.ctypes.data, len(pts) + 8, C.byref(nseq))
+        assert r == len(data) and out.tobytes() == data
+        assert nseq.value == k, (codec, nseq.value, k)
+        got = sync[:2 * len(pts)].reshape(-1, 2)
+        exp = np.array(pts, dtype=np.uint32).reshape(-1, 2)
+        if codec == N.CODEC_SNAPPY_RAW: pass
+        bad = np.nonzero((got != exp).any(axis=1))[0]
+        assert bad.size == 0, (codec, int(bad[0]), got[bad[0]].tolist(), exp[bad[0]].tolist())

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(64) void big_mark_kernel(BigParse a) {
             const uint32_t r = pos - B;
             asm volatile("ds_or_b32 %0, %1" :: "v"(a_bits + 4u * (r >> 5)), "v"(1u << (r & 31u)) : "memory");
             Seq s;
-            pos = G::at(rd, pos, a.iend, s) ? s.next : kPosErr;
+            pos = G::at(rd, pos, a.iend, s, a.in) ? s.next : kPosErr;
         }
     }
     __syncthreads();
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(64) void big_mark_kernel(BigParse a) {
                 if ((w >> (r & 31u)) & 1u) going = false;
                 else {
                     Seq s;
-                    pos = G::at(rd, pos, a.iend, s) ? s.next : kPosErr;
+                    pos = G::at(rd, pos, a.iend, s, a.in) ? s.next : kPosErr;
                     if (pos >= E) going = false;
                 }
             }
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64) void big_thread_kernel(BigParse a) {
             const uint32_t r = q - B;
             if ((gb[r >> 5] >> (r & 31u)) & 1u) break;
             Seq s;
-            q = G::at(rd, q, a.iend, s) ? s.next : kPosErr;
+            q = G::at(rd, q, a.iend, s, a.in) ? s.next : kPosErr;
         }
         uint32_t first_end, nxt;
         if (q < E) {
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(64) void big_count_kernel(BigParse a) {
     while (ballot64(q < E && q != end) != 0ull) {
         if (q < E && q != end) {
             Seq s;
-            if (G::at(rd, q, a.iend, s)) { cnt += 1; outb += (uint64_t)s.lit + s.mlen; q = s.next; }
+            if (G::at(rd, q, a.iend, s, a.in)) { cnt += 1; outb += (uint64_t)s.lit + s.mlen; q = s.next; }
             else q = kPosErr;
         }
     }
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(64) void big_emit_kernel(BigParse a) {
             if ((idx % kSyncEvery) == 0u) a.sync[idx / kSyncEvery] = make_uint2(q, (uint32_t)op);
             Seq s;
             bool fin = false;
-            if (!G::at(rd, q, a.iend, s) || !G::check(s, op, a.cap, fin)) bad = true;
+            if (!G::at(rd, q, a.iend, s, a.in) || !G::check(s, op, a.cap, fin)) bad = true;
             else if (fin) {
                 if (!G::result_ok(op, a.cap)) bad = true;
                 else { a.status[6] = (uint32_t)op; a.status[7] = (uint32_t)(op >> 32); a.status[8] = 1u; }

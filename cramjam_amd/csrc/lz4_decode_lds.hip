@@ -490,10 +490,9 @@ constexpr uint32_t kL2LinkedBytes = 2u * 65536u + 8192u + 384u;        // 139 64
 // published its completion flag.  Slabs are claimed in order, so the slab a workgroup waits for is always running.
 struct SlabArgs { uint32_t* done; uint4* cross; uint32_t tab_stride, cross_stride; };
 
-template <int kCodec, bool kLinked = false, bool kSlab = false>
-__global__ __launch_bounds__(kL2Threads) CJ_L2_ATTR void lz4_decode_lds2_kernel(BatchArgs a, const uint2* sync, const ParseMeta* meta,
-                                                                     uint4* tabs, uint32_t* counter,
-                                                                     const uint2* frames, uint32_t n_frames, SlabArgs sl) {
+template <int kCodec, bool kLinked, bool kSlab>
+__device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync, const ParseMeta* meta, uint4* tabs, uint32_t* counter,
+                                          const uint2* frames, uint32_t n_frames, const SlabArgs& sl) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr uint32_t kOffBits = kLinked ? 131072u : kL2OffBits, kOffVars = kOffBits + 8192u;
     uint8_t* s_out = smem;
@@ -600,8 +599,9 @@ __global__ __launch_bounds__(kL2Threads) CJ_L2_ATTR void lz4_decode_lds2_kernel(
                 int64_t op = (int64_t)(uint64_t)p.y - (int64_t)S;       // may be negative: the group starts before the slab
                 uint32_t sq = sp * kSyncEvery;
                 for (uint32_t j = 0; j < kSyncEvery && sq < nseq; j++, sq++) {
+                    if (op >= (int64_t)U) { table[sq] = make_uint4(0u, 0u, U, 0u); continue; }     // the rest of the group lies past the slab
                     Seq q;
-                    (void)G::at(rd, ip, s_iend, q);                      // the parse stage accepted this stream
+                    (void)G::at(rd, ip, s_iend, q, in);                      // the parse stage accepted this stream
                     uint32_t lit = q.lit, src = q.lit_at, mlen = q.mlen;
                     int64_t o0 = op;
                     if (o0 < 0) { const uint32_t cut = (uint64_t)(-o0) < lit ? (uint32_t)(-o0) : lit; src += cut; lit -= cut; o0 += cut; }
@@ -888,12 +888,27 @@ __global__ __launch_bounds__(kL2Threads) CJ_L2_ATTR void lz4_decode_lds2_kernel(
                         longm &= longm - 1ull;
                         const uint32_t lmm = rdlane(m, l), lo = rdlane(off, l), ld = rdlane(dst, l);
                         const uint8_t* sb = (kLinked && lo > ld) ? smem + (a_prev - (uint32_t)(uintptr_t)smem) + 65536u - (lo - ld) : s_out + (ld - lo);
+                        if (lo == 1u || lo == 2u || lo == 4u) {
+                            // run of a 1/2/4-byte pattern (zero fill, padding): every 16-byte aligned vector of the run holds the
+                            // same bytes, so the body is written 16 bytes per lane instead of one
+                            const uint32_t h = (0u - ld) & 15u, hh = h < lmm ? h : lmm;
+                            if (lane < hh) s_out[ld + lane] = sb[lane % lo];
+                            uint32_t w = 0;
+#pragma unroll
+                            for (uint32_t i = 0; i < 4u; i++) w |= (uint32_t)sb[(hh + i) % lo] << (8u * i);
+                            const uint32_t nv = (lmm - hh) >> 4;
+                            uint4* dv = reinterpret_cast<uint4*>(s_out + ld + hh);
+                            for (uint32_t q = lane; q < nv; q += 64u) dv[q] = make_uint4(w, w, w, w);
+                            const uint32_t t0 = hh + (nv << 4);
+                            if (t0 + lane < lmm) s_out[ld + t0 + lane] = sb[(t0 + lane) % lo];
+                        } else {
                         uint32_t rr = lane, step = 64u;
                         if (lo <= 64u) { rr = lane % lo; step = 64u % lo; }
                         for (uint32_t k = lane; k < lmm; k += 64u) {
                             s_out[ld + k] = sb[lo >= lmm ? k : rr];
                             rr += step;
                             if (rr >= lo) rr -= lo;
+                        }
                         }
                         wave_bits_set(s_bits, ld, ld + lmm);
                         if (lane == l) pending = false;
@@ -931,13 +946,33 @@ __global__ __launch_bounds__(kL2Threads) CJ_L2_ATTR void lz4_decode_lds2_kernel(
             for (uint32_t i = (nvec << 4) + tid; i < U; i += kL2Threads) out[i] = s_out[i];
         }
         if (tid == 0 && *s_fail) a.result[c] = CJ_E_CORRUPT;    // cannot happen for a stream the parse kernel accepted
-        if constexpr (kSlab) {                               // publish: every wave's stores are out before the flag is
+        if constexpr (kSlab) {
+            // publish.  done[c] means "slabs 0..c are complete" (a Snappy copy may reach back over many slabs, and a slab
+            // without cross matches never waited for its predecessor): the flag is set after done[c-1] has been seen.
+            // Every wave's stores are out (release fence + barrier) before thread 0 stores the flag.
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __syncthreads();
-            if (tid == 0) __hip_atomic_store(&sl.done[c], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) {
+                if (c > 0u) while (__hip_atomic_load(&sl.done[c - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
+                __hip_atomic_store(&sl.done[c], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         if (prof) { __syncthreads(); CJ_PHASE_MARK(4); if (tid == 0) atomicAdd(&g_lds_phase_cycles[5], 1ull); }
     }
+}
+
+template <int kCodec, bool kLinked = false>
+__global__ __launch_bounds__(kL2Threads) CJ_L2_ATTR void lz4_decode_lds2_kernel(BatchArgs a, const uint2* sync, const ParseMeta* meta,
+                                                                     uint4* tabs, uint32_t* counter,
+                                                                     const uint2* frames, uint32_t n_frames) {
+    lds2_body<kCodec, kLinked, false>(a, sync, meta, tabs, counter, frames, n_frames, SlabArgs{nullptr, nullptr, 0u, 0u});
+}
+
+// the slab mode carries the cross-list copy inside D3's loop: capped at 128 VGPRs so that two workgroups still share a CU
+template <int kCodec>
+__global__ __launch_bounds__(kL2Threads) __attribute__((amdgpu_waves_per_eu(4, 4))) void lz4_decode_slabs_kernel(
+        BatchArgs a, const uint2* sync, const ParseMeta* meta, uint4* tabs, uint32_t* counter, const uint2* first, uint32_t stream_len, SlabArgs sl) {
+    lds2_body<kCodec, false, true>(a, sync, meta, tabs, counter, first, stream_len, sl);
 }
 
 size_t lz4_lds2_tab_bytes(uint32_t grid) { return (size_t)grid * kL2TabRecords * sizeof(uint4); }
@@ -949,13 +984,13 @@ void launch_lz4_decode_lds2(const BatchArgs& a, const void* sync, const void* me
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_lds2_kernel<CJ_CODEC_SNAPPY_RAW, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kL2Bytes);
         hipLaunchKernelGGL((lz4_decode_lds2_kernel<CJ_CODEC_SNAPPY_RAW, false>), dim3(grid), dim3(kL2Threads), kL2Bytes, s, a,
-                           (const uint2*)sync, (const ParseMeta*)meta, (uint4*)tabs, counter, (const uint2*)nullptr, 0u, SlabArgs{nullptr, nullptr, 0u, 0u});
+                           (const uint2*)sync, (const ParseMeta*)meta, (uint4*)tabs, counter, (const uint2*)nullptr, 0u);
         return;
     }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_lds2_kernel<CJ_CODEC_LZ4_BLOCK, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kL2Bytes);
     hipLaunchKernelGGL((lz4_decode_lds2_kernel<CJ_CODEC_LZ4_BLOCK, false>), dim3(grid), dim3(kL2Threads), kL2Bytes, s, a,
-                       (const uint2*)sync, (const ParseMeta*)meta, (uint4*)tabs, counter, (const uint2*)nullptr, 0u, SlabArgs{nullptr, nullptr, 0u, 0u});
+                       (const uint2*)sync, (const ParseMeta*)meta, (uint4*)tabs, counter, (const uint2*)nullptr, 0u);
 }
 
 void launch_lz4_decode_lds2_linked(const BatchArgs& a, const void* sync, const void* meta, void* tabs, uint32_t* counter,
@@ -964,7 +999,7 @@ void launch_lz4_decode_lds2_linked(const BatchArgs& a, const void* sync, const v
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_lds2_kernel<CJ_CODEC_LZ4_BLOCK, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kL2LinkedBytes);
     hipLaunchKernelGGL((lz4_decode_lds2_kernel<CJ_CODEC_LZ4_BLOCK, true>), dim3(grid), dim3(kL2Threads), kL2LinkedBytes, s, a,
-                       (const uint2*)sync, (const ParseMeta*)meta, (uint4*)tabs, counter, (const uint2*)frames, n_frames, SlabArgs{nullptr, nullptr, 0u, 0u});
+                       (const uint2*)sync, (const ParseMeta*)meta, (uint4*)tabs, counter, (const uint2*)frames, n_frames);
 }
 
 // large.hip: the slabs of one large stream.  tabs: grid * tab_stride records; cross: grid * cross_stride entries; done: one
@@ -975,15 +1010,15 @@ void launch_lz4_decode_lds2_slabs(const BatchArgs& a, const void* sync, const vo
     if (a.n_chunks == 0) return;
     const SlabArgs sl = {done, (uint4*)cross, tab_stride, cross_stride};
     if (codec == CJ_CODEC_SNAPPY_RAW) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_lds2_kernel<CJ_CODEC_SNAPPY_RAW, false, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_slabs_kernel<CJ_CODEC_SNAPPY_RAW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kL2Bytes);
-        hipLaunchKernelGGL((lz4_decode_lds2_kernel<CJ_CODEC_SNAPPY_RAW, false, true>), dim3(grid), dim3(kL2Threads), kL2Bytes, s, a,
+        hipLaunchKernelGGL((lz4_decode_slabs_kernel<CJ_CODEC_SNAPPY_RAW>), dim3(grid), dim3(kL2Threads), kL2Bytes, s, a,
                            (const uint2*)sync, (const ParseMeta*)meta, (uint4*)tabs, counter, (const uint2*)first, stream_len, sl);
         return;
     }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_lds2_kernel<CJ_CODEC_LZ4_BLOCK, false, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_slabs_kernel<CJ_CODEC_LZ4_BLOCK>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kL2Bytes);
-    hipLaunchKernelGGL((lz4_decode_lds2_kernel<CJ_CODEC_LZ4_BLOCK, false, true>), dim3(grid), dim3(kL2Threads), kL2Bytes, s, a,
+    hipLaunchKernelGGL((lz4_decode_slabs_kernel<CJ_CODEC_LZ4_BLOCK>), dim3(grid), dim3(kL2Threads), kL2Bytes, s, a,
                        (const uint2*)sync, (const ParseMeta*)meta, (uint4*)tabs, counter, (const uint2*)first, stream_len, sl);
 }
 

@@ -15,9 +15,25 @@ constexpr uint32_t kPosErr = 0xFFFFFFFFu;                // the walk ran into a 
 // decoder's rules that need the output position (phase 4).
 struct Seq { uint32_t lit, mlen, offset, next, lit_at; bool last; };      // lit_at = position of the literal bytes
 
+// number of 0xFF bytes at g[ip..] counted in whole 64-byte steps (the caller's byte loop finishes the run); stays 16 bytes
+// clear of iend
+__device__ __forceinline__ uint32_t count_ff(const uint8_t* g, uint32_t ip, uint32_t iend) {
+    uint32_t k = 0;
+    while (ip + k + 80u <= iend) {
+        uint4 a, b, c, d;
+        __builtin_memcpy(&a, g + ip + k, 16); __builtin_memcpy(&b, g + ip + k + 16u, 16);
+        __builtin_memcpy(&c, g + ip + k + 32u, 16); __builtin_memcpy(&d, g + ip + k + 48u, 16);
+        if ((a.x & a.y & a.z & a.w & b.x & b.y & b.z & b.w & c.x & c.y & c.z & c.w & d.x & d.y & d.z & d.w) != 0xFFFFFFFFu) break;
+        k += 64u;
+    }
+    return k;
+}
+
 struct Lz4Grammar {
     template <class Rd>
-    static __device__ __forceinline__ bool at(const Rd& rd, uint32_t ip, uint32_t iend, Seq& s) {
+    static __device__ __forceinline__ bool at(const Rd& rd, uint32_t ip, uint32_t iend, Seq& s, const uint8_t* g = nullptr) {
+        // g (optional) = global pointer to stream position 0: lets a long run of 0xFF length bytes (a literal run or a match
+        // of megabytes: one length byte per 255 bytes) be skipped 64 bytes at a time instead of one dependent read each
         const uint32_t t4 = rd(ip);
         const uint32_t token = t4 & 0xffu;
         ip += 1;
@@ -27,7 +43,13 @@ struct Lz4Grammar {
             uint32_t b = (t4 >> 8) & 0xffu;
             ip += 1; lit += b;
             if (ip + 15u > iend) return false;
+            uint32_t streak = 0;
             while (b == 255u) {
+                if (g != nullptr && ++streak == 8u) {
+                    const uint32_t k = count_ff(g, ip, iend);
+                    if (k > 0x00800000u) return false;            // > 2 GiB of literals: no valid block
+                    lit += 255u * k; ip += k;
+                }
                 b = rd(ip) & 0xffu;
                 ip += 1; lit += b;
                 if (ip + 15u > iend) return false;
@@ -50,7 +72,13 @@ struct Lz4Grammar {
             uint32_t b = (o4 >> 16) & 0xffu;
             ip += 1; mlen += b;
             if (ip + 4u > iend) return false;
+            uint32_t streak = 0;
             while (b == 255u) {
+                if (g != nullptr && ++streak == 8u) {
+                    const uint32_t k = count_ff(g, ip, iend);
+                    if (k > 0x00800000u) return false;
+                    mlen += 255u * k; ip += k;
+                }
                 b = rd(ip) & 0xffu;
                 ip += 1; mlen += b;
                 if (ip + 4u > iend) return false;
@@ -85,7 +113,7 @@ struct Lz4Grammar {
 // Snappy: a record = optional literal element + optional copy element (snappy_records.hpp); cap = the decoded length dn
 struct SnappyGrammar {
     template <class Rd>
-    static __device__ __forceinline__ bool at(const Rd& rd, uint32_t ip, uint32_t iend, Seq& s) {
+    static __device__ __forceinline__ bool at(const Rd& rd, uint32_t ip, uint32_t iend, Seq& s, const uint8_t* = nullptr) {
         uint32_t t4 = rd(ip);
         uint32_t tag = t4 & 0xffu;
         s.lit = 0; s.mlen = 0; s.offset = 0; s.last = false; s.lit_at = ip;

@@ -75,6 +75,11 @@ int cj_device_count(void);
  * (CJ_DEVICE env var overrides), created lazily.
  * ===================================================================================== */
 
+/* Single-buffer entry points.  A buffer above 64 KiB (input, or announced output) is not run as one serial stream on one
+ * wavefront: compress cuts it into 64 KiB pieces, compresses them as a batch and joins them into ONE valid block / raw
+ * stream; decompress parses the stream in parallel and decodes it in 64 KiB slabs of output.  Same
+ * arguments, results and error codes either way. */
+
 /* src/lz4.rs:228  libcramjam::lz4::block::compress_bound(len, Some(prepend))
  * = LZ4_compressBound(len) (+4 when prepend); 0 when len > 0x7E000000. Pure arithmetic, no device. */
 size_t cj_lz4_block_compress_bound(size_t len, int prepend);

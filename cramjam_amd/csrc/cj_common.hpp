@@ -60,7 +60,7 @@ int64_t large_lz4_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap
 int64_t large_decompress(int codec, uint32_t flags, const uint8_t* in, size_t n, uint8_t* out, size_t cap);
 void launch_lz4_decode_lds2_slabs(const BatchArgs& a, const void* sync, const void* meta, void* tabs, uint32_t* counter,
                                   const void* first, uint32_t stream_len, uint32_t* done, void* cross, uint32_t tab_stride,
-                                  uint32_t cross_stride, uint32_t grid, hipStream_t s, int codec);
+                                  uint32_t cross_stride, uint32_t grid, hipStream_t s, int codec, bool rel = false);
 void launch_snappy_parse_spec(const BatchArgs& a, void* sync, void* meta, hipStream_t s);  // wavefront per chunk, 64 segments parsed at once
 void launch_snappy_parse_wave(const BatchArgs& a, void* sync, void* meta, hipStream_t s);  // wavefront per chunk: small / medium batches           // parse + LDS pipeline, like launch_lz4_parse
 void launch_snappy_decode_routed(const BatchArgs& a, const void* meta, hipStream_t s);       // wave kernel on chunks the parse kernel routed to it

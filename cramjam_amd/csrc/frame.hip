@@ -8,6 +8,7 @@
 // assembles the stream (copy_segments).  No codec or checksum arithmetic runs on the host.
 #include "cj_engine.hpp"
 #include "xxh32_host.hpp"
+#include "lz4_lane_walk.hpp"
 
 #include <atomic>
 
@@ -337,8 +338,8 @@ int lz4_frame_linked_lds(cj_engine* e, const Lz4Frame& f, const uint8_t* d_in, s
     const uint64_t B = 65536;
     hipStream_t s = e->stream;
     std::lock_guard<std::mutex> lock(e->scratch_mu);
-    // rows: in_off | in_len | out_off | out_cap | result | hist(u32) | frames(uint2)
-    const size_t hw = (nb * 4 + 7) / 8, rows = 5 * nb + hw + 1;
+    // rows: in_off | in_len | out_off | out_cap | result | hist(u32) | frames(uint2) | first(uint2 per block) | counter | done(u32 per block)
+    const size_t hw = (nb * 4 + 7) / 8, r_first = 5 * nb + hw + 1, r_cnt = r_first + nb, r_done = r_cnt + 1, rows = r_done + hw;
     const size_t list_bytes = 16;
     if (e->scratch_free) HIP_TRY(hipEventSynchronize(e->scratch_free), CJ_E_NO_DEVICE);
     if (!e->d_out.reserve(nb * B + 16) || !e->d_meta.reserve(rows * 8) || !e->d_sync.reserve(cj::lz4_lds_scratch_sync_bytes(nb)) ||
@@ -358,6 +359,8 @@ int lz4_frame_linked_lds(cj_engine* e, const Lz4Frame& f, const uint8_t* d_in, s
     }
     uint32_t* fr = reinterpret_cast<uint32_t*>(m.data() + 5 * nb + hw);
     fr[0] = 0u; fr[1] = (uint32_t)nb;
+    uint32_t* first = reinterpret_cast<uint32_t*>(m.data() + r_first);
+    for (size_t i = 0; i < nb; i++) { first[2 * i] = (uint32_t)(i * cj::kSyncStride); first[2 * i + 1] = 0u; }
     HIP_TRY(hipMemcpyAsync(d_meta, m.data(), rows * 8, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
     HIP_TRY(hipMemsetAsync(e->d_pmeta.p, 0, cj::lz4_lds_scratch_meta_bytes(nb), s), CJ_E_NO_DEVICE);
     HIP_TRY(hipMemsetAsync(e->d_lanelist.p, 0, 16, s), CJ_E_NO_DEVICE);
@@ -377,9 +380,27 @@ int lz4_frame_linked_lds(cj_engine* e, const Lz4Frame& f, const uint8_t* d_in, s
         if (i + 1 < nb && (uint64_t)res[i] != B) return 1;            // a short block in the middle: positions are not k * 64 KiB
         if (res[i] == 0 && !(in_skip & 0x20000000u)) return 1;
     }
-    cj::launch_lz4_decode_lds2_linked(a, e->d_sync.p, e->d_pmeta.p, e->d_tab.p, (uint32_t*)e->d_lanelist.p + 2,
-                                      d_meta + 5 * nb + hw, 1u, 1u, s);
+    static const bool one_wg = std::getenv("CJ_LZ4F_ONE_WORKGROUP") != nullptr;
+    if (one_wg) {
+        // one workgroup walks the frame's blocks in order, the previous block in a second LDS window
+        cj::launch_lz4_decode_lds2_linked(a, e->d_sync.p, e->d_pmeta.p, e->d_tab.p, (uint32_t*)e->d_lanelist.p + 2,
+                                          d_meta + 5 * nb + hw, 1u, 1u, s);
+    } else {
+        // every block is a slab of the large-stream decoder (large.hip / DESIGN 5.6): two workgroups per CU take the blocks in
+        // order, a match that reaches into earlier blocks is copied from their finished output once the predecessor's
+        // completion flag is up, everything else is resolved meanwhile
+        if (e->n_cu == 0) HIP_TRY(hipDeviceGetAttribute(&e->n_cu, hipDeviceAttributeMultiprocessorCount, e->device), CJ_E_NO_DEVICE);
+        const uint32_t grid = (uint32_t)std::min<size_t>(2u * (size_t)e->n_cu, nb);
+        const uint32_t cross_stride = cj::kSyncStride * cj::kSyncEvery, tab_stride = 2u * cross_stride;
+        const size_t tab_bytes = (size_t)grid * tab_stride * 16;
+        if (!e->d_bigtab.reserve(tab_bytes + (size_t)grid * cross_stride * 16 + (size_t)grid * (tab_stride + 512u) * 4)) return CJ_E_OOM;
+        cj::launch_lz4_decode_lds2_slabs(a, e->d_sync.p, e->d_pmeta.p, e->d_bigtab.p, (uint32_t*)(d_meta + r_cnt), d_meta + r_first, 0u,
+                                         (uint32_t*)(d_meta + r_done), (uint8_t*)e->d_bigtab.p + tab_bytes, tab_stride, cross_stride,
+                                         grid, s, CJ_CODEC_LZ4_BLOCK, true);
+    }
     HIP_TRY(hipGetLastError(), CJ_E_NO_DEVICE);
+    HIP_TRY(hipMemcpyAsync(res.data(), d_meta + 4 * nb, nb * 8, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);     // the decoder's stall guard reports here
+    HIP_TRY(hipStreamSynchronize(s), CJ_E_NO_DEVICE);
     *d_final = (uint8_t*)e->d_out.p;
     g_linked_lds_frames.fetch_add(1);
     return 0;

@@ -311,7 +311,7 @@ int64_t large_decompress(int codec, uint32_t flags, const uint8_t* in, size_t n,
     const uint32_t grid = std::min<uint32_t>(2u * (uint32_t)e->n_cu, n_slabs);
     const uint32_t cross_stride = (max_rec + 63u) & ~63u, tab_stride = 2u * cross_stride;
     const size_t tab_bytes = (size_t)grid * tab_stride * 16, cross_bytes = (size_t)grid * cross_stride * 16;
-    if (!e->d_bigtab.reserve(tab_bytes + cross_bytes) || !e->d_out.reserve(total + 256)) return CJ_E_OOM;
+    if (!e->d_bigtab.reserve(tab_bytes + cross_bytes + (size_t)grid * (tab_stride + 512u) * 4) || !e->d_out.reserve(total + 256)) return CJ_E_OOM;
     BatchArgs a;
     fill_args(a, 0u, n_slabs, d_in, sd.in_off, sd.in_len, (uint8_t*)e->d_out.p, sd.out_off, sd.out_cap, sd.result);
     launch_lz4_decode_lds2_slabs(a, bp.sync, sd.meta, e->d_bigtab.p, (uint32_t*)(d_meta + r_misc) + 1, sd.first, iend,

@@ -488,7 +488,16 @@ constexpr uint32_t kL2LinkedBytes = 2u * 65536u + 8192u + 384u;        // 139 64
 // length): sequences that begin before the slab or end after it are clipped, and the part of a match whose source lies
 // before the slab ("cross") is copied from the finished output of the earlier slabs in global memory once slab c-1 has
 // published its completion flag.  Slabs are claimed in order, so the slab a workgroup waits for is always running.
-struct SlabArgs { uint32_t* done; uint4* cross; uint32_t tab_stride, cross_stride; };
+#ifndef CJ_SLAB_POLL_MASK
+#define CJ_SLAB_POLL_MASK 1u
+#endif
+struct SlabArgs { uint32_t* done; uint4* cross; uint32_t tab_stride, cross_stride, rel; uint32_t* defer; uint32_t defer_stride; };
+#ifndef CJ_SLAB_PATIENCE
+#define CJ_SLAB_PATIENCE 64u
+#endif
+constexpr uint32_t kSlabPatience = CJ_SLAB_PATIENCE;
+// rel = 1 (LZ4 frames with linked blocks, frame.hip): chunk c is block c of the frame — its sync points are its own (ip, op
+// relative to the block), the stream length is the block's, a STORED block is copied; history = the blocks before it.
 
 template <int kCodec, bool kLinked, bool kSlab>
 __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync, const ParseMeta* meta, uint4* tabs, uint32_t* counter,
@@ -557,7 +566,33 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 continue;                                    // the barrier at the top of the next block orders these LDS writes
             }
         }
-        if (pm.nseq == 0u) continue;                         // error, empty, or routed to another kernel
+        // kSlab: done[c] means "chunks 0..c are complete" (a Snappy copy may reach back over many slabs, and a slab without
+        // cross matches never waited for its predecessor): the flag is set after done[c-1] has been seen.  Every wave's
+        // stores are out (release fence + barrier) before thread 0 stores the flag.
+        const auto publish = [&]() {
+            if constexpr (kSlab) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __syncthreads();
+                if (tid == 0) {
+                    if (c > 0u) while (__hip_atomic_load(&sl.done[c - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
+                    __hip_atomic_store(&sl.done[c], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        };
+        if constexpr (kSlab) {
+            if (pm.in_skip & kRouteStored) {                 // linked frame: a stored block is its own output
+                const uint32_t len = (uint32_t)a.result[c];
+                const uint8_t* src = a.in_base + a.in_off[c];
+                uint8_t* dsto = a.out_base + a.out_off[c];
+                for (uint32_t i = tid * 16u; i < len; i += kL2Threads * 16u) {
+                    if (i + 16u <= len) st16u_nt(dsto + i, ld16u(src + i));
+                    else for (uint32_t q = i; q < len; q++) dsto[q] = src[q];
+                }
+                publish();
+                continue;
+            }
+        }
+        if (pm.nseq == 0u) { publish(); continue; }          // error, empty, or routed to another kernel
         const uint32_t nseq = pm.nseq;
         const uint32_t U = (uint32_t)a.result[c];            // decoded size, 1..65536
         const uint8_t* in = a.in_base + a.in_off[c] + pm.in_skip;
@@ -589,14 +624,15 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         if constexpr (kSlab) {
             using G = typename std::conditional<kCodec == CJ_CODEC_SNAPPY_RAW, SnappyGrammar, Lz4Grammar>::type;
             const uint32_t in_lo = frames[c].y;
-            const uint32_t s_iend = n_frames - in_lo;        // the stream's end, relative to this slab's input
+            const uint32_t s_iend = sl.rel ? iend : n_frames - in_lo;     // the stream's end, relative to this slab's input
             const uint64_t S = a.out_off[c];
+            const int64_t op_bias = sl.rel ? 0 : (int64_t)S;
             const auto rd = [&](uint32_t p) { return staged ? lds_ld32(a_in + p) : ld32u(in + p); };
             uint4* cross = sl.cross + (size_t)blockIdx.x * sl.cross_stride;
             for (uint32_t sp = tid; sp < nsp; sp += kL2Threads) {
                 const uint2 p = csync[sp];
                 uint32_t ip = p.x - in_lo;
-                int64_t op = (int64_t)(uint64_t)p.y - (int64_t)S;       // may be negative: the group starts before the slab
+                int64_t op = (int64_t)(uint64_t)p.y - op_bias;          // may be negative: the group starts before the slab
                 uint32_t sq = sp * kSyncEvery;
                 for (uint32_t j = 0; j < kSyncEvery && sq < nseq; j++, sq++) {
                     if (op >= (int64_t)U) { table[sq] = make_uint4(0u, 0u, U, 0u); continue; }     // the rest of the group lies past the slab
@@ -785,12 +821,39 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
 
         // ---- D3: matches (same resolver as variant 1).  No barrier after D2: readiness is exact per byte through the
         //      bitmap, so a wave starts on its matches while other waves are still placing literals ----
+        // kSlab: a wave must not sit on a batch whose lanes wait for bytes of an EARLIER slab while its later batches could be
+        // resolved: as long as the predecessor's flag has not been seen (or something is already deferred), a batch that
+        // made no progress for kPatience polls is abandoned — its pending lanes go to the wave's deferred list (global
+        // memory, record indices in increasing order) and are finished in a second pass after the cross copy.  Progress:
+        // pass 1 always terminates; in pass 2 the lowest unfinished record of the slab is always in the batch its wave is
+        // standing on (the lists are sorted and a record waits only for records before it).
+        uint32_t* dlist = nullptr;
+        uint32_t ndef = 0, dpos = 0;
+        bool pass2 = false;
+        if constexpr (kSlab) dlist = sl.defer + (size_t)blockIdx.x * sl.defer_stride + (size_t)wave * (sl.defer_stride / 8u);
         rec_nx = make_uint4(0, 0, 0, 0);
         if (wave * 64u + lane < nrec_all) rec_nx = table[wave * 64u + lane];
-        for (uint32_t base = wave * 64u; base < nrec_all; base += kL2Threads) {
-            const uint4 rec = rec_nx;
-            rec_nx = make_uint4(0, 0, 0, 0);
-            if (base + kL2Threads + lane < nrec_all) rec_nx = table[base + kL2Threads + lane];
+        for (uint32_t base = wave * 64u;; base += kL2Threads) {
+            uint4 rec;
+            uint32_t ridx = base + lane;
+            if constexpr (kSlab) {
+                if (!pass2 && base >= nrec_all) { pass2 = true; if (!cross_done) try_cross(true); }
+                if (pass2) {
+                    if (dpos >= ndef) break;
+                    rec = make_uint4(0, 0, 0, 0);
+                    if (dpos + lane < ndef) { ridx = dlist[dpos + lane]; rec = table[ridx]; }
+                    dpos += 64u;
+                } else {
+                    rec = rec_nx;
+                    rec_nx = make_uint4(0, 0, 0, 0);
+                    if (base + kL2Threads + lane < nrec_all) rec_nx = table[base + kL2Threads + lane];
+                }
+            } else {
+                if (base >= nrec_all) break;
+                rec = rec_nx;
+                rec_nx = make_uint4(0, 0, 0, 0);
+                if (base + kL2Threads + lane < nrec_all) rec_nx = table[base + kL2Threads + lane];
+            }
             const uint32_t dst = rec.z, off = rec.w & 0xffffu, m = rec.w >> 16;
             const uint32_t src = dst - off;                   // kLinked: "negative" (wraps) when the source starts in the previous block
             const uint32_t need = off < m ? off : m;
@@ -812,7 +875,8 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 qm1 = de > 32u ? ((1u << (de - 32u)) - 1u) : 0u;
             }
             const bool any_slow = ballot64(pending && !fast) != 0ull;
-            uint32_t spins = 0, idle = 0;
+            uint32_t spins = 0, idle = 0, stall = 0;
+            uint64_t prev_mask = 0ull;
             while (ballot64(pending) != 0ull) {
                 bool ready = false;
                 if (pending && fast) {
@@ -917,7 +981,16 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 if constexpr (kSlab) {
                     if (!cross_done) {                             // waiting on an earlier slab is not a stall of this one
                         spins = 0;
-                        if (rm == 0ull && (++idle & 7u) == 0u) try_cross(false);
+                        if (rm == 0ull && (++idle & CJ_SLAB_POLL_MASK) == 0u) try_cross(false);
+                    }
+                    if (!pass2 && (!cross_done || ndef > 0u)) {
+                        const uint64_t pmask = ballot64(pending);
+                        if (pmask != prev_mask) { prev_mask = pmask; stall = 0; }
+                        else if (++stall > kSlabPatience) {        // abandon: the pending lanes are finished in pass 2
+                            if (pending) dlist[ndef + (uint32_t)__popcll(pmask & ((1ull << lane) - 1ull))] = ridx;
+                            ndef += (uint32_t)__popcll(pmask);
+                            pending = false;
+                        }
                     }
                 }
                 if (++spins > kSpinLimit) {
@@ -934,7 +1007,6 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 }
             }
         }
-        if constexpr (kSlab) { if (!cross_done) try_cross(true); }
         __syncthreads();
         CJ_PHASE_MARK(3);
 
@@ -946,17 +1018,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             for (uint32_t i = (nvec << 4) + tid; i < U; i += kL2Threads) out[i] = s_out[i];
         }
         if (tid == 0 && *s_fail) a.result[c] = CJ_E_CORRUPT;    // cannot happen for a stream the parse kernel accepted
-        if constexpr (kSlab) {
-            // publish.  done[c] means "slabs 0..c are complete" (a Snappy copy may reach back over many slabs, and a slab
-            // without cross matches never waited for its predecessor): the flag is set after done[c-1] has been seen.
-            // Every wave's stores are out (release fence + barrier) before thread 0 stores the flag.
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __syncthreads();
-            if (tid == 0) {
-                if (c > 0u) while (__hip_atomic_load(&sl.done[c - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
-                __hip_atomic_store(&sl.done[c], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
+        publish();
         if (prof) { __syncthreads(); CJ_PHASE_MARK(4); if (tid == 0) atomicAdd(&g_lds_phase_cycles[5], 1ull); }
     }
 }
@@ -965,7 +1027,7 @@ template <int kCodec, bool kLinked = false>
 __global__ __launch_bounds__(kL2Threads) CJ_L2_ATTR void lz4_decode_lds2_kernel(BatchArgs a, const uint2* sync, const ParseMeta* meta,
                                                                      uint4* tabs, uint32_t* counter,
                                                                      const uint2* frames, uint32_t n_frames) {
-    lds2_body<kCodec, kLinked, false>(a, sync, meta, tabs, counter, frames, n_frames, SlabArgs{nullptr, nullptr, 0u, 0u});
+    lds2_body<kCodec, kLinked, false>(a, sync, meta, tabs, counter, frames, n_frames, SlabArgs{nullptr, nullptr, 0u, 0u, 0u, nullptr, 0u});
 }
 
 // the slab mode carries the cross-list copy inside D3's loop: capped at 128 VGPRs so that two workgroups still share a CU
@@ -1006,9 +1068,12 @@ void launch_lz4_decode_lds2_linked(const BatchArgs& a, const void* sync, const v
 // zeroed word per slab
 void launch_lz4_decode_lds2_slabs(const BatchArgs& a, const void* sync, const void* meta, void* tabs, uint32_t* counter,
                                   const void* first, uint32_t stream_len, uint32_t* done, void* cross, uint32_t tab_stride,
-                                  uint32_t cross_stride, uint32_t grid, hipStream_t s, int codec) {
+                                  uint32_t cross_stride, uint32_t grid, hipStream_t s, int codec, bool rel) {
     if (a.n_chunks == 0) return;
-    const SlabArgs sl = {done, (uint4*)cross, tab_stride, cross_stride};
+    // the deferred lists (one per wave: at most its share of the records + a batch) follow the cross lists
+    const uint32_t defer_stride = tab_stride + 8u * 64u;
+    const SlabArgs sl = {done, (uint4*)cross, tab_stride, cross_stride, rel ? 1u : 0u,
+                         reinterpret_cast<uint32_t*>((uint4*)cross + (size_t)grid * cross_stride), defer_stride};
     if (codec == CJ_CODEC_SNAPPY_RAW) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_slabs_kernel<CJ_CODEC_SNAPPY_RAW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kL2Bytes);

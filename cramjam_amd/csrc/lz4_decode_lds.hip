@@ -491,6 +491,10 @@ constexpr uint32_t kL2LinkedBytes = 2u * 65536u + 8192u + 384u;        // 139 64
 #ifndef CJ_SLAB_POLL_MASK
 #define CJ_SLAB_POLL_MASK 1u
 #endif
+#ifndef CJ_FWD_ROUNDS
+#define CJ_FWD_ROUNDS 16u
+#endif
+constexpr uint32_t kFwdMaxRecords = 4096, kFwdMaxRounds = CJ_FWD_ROUNDS, kFwdNear = 4096;      // D1f (match forwarding)
 struct SlabArgs { uint32_t* done; uint4* cross; uint32_t tab_stride, cross_stride, rel; uint32_t* defer; uint32_t defer_stride; };
 #ifndef CJ_SLAB_PATIENCE
 #define CJ_SLAB_PATIENCE 64u
@@ -516,6 +520,8 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
     uint4* table = tabs + (size_t)blockIdx.x * (kSlab ? sl.tab_stride : kL2TabRecords);
     uint32_t* s_ncross = reinterpret_cast<uint32_t*>(smem + kOffVars + 16u);     // kSlab: entries in the cross list / extra records
     uint32_t* s_nextra = reinterpret_cast<uint32_t*>(smem + kOffVars + 20u);
+    uint32_t* s_fwd = reinterpret_cast<uint32_t*>(smem + kOffVars + 24u);          // D1f: rounds in which a record moved
+    uint32_t* s_small = reinterpret_cast<uint32_t*>(smem + kOffVars + 28u);        // D1: matches with an offset below kFwdNear
     const bool prof = (a.flags & 0x1000u) != 0;
     unsigned long long t_prev = prof ? __builtin_readcyclecounter() : 0ull;
     uint32_t fr_first = 0, fr_n = 0, fr_k = 0;               // kLinked: current frame and position in it
@@ -541,7 +547,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             for (uint32_t i = tid; i < 2048u; i += kL2Threads) s_bits[i] = 0u;
             __syncthreads();                                 // also: the previous block's D4 has finished reading its window
         } else {
-            if (tid == 0) { *s_chunk = atomicAdd(counter, 1u); *s_fail = 0u; *s_ncross = 0u; *s_nextra = 0u; }
+            if (tid == 0) { *s_chunk = atomicAdd(counter, 1u); *s_fail = 0u; *s_ncross = 0u; *s_nextra = 0u; *s_small = 0u; }
             for (uint32_t i = tid; i < 2048u; i += kL2Threads) s_bits[i] = 0u;
             __syncthreads();
             c = *s_chunk;
@@ -633,7 +639,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 const uint2 p = csync[sp];
                 uint32_t ip = p.x - in_lo;
                 int64_t op = (int64_t)(uint64_t)p.y - op_bias;          // may be negative: the group starts before the slab
-                uint32_t sq = sp * kSyncEvery;
+                uint32_t sq = sp * kSyncEvery, near = 0;
                 for (uint32_t j = 0; j < kSyncEvery && sq < nseq; j++, sq++) {
                     if (op >= (int64_t)U) { table[sq] = make_uint4(0u, 0u, U, 0u); continue; }     // the rest of the group lies past the slab
                     Seq q;
@@ -668,11 +674,13 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                                 rec = make_uint4(0u, 0u, dst + n1, off | ((mlen - n1) << 16));
                             }
                         } else rec.w = off | (mlen << 16);
+                        near += off < kFwdNear ? 1u : 0u;
                     }
                     table[sq] = rec;
                     ip = q.next;
                     op += (int64_t)q.lit + q.mlen;
                 }
+                if (near) atomicAdd(s_small, near);
             }
             __syncthreads();
             nrec_all = nseq + *s_nextra;
@@ -684,17 +692,20 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 const uint2 p = csync[sp];
                 uint32_t ip = p.x, op = p.y;
                 uint32_t s = sp * kSyncEvery;
+                uint32_t near = 0;
                 for (uint32_t j = 0; j < kSyncEvery && s < nseq; j++, s++) {
                     SnRecord rec;
                     (void)snappy_record_step(rd, ip, op, iend, U, rec);     // the parse kernel accepted this stream
                     table[s] = make_uint4(rec.lit_src, rec.lit_len, rec.dst, rec.w);
+                    near += (rec.w != 0u && (rec.w & 0xffffu) < kFwdNear) ? 1u : 0u;
                 }
+                if (near) atomicAdd(s_small, near);
             }
         } else
         for (uint32_t sp = tid; sp < nsp; sp += kL2Threads) {
             const uint2 p = csync[sp];
             uint32_t ip = p.x, op = p.y;
-            uint32_t s = sp * kSyncEvery;
+            uint32_t s = sp * kSyncEvery, near = 0;
             for (uint32_t j = 0; j < kSyncEvery && s < nseq; j++, s++) {
                 const uint32_t t4 = lds_ld32(a_in + ip);           // token + 3 following bytes (may over-read: harmless)
                 const uint32_t token = t4 & 0xffu;
@@ -720,13 +731,86 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                     }
                     mlen += 4u;
                     w = offset | (mlen << 16);
+                    near += offset < kFwdNear ? 1u : 0u;
                 }
                 table[s] = make_uint4(lit_src, lit, op, w);
                 op += mlen;
             }
+            if (near) atomicAdd(s_small, near);
         }
         __syncthreads();
         CJ_PHASE_MARK(1);
+
+#ifndef CJ_NO_FORWARD
+        // ---- D1f: MATCH FORWARDING.  D3 resolves matches as a dependency DAG and pays its latency per LEVEL; real data
+        //      (text, logs, records) is deep: a phrase is copied from its previous occurrence, which was copied from the one
+        //      before ... (thousands of levels in 64 KiB).  But if the source range of match A lies entirely inside the
+        //      destination of an earlier non-overlapping match B, A can copy from B's SOURCE instead (offset += B's offset),
+        //      and if it lies inside a literal run, A is a literal copy from the input and depends on nothing.  Iterated
+        //      (each round reads the other records' current offsets: pointer doubling), chains collapse: depth 7 048 -> 67 on
+        //      the "bottles" text, 562 -> 44 on log lines, 40 -> 23 on the benchmark data, where a third of the matches
+        //      become literal copies.  The record index lives in the output window (free between D1 and D2): per record
+        //      start|dst, length|literal source, current offset; plus "last record starting at or before byte 16 b".
+        if constexpr (!kLinked) {
+            if (nseq <= kFwdMaxRecords && staged && *s_small * 2u > nseq) {      // mostly near matches: the chains are deep, forwarding pays (it costs ~25 k cycles + 10 k per round)
+                uint32_t* f_w0 = reinterpret_cast<uint32_t*>(s_out);
+                uint32_t* f_w1 = f_w0 + kFwdMaxRecords;
+                uint32_t* f_st = f_w1 + kFwdMaxRecords;
+                uint16_t* f_blk = reinterpret_cast<uint16_t*>(f_st + kFwdMaxRecords);
+                constexpr uint32_t kLit = 0x80000000u;
+                for (uint32_t i = tid; i < nseq; i += kL2Threads) {
+                    const uint4 r = table[i];
+                    const uint32_t start = r.z - r.y;
+                    f_w0[i] = (start < 65535u ? start : 65535u) | ((r.z < 65535u ? r.z : 65535u) << 16);
+                    f_w1[i] = (r.w >> 16) | ((r.x & 0xffffu) << 16);
+                    f_st[i] = r.w & 0xffffu;
+                }
+                if (tid == 0) *s_fwd = 0u;
+                __syncthreads();
+                for (uint32_t i = tid; i < nseq; i += kL2Threads) {          // blocks whose first byte lies in [start_i, start_{i+1})
+                    const uint32_t b0 = ((f_w0[i] & 0xffffu) + 15u) >> 4;
+                    const uint32_t b1 = i + 1u < nseq ? ((f_w0[i + 1u] & 0xffffu) + 15u) >> 4 : 4096u;
+                    for (uint32_t b = i == 0u ? 0u : b0; b < b1; b++) f_blk[b] = (uint16_t)i;
+                }
+                __syncthreads();
+                for (uint32_t round = 0; round < kFwdMaxRounds; round++) {
+                    uint32_t changed = 0;
+                    for (uint32_t i = tid; i < nseq; i += kL2Threads) {
+                        const uint32_t st = f_st[i], m = f_w1[i] & 0xffffu, dst = f_w0[i] >> 16;
+                        if (m == 0u || (st & kLit) || st < m) continue;            // no match / already a literal copy / self-overlapping
+                        const uint32_t sp = dst - st;                              // current source position
+                        uint32_t r = f_blk[sp >> 4];
+                        while (r + 1u < nseq && (f_w0[r + 1u] & 0xffffu) <= sp) r++;
+                        if (r > i) continue;                                       // (r == i: the source lies in the record's own literal run)
+                        const uint32_t w0 = f_w0[r], w1 = f_w1[r], bst = f_st[r];
+                        const uint32_t bstart = w0 & 0xffffu, bdst = w0 >> 16, bm = w1 & 0xffffu;
+                        if (sp >= bstart && sp + m <= bdst) { f_st[i] = kLit | ((w1 >> 16) + (sp - bstart)); changed = 1; }
+                        else if (bm > 0u && sp >= bdst && sp + m <= bdst + bm) {
+                            if (bst & kLit) { f_st[i] = kLit | ((bst & ~kLit) + (sp - bdst)); changed = 1; }
+                            else if (bst >= bm) { f_st[i] = st + bst; changed = 1; }
+                        }
+                    }
+                    if (changed) atomicOr(s_fwd, 1u << (round & 31u));
+                    __syncthreads();
+                    if (((*s_fwd >> (round & 31u)) & 1u) == 0u) break;          // uniform: nothing moved in this round
+                }
+                for (uint32_t i = tid; i < nseq; i += kL2Threads) {
+                    const uint32_t st = f_st[i], m = f_w1[i] & 0xffffu;
+                    if (m == 0u) continue;
+                    if (st & kLit) {
+                        const uint4 r = table[i];
+                        table[nseq + atomicAdd(s_nextra, 1u)] = make_uint4(st & ~kLit, m, r.z + m, 0u);      // a literal copy of m bytes ending at dst + m
+                        table[i] = make_uint4(r.x, r.y, r.z, 0u);
+                    } else if (st != (table[i].w & 0xffffu)) {
+                        const uint4 r = table[i];
+                        table[i] = make_uint4(r.x, r.y, r.z, st | (m << 16));
+                    }
+                }
+                __syncthreads();
+                nrec_all = nseq + *s_nextra;
+            }
+        }
+#endif
 
         // ---- D2: literals, one lane per sequence: global -> LDS window ----
         // (the next batch's records are requested before the current batch is processed: a coalesced table read is a

@@ -494,6 +494,7 @@ constexpr uint32_t kL2LinkedBytes = 2u * 65536u + 8192u + 384u;        // 139 64
 #ifndef CJ_FWD_ROUNDS
 #define CJ_FWD_ROUNDS 16u
 #endif
+__device__ unsigned long long g_fwd_chunks = 0ull;            // test hook: chunks / slabs that went through D1f
 constexpr uint32_t kFwdMaxRecords = 4096, kFwdMaxRounds = CJ_FWD_ROUNDS, kFwdNear = 4096;      // D1f (match forwarding)
 struct SlabArgs { uint32_t* done; uint4* cross; uint32_t tab_stride, cross_stride, rel; uint32_t* defer; uint32_t defer_stride; };
 #ifndef CJ_SLAB_PATIENCE
@@ -765,7 +766,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                     f_w1[i] = (r.w >> 16) | ((r.x & 0xffffu) << 16);
                     f_st[i] = r.w & 0xffffu;
                 }
-                if (tid == 0) *s_fwd = 0u;
+                if (tid == 0) { *s_fwd = 0u; atomicAdd(&g_fwd_chunks, 1ull); }
                 __syncthreads();
                 for (uint32_t i = tid; i < nseq; i += kL2Threads) {          // blocks whose first byte lies in [start_i, start_{i+1})
                     const uint32_t b0 = ((f_w0[i] & 0xffffu) + 15u) >> 4;
@@ -1180,6 +1181,12 @@ void launch_lz4_decode_lds(const BatchArgs& a, const void* sync, const void* met
 }
 
 }  // namespace cj
+extern "C" long long cj_debug_forwarded_chunks(int reset) {
+    unsigned long long v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(cj::g_fwd_chunks), 8) != hipSuccess) return -1;
+    if (reset) { unsigned long long z = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(cj::g_fwd_chunks), &z, 8) != hipSuccess) return -1; }
+    return (long long)v;
+}
 extern "C" int cj_debug_lds_phase_cycles(unsigned long long* out8, int reset) {
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(cj::g_lds_phase_cycles), 64) != hipSuccess) return -1;
     if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(cj::g_lds_phase_cycles), z, 64) != hipSuccess) return -1; }

@@ -437,3 +437,30 @@ def test_lds_pipeline_on_damaged_large_chunks(eng, codec):
             assert r == er and o == eo, (i, r, er)
             n_ok += 1
     assert 0 < n_ok < len(streams)              # both outcomes occur (a flipped literal byte still decodes)
+
+
+def test_deep_chain_chunks_take_match_forwarding(eng):
+    """text-like chunks (every phrase copied from its previous occurrence: dependency chains thousands of levels deep) go
+    through the decoder's match-forwarding phase (lz4_decode_lds.hip, D1f) and must decode bit-exactly"""
+    import json, random
+    rnd = random.Random(12)
+    def lines(fn, n=65536):
+        out = bytearray()
+        while len(out) < n: out += fn()
+        return bytes(out[:n])
+    kinds = [
+        lambda: b"%d bottles of beer on the wall, %d bottles of beer\n" % (rnd.randrange(977), rnd.randrange(1013)),
+        lambda: b"2026-09-28T12:%02d:%02d.%03d INFO worker-%d request id=%08x path=/api/v1/items/%d status=%d\n" % (
+            rnd.randrange(60), rnd.randrange(60), rnd.randrange(1000), rnd.randrange(16), rnd.getrandbits(32), rnd.randrange(5000), rnd.choice([200, 404, 500])),
+        lambda: json.dumps({"id": rnd.randrange(10 ** 6), "name": "user%d" % rnd.randrange(1000), "tags": ["a", "b", rnd.choice("xyz")]}).encode() + b"\n",
+        lambda: b"abcabcabc" * rnd.randrange(1, 9) + bytes([rnd.randrange(97, 123)]),
+    ]
+    chunks = [lines(k, 65536 - 1000 * (i % 3)) for i, k in enumerate(kinds * 6)]
+    L = N.lib()
+    for codec, comp in ((LZ4, lambda c: oracle.lz4_compress_raw(c)[1]), (SNAPPY, lambda c: oracle.snappy_compress(c)[1])):
+        blobs = [comp(c) for c in chunks]
+        L.cj_debug_forwarded_chunks(1)
+        res, outs = eng.batch_host(codec, DEC, N.FLAG_FORCE_LDS_PER_CHUNK, blobs, [len(c) for c in chunks])
+        assert [int(r) for r in res] == [len(c) for c in chunks]
+        assert all(bytes(o) == c for o, c in zip(outs, chunks))
+        assert L.cj_debug_forwarded_chunks(0) >= len(chunks) // 2, codec

@@ -1,8 +1,8 @@
 // big_parse.hip — the parse stage for ONE LARGE stream (large.hip: decompress_block / decompress_raw on a single buffer
 // of megabytes; reference call sites /root/reference/src/lz4.rs:143 decompress_block, /root/reference/src/snappy.rs:106
-// decompress_raw).  The element chain of such a stream is serial; lz4_parse_spec.hip breaks that for one 64 KiB chunk
+// decompress_raw).  The element chain of such a stream is serial; parse_spec.hip breaks that for one 64 KiB chunk
 // inside one wavefront, this file does it for a stream of any length across the whole GPU:
-//   K1  mark     one wavefront per PIECE of the input (16 KiB): 64 lanes walk 64 sub-segments from guessed positions,
+//   K1  mark     one wavefront per PIECE of the input (16 KiB; 64 KiB for streams from 4 MiB, fewer serial steps in K2): 64 lanes walk 64 sub-segments from guessed positions,
 //                marking what they visit (1a), then walk on until they join a later lane's path or leave the piece (1b).
 //                Output: the piece's bitmap, and per lane where its path joins (merge) and where it leaves the piece (exit).
 //   K2  thread   ONE lane walks the pieces in order: from the true entry of piece p it steps until it stands on a marked

@@ -1,4 +1,4 @@
-// parse_grammar.hpp — the two element grammars of the parallel parse kernels (lz4_parse_spec.hip: one chunk per
+// parse_grammar.hpp — the two element grammars of the parallel parse kernels (parse_spec.hip: one chunk per
 // wavefront; big_parse.hip: one large stream cut into pieces).  `at` reads the stream through rd(p) = the 4 bytes at
 // stream offset p (little endian; bytes past the end may be anything — every length is bounds-checked against iend).
 #pragma once

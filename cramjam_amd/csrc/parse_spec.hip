@@ -1,4 +1,4 @@
-// lz4_parse_spec.hip — the LZ4 parse stage for small and medium batches: ONE WAVEFRONT PER CHUNK, 64 lanes parsing 64
+// parse_spec.hip — the parse stage for small and medium batches (LZ4 sequences and Snappy records): ONE WAVEFRONT PER CHUNK, 64 lanes parsing 64
 // SEGMENTS of the same chunk at once.
 //
 // The token chain of an LZ4 block is serial: where sequence k+1 starts is only known after sequence k has been read,

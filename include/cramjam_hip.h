@@ -165,7 +165,7 @@ typedef enum { CJ_OP_DECOMPRESS = 0, CJ_OP_COMPRESS = 1 } cj_op;
  * batch size but one chunk per wave: 2.2 ms for 4 096 chunks), above it one LANE per chunk (3.5 ms flat, 64 chunks per
  * wave: 3.2 ms for 4 096, 4.5 ms for 16 384); env CJ_WAVE_PARSE_MAX overrides */
 #define CJ_WAVE_PARSE_MAX_DEFAULT 6144
-/* LZ4: below this many chunks the parse stage walks 64 segments of each chunk at once (lz4_parse_spec.hip); env
+/* LZ4: below this many chunks the parse stage walks 64 segments of each chunk at once (parse_spec.hip); env
  * CJ_SPEC_PARSE_MAX overrides, 0 disables */
 #define CJ_SPEC_PARSE_MAX_DEFAULT 8192
 /* share (n/20) of the short-sequence chunks of such a batch that is decoded by the lane-per-chunk kernel on an

@@ -1,4 +1,4 @@
-"""CPU model of the segmented parse (cramjam_amd/csrc/lz4_parse_spec.hip): 64 lanes walk 64 segments of a block from
+"""CPU model of the segmented parse (cramjam_amd/csrc/parse_spec.hip): 64 lanes walk 64 segments of a block from
 guessed start positions, join each other's paths, and the true path is stitched from the pieces.  The model mirrors the
 kernel phase by phase, for both grammars (LZ4 sequences, Snappy records), and is checked against the oracle decoders:
 same verdict, same decoded size, and sync points that are exactly the (ip, op) of every 8th sequence of a serial walk."""

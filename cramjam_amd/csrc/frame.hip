@@ -360,7 +360,7 @@ int lz4_frame_linked_lds(cj_engine* e, const Lz4Frame& f, const uint8_t* d_in, s
     uint32_t* fr = reinterpret_cast<uint32_t*>(m.data() + 5 * nb + hw);
     fr[0] = 0u; fr[1] = (uint32_t)nb;
     uint32_t* first = reinterpret_cast<uint32_t*>(m.data() + r_first);
-    for (size_t i = 0; i < nb; i++) { first[2 * i] = (uint32_t)(i * cj::kSyncStride); first[2 * i + 1] = 0u; }
+    for (size_t i = 0; i < nb; i++) { first[2 * i] = (uint32_t)(i * cj::kSyncPitch); first[2 * i + 1] = 0u; }
     HIP_TRY(hipMemcpyAsync(d_meta, m.data(), rows * 8, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
     HIP_TRY(hipMemsetAsync(e->d_pmeta.p, 0, cj::lz4_lds_scratch_meta_bytes(nb), s), CJ_E_NO_DEVICE);
     HIP_TRY(hipMemsetAsync(e->d_lanelist.p, 0, 16, s), CJ_E_NO_DEVICE);

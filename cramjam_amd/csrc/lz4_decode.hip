@@ -174,7 +174,7 @@ __global__ __launch_bounds__(kBlockThreads) void lz4_parse_wave_kernel(BatchArgs
     }
     if (walk) {
         const uint32_t cap = (uint32_t)cap64;
-        uint2* csync = sync + (size_t)c * kSyncStride;
+        uint2* csync = sync + (size_t)c * kSyncPitch;
         ParseWindow w;
         const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(in) & 3u);
         w.base = in - mis;
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(kBlockThreads) void snappy_parse_wave_kernel(BatchA
         else { dn = (uint32_t)ulen; walk = true; }
     }
     if (walk) {
-        uint2* csync = sync + (size_t)c * kSyncStride;
+        uint2* csync = sync + (size_t)c * kSyncPitch;
         ParseWindow w;
         const uint8_t* body = in + hdr;
         const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(body) & 3u);

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(64 * kParseWaves) void lz4_parse_kernel(BatchArgs a
     st.end = done ? 0u : mis + (uint32_t)n64;
     st.ring = wave_ring + lane * kRingStride;
     const uint32_t iend = st.end;
-    uint2* csync = sync + (size_t)c * kSyncStride;
+    uint2* csync = sync + (size_t)c * kSyncPitch;
 
     uint32_t ip = mis, op = 0, nseq = 0;
     // ---- wave-convergent walk: refill rounds, then one sequence per active lane ----

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(kLdsThreads) void lz4_decode_lds_kernel(BatchArgs a
     unsigned long long t_prev = prof ? __builtin_readcyclecounter() : 0ull;
 
     // sync point of this thread for the first slab: issued now so its global-load latency hides behind S0
-    const uint2* csync = sync + (size_t)c * kSyncStride;
+    const uint2* csync = sync + (size_t)c * kSyncPitch;
     const uint32_t nsp = (nseq + kSyncEvery - 1u) / kSyncEvery;
     uint2 sp_first = make_uint2(0, 0);
     if (tid < nsp) sp_first = csync[tid];
@@ -609,7 +609,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         // offset (relative to in) up to which reads are safe: the end of the 16 B granule holding the last input byte
         const uint32_t safe_end = ((((uint32_t)(reinterpret_cast<uintptr_t>(in) & 15u)) + iend + 15u) & ~15u) - (uint32_t)(reinterpret_cast<uintptr_t>(in) & 15u);
         uint8_t* out = a.out_base + a.out_off[c];
-        const uint2* csync = kSlab ? sync + frames[c].x : sync + (size_t)c * kSyncStride;
+        const uint2* csync = kSlab ? sync + frames[c].x : sync + (size_t)c * kSyncPitch;
         const uint32_t nsp = (nseq + kSyncEvery - 1u) / kSyncEvery;
         const bool staged = !kSlab || iend <= kLdsInMax;   // kSlab: a slab inside a long literal run may span more input than the window holds
         // ---- S0: stage the compressed chunk in the (still unused) output window so that D1's dependent token
@@ -1193,7 +1193,7 @@ extern "C" int cj_debug_lds_phase_cycles(unsigned long long* out8, int reset) {
     return 0;
 }
 namespace cj {
-size_t lz4_lds_scratch_sync_bytes(size_t n_chunks) { return n_chunks * (size_t)kSyncStride * sizeof(uint2); }
+size_t lz4_lds_scratch_sync_bytes(size_t n_chunks) { return n_chunks * (size_t)kSyncPitch * sizeof(uint2); }
 size_t lz4_lds_scratch_meta_bytes(size_t n_chunks) { return n_chunks * sizeof(ParseMeta); }
 
 }  // namespace cj

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(64) void lz4_parse_spec_kernel(BatchArgs a, uint2* 
     }
     if (walk) {
         uint32_t nseq = 0;
-        r = spec_walk<Lz4Grammar>(in, (uint32_t)n64, (uint32_t)cap64, sync + (size_t)c * kSyncStride, smem, nseq);
+        r = spec_walk<Lz4Grammar>(in, (uint32_t)n64, (uint32_t)cap64, sync + (size_t)c * kSyncPitch, smem, nseq);
         if (r < 0) r = CJ_E_CORRUPT;
         else if (r > 0) {
             if ((nseq + kSyncEvery - 1u) / kSyncEvery > kSyncStride || nseq < kLdsMinSeq) pm.in_skip = kRouteWave;
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(64) void snappy_parse_spec_kernel(BatchArgs a, uint
     }
     if (walk) {
         uint32_t nrec = 0;
-        r = spec_walk<SnappyGrammar>(in + hdr, (uint32_t)n64 - hdr, dn, sync + (size_t)c * kSyncStride, smem, nrec);
+        r = spec_walk<SnappyGrammar>(in + hdr, (uint32_t)n64 - hdr, dn, sync + (size_t)c * kSyncPitch, smem, nrec);
         if (r < 0) r = CJ_E_SNAPPY_CORRUPT;
         else {
             if ((nrec + kSyncEvery - 1u) / kSyncEvery > kSyncStride || nrec < kLdsMinSeq) pm.in_skip = kRouteWave;

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(64 * kParseWaves) void snappy_parse_kernel(BatchArg
     st.end = done ? 0u : mis + (uint32_t)n64 - hdr;
     st.ring = wave_ring + lane * kRingStride;
     const uint32_t iend = st.end;
-    uint2* csync = sync + (size_t)c * kSyncStride;
+    uint2* csync = sync + (size_t)c * kSyncPitch;
     const auto rd = [&st](uint32_t p) { return st.ld32(p); };
 
     uint32_t ip = mis, op = 0, nrec = 0;

@@ -5,9 +5,10 @@
 //   K1  mark     one wavefront per PIECE of the input (16 KiB; 64 KiB for streams from 4 MiB, fewer serial steps in K2): 64 lanes walk 64 sub-segments from guessed positions,
 //                marking what they visit (1a), then walk on until they join a later lane's path or leave the piece (1b).
 //                Output: the piece's bitmap, and per lane where its path joins (merge) and where it leaves the piece (exit).
-//   K2  thread   ONE lane walks the pieces in order: from the true entry of piece p it steps until it stands on a marked
-//                position (a few steps: LZ4 / Snappy streams resynchronise quickly), and the owner's precomputed exit
-//                is the true entry of the next piece.  This is the only serial part: a few global round trips per piece.
+//   K1c          for each of the first 64 bytes of the piece (the true entry almost always lies there): where a walk from
+//                that byte joins the marked paths, i.e. the entry of the NEXT piece for a true entry at that byte.
+//   K2  thread   one wavefront threads the pieces in order through K1c's tables (64 pieces per round, tables in LDS, a
+//                chain of dependent LDS reads); an entry beyond byte 64 walks the stream itself.  The only serial part.
 //   K3  count    per piece, with the true entry known: the true path is stitched from the lanes' pieces and every lane
 //                counts its sequences and output bytes.
 //   K4  scan     exclusive prefix over the pieces (sequence index, output position).
@@ -151,42 +152,100 @@ __global__ __launch_bounds__(64) void big_mark_kernel(BigParse a) {
     }
     a.merge[(size_t)p * 64u + lane] = merge;
     a.exitp[(size_t)p * 64u + lane] = ex;
+    // 1c: the true entry of a piece almost always lies in its first 64 bytes (the overhang of the sequence that crosses the
+    //     piece's start).  For each of them: where a walk from there joins the marked paths, and with it the entry of the
+    //     NEXT piece — K2 then only chases these tables (next[p][e - B]) instead of walking the stream itself.
+    s_link[lane] = ex;
+    __syncthreads();
+    {
+        const uint32_t merge0 = rdlane(merge, 0);
+        uint32_t q = B + lane < E ? B + lane : kPosErr;
+        bool going = q < E;
+        while (ballot64(going) != 0ull) {
+            if (going) {
+                const uint32_t r = q - B;
+                uint32_t w;
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(a_bits + 4u * (r >> 5)) : "memory");
+                if ((w >> (r & 31u)) & 1u) going = false;
+                else {
+                    Seq s;
+                    q = G::at(rd, q, a.iend, s, a.in) ? s.next : kPosErr;
+                    if (q >= E) going = false;
+                }
+            }
+        }
+        uint32_t fe = q, nxt = q;
+        if (q < E) {
+            const uint32_t o = (q - B) / sub;                 // the entry itself is in lane 0's sub-segment (sub >= 256)
+            fe = o == 0u ? merge0 : q;
+            nxt = s_link[o];
+        }
+        a.next_tab[(size_t)p * 64u + lane] = nxt;
+        a.fe_tab[(size_t)p * 64u + lane] = fe;
+    }
     uint32_t* gb = a.bits + (size_t)p * (P / 32u);
     for (uint32_t i = lane; i < P / 32u; i += 64u) gb[i] = s_bits[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // K2: the true entry of every piece.  entry[p] = (entry position | kPosEnd = the chain does not touch this piece,
-// end of the entry lane's part of the chain)
+// end of the entry lane's part of the chain).  One wavefront, 64 pieces per round: the lanes fetch the pieces' next-entry
+// tables (K1, phase 1c) into LDS, lane 0's chain of 64 dependent LDS reads threads the entries through them, then the lanes
+// write the entries out in parallel.  An entry beyond the first 64 bytes of its piece (a sequence longer than that crosses
+// the piece's start) takes the walk through global memory, as does a piece the chain jumps over.
 template <class G>
 __global__ __launch_bounds__(64) void big_thread_kernel(BigParse a) {
-    if (threadIdx.x != 0) return;
-    const uint32_t P = a.piece, sub = P / 64u;
+    __shared__ uint32_t s_next[64 * 64];
+    __shared__ uint32_t s_ent[64], s_fe[64];
+    const uint32_t P = a.piece, sub = P / 64u, lane = lane_id();
     GlobalReader rd = {a.in};
-    uint32_t e = a.start;
-    for (uint32_t p = 0; p < a.np; p++) {
-        const uint32_t B = a.start + p * P;
-        const uint32_t E = a.iend - B > P ? B + P : a.iend;
-        if (e >= E) { a.entry[p] = make_uint2(kPosEnd, kPosEnd); continue; }      // a long sequence spans the piece, or the chain is over
-        const uint32_t* gb = a.bits + (size_t)p * (P / 32u);
-        const uint32_t lx = (e - B) / sub;
-        uint32_t q = e;
-        while (q < E) {
-            const uint32_t r = q - B;
-            if ((gb[r >> 5] >> (r & 31u)) & 1u) break;
-            Seq s;
-            q = G::at(rd, q, a.iend, s, a.in) ? s.next : kPosErr;
+    uint32_t e = a.start;                                   // uniform
+    for (uint32_t p0 = 0; p0 < a.np; p0 += 64u) {
+        const uint32_t cnt = a.np - p0 < 64u ? a.np - p0 : 64u;
+        {   // 64 tables of 64 entries, coalesced: 16 B per lane and step
+            const uint4* src = reinterpret_cast<const uint4*>(a.next_tab + (size_t)p0 * 64u);
+            uint4* dst = reinterpret_cast<uint4*>(s_next);
+            for (uint32_t i = lane; i < cnt * 16u; i += 64u) dst[i] = src[i];
         }
-        uint32_t first_end, nxt;
-        if (q < E) {
-            const uint32_t o = (q - B) / sub;
-            first_end = o == lx ? a.merge[(size_t)p * 64u + lx] : q;
-            nxt = a.exitp[(size_t)p * 64u + o];
-        } else { first_end = q; nxt = q; }
-        a.entry[p] = make_uint2(e, first_end);
-        e = nxt;
+        __syncthreads();
+        for (uint32_t i = 0; i < cnt; i++) {                // uniform control flow; the chain runs through LDS
+            const uint32_t p = p0 + i;
+            const uint32_t B = a.start + p * P;
+            const uint32_t E = a.iend - B > P ? B + P : a.iend;
+            uint32_t ent = kPosEnd, fe = kPosErr;           // fe = kPosErr: "take it from K1's table" (phase 3 below)
+            if (e < E) {
+                ent = e;
+                if (e - B < 64u) e = s_next[i * 64u + (e - B)];
+                else {                                       // rare: walk the stream itself
+                    const uint32_t* gb = a.bits + (size_t)p * (P / 32u);
+                    const uint32_t lx = (e - B) / sub;
+                    uint32_t q = e;
+                    while (q < E) {
+                        const uint32_t r = q - B;
+                        if ((gb[r >> 5] >> (r & 31u)) & 1u) break;
+                        Seq s;
+                        q = G::at(rd, q, a.iend, s, a.in) ? s.next : kPosErr;
+                    }
+                    if (q < E) {
+                        const uint32_t o = (q - B) / sub;
+                        fe = o == lx ? a.merge[(size_t)p * 64u + lx] : q;
+                        e = a.exitp[(size_t)p * 64u + o];
+                    } else { fe = q; e = q; }
+                    if (fe == kPosErr) fe = kPosErr - 2u;    // (keep the marker value free; any value >= E means the same to K3 / K5)
+                }
+            }
+            if (lane == 0) { s_ent[i] = ent; s_fe[i] = fe; }
+        }
+        __syncthreads();
+        if (lane < cnt) {
+            const uint32_t p = p0 + lane, B = a.start + p * P;
+            uint32_t ent = s_ent[lane], fe = s_fe[lane];
+            if (ent != kPosEnd && fe == kPosErr) fe = a.fe_tab[(size_t)p * 64u + (ent - B)];
+            a.entry[p] = make_uint2(ent, ent == kPosEnd ? kPosEnd : fe);
+        }
+        __syncthreads();
     }
-    a.status[0] = e == kPosEnd ? 0u : 1u;                   // the chain must end with a last sequence exactly at the end of the input
+    if (lane == 0) a.status[0] = e == kPosEnd ? 0u : 1u;    // the chain must end with a last sequence exactly at the end of the input
 }
 
 // the chain inside one piece: per lane (entry, end); end < E = the next lane's entry, else the piece's exit / kPosEnd / kPosErr

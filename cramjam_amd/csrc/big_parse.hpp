@@ -18,6 +18,8 @@ struct BigParse {
     uint32_t* bits;          // np * piece / 32 words: positions visited by the lanes' own walks
     uint32_t* merge;         // np * 64
     uint32_t* exitp;         // np * 64
+    uint32_t* next_tab;      // np * 64: entry of the next piece for a true entry at byte j of this piece
+    uint32_t* fe_tab;        // np * 64: end of the entry lane's part of the chain for that entry
     uint2* entry;            // np
     uint32_t* lane_idx;      // np * 64
     uint64_t* lane_op;       // np * 64

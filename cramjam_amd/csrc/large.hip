@@ -262,7 +262,7 @@ int64_t large_decompress(int codec, uint32_t flags, const uint8_t* in, size_t n,
     size_t off = 0;
     const auto region = [&off](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     const size_t o_status = region(64), o_bits = region((size_t)np * (piece / 8)), o_merge = region((size_t)np * 256),
-                 o_exit = region((size_t)np * 256), o_entry = region((size_t)np * 8), o_lidx = region((size_t)np * 256),
+                 o_exit = region((size_t)np * 256), o_next = region((size_t)np * 256), o_fe = region((size_t)np * 256), o_entry = region((size_t)np * 8), o_lidx = region((size_t)np * 256),
                  o_lop = region((size_t)np * 512), o_tot = region((size_t)np * 16), o_sync = region(((size_t)iend / 16 + 2) * 8);
     if (!e->d_in.reserve(n + 64) || !e->d_big.reserve(off)) return CJ_E_OOM;
     uint8_t* d_in = (uint8_t*)e->d_in.p;
@@ -271,7 +271,7 @@ int64_t large_decompress(int codec, uint32_t flags, const uint8_t* in, size_t n,
     HIP_TRY(hipMemsetAsync(b + o_status, 0, 64, s), CJ_E_NO_DEVICE);
     BigParse bp;
     bp.in = d_in + skip; bp.iend = iend; bp.start = (uint32_t)start; bp.piece = piece; bp.np = np; bp.cap = cap64;
-    bp.bits = (uint32_t*)(b + o_bits); bp.merge = (uint32_t*)(b + o_merge); bp.exitp = (uint32_t*)(b + o_exit);
+    bp.bits = (uint32_t*)(b + o_bits); bp.merge = (uint32_t*)(b + o_merge); bp.exitp = (uint32_t*)(b + o_exit); bp.next_tab = (uint32_t*)(b + o_next); bp.fe_tab = (uint32_t*)(b + o_fe);
     bp.entry = (uint2*)(b + o_entry); bp.lane_idx = (uint32_t*)(b + o_lidx); bp.lane_op = (uint64_t*)(b + o_lop);
     bp.totals = (uint64_t*)(b + o_tot); bp.sync = (uint2*)(b + o_sync); bp.status = (uint32_t*)(b + o_status);
     launch_big_parse(bp, codec, s);

@@ -264,3 +264,42 @@ def test_big_parse_sync_points_equal_a_serial_walk(name, data):
         if codec == N.CODEC_SNAPPY_RAW: pass
         bad = np.nonzero((got != exp).any(axis=1))[0]
         assert bad.size == 0, (codec, int(bad[0]), got[bad[0]].tolist(), exp[bad[0]].tolist())
+
+
+def _lz4_seq(lit, off, mlen, last=False):
+    """one LZ4 sequence: literal bytes, then (unless last) a match of mlen >= 4 at distance off"""
+    out = bytearray()
+    ll = len(lit); ml = 0 if last else mlen - 4
+    out.append((min(ll, 15) << 4) | min(ml, 15))
+    if ll >= 15:
+        r = ll - 15
+        out += b"\xff" * (r // 255) + bytes([r % 255])
+    out += lit
+    if not last:
+        out += off.to_bytes(2, "little")
+        if ml >= 15:
+            r = ml - 15
+            out += b"\xff" * (r // 255) + bytes([r % 255])
+    return bytes(out)
+
+
+def test_random_hand_made_lz4_streams_across_slabs():
+    """streams no encoder would emit: matches of every length (4 .. 300 000) and distance, self-overlapping runs that
+    begin in one slab and end several slabs later, literal runs of every length — cut into slabs at arbitrary places"""
+    rnd = random.Random(2024)
+    for t in range(24):
+        blob = bytearray(); op = 0
+        target = rnd.choice([70000, 140000, 300000, 600000])
+        while op < target:
+            ll = rnd.choice([0, 0, 1, 3, 14, 15, 16, 40, 270, 5000]) if op else rnd.choice([1, 9, 400])
+            lit = rnd.randbytes(ll)
+            off = min(op + ll, rnd.choice([1, 2, 3, 4, 7, 16, 100, 4000, 65535, rnd.randrange(1, 65536)]))
+            ml = rnd.choice([4, 5, 18, 19, 20, 64, 300, 7000, 66000, rnd.randrange(4, 300000)])
+            blob += _lz4_seq(lit, off, ml); op += ll + ml
+        blob += _lz4_seq(rnd.randbytes(rnd.choice([5, 12, 300])), 0, 0, last=True)
+        blob = bytes(blob)
+        n, want = oracle.lz4_decompress_raw(blob, 4 << 20)
+        assert n > 65536, t
+        if len(blob) > PIECE or n > PIECE:
+            got = bytes(cramjam.lz4.decompress_block(blob, output_len=n))
+            assert got == want[:n], (t, len(blob), n)

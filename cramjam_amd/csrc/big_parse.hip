@@ -269,7 +269,7 @@ __device__ __forceinline__ void bp_chain(const BigParse& a, uint32_t p, uint32_t
 // K3
 template <class G>
 __global__ __launch_bounds__(64) void big_count_kernel(BigParse a) {
-    const uint32_t P = a.piece, sub = P / 64u;
+    const uint32_t P = a.piece;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t p = blockIdx.x, lane = lane_id();
     const uint32_t B = a.start + p * P;
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(64) void big_scan_kernel(BigParse a) {
 // that meets the last sequence)
 template <class G>
 __global__ __launch_bounds__(64) void big_emit_kernel(BigParse a) {
-    const uint32_t P = a.piece, sub = P / 64u;
+    const uint32_t P = a.piece;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t p = blockIdx.x, lane = lane_id();
     const uint32_t B = a.start + p * P;

@@ -24,6 +24,7 @@ struct BatchArgs {
 // internal flag bits (never part of the C-ABI): 0x1000 = LDS decoder phase profile, 0x2000 = linked-frame parse
 // (bit 63 of in_len marks a STORED block; no minimum sequence count for the LDS decoder)
 constexpr uint32_t kFlagLinkedFrame = 0x2000u;
+constexpr uint32_t kFlagSplitPieces = 0x8000u;     // encoders (large.hip): chunks 4b .. 4b+3 are the quarters of one piece, compressed by one block
 constexpr uint32_t kFlagReportTail = 0x4000u;      // LZ4 encoder (large.hip): result = size | length of the final literal run << 32
 
 constexpr int kWavesPerBlock = 4;

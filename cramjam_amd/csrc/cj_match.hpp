@@ -30,6 +30,19 @@ __device__ __forceinline__ void ht_clear(uint16_t* ht) {
     for (uint32_t i = lane_id(); i < kHashSize / 2; i += 64u) p[i] = 0u;
 }
 
+// kSplit encoders: index the data BEFORE this wave's quarter (positions [0, q0), every kPreStep-th one, ascending so that
+// the most recent position wins a slot), so that the quarter finds the matches a serial walk over the piece would
+#ifndef CJ_PRE_STEP
+#define CJ_PRE_STEP 1u
+#endif
+constexpr uint32_t kPreStep = CJ_PRE_STEP;
+__device__ __forceinline__ void ht_preindex(const uint8_t* in, uint16_t* ht, uint32_t q0) {
+    for (uint32_t p = lane_id() * kPreStep; p < q0; p += 64u * kPreStep) {
+        const uint32_t h = (ld32u(in + p) * 2654435761u) >> (32 - kHashBits);
+        ht[h] = (uint16_t)p;
+    }
+}
+
 // count equal bytes of in[a..] vs in[b..] (b < a), stopping at position `limit` for a
 __device__ __forceinline__ uint32_t wave_extend(const uint8_t* in, uint32_t a, uint32_t b, uint32_t limit) {
     uint32_t cnt = 0;

@@ -27,14 +27,19 @@ namespace {
 constexpr size_t kPiece = 65536;
 constexpr size_t kLz4Stride = 65824;          // LZ4_compressBound(65536) = 65809, rounded up to 16
 constexpr size_t kSnStride = 76512;           // snap max_compress_len(65536) = 76490, rounded up to 16
+// buffers of up to kSplitMax bytes: quarter pieces, four wavefronts per 64 KiB (lz4_encode.hip, kSplit) — one wavefront needs
+// ~1.7 ms for 64 KiB, and below ~500 pieces most of the GPU's wavefront slots are idle anyway
+constexpr size_t kSplitMax = 32u << 20, kQuarter = 16384;
+constexpr size_t kLz4QStride = 16480;         // LZ4_compressBound(16384) = 16464
+constexpr size_t kSnQStride = 19152;          // snap max_compress_len(16384) = 19146
 
 __host__ __device__ inline uint32_t lz4_len_ext(uint32_t len) { return len < 15u ? 0u : (len - 15u) / 255u + 1u; }
 
 // first_lit[i] = literal length of the first sequence of piece i's stream
-__global__ __launch_bounds__(256) void lz4_stitch_plan_kernel(const uint8_t* tmp, uint32_t* first_lit, uint32_t np) {
+__global__ __launch_bounds__(256) void lz4_stitch_plan_kernel(const uint8_t* tmp, uint32_t stride, uint32_t* first_lit, uint32_t np) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= np) return;
-    const uint8_t* p = tmp + (size_t)i * kLz4Stride;
+    const uint8_t* p = tmp + (size_t)i * stride;
     uint32_t lit = p[0] >> 4, q = 1;
     if (lit == 15u) {
         uint32_t b;
@@ -73,7 +78,7 @@ inline uint32_t varint_len(uint64_t v) { uint32_t k = 1; while (v >= 0x80u) { v 
 }  // namespace
 
 // compress the np pieces of d_in as one batch into d_tmp (stride bytes apart); results -> res
-static int compress_pieces(cj_engine* e, cj_codec codec, uint32_t flags, const uint8_t* in, size_t n, size_t np, size_t stride,
+static int compress_pieces(cj_engine* e, cj_codec codec, uint32_t flags, const uint8_t* in, size_t n, size_t piece, size_t np, size_t stride,
                            std::vector<int64_t>& res) {
     hipStream_t s = e->stream;
     if (!e->d_in.reserve(n + 16) || !e->d_out.reserve(np * stride + 16) || !e->d_meta.reserve(12 * np * 8)) return CJ_E_OOM;
@@ -82,8 +87,8 @@ static int compress_pieces(cj_engine* e, cj_codec codec, uint32_t flags, const u
     std::vector<uint64_t>& m = e->h_meta;
     m.assign(12 * np, 0);
     for (size_t i = 0; i < np; i++) {
-        m[i] = i * kPiece;
-        m[np + i] = std::min(kPiece, n - i * kPiece);
+        m[i] = i * piece;
+        m[np + i] = std::min(piece, n - i * piece);
         m[2 * np + i] = i * stride;
         m[3 * np + i] = stride;
     }
@@ -102,12 +107,14 @@ int64_t large_snappy_compress(const uint8_t* in, size_t n, uint8_t* out, size_t 
     cj_engine* e = default_engine();
     if (!e) return CJ_E_NO_DEVICE;
     if (n > 0xFFFFFFFFull) return CJ_E_SNAPPY_TOO_BIG;
-    const size_t np = (n + kPiece - 1) / kPiece;
+    const bool split = n <= kSplitMax;
+    const size_t piece = split ? kQuarter : kPiece, stride = split ? kSnQStride : kSnStride;
+    const size_t np = (n + piece - 1) / piece;
     std::lock_guard<std::mutex> lock(e->mu);
     HIP_TRY(hipSetDevice(e->device), CJ_E_NO_DEVICE);
     hipStream_t s = e->stream;
     std::vector<int64_t> res;
-    int rc = compress_pieces(e, CJ_CODEC_SNAPPY_RAW, 0u, in, n, np, kSnStride, res);
+    int rc = compress_pieces(e, CJ_CODEC_SNAPPY_RAW, split ? kFlagSplitPieces : 0u, in, n, piece, np, stride, res);
     if (rc != 0) return rc;
     HIP_TRY(hipStreamSynchronize(s), CJ_E_NO_DEVICE);
 
@@ -121,7 +128,7 @@ int64_t large_snappy_compress(const uint8_t* in, size_t n, uint8_t* out, size_t 
         if (res[i] < 0) return res[i];
         const uint32_t ph = varint_len(m[np + i]);             // the piece's own length header is dropped
         const uint64_t body = (uint64_t)res[i] - ph;
-        m[5 * np + i] = (uint64_t)(uintptr_t)(d_tmp + i * kSnStride + ph);
+        m[5 * np + i] = (uint64_t)(uintptr_t)(d_tmp + i * stride + ph);
         m[6 * np + i] = pos;
         m[7 * np + i] = body;
         pos += body;
@@ -142,19 +149,21 @@ int64_t large_snappy_compress(const uint8_t* in, size_t n, uint8_t* out, size_t 
 int64_t large_lz4_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap, bool prefix) {
     cj_engine* e = default_engine();
     if (!e) return CJ_E_NO_DEVICE;
-    const size_t np = (n + kPiece - 1) / kPiece;
+    const bool split = n <= kSplitMax;
+    const size_t piece = split ? kQuarter : kPiece, stride = split ? kLz4QStride : kLz4Stride;
+    const size_t np = (n + piece - 1) / piece;
     const size_t pre = prefix ? 4 : 0;
     if (cap < pre) return CJ_E_COMPRESS_FAILED;
     std::lock_guard<std::mutex> lock(e->mu);
     HIP_TRY(hipSetDevice(e->device), CJ_E_NO_DEVICE);
     hipStream_t s = e->stream;
     std::vector<int64_t> res;
-    int rc = compress_pieces(e, CJ_CODEC_LZ4_BLOCK, kFlagReportTail, in, n, np, kLz4Stride, res);
+    int rc = compress_pieces(e, CJ_CODEC_LZ4_BLOCK, kFlagReportTail | (split ? kFlagSplitPieces : 0u), in, n, piece, np, stride, res);
     if (rc != 0) return rc;
     uint64_t* d_meta = (uint64_t*)e->d_meta.p;
     uint8_t* d_tmp = (uint8_t*)e->d_out.p;
     uint32_t* d_first = (uint32_t*)(d_meta + 5 * np);
-    hipLaunchKernelGGL(lz4_stitch_plan_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, d_tmp, d_first, (uint32_t)np);
+    hipLaunchKernelGGL(lz4_stitch_plan_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, d_tmp, (uint32_t)stride, d_first, (uint32_t)np);
     HIP_TRY(hipGetLastError(), CJ_E_NO_DEVICE);
     std::vector<uint32_t> first(np);
     HIP_TRY(hipMemcpyAsync(first.data(), d_first, np * 4, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
@@ -164,17 +173,17 @@ int64_t large_lz4_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap
     uint64_t pos = 0, pending = 0;                 // pending = literal bytes before this piece that no sequence carries yet
     for (size_t i = 0; i < np; i++) {
         if (res[i] < 0) return res[i];
-        const uint64_t len = std::min(kPiece, n - i * kPiece);
+        const uint64_t len = std::min(piece, n - i * piece);
         const uint32_t r = (uint32_t)((uint64_t)res[i] & 0xFFFFFFFFull), tail = (uint32_t)((uint64_t)res[i] >> 32);
         const uint32_t l2 = first[i];
         const bool last = i + 1 == np, has_match = l2 < len;
-        Stitch d = {pos, i * kPiece - pending, 0, 0, 0, 0};
+        Stitch d = {pos, i * piece - pending, 0, 0, 0, 0};
         if (has_match) {
             const uint32_t skip = 1u + lz4_len_ext(l2) + l2;                         // token, length bytes and literals of the first sequence
             const uint32_t end = last ? r : r - (1u + lz4_len_ext(tail) + tail);     // non-final pieces lose their literal-only last sequence
             const uint64_t run = pending + l2;
             d.run = run;
-            d.tok_src = (uint64_t)(uintptr_t)(d_tmp + i * kLz4Stride);
+            d.tok_src = (uint64_t)(uintptr_t)(d_tmp + i * stride);
             d.body_src = d.tok_src + skip;
             d.body_len = end - skip;
             pos += 1u + lz4_len_ext((uint32_t)run) + run + d.body_len;

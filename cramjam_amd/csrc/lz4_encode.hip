@@ -46,14 +46,23 @@ __device__ __forceinline__ void lz4_emit_queue(const uint8_t* in, uint8_t* out, 
     }
 }
 
-__global__ __launch_bounds__(kEncThreads) void lz4_encode_kernel(BatchArgs a) {
-    __shared__ uint16_t ht_all[kEncWaves][kHashSize];
+// kSplit (large.hip, buffers of up to 32 MiB, where one wavefront per 64 KiB piece would leave most of the GPU idle and
+// every call would take the 1.7 ms one wavefront needs for 64 KiB): a block of FOUR wavefronts compresses one 64 KiB piece —
+// chunks 4b .. 4b+3 are its consecutive quarters, position 0 = the start of the piece.  Each wavefront has its own hash
+// table and first indexes the data BEFORE its quarter (ht_preindex: a few µs), so it finds what a serial walk over the
+// piece would (ratio 1.62 vs 1.63 on the benchmark data, 4.79 vs 4.88 on text); each writes its own stream, and the
+// streams are stitched / concatenated like any other pieces.  256 KiB .. 4 MiB: 1.8-1.9 ms -> 0.6-0.7 ms per call.
+template <bool kSplit>
+__global__ __launch_bounds__(kSplit ? 256 : kEncThreads) void lz4_encode_kernel(BatchArgs a) {
+    __shared__ uint16_t ht_all[kSplit ? 4 : kEncWaves][kHashSize];
     const uint32_t wave = uni(threadIdx.x >> 6);
-    const uint32_t chunk = uni(blockIdx.x * kEncWaves + wave);
-    if (chunk >= a.n_chunks) return;
+    const uint32_t chunk = uni(kSplit ? blockIdx.x * 4u + wave : blockIdx.x * kEncWaves + wave);
     uint16_t* ht = ht_all[wave];
-    const uint8_t* in = a.in_base + a.in_off[chunk];
-    const uint64_t n64 = a.in_len[chunk];
+    if (chunk >= a.n_chunks) return;
+    const uint64_t base_off = kSplit ? a.in_off[blockIdx.x * 4u] : a.in_off[chunk];
+    const uint8_t* in = a.in_base + base_off;               // position 0 = start of the piece
+    const uint32_t q0 = (uint32_t)(a.in_off[chunk] - base_off);      // this wave's range = [q0, n)
+    const uint64_t n64 = q0 + a.in_len[chunk];
     uint8_t* out = a.out_base + a.out_off[chunk];
     uint64_t cap64 = a.out_cap[chunk];
     const uint32_t lane = lane_id();
@@ -62,19 +71,20 @@ __global__ __launch_bounds__(kEncThreads) void lz4_encode_kernel(BatchArgs a) {
     if (n64 > 0x7E000000ull) { if (lane == 0) a.result[chunk] = CJ_E_INPUT_TOO_LARGE; return; }
     const uint32_t n = (uint32_t)n64;
     // the engine only launches with capacity >= LZ4_compressBound(n) (+4); anything smaller is refused here
-    const uint64_t need = (uint64_t)n + n / 255u + 16u + (prefix ? 4u : 0u);
+    const uint64_t need = (uint64_t)(n - q0) + (n - q0) / 255u + 16u + (prefix ? 4u : 0u);
     if (cap64 < need) { if (lane == 0) a.result[chunk] = CJ_E_COMPRESS_FAILED; return; }
     if (prefix) {
         if (lane < 4) out[lane] = (uint8_t)(n >> (8u * lane));
         out += 4;
     }
 
-    uint32_t anchor = 0, op = 0;
-    if (n >= 13u) {
+    uint32_t anchor = q0, op = 0;
+    if (n - q0 >= 13u) {
         ht_clear(ht);
+        if constexpr (kSplit) ht_preindex(in, ht, q0);
         const uint32_t last_start = n - 12u;    // a match may start here at the latest
         const uint32_t matchlimit = n - 5u;     // and must end here at the latest
-        uint32_t pos = 0;
+        uint32_t pos = q0;
         while (pos <= last_start) {
             Round r;
             probe_round(in, ht, pos, last_start, matchlimit, anchor, r);
@@ -177,7 +187,11 @@ __global__ __launch_bounds__(kEncThreads) void lz4_encode_kernel(BatchArgs a) {
 void launch_lz4_encode(const BatchArgs& a, hipStream_t s) {
     if (a.n_chunks == 0) return;
     dim3 grid((a.n_chunks + kEncWaves - 1) / kEncWaves), block(kEncThreads);
-    hipLaunchKernelGGL(lz4_encode_kernel, grid, block, 0, s, a);
+    if (a.flags & kFlagSplitPieces) {
+        hipLaunchKernelGGL(lz4_encode_kernel<true>, dim3((a.n_chunks + 3u) / 4u), dim3(256), 0, s, a);
+        return;
+    }
+    hipLaunchKernelGGL(lz4_encode_kernel<false>, grid, block, 0, s, a);
 }
 
 }  // namespace cj

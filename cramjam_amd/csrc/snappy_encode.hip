@@ -94,37 +94,42 @@ __device__ __forceinline__ void snappy_emit_queue(const uint8_t* in, uint8_t* ou
     else { o[0] = (uint8_t)(2u | ((len - 1u) << 2)); o[1] = (uint8_t)off; o[2] = (uint8_t)(off >> 8); }
 }
 
-__global__ __launch_bounds__(kEncThreads) void snappy_encode_kernel(BatchArgs a) {
-    __shared__ uint16_t ht_all[kEncWaves][kHashSize];
+// kSplit: four wavefronts per 64 KiB piece, each with its own pre-indexed hash table — see lz4_encode.hip
+template <bool kSplit>
+__global__ __launch_bounds__(kSplit ? 256 : kEncThreads) void snappy_encode_kernel(BatchArgs a) {
+    __shared__ uint16_t ht_all[kSplit ? 4 : kEncWaves][kHashSize];
     const uint32_t wave = uni(threadIdx.x >> 6);
-    const uint32_t chunk = uni(blockIdx.x * kEncWaves + wave);
-    if (chunk >= a.n_chunks) return;
+    const uint32_t chunk = uni(kSplit ? blockIdx.x * 4u + wave : blockIdx.x * kEncWaves + wave);
     uint16_t* ht = ht_all[wave];
-    const uint8_t* in = a.in_base + a.in_off[chunk];
-    const uint64_t n64 = a.in_len[chunk];
+    if (chunk >= a.n_chunks) return;
+    const uint64_t base_off = kSplit ? a.in_off[blockIdx.x * 4u] : a.in_off[chunk];
+    const uint8_t* in = a.in_base + base_off;               // position 0 = start of the piece
+    const uint32_t q0 = (uint32_t)(a.in_off[chunk] - base_off);      // this wave's range = [q0, n)
+    const uint64_t n64 = q0 + a.in_len[chunk];
     uint8_t* out = a.out_base + a.out_off[chunk];
     const uint64_t cap64 = a.out_cap[chunk];
     const uint32_t lane = lane_id();
 
     // snap: TooBig above u32::MAX (we also keep positions in 32 bits); BufferTooSmall below max_compress_len
     if (n64 > 0xFFFFFFFFull - 64u) { if (lane == 0) a.result[chunk] = CJ_E_SNAPPY_TOO_BIG; return; }
-    const uint64_t need = 32u + n64 + n64 / 6u;
+    const uint64_t need = 32u + (n64 - q0) + (n64 - q0) / 6u;
     if (need > 0xFFFFFFFFull) { if (lane == 0) a.result[chunk] = CJ_E_SNAPPY_TOO_BIG; return; }
     if (cap64 < need) { if (lane == 0) a.result[chunk] = CJ_E_SNAPPY_BUF_SMALL; return; }
     const uint32_t n = (uint32_t)n64;
 
     uint32_t op = 0;
     {   // varint preamble
-        uint32_t v = n;
+        uint32_t v = n - q0;
         while (v >= 0x80u) { if (lane == 0) out[op] = (uint8_t)(v | 0x80u); op += 1; v >>= 7; }
         if (lane == 0) out[op] = (uint8_t)v;
         op += 1;
     }
-    uint32_t anchor = 0;
-    if (n >= 8u) {
+    uint32_t anchor = q0;
+    if (n - q0 >= 8u) {
         ht_clear(ht);
+        if constexpr (kSplit) ht_preindex(in, ht, q0);
         const uint32_t last_start = n - 4u;
-        uint32_t pos = 0;
+        uint32_t pos = q0;
         while (pos <= last_start) {
             Round r;
             probe_round(in, ht, pos, last_start, n, anchor, r);
@@ -210,7 +215,11 @@ __global__ __launch_bounds__(kEncThreads) void snappy_encode_kernel(BatchArgs a)
 void launch_snappy_encode(const BatchArgs& a, hipStream_t s) {
     if (a.n_chunks == 0) return;
     dim3 grid((a.n_chunks + kEncWaves - 1) / kEncWaves), block(kEncThreads);
-    hipLaunchKernelGGL(snappy_encode_kernel, grid, block, 0, s, a);
+    if (a.flags & kFlagSplitPieces) {
+        hipLaunchKernelGGL(snappy_encode_kernel<true>, dim3((a.n_chunks + 3u) / 4u), dim3(256), 0, s, a);
+        return;
+    }
+    hipLaunchKernelGGL(snappy_encode_kernel<false>, grid, block, 0, s, a);
 }
 
 }  // namespace cj

@@ -243,6 +243,8 @@ using cj::launch;
 
 // single buffers above this size take large.hip's piece-parallel path (compress)
 constexpr size_t kLargeMin = 65536;
+// compress: already above one quarter piece (four wavefronts on a 64 KiB buffer instead of one: 1.7 -> 0.6 ms)
+constexpr size_t kLargeMinCompress = 16384;
 
 int64_t single(cj_codec codec, cj_op op, uint32_t flags, const uint8_t* in, size_t n, uint8_t* out, size_t cap) {
     cj_engine* e = default_engine();
@@ -487,7 +489,7 @@ int64_t cj_lz4_block_compress(const uint8_t* in, size_t n, uint8_t* out, size_t 
     const bool pre = prepend != 0;   // -1 (None) and 1 -> prefix
     if (n > 0x7FFFFFFFull || cj_lz4_block_compress_bound(n, 0) == 0) return CJ_E_INPUT_TOO_LARGE;
     if (pre && cap < 4) return CJ_E_COMPRESS_FAILED;
-    if (n > kLargeMin && in && out) return cj::large_lz4_compress(in, n, out, cap, pre);      // pieces compressed as a batch, stitched into one block
+    if (n > kLargeMinCompress && in && out) return cj::large_lz4_compress(in, n, out, cap, pre);      // pieces compressed as a batch, stitched into one block
     return single(CJ_CODEC_LZ4_BLOCK, CJ_OP_COMPRESS, pre ? CJ_FLAG_LZ4_SIZE_PREFIX : 0u, in, n, out, cap);
 }
 
@@ -501,7 +503,7 @@ int64_t cj_lz4_block_decompress(const uint8_t* in, size_t n, uint8_t* out, size_
 }
 
 int64_t cj_snappy_raw_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap) {
-    if (n > kLargeMin && in && out) return cj::large_snappy_compress(in, n, out, cap);
+    if (n > kLargeMinCompress && in && out) return cj::large_snappy_compress(in, n, out, cap);
     return single(CJ_CODEC_SNAPPY_RAW, CJ_OP_COMPRESS, 0u, in, n, out, cap);
 }
 

@@ -58,6 +58,9 @@ void launch_snappy_parse(const BatchArgs& a, void* sync, void* meta, hipStream_t
 // large.hip: one large buffer cut into pieces that are compressed as a batch and joined into one stream
 int64_t large_snappy_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap);
 int64_t large_lz4_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap, bool prefix);
+int64_t large_lz4_frame_blocks(const uint8_t* in, size_t n, uint8_t* out, size_t cap);      // <= large_split_max() bytes
+int64_t large_snappy_frame(const uint8_t* in, size_t n, uint8_t* out, size_t cap);           // <= large_split_max() bytes
+size_t large_split_max();
 int64_t large_decompress(int codec, uint32_t flags, const uint8_t* in, size_t n, uint8_t* out, size_t cap);
 void launch_lz4_decode_lds2_slabs(const BatchArgs& a, const void* sync, const void* meta, void* tabs, uint32_t* counter,
                                   const void* first, uint32_t stream_len, uint32_t* done, void* cross, uint32_t tab_stride,

@@ -21,6 +21,7 @@ namespace cj {
 
 void launch_copy_segments(const uint64_t* src, uint8_t* dst_base, const uint64_t* dst_off, const uint64_t* len,
                           const uint64_t* hdr, uint32_t hdr_len, uint32_t n, hipStream_t s);      // frame_kernels.hip
+void launch_crc32c_pieces(const uint8_t* base, const uint64_t* off, const uint64_t* len, uint32_t* out, uint32_t n, hipStream_t s);
 
 namespace {
 
@@ -103,6 +104,42 @@ static int compress_pieces(cj_engine* e, cj_codec codec, uint32_t flags, const u
     return 0;
 }
 
+// Plan the join of the pieces [i0, i1) (consecutive pieces of `piece` bytes of an n-byte input) into ONE LZ4 block written
+// at out_pos: fills plan[i] and returns the block's length.  res[i] = stream length | tail literal length << 32 (the
+// encoder's kFlagReportTail), first[i] = literal length of the piece's first sequence.
+static uint64_t plan_stitch(std::vector<Stitch>& plan, size_t i0, size_t i1, uint64_t out_pos, size_t n, size_t piece, size_t stride,
+                            const uint8_t* d_tmp, const std::vector<int64_t>& res, const std::vector<uint32_t>& first) {
+    uint64_t pos = out_pos, pending = 0;           // pending = literal bytes before this piece that no sequence carries yet
+    for (size_t i = i0; i < i1; i++) {
+        const uint64_t len = std::min(piece, n - i * piece);
+        const uint32_t r = (uint32_t)((uint64_t)res[i] & 0xFFFFFFFFull), tail = (uint32_t)((uint64_t)res[i] >> 32);
+        const uint32_t l2 = first[i];
+        const bool last = i + 1 == i1, has_match = l2 < len;
+        Stitch d = {pos, i * piece - pending, 0, 0, 0, 0};
+        if (has_match) {
+            const uint32_t skip = 1u + lz4_len_ext(l2) + l2;                         // token, length bytes and literals of the first sequence
+            const uint32_t end = last ? r : r - (1u + lz4_len_ext(tail) + tail);     // non-final pieces lose their literal-only last sequence
+            const uint64_t run = pending + l2;
+            d.run = run;
+            d.tok_src = (uint64_t)(uintptr_t)(d_tmp + i * stride);
+            d.body_src = d.tok_src + skip;
+            d.body_len = end - skip;
+            pos += 1u + lz4_len_ext((uint32_t)run) + run + d.body_len;
+            pending = last ? 0 : tail;
+        } else {
+            pending += len;
+            if (last) {                                                               // the block ends with one literal-only sequence
+                d.run = pending;
+                pos += 1u + lz4_len_ext((uint32_t)pending) + pending;
+                pending = 0;
+            }
+        }
+        plan[i] = d;
+    }
+    return pos - out_pos;
+}
+
+
 int64_t large_snappy_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap) {
     cj_engine* e = default_engine();
     if (!e) return CJ_E_NO_DEVICE;
@@ -170,34 +207,8 @@ int64_t large_lz4_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap
     HIP_TRY(hipStreamSynchronize(s), CJ_E_NO_DEVICE);
 
     std::vector<Stitch> plan(np);
-    uint64_t pos = 0, pending = 0;                 // pending = literal bytes before this piece that no sequence carries yet
-    for (size_t i = 0; i < np; i++) {
-        if (res[i] < 0) return res[i];
-        const uint64_t len = std::min(piece, n - i * piece);
-        const uint32_t r = (uint32_t)((uint64_t)res[i] & 0xFFFFFFFFull), tail = (uint32_t)((uint64_t)res[i] >> 32);
-        const uint32_t l2 = first[i];
-        const bool last = i + 1 == np, has_match = l2 < len;
-        Stitch d = {pos, i * piece - pending, 0, 0, 0, 0};
-        if (has_match) {
-            const uint32_t skip = 1u + lz4_len_ext(l2) + l2;                         // token, length bytes and literals of the first sequence
-            const uint32_t end = last ? r : r - (1u + lz4_len_ext(tail) + tail);     // non-final pieces lose their literal-only last sequence
-            const uint64_t run = pending + l2;
-            d.run = run;
-            d.tok_src = (uint64_t)(uintptr_t)(d_tmp + i * stride);
-            d.body_src = d.tok_src + skip;
-            d.body_len = end - skip;
-            pos += 1u + lz4_len_ext((uint32_t)run) + run + d.body_len;
-            pending = last ? 0 : tail;
-        } else {
-            pending += len;
-            if (last) {                                                               // the block ends with one literal-only sequence
-                d.run = pending;
-                pos += 1u + lz4_len_ext((uint32_t)pending) + pending;
-                pending = 0;
-            }
-        }
-        plan[i] = d;
-    }
+    for (size_t i = 0; i < np; i++) if (res[i] < 0) return res[i];
+    const uint64_t pos = plan_stitch(plan, 0, np, 0, n, piece, stride, d_tmp, res, first);
     if (pos + pre > cap) return CJ_E_COMPRESS_FAILED;
     if (!e->d_frame.reserve(pos + np * sizeof(Stitch) + 64)) return CJ_E_OOM;
     uint8_t* d_frame = (uint8_t*)e->d_frame.p;
@@ -212,6 +223,141 @@ int64_t large_lz4_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap
     return (int64_t)(pos + pre);
 }
 
+
+// The block sequence of an LZ4 frame (u32 size word + data per 64 KiB of input; frame.hip: cj_lz4_frame_compress_blocks) for
+// inputs of up to kSplitMax bytes: every 64 KiB block is compressed by four wavefronts (quarter pieces) and joined into one
+// LZ4 block; a block that does not shrink is stored.
+int64_t large_lz4_frame_blocks(const uint8_t* in, size_t n, uint8_t* out, size_t cap) {
+    cj_engine* e = default_engine();
+    if (!e) return CJ_E_NO_DEVICE;
+    const size_t nq = (n + kQuarter - 1) / kQuarter, nb = (n + kPiece - 1) / kPiece;
+    std::lock_guard<std::mutex> lock(e->mu);
+    HIP_TRY(hipSetDevice(e->device), CJ_E_NO_DEVICE);
+    hipStream_t s = e->stream;
+    std::vector<int64_t> res;
+    int rc = compress_pieces(e, CJ_CODEC_LZ4_BLOCK, kFlagReportTail | kFlagSplitPieces, in, n, kQuarter, nq, kLz4QStride, res);
+    if (rc != 0) return rc;
+    uint64_t* d_meta = (uint64_t*)e->d_meta.p;
+    uint8_t* d_tmp = (uint8_t*)e->d_out.p;
+    uint8_t* d_in = (uint8_t*)e->d_in.p;
+    uint32_t* d_first = (uint32_t*)(d_meta + 5 * nq);
+    hipLaunchKernelGGL(lz4_stitch_plan_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, d_tmp, (uint32_t)kLz4QStride, d_first, (uint32_t)nq);
+    HIP_TRY(hipGetLastError(), CJ_E_NO_DEVICE);
+    std::vector<uint32_t> first(nq);
+    HIP_TRY(hipMemcpyAsync(first.data(), d_first, nq * 4, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
+    HIP_TRY(hipStreamSynchronize(s), CJ_E_NO_DEVICE);
+    for (size_t i = 0; i < nq; i++) if (res[i] < 0) return res[i];
+
+    std::vector<Stitch> plan(nq);
+    std::vector<uint64_t> seg(4 * nb);                     // src | dst_off | len | hdr per block (copy_segments)
+    uint64_t fpos = 0;
+    for (size_t b = 0; b < nb; b++) {
+        const size_t q0 = 4 * b, q1 = std::min(nq, q0 + 4);
+        const uint64_t len = std::min(kPiece, n - b * kPiece);
+        const uint64_t cl = plan_stitch(plan, q0, q1, fpos + 4, n, kQuarter, kLz4QStride, d_tmp, res, first);
+        const bool stored = cl >= len;                     // LZ4F_makeBlock: a block that does not shrink is stored
+        if (stored) for (size_t q = q0; q < q1; q++) plan[q] = Stitch{0, 0, 0, 0, 0, 0};
+        const uint64_t body = stored ? len : cl;
+        seg[b] = (uint64_t)(uintptr_t)(d_in + b * kPiece);
+        seg[nb + b] = fpos + 4;
+        seg[2 * nb + b] = stored ? len : 0;               // compressed blocks: the size word only, the stitch kernel writes the body
+        seg[3 * nb + b] = body | (stored ? 0x80000000ull : 0ull);
+        fpos += 4 + body;
+    }
+    if (fpos > cap) return CJ_E_FRAME_WRITE;
+    const size_t plan_bytes = nq * sizeof(Stitch), seg_bytes = 4 * nb * 8, tail_off = (fpos + 15u) & ~(uint64_t)15u;
+    if (!e->d_frame.reserve(tail_off + plan_bytes + seg_bytes + 64)) return CJ_E_OOM;
+    uint8_t* d_frame = (uint8_t*)e->d_frame.p;
+    Stitch* d_plan = reinterpret_cast<Stitch*>(d_frame + tail_off);
+    uint64_t* d_seg = reinterpret_cast<uint64_t*>(d_frame + tail_off + plan_bytes);
+    HIP_TRY(hipMemcpyAsync(d_plan, plan.data(), plan_bytes, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
+    HIP_TRY(hipMemcpyAsync(d_seg, seg.data(), seg_bytes, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
+    launch_copy_segments(d_seg, d_frame, d_seg + nb, d_seg + 2 * nb, d_seg + 3 * nb, 4, (uint32_t)nb, s);
+    hipLaunchKernelGGL(lz4_stitch_kernel, dim3((unsigned)((nq + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlockThreads), 0, s,
+                       d_plan, (const uint8_t*)d_in, d_frame, (uint32_t)nq);
+    HIP_TRY(hipGetLastError(), CJ_E_NO_DEVICE);
+    HIP_TRY(hipMemcpyAsync(out, d_frame, fpos, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
+    HIP_TRY(hipStreamSynchronize(s), CJ_E_NO_DEVICE);
+    return (int64_t)fpos;
+}
+
+// A Snappy framed stream (frame.hip: cj_snappy_frame_compress) for inputs of up to kSplitMax bytes: every 64 KiB piece is
+// compressed by four wavefronts; its chunk = header (type, length, masked CRC-32C of the uncompressed piece) + varint(piece
+// length) + the four quarters' element streams.  snap's rule: a piece is stored when it does not shrink by an eighth.
+int64_t large_snappy_frame(const uint8_t* in, size_t n, uint8_t* out, size_t cap) {
+    static const uint8_t kIdent[10] = {0xff, 0x06, 0x00, 0x00, 's', 'N', 'a', 'P', 'p', 'Y'};
+    cj_engine* e = default_engine();
+    if (!e) return CJ_E_NO_DEVICE;
+    const size_t nq = (n + kQuarter - 1) / kQuarter, np = (n + kPiece - 1) / kPiece;
+    std::lock_guard<std::mutex> lock(e->mu);
+    HIP_TRY(hipSetDevice(e->device), CJ_E_NO_DEVICE);
+    hipStream_t s = e->stream;
+    std::vector<int64_t> res;
+    int rc = compress_pieces(e, CJ_CODEC_SNAPPY_RAW, kFlagSplitPieces, in, n, kQuarter, nq, kSnQStride, res);
+    if (rc != 0) return rc;
+    uint64_t* d_meta = (uint64_t*)e->d_meta.p;             // 12 nq rows reserved; 0 .. 5 nq in use
+    uint8_t* d_tmp = (uint8_t*)e->d_out.p;
+    uint8_t* d_in = (uint8_t*)e->d_in.p;
+    std::vector<uint64_t> pm(2 * np);
+    for (size_t p = 0; p < np; p++) { pm[p] = p * kPiece; pm[np + p] = std::min(kPiece, n - p * kPiece); }
+    HIP_TRY(hipMemcpyAsync(d_meta + 6 * nq, pm.data(), 2 * np * 8, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
+    launch_crc32c_pieces(d_in, d_meta + 6 * nq, d_meta + 6 * nq + np, (uint32_t*)(d_meta + 9 * nq), (uint32_t)np, s);
+    HIP_TRY(hipGetLastError(), CJ_E_NO_DEVICE);
+    std::vector<uint32_t> crc(np);
+    HIP_TRY(hipMemcpyAsync(crc.data(), d_meta + 9 * nq, np * 4, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
+    HIP_TRY(hipStreamSynchronize(s), CJ_E_NO_DEVICE);
+    for (size_t i = 0; i < nq; i++) if (res[i] < 0) return res[i];
+
+    std::vector<uint64_t> sa(4 * np), sb(3 * nq, 0);       // with header: src | dst | len | hdr per piece; without: src | dst | len per quarter
+    std::vector<uint32_t> vints(np, 0);
+    uint64_t fpos = 10;
+    for (size_t p = 0; p < np; p++) {
+        const size_t q0 = 4 * p, q1 = std::min(nq, q0 + 4);
+        const uint64_t len = pm[np + p];
+        uint32_t vl = 0, v = 0;
+        for (uint64_t x = len;; ) { if (x < 0x80u) { v |= (uint32_t)x << (8 * vl); vl++; break; } v |= (uint32_t)((x & 0x7f) | 0x80u) << (8 * vl); vl++; x >>= 7; }
+        vints[p] = v;
+        uint64_t comp = vl;
+        for (size_t q = q0; q < q1; q++) comp += (uint64_t)res[q] - varint_len(std::min(kQuarter, n - q * kQuarter));
+        const bool stored = comp >= len - len / 8;
+        const uint64_t body = stored ? len : comp;
+        sa[p] = stored ? (uint64_t)(uintptr_t)(d_in + p * kPiece) : 0ull;       // compressed: the varint (address patched below)
+        sa[np + p] = fpos + 8;
+        sa[2 * np + p] = stored ? len : vl;
+        sa[3 * np + p] = (stored ? 1ull : 0ull) | ((body + 4) << 8) | ((uint64_t)crc[p] << 32);
+        if (!stored) {
+            uint64_t pos = fpos + 8 + vl;
+            for (size_t q = q0; q < q1; q++) {
+                const uint32_t ph = varint_len(std::min(kQuarter, n - q * kQuarter));
+                sb[q] = (uint64_t)(uintptr_t)(d_tmp + q * kSnQStride + ph);
+                sb[nq + q] = pos;
+                sb[2 * nq + q] = (uint64_t)res[q] - ph;
+                pos += sb[2 * nq + q];
+            }
+        }
+        fpos += 8 + body;
+    }
+    if (fpos > cap) return CJ_E_FRAME_WRITE;
+    const size_t tail_off = (fpos + 15u) & ~(uint64_t)15u, sa_bytes = sa.size() * 8, sb_bytes = sb.size() * 8;
+    if (!e->d_frame.reserve(tail_off + sa_bytes + sb_bytes + np * 4 + 64)) return CJ_E_OOM;
+    uint8_t* d_frame = (uint8_t*)e->d_frame.p;
+    uint64_t* d_sa = reinterpret_cast<uint64_t*>(d_frame + tail_off);
+    uint64_t* d_sb = d_sa + sa.size();
+    uint32_t* d_v = reinterpret_cast<uint32_t*>(d_sb + sb.size());
+    for (size_t p = 0; p < np; p++) if (sa[p] == 0ull) sa[p] = (uint64_t)(uintptr_t)(d_v + p);
+    HIP_TRY(hipMemcpyAsync(d_frame, kIdent, 10, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
+    HIP_TRY(hipMemcpyAsync(d_sa, sa.data(), sa_bytes, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
+    HIP_TRY(hipMemcpyAsync(d_sb, sb.data(), sb_bytes, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
+    HIP_TRY(hipMemcpyAsync(d_v, vints.data(), np * 4, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
+    launch_copy_segments(d_sa, d_frame, d_sa + np, d_sa + 2 * np, d_sa + 3 * np, 8, (uint32_t)np, s);
+    launch_copy_segments(d_sb, d_frame, d_sb + nq, d_sb + 2 * nq, nullptr, 0, (uint32_t)nq, s);
+    HIP_TRY(hipGetLastError(), CJ_E_NO_DEVICE);
+    HIP_TRY(hipMemcpyAsync(out, d_frame, fpos, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
+    HIP_TRY(hipStreamSynchronize(s), CJ_E_NO_DEVICE);
+    return (int64_t)fpos;
+}
+
+size_t large_split_max() { return kSplitMax; }
 
 // =====================================================================================================================
 // decompress ONE large stream: parallel parse (big_parse.hip) -> one decoder workgroup per 64 KiB slab of output

@@ -439,7 +439,7 @@ constexpr uint32_t kL2Threads = CJ_L2_THREADS;
 constexpr uint32_t kL2OffBits = 65536;
 constexpr uint32_t kL2OffVars = kL2OffBits + 8192;         // [0] fail flag, [8] current chunk, [64,128) dummy bytes, [128,384) dummy dwords
 constexpr uint32_t kL2Bytes = kL2OffVars + 384;            // 74112 B: two workgroups fit one CU's LDS
-constexpr uint32_t kL2TabRecords = kSyncStride * kSyncEvery;   // the parse kernel routes chunks with more sequences elsewhere
+constexpr uint32_t kL2TabRecords = 2u * kSyncStride * kSyncEvery;   // records of a chunk (the parse kernel routes chunks with more than 8 192 sequences elsewhere) + as many forwarded literal copies (D1f)
 
 template <int ND>
 __device__ __forceinline__ DW<ND> gl_ld_aligned(const uint8_t* pa, const uint8_t* last) {   // ND aligned dwords, clamped to the last valid one
@@ -495,7 +495,8 @@ constexpr uint32_t kL2LinkedBytes = 2u * 65536u + 8192u + 384u;        // 139 64
 #define CJ_FWD_ROUNDS 16u
 #endif
 __device__ unsigned long long g_fwd_chunks = 0ull;            // test hook: chunks / slabs that went through D1f
-constexpr uint32_t kFwdMaxRecords = 4096, kFwdMaxRounds = CJ_FWD_ROUNDS, kFwdNear = 4096;      // D1f (match forwarding)
+constexpr uint32_t kFwdMaxRecords = 6144;      // D1f (match forwarding): 10 bytes of index per record in the 64 KiB window
+constexpr uint32_t kFwdMaxRounds = CJ_FWD_ROUNDS, kFwdNear = 4096;
 struct SlabArgs { uint32_t* done; uint4* cross; uint32_t tab_stride, cross_stride, rel; uint32_t* defer; uint32_t defer_stride; };
 #ifndef CJ_SLAB_PATIENCE
 #define CJ_SLAB_PATIENCE 64u
@@ -666,13 +667,14 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                             const uint64_t src_abs = S + dst - off;
                             const uint32_t k = atomicAdd(s_ncross, 1u);
                             cross[k] = make_uint4((uint32_t)src_abs, (uint32_t)(src_abs >> 32), dst, n1);
+                            if (mlen == n1 && off <= 0xffffu) rec.w = off | (n1 << 16);      // (off > dst marks it as a cross copy: D3 skips it, D1f forwards into it; Snappy's 4-byte offsets stay in the cross list only)
                             if (mlen > n1) {
                                 // the rest of the match repeats bytes from the start of THIS slab: an ordinary match at dst + n1.
                                 // It keeps the sequence's place in the record order (D3's progress argument: a record waits
                                 // only for records before it), so the sequence's literals move to an extra record instead —
                                 // literals depend on nothing and may sit anywhere.
                                 if (lit > 0u) table[nseq + atomicAdd(s_nextra, 1u)] = rec;
-                                rec = make_uint4(0u, 0u, dst + n1, off | ((mlen - n1) << 16));
+                                rec = make_uint4(0x80000000u | (lit + n1), 0u, dst + n1, off | ((mlen - n1) << 16));     // x: bytes before it that no record describes (D1f)
                             }
                         } else rec.w = off | (mlen << 16);
                         near += off < kFwdNear ? 1u : 0u;
@@ -750,21 +752,30 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         //      and if it lies inside a literal run, A is a literal copy from the input and depends on nothing.  Iterated
         //      (each round reads the other records' current offsets: pointer doubling), chains collapse: depth 7 048 -> 67 on
         //      the "bottles" text, 562 -> 44 on log lines, 40 -> 23 on the benchmark data, where a third of the matches
-        //      become literal copies.  The record index lives in the output window (free between D1 and D2): per record
-        //      start|dst, length|literal source, current offset; plus "last record starting at or before byte 16 b".
+        //      become literal copies.  kSlab: a match forwarded into a copy from an earlier slab becomes such a copy itself.
+        //      The record index lives in the output window and the bitmap (both free between D1 and D2), 8 bytes per record:
+        //      start | dst << 16 and the state word (current offset / input position + flags); the records tile the window
+        //      (start[i+1] = end of record i), so a match's length is start[i+1] - dst[i]; plus, per 16 bytes of output,
+        //      the last record that starts at or before them.
         if constexpr (!kLinked) {
-            if (nseq <= kFwdMaxRecords && staged && *s_small * 2u > nseq) {      // mostly near matches: the chains are deep, forwarding pays (it costs ~25 k cycles + 10 k per round)
+            // mostly near matches: the chains are deep, forwarding pays (it costs ~25 k cycles + 10 k per round).  kSlab: always
+            // when the slab waits for bytes of earlier slabs — the forwarding runs before that wait, what it removes from
+            // the dependency depth comes off the serial chain through the slabs
+            if (nseq <= kFwdMaxRecords && staged && (*s_small * 2u > nseq || (kSlab && *s_ncross > 0u))) {
                 uint32_t* f_w0 = reinterpret_cast<uint32_t*>(s_out);
-                uint32_t* f_w1 = f_w0 + kFwdMaxRecords;
-                uint32_t* f_st = f_w1 + kFwdMaxRecords;
-                uint16_t* f_blk = reinterpret_cast<uint16_t*>(f_st + kFwdMaxRecords);
-                constexpr uint32_t kLit = 0x80000000u;
+                uint32_t* f_st = f_w0 + kFwdMaxRecords;
+                uint16_t* f_ls = reinterpret_cast<uint16_t*>(f_st + kFwdMaxRecords);      // literal source of every record (16 bits: the chunk is staged)
+                uint16_t* f_blk = reinterpret_cast<uint16_t*>(s_bits);
+                constexpr uint32_t kLit = 0x80000000u, kHole = 0x40000000u, kStop = 0x20000000u, kVal = 0x1fffffffu;
                 for (uint32_t i = tid; i < nseq; i += kL2Threads) {
                     const uint4 r = table[i];
-                    const uint32_t start = r.z - r.y;
+                    const bool hole = r.y == 0u && (r.x & 0x80000000u) != 0u;      // kSlab remainder record: x = bytes before it that no record describes
+                    const uint32_t start = r.z - r.y - (hole ? (r.x & 0x7fffffffu) : 0u);
+                    const uint32_t off = r.w & 0xffffu, m = r.w >> 16;
                     f_w0[i] = (start < 65535u ? start : 65535u) | ((r.z < 65535u ? r.z : 65535u) << 16);
-                    f_w1[i] = (r.w >> 16) | ((r.x & 0xffffu) << 16);
-                    f_st[i] = r.w & 0xffffu;
+                    f_ls[i] = (uint16_t)r.x;
+                    // not forwardable: no match, self-overlapping, a cross copy already, the last record
+                    f_st[i] = off | (hole ? kHole : 0u) | ((m == 0u || off < m || off > r.z || i + 1u == nseq) ? kStop : 0u);
                 }
                 if (tid == 0) { *s_fwd = 0u; atomicAdd(&g_fwd_chunks, 1ull); }
                 __syncthreads();
@@ -776,37 +787,56 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 __syncthreads();
                 for (uint32_t round = 0; round < kFwdMaxRounds; round++) {
                     uint32_t changed = 0;
-                    for (uint32_t i = tid; i < nseq; i += kL2Threads) {
-                        const uint32_t st = f_st[i], m = f_w1[i] & 0xffffu, dst = f_w0[i] >> 16;
-                        if (m == 0u || (st & kLit) || st < m) continue;            // no match / already a literal copy / self-overlapping
-                        const uint32_t sp = dst - st;                              // current source position
+                    for (uint32_t i = tid; i + 1u < nseq; i += kL2Threads) {
+                        const uint32_t st = f_st[i];
+                        if (st & (kLit | kStop)) continue;
+                        const uint32_t dst = f_w0[i] >> 16, nstart = f_w0[i + 1u] & 0xffffu;
+                        if (nstart >= 65535u) { f_st[i] = st | kStop; continue; }  // (the clamp hides whether the match ends at 65535 or 65536)
+                        const uint32_t m = nstart - dst, off = st & kVal;
+                        const uint32_t sp = dst - off;                             // current source position
                         uint32_t r = f_blk[sp >> 4];
                         while (r + 1u < nseq && (f_w0[r + 1u] & 0xffffu) <= sp) r++;
-                        if (r > i) continue;                                       // (r == i: the source lies in the record's own literal run)
-                        const uint32_t w0 = f_w0[r], w1 = f_w1[r], bst = f_st[r];
-                        const uint32_t bstart = w0 & 0xffffu, bdst = w0 >> 16, bm = w1 & 0xffffu;
-                        if (sp >= bstart && sp + m <= bdst) { f_st[i] = kLit | ((w1 >> 16) + (sp - bstart)); changed = 1; }
-                        else if (bm > 0u && sp >= bdst && sp + m <= bdst + bm) {
-                            if (bst & kLit) { f_st[i] = kLit | ((bst & ~kLit) + (sp - bdst)); changed = 1; }
-                            else if (bst >= bm) { f_st[i] = st + bst; changed = 1; }
-                        }
+                        if (r > i || r + 1u >= nseq) { f_st[i] = st | kStop; continue; }
+                        const uint32_t w0 = f_w0[r], bst = f_st[r];
+                        const uint32_t bstart = w0 & 0xffffu, bdst = w0 >> 16, bend = f_w0[r + 1u] & 0xffffu;
+                        if (sp >= bstart && sp + m <= bdst) {                      // inside B's literal run (r == i: the record's own)
+                            if (bst & kHole) { f_st[i] = st | kStop; continue; }   // ... which is not one
+                            f_st[i] = kLit | (st & kHole) | (((uint32_t)f_ls[r] + (sp - bstart)) & kVal); changed = 1;
+                        } else if (sp >= bdst && sp + m <= bend && bend > bdst) {  // inside B's match
+                            const uint32_t boff = bst & kVal, bm = bend - bdst;
+                            if (bst & kLit) { f_st[i] = kLit | (st & kHole) | ((boff + (sp - bdst)) & kVal); changed = 1; }
+                            else if (boff >= bm && off + boff <= kVal) {           // (B a cross copy: A becomes one too — and is final)
+                                f_st[i] = (st & kHole) | (off + boff) | (off + boff > dst ? kStop : 0u); changed = 1;
+                            }
+                            else f_st[i] = st | kStop;                             // B repeats itself: A stays
+                        } else f_st[i] = st | kStop;                               // straddles two records: stays
                     }
                     if (changed) atomicOr(s_fwd, 1u << (round & 31u));
                     __syncthreads();
                     if (((*s_fwd >> (round & 31u)) & 1u) == 0u) break;          // uniform: nothing moved in this round
                 }
-                for (uint32_t i = tid; i < nseq; i += kL2Threads) {
-                    const uint32_t st = f_st[i], m = f_w1[i] & 0xffffu;
+                for (uint32_t i = tid; i + 1u < nseq; i += kL2Threads) {
+                    const uint32_t st = f_st[i], v = st & kVal;
+                    const uint4 r = table[i];
+                    const uint32_t m = r.w >> 16;
                     if (m == 0u) continue;
                     if (st & kLit) {
-                        const uint4 r = table[i];
-                        table[nseq + atomicAdd(s_nextra, 1u)] = make_uint4(st & ~kLit, m, r.z + m, 0u);      // a literal copy of m bytes ending at dst + m
+                        table[nseq + atomicAdd(s_nextra, 1u)] = make_uint4(v, m, r.z + m, 0u);      // a literal copy of m bytes ending at dst + m
                         table[i] = make_uint4(r.x, r.y, r.z, 0u);
-                    } else if (st != (table[i].w & 0xffffu)) {
-                        const uint4 r = table[i];
-                        table[i] = make_uint4(r.x, r.y, r.z, st | (m << 16));
+                    } else if (v != (r.w & 0xffffu)) {
+                        if constexpr (kSlab) {
+                            if (v > r.z) {                                        // forwarded into an earlier slab: a cross copy of its own
+                                const uint64_t src_abs = a.out_off[c] + r.z - v;
+                                (sl.cross + (size_t)blockIdx.x * sl.cross_stride)[atomicAdd(s_ncross, 1u)] = make_uint4((uint32_t)src_abs, (uint32_t)(src_abs >> 32), r.z, m);
+                                table[i] = make_uint4(r.x, r.y, r.z, 0u);
+                                continue;
+                            }
+                        }
+                        table[i] = make_uint4(r.x, r.y, r.z, v | (m << 16));
                     }
                 }
+                __syncthreads();                                               // the index is dead: the bitmap is a bitmap again
+                for (uint32_t i = tid; i < 2048u; i += kL2Threads) s_bits[i] = 0u;
                 __syncthreads();
                 nrec_all = nseq + *s_nextra;
             }
@@ -887,8 +917,8 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                         wave_bits_set(s_bits, ld, ld + ln);
                         if (lane == l) n = 0;
                     }
-                    while (ballot64(n > 0u)) {                 // <=16 bytes per pass (register budget: this sits inside D3's loop); the
-                        const uint32_t step = n < 16u ? n : 16u;   // output buffer is padded, over-reads are harmless
+                    while (ballot64(n > 0u)) {                 // <=16 bytes per pass (register budget: this sits inside D3's loop; 32-byte
+                        const uint32_t step = n < 16u ? n : 16u;   // passes measured no faster); the output buffer is padded, over-reads are harmless
                         if (step > 0u) {
                             lds_store_tier<16>(gl_ld_vec<6>(g), a_out + dst, 0u, step, dm);
                             bits_set(s_bits, dst, dst + step);
@@ -942,7 +972,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             const uint32_t dst = rec.z, off = rec.w & 0xffffu, m = rec.w >> 16;
             const uint32_t src = dst - off;                   // kLinked: "negative" (wraps) when the source starts in the previous block
             const uint32_t need = off < m ? off : m;
-            bool pending = m > 0u;
+            bool pending = m > 0u && !(kSlab && off > dst);      // kSlab: off > dst = copied from earlier slabs (cross list)
             // kLinked: cross = source starts in the previous window; cross_full = it also ends there (final bytes, no polling)
             const bool cross = kLinked && off > dst;
             const bool cross_full = cross && off - dst >= m;

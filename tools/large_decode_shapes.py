@@ -19,5 +19,16 @@ run("synth-v1, off the slab grid", data); run("synth-v1, off the slab grid", dat
 text = b"".join(b"%d bottles of beer on the wall, %d bottles of beer\n" % (i % 977, i % 1013) for i in range(600000))
 run("text lines (deep chains)", text); run("text lines (deep chains)", text, "snappy")
 run("zeros", bytes(40 << 20)); run("zeros", bytes(40 << 20), "snappy")
-import random
+import json, random
+rnd = random.Random(7)
+log = b"".join(b"2026-09-28T12:%02d:%02d.%03d INFO worker-%d request id=%08x path=/api/v1/items/%d status=%d latency_ms=%d\n" % (
+    rnd.randrange(60), rnd.randrange(60), rnd.randrange(1000), rnd.randrange(16), rnd.getrandbits(32), rnd.randrange(5000),
+    rnd.choice([200, 200, 200, 404, 500]), rnd.randrange(900)) for _ in range(300000))
+run("log lines", log); run("log lines", log, "snappy")
+js = b"".join(json.dumps({"id": i, "name": "user%d" % rnd.randrange(1000), "tags": ["a", "b", rnd.choice("xyz")], "score": rnd.random()}).encode() + b"\n" for i in range(300000))
+run("JSON lines", js); run("JSON lines", js, "snappy")
+src = b"".join(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cramjam_amd", "csrc", f), "rb").read()
+               for f in sorted(os.listdir(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cramjam_amd", "csrc")))
+               if f.endswith((".hip", ".hpp", ".cpp"))) * 12
+run("C++ source", src); run("C++ source", src, "snappy")
 run("random (stored)", random.Random(1).randbytes(32 << 20)); run("random (stored)", random.Random(1).randbytes(32 << 20), "snappy")

@@ -392,7 +392,7 @@ int lz4_frame_linked_lds(cj_engine* e, const Lz4Frame& f, const uint8_t* d_in, s
         // completion flag is up, everything else is resolved meanwhile
         if (e->n_cu == 0) HIP_TRY(hipDeviceGetAttribute(&e->n_cu, hipDeviceAttributeMultiprocessorCount, e->device), CJ_E_NO_DEVICE);
         const uint32_t grid = (uint32_t)std::min<size_t>(2u * (size_t)e->n_cu, nb);
-        const uint32_t cross_stride = 2u * cj::kSyncStride * cj::kSyncEvery, tab_stride = 3u * cj::kSyncStride * cj::kSyncEvery;
+        const uint32_t cross_stride = 3u * cj::kSyncStride * cj::kSyncEvery, tab_stride = 4u * cj::kSyncStride * cj::kSyncEvery;
         const size_t tab_bytes = (size_t)grid * tab_stride * 16;
         if (!e->d_bigtab.reserve(tab_bytes + (size_t)grid * cross_stride * 16 + (size_t)grid * (tab_stride + 512u) * 4)) return CJ_E_OOM;
         cj::launch_lz4_decode_lds2_slabs(a, e->d_sync.p, e->d_pmeta.p, e->d_bigtab.p, (uint32_t*)(d_meta + r_cnt), d_meta + r_first, 0u,

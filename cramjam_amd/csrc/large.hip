@@ -464,7 +464,7 @@ int64_t large_decompress(int codec, uint32_t flags, const uint8_t* in, size_t n,
 
     if (e->n_cu == 0) HIP_TRY(hipDeviceGetAttribute(&e->n_cu, hipDeviceAttributeMultiprocessorCount, e->device), CJ_E_NO_DEVICE);
     const uint32_t grid = std::min<uint32_t>(2u * (uint32_t)e->n_cu, n_slabs);
-    const uint32_t cross_stride = 2u * ((max_rec + 63u) & ~63u), tab_stride = 3u * ((max_rec + 63u) & ~63u);      // cross: D1's + forwarded ones      // records + slab extras + forwarded literal copies
+    const uint32_t cross_stride = 3u * ((max_rec + 63u) & ~63u), tab_stride = 4u * ((max_rec + 63u) & ~63u);      // D1's entries + what D1f adds (forwarded copies, split straddlers)      // records + slab extras + forwarded literal copies
     const size_t tab_bytes = (size_t)grid * tab_stride * 16, cross_bytes = (size_t)grid * cross_stride * 16;
     if (!e->d_bigtab.reserve(tab_bytes + cross_bytes + (size_t)grid * (tab_stride + 512u) * 4) || !e->d_out.reserve(total + 256)) return CJ_E_OOM;
     BatchArgs a;

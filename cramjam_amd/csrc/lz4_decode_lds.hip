@@ -439,7 +439,7 @@ constexpr uint32_t kL2Threads = CJ_L2_THREADS;
 constexpr uint32_t kL2OffBits = 65536;
 constexpr uint32_t kL2OffVars = kL2OffBits + 8192;         // [0] fail flag, [8] current chunk, [64,128) dummy bytes, [128,384) dummy dwords
 constexpr uint32_t kL2Bytes = kL2OffVars + 384;            // 74112 B: two workgroups fit one CU's LDS
-constexpr uint32_t kL2TabRecords = 2u * kSyncStride * kSyncEvery;   // records of a chunk (the parse kernel routes chunks with more than 8 192 sequences elsewhere) + as many forwarded literal copies (D1f)
+constexpr uint32_t kL2TabRecords = 3u * kSyncStride * kSyncEvery;   // records of a chunk (the parse kernel routes chunks with more than 8 192 sequences elsewhere) + the extra literal copies of D1f (at most two per record, D1f takes at most 6 144 records)
 
 template <int ND>
 __device__ __forceinline__ DW<ND> gl_ld_aligned(const uint8_t* pa, const uint8_t* last) {   // ND aligned dwords, clamped to the last valid one
@@ -766,7 +766,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 uint32_t* f_st = f_w0 + kFwdMaxRecords;
                 uint16_t* f_ls = reinterpret_cast<uint16_t*>(f_st + kFwdMaxRecords);      // literal source of every record (16 bits: the chunk is staged)
                 uint16_t* f_blk = reinterpret_cast<uint16_t*>(s_bits);
-                constexpr uint32_t kLit = 0x80000000u, kHole = 0x40000000u, kStop = 0x20000000u, kVal = 0x1fffffffu;
+                constexpr uint32_t kLit = 0x80000000u, kHole = 0x40000000u, kStop = 0x20000000u, kSplit = 0x10000000u, kVal = 0x0fffffffu;
                 for (uint32_t i = tid; i < nseq; i += kL2Threads) {
                     const uint4 r = table[i];
                     const bool hole = r.y == 0u && (r.x & 0x80000000u) != 0u;      // kSlab remainder record: x = bytes before it that no record describes
@@ -815,11 +815,59 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                     __syncthreads();
                     if (((*s_fwd >> (round & 31u)) & 1u) == 0u) break;          // uniform: nothing moved in this round
                 }
+                // Straddlers: a match whose source spans the boundary between two records cannot be forwarded as a whole, and the
+                // chains that remain after the rounds run through such matches.  If each of its two parts, taken alone, ends in a
+                // literal run or in a copy from an earlier slab (one step, with the final states of the rounds), the match is
+                // replaced by those two dependency-free copies.
+                for (uint32_t i = tid; i + 2u < nseq; i += kL2Threads) {
+                    const uint32_t st = f_st[i];
+                    if ((st & kLit) || !(st & kStop)) continue;
+                    const uint32_t dst = f_w0[i] >> 16, nstart = f_w0[i + 1u] & 0xffffu, off = st & kVal;
+                    if (nstart >= 65535u || nstart <= dst) continue;
+                    const uint32_t m = nstart - dst;
+                    if (off < m || off > dst) continue;                            // self-overlapping / a cross copy
+                    const uint32_t sp = dst - off;
+                    uint32_t r = f_blk[sp >> 4];
+                    while (r + 1u < nseq && (f_w0[r + 1u] & 0xffffu) <= sp) r++;
+                    if (r + 2u >= nseq || r + 1u > i) continue;
+                    const uint32_t cut = f_w0[r + 1u] & 0xffffu;                   // the boundary inside the source range
+                    if (sp + m <= cut || sp + m > (f_w0[r + 2u] & 0xffffu)) continue;     // not a two-record straddler
+                    uint32_t kind[2], val[2];                                      // per part: 1 = literal copy (input position), 2 = cross copy (distance)
+                    bool ok = true;
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const uint32_t q = r + (uint32_t)h, p0 = h ? cut : sp, p1 = h ? sp + m : cut;
+                        const uint32_t qs = f_w0[q] & 0xffffu, qd = f_w0[q] >> 16, qe = f_w0[q + 1u] & 0xffffu, qst = f_st[q];
+                        kind[h] = 0; val[h] = 0;
+                        if (p0 >= qs && p1 <= qd && !(qst & kHole)) { kind[h] = 1; val[h] = (uint32_t)f_ls[q] + (p0 - qs); }
+                        else if (p0 >= qd && p1 <= qe && !(qst & kSplit)) {
+                            const uint32_t qv = qst & kVal;
+                            if (qst & kLit) { kind[h] = 1; val[h] = qv + (p0 - qd); }
+                            else if (kSlab && qv > qd && qv >= qe - qd) { kind[h] = 2; val[h] = qv; }
+                        }
+                        ok = ok && kind[h] != 0u;
+                    }
+                    if (!ok) continue;
+                    const uint32_t len[2] = {cut - sp, sp + m - cut};
+                    uint32_t d = dst;
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        if (kind[h] == 1u) table[nseq + atomicAdd(s_nextra, 1u)] = make_uint4(val[h], len[h], d + len[h], 0u);
+                        else if constexpr (kSlab) {
+                            const uint64_t src_abs = a.out_off[c] + (h ? cut : sp) - val[h];
+                            (sl.cross + (size_t)blockIdx.x * sl.cross_stride)[atomicAdd(s_ncross, 1u)] = make_uint4((uint32_t)src_abs, (uint32_t)(src_abs >> 32), d, len[h]);
+                        }
+                        d += len[h];
+                    }
+                    f_st[i] = st | kSplit;
+                }
+                __syncthreads();
                 for (uint32_t i = tid; i + 1u < nseq; i += kL2Threads) {
                     const uint32_t st = f_st[i], v = st & kVal;
                     const uint4 r = table[i];
                     const uint32_t m = r.w >> 16;
                     if (m == 0u) continue;
+                    if (st & kSplit) { table[i] = make_uint4(r.x, r.y, r.z, 0u); continue; }
                     if (st & kLit) {
                         table[nseq + atomicAdd(s_nextra, 1u)] = make_uint4(v, m, r.z + m, 0u);      // a literal copy of m bytes ending at dst + m
                         table[i] = make_uint4(r.x, r.y, r.z, 0u);

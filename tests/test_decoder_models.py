@@ -72,8 +72,29 @@ def forward(recs, max_rounds=16):
         st = new; rounds += 1
         if not changed: break
     out, extras = [], []
+    split = set()
+    for i in range(n - 2):                                 # straddlers: both halves end in literal runs -> two literal copies
+        s = st[i]
+        if m[i] == 0 or (s & LIT) or s < m[i] or s > dst[i]: continue
+        sp = dst[i] - s
+        r = blk[sp >> 4]
+        while r + 1 < n and start[r + 1] <= sp: r += 1
+        if r + 2 >= n or r + 1 > i: continue
+        cut = start[r + 1]
+        if sp + m[i] <= cut or sp + m[i] > start[r + 2]: continue
+        parts = []
+        for q, p0, p1 in ((r, sp, cut), (r + 1, cut, sp + m[i])):
+            if p0 >= start[q] and p1 <= dst[q]: parts.append(litsrc[q] + (p0 - start[q]))
+            elif p0 >= dst[q] and p1 <= dst[q] + m[q] and (st[q] & LIT) and q not in split: parts.append((st[q] & ~LIT) + (p0 - dst[q]))
+        if len(parts) != 2: continue
+        d = recs[i][2]
+        for pos, ln in zip(parts, (cut - sp, sp + m[i] - cut)):
+            extras.append((pos, ln, d + ln, 0, 0)); d += ln
+        split.add(i)
     for i, (src, lit, d, off, mm) in enumerate(recs):
-        if mm and (st[i] & LIT):
+        if i in split:
+            out.append((src, lit, d, 0, 0))
+        elif mm and (st[i] & LIT):
             extras.append((st[i] & ~LIT, mm, d + mm, 0, 0)); out.append((src, lit, d, 0, 0))
         else:
             out.append((src, lit, d, st[i] if mm else 0, mm))

@@ -494,6 +494,14 @@ constexpr uint32_t kL2LinkedBytes = 2u * 65536u + 8192u + 384u;        // 139 64
 #ifndef CJ_FWD_ROUNDS
 #define CJ_FWD_ROUNDS 16u
 #endif
+#ifdef CJ_SLAB_TRACE
+__device__ unsigned long long g_slab_trace[8192 * 8];
+#define CJ_TRACE(slot) do { if (c < 8192u && lane == 0) g_slab_trace[c * 8u + (slot)] = wall_clock64(); } while (0)
+#define CJ_TRACE_T0(slot) do { if (c < 8192u && tid == 0) g_slab_trace[c * 8u + (slot)] = wall_clock64(); } while (0)
+#else
+#define CJ_TRACE(slot) do {} while (0)
+#define CJ_TRACE_T0(slot) do {} while (0)
+#endif
 __device__ unsigned long long g_fwd_chunks = 0ull;            // test hook: chunks / slabs that went through D1f
 constexpr uint32_t kFwdMaxRecords = 6144;      // D1f (match forwarding): 10 bytes of index per record in the 64 KiB window
 constexpr uint32_t kFwdMaxRounds = CJ_FWD_ROUNDS, kFwdNear = 4096;
@@ -524,6 +532,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
     uint32_t* s_nextra = reinterpret_cast<uint32_t*>(smem + kOffVars + 20u);
     uint32_t* s_fwd = reinterpret_cast<uint32_t*>(smem + kOffVars + 24u);          // D1f: rounds in which a record moved
     uint32_t* s_small = reinterpret_cast<uint32_t*>(smem + kOffVars + 28u);        // D1: matches with an offset below kFwdNear
+    volatile uint32_t* s_prevok = reinterpret_cast<volatile uint32_t*>(smem + kOffVars + 32u);      // kSlab: a wave has seen the previous slab's flag and fenced
     const bool prof = (a.flags & 0x1000u) != 0;
     unsigned long long t_prev = prof ? __builtin_readcyclecounter() : 0ull;
     uint32_t fr_first = 0, fr_n = 0, fr_k = 0;               // kLinked: current frame and position in it
@@ -549,7 +558,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             for (uint32_t i = tid; i < 2048u; i += kL2Threads) s_bits[i] = 0u;
             __syncthreads();                                 // also: the previous block's D4 has finished reading its window
         } else {
-            if (tid == 0) { *s_chunk = atomicAdd(counter, 1u); *s_fail = 0u; *s_ncross = 0u; *s_nextra = 0u; *s_small = 0u; }
+            if (tid == 0) { *s_chunk = atomicAdd(counter, 1u); *s_fail = 0u; *s_ncross = 0u; *s_nextra = 0u; *s_small = 0u; *s_prevok = 0u; }
             for (uint32_t i = tid; i < 2048u; i += kL2Threads) s_bits[i] = 0u;
             __syncthreads();
             c = *s_chunk;
@@ -577,13 +586,24 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         // kSlab: done[c] means "chunks 0..c are complete" (a Snappy copy may reach back over many slabs, and a slab without
         // cross matches never waited for its predecessor): the flag is set after done[c-1] has been seen.  Every wave's
         // stores are out (release fence + barrier) before thread 0 stores the flag.
+        bool wt_tail = false;                                // kSlab: the chunk ends with plain byte stores (size not a multiple of 16)
         const auto publish = [&]() {
             if constexpr (kSlab) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                // the chunk's bytes were stored write-through (sc0 sc1): acknowledged = in memory.  Every wave waits for its stores,
+                // barrier, relaxed flag store.  No L2 write-back (buffer_wbl2: several µs with 64 KiB freshly written) — except
+                // after plain byte stores (a chunk tail), where ONE agent-scope release + an explicit s_waitcnt (the compiler may
+                // drop the fence's own) precede the flag
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
+                CJ_TRACE_T0(4);                                            // stores acknowledged
                 if (tid == 0) {
                     if (c > 0u) while (__hip_atomic_load(&sl.done[c - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
-                    __hip_atomic_store(&sl.done[c], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    if (wt_tail) {                           // a chunk whose size is not a multiple of 16 ended with plain byte stores
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    __hip_atomic_store(&sl.done[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    CJ_TRACE_T0(5);                                        // flag stored
                 }
             }
         };
@@ -593,9 +613,10 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 const uint8_t* src = a.in_base + a.in_off[c];
                 uint8_t* dsto = a.out_base + a.out_off[c];
                 for (uint32_t i = tid * 16u; i < len; i += kL2Threads * 16u) {
-                    if (i + 16u <= len) st16u_nt(dsto + i, ld16u(src + i));
+                    if (i + 16u <= len) st16u_wt(dsto + i, ld16u(src + i));
                     else for (uint32_t q = i; q < len; q++) dsto[q] = src[q];
                 }
+                wt_tail = (len & 15u) != 0u;
                 publish();
                 continue;
             }
@@ -940,15 +961,24 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         if constexpr (kSlab) { ncross = *s_ncross; cross_done = ncross <= wave * 64u; }      // complete since the barrier after D1
         const auto try_cross = [&](bool block) {
             if constexpr (kSlab) {
-                uint32_t f = 0;
-                for (;;) {
-                    if (lane == 0) f = __hip_atomic_load(&sl.done[c - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    f = rdlane(f, 0);
-                    if (f != 0u || !block) break;
-                    __builtin_amdgcn_s_sleep(8);
+                // one relaxed poll -> ONE agent-scope acquire per workgroup (it invalidates the CU's L1, which all its waves share,
+                // and costs µs): the wave that sees the flag first fences and tells the others through LDS
+                if (*s_prevok == 0u) {
+                    uint32_t f = 0;
+                    for (;;) {
+                        if (lane == 0) f = __hip_atomic_load(&sl.done[c - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        f = rdlane(f, 0);
+                        if (f != 0u || !block || *s_prevok != 0u) break;
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                    if (f == 0u && *s_prevok == 0u) return;
+                    if (*s_prevok == 0u) {
+                        CJ_TRACE(0);                                       // flag seen
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        if (lane == 0) *s_prevok = 1u;
+                        CJ_TRACE(1);                                       // acquire done
+                    }
                 }
-                if (f == 0u) return;
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 const uint4* cross = sl.cross + (size_t)blockIdx.x * sl.cross_stride;
                 for (uint32_t base = wave * 64u; base < ncross; base += kL2Threads) {
                     uint4 e = make_uint4(0, 0, 0, 0);
@@ -975,6 +1005,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                     }
                 }
                 cross_done = true;
+                if (wave == 0u) CJ_TRACE(2);                                   // wave 0's cross share copied
             }
         };
 #ifdef CJ_D23_BARRIER
@@ -1171,14 +1202,19 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             }
         }
         __syncthreads();
+        CJ_TRACE_T0(3);                                         // D3 done
         CJ_PHASE_MARK(3);
 
         // ---- D4: stream the window out (16 B per lane), exact tail ----
         {
             const uint32_t nvec = U >> 4;
             const uint4* src = reinterpret_cast<const uint4*>(s_out);
+            if constexpr (kSlab) {
+                for (uint32_t i = tid; i < nvec; i += kL2Threads) st16u_wt(out + 16u * i, src[i]);   // another workgroup waits for these bytes: write-through
+            } else
             for (uint32_t i = tid; i < nvec; i += kL2Threads) st16u_nt(out + 16u * i, src[i]);   // streamed out, never re-read: keep L2 for the record tables
             for (uint32_t i = (nvec << 4) + tid; i < U; i += kL2Threads) out[i] = s_out[i];
+            if constexpr (kSlab) wt_tail = (U & 15u) != 0u;
         }
         if (tid == 0 && *s_fail) a.result[c] = CJ_E_CORRUPT;    // cannot happen for a stream the parse kernel accepted
         publish();
@@ -1259,6 +1295,11 @@ void launch_lz4_decode_lds(const BatchArgs& a, const void* sync, const void* met
 }
 
 }  // namespace cj
+#ifdef CJ_SLAB_TRACE
+extern "C" int cj_debug_slab_trace(unsigned long long* out, int n_slabs) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(cj::g_slab_trace), (size_t)n_slabs * 64) == hipSuccess ? 0 : -1;
+}
+#endif
 extern "C" long long cj_debug_forwarded_chunks(int reset) {
     unsigned long long v = 0;
     if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(cj::g_fwd_chunks), 8) != hipSuccess) return -1;

@@ -36,6 +36,7 @@ __device__ __forceinline__ void st16u(uint8_t* p, const uint4& v) { __builtin_me
 #if defined(CJ_HOST_SIM)
 __device__ __forceinline__ uint4 ld16u_nt(const uint8_t* p) { return ld16u(p); }
 __device__ __forceinline__ void st16u_nt(uint8_t* p, const uint4& v) { st16u(p, v); }
+__device__ __forceinline__ void st16u_wt(uint8_t* p, const uint4& v) { st16u(p, v); }
 #else
 // Non-temporal 16 B load for the match sources: those reads land anywhere in the last 64 KiB of the chunk's output
 // and are never reused, but through the normal path they evict the partially written output lines of every lane
@@ -49,6 +50,14 @@ __device__ __forceinline__ uint4 ld16u_nt(const uint8_t* p) {
 __device__ __forceinline__ void st16u_nt(uint8_t* p, const uint4& v) {
     cj_u32x4_unaligned t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
     __builtin_nontemporal_store(t, reinterpret_cast<cj_u32x4_unaligned*>(p));
+}
+// Write-through 16 B store (sc0 sc1): the bytes are in memory once the store is acknowledged (s_waitcnt vmcnt(0)), visible to
+// the other XCDs without an L2 write-back (buffer_wbl2 costs several µs with 64 KiB freshly written).  Used where another
+// workgroup waits for exactly these bytes (slab mode of the LDS decoder).
+typedef uint32_t cj_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st16u_wt(uint8_t* p, const uint4& v) {
+    cj_u32x4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(t) : "memory");
 }
 #endif
 

@@ -304,3 +304,39 @@ def test_random_hand_made_lz4_streams_across_slabs():
         if len(blob) > PIECE or n > PIECE:
             got = bytes(cramjam.lz4.decompress_block(blob, output_len=n))
             assert got == want[:n], (t, len(blob), n)
+
+
+def test_large_streams_under_concurrent_load():
+    """the slab decoder's hand-over between workgroups (completion flags, write-through stores, acquire) under uneven load:
+    host threads decompress large streams of different shapes while another thread keeps a second engine busy with batches
+    on its own HIP stream; every byte is checked (tools/stress_large.py is the long version)"""
+    import threading, time
+    from cramjam_amd import _native as N
+    rnd = random.Random(5)
+    parts = [oracle.synth_v1(PIECE, i) for i in range(8)]
+    shifted = bytes(777) + b"".join(parts[i % 8] for i in range(60))
+    text = b"".join(b"%d bottles of beer on the wall, %d bottles of beer\n" % (rnd.randrange(977), rnd.randrange(1013)) for _ in range(40000))
+    work = [(cramjam.lz4.decompress_block, oracle.lz4_compress_raw(shifted)[1], shifted, True),
+            (cramjam.lz4.decompress_block, oracle.lz4_compress_raw(text)[1], text, True),
+            (cramjam.snappy.decompress_raw, oracle.snappy_compress(shifted)[1], shifted, False),
+            (cramjam.lz4.decompress, oracle.lz4_frame_compress(shifted, 4, 1)[1], shifted, False)]
+    stop = time.time() + 3.0
+    errors = []
+
+    def loop(fn, blob, want, olen):
+        while time.time() < stop and not errors:
+            got = bytes(fn(blob, output_len=len(want))) if olen else bytes(fn(blob))
+            if got != want: errors.append((fn.__name__, len(got)))
+
+    def batches():
+        e = N.Engine(0)
+        blobs = [oracle.lz4_compress_raw(p)[1] for p in parts] * 64
+        while time.time() < stop and not errors:
+            res, outs = e.batch_host(N.CODEC_LZ4_BLOCK, N.OP_DECOMPRESS, 0, blobs, [PIECE] * len(blobs))
+            if any(int(r) != PIECE for r in res) or bytes(outs[5]) != parts[5]: errors.append(("batch",))
+        e.close()
+
+    ths = [threading.Thread(target=loop, args=w) for w in work] + [threading.Thread(target=batches)]
+    for t in ths: t.start()
+    for t in ths: t.join()
+    assert not errors, errors

@@ -131,18 +131,31 @@ struct Round {
     uint64_t mask[kSub];         // verified lanes of each sub-round (wave-uniform)
 };
 
+// the round's own dwords (position pos + 64 j + lane); the caller may request them one round ahead (OwnDwords::load at the
+// expected next position while the current round is selected and emitted: one of the round's four dependent round trips)
+struct OwnDwords {
+    uint32_t v[kSub];
+    uint32_t pos;
+    __device__ __forceinline__ void load(const uint8_t* in, uint32_t p, uint32_t last_start) {
+        pos = p;
+#pragma unroll
+        for (int j = 0; j < kSub; j++) {
+            const uint32_t my = p + 64u * j + lane_id();
+            v[j] = 0u;
+            if (my <= last_start) v[j] = ld32u(in + my);
+        }
+    }
+};
+
 __device__ __forceinline__ void probe_round(const uint8_t* in, const uint16_t* ht, uint32_t pos, uint32_t last_start,
-                                            uint32_t limit, uint32_t anchor, Round& r) {
+                                            uint32_t limit, uint32_t anchor, Round& r, const OwnDwords& own) {
     const uint32_t lane = lane_id();
     uint32_t v[kSub];
     bool ok[kSub];
-    // own dwords: kSub coalesced loads in flight
 #pragma unroll
     for (int j = 0; j < kSub; j++) {
-        const uint32_t my = pos + 64u * j + lane;
-        v[j] = 0u;
+        v[j] = own.v[j];
         r.hslot[j] = kNoSlot;
-        if (my <= last_start) v[j] = ld32u(in + my);
     }
     // table lookups, then the candidate dwords: kSub divergent loads in flight
     uint32_t w[kSub];

@@ -85,10 +85,14 @@ __global__ __launch_bounds__(kSplit ? 256 : kEncThreads) void lz4_encode_kernel(
         const uint32_t last_start = n - 12u;    // a match may start here at the latest
         const uint32_t matchlimit = n - 5u;     // and must end here at the latest
         uint32_t pos = q0;
+        OwnDwords own;
+        own.load(in, pos, last_start);
         while (pos <= last_start) {
             Round r;
-            probe_round(in, ht, pos, last_start, matchlimit, anchor, r);
+            if (own.pos != pos) own.load(in, pos, last_start);      // a match ran past the expected start of this round
+            probe_round(in, ht, pos, last_start, matchlimit, anchor, r, own);
             const uint32_t round_end = pos + kRoundPositions;
+            own.load(in, round_end, last_start);                  // next round's dwords: in flight during selection and emission
             bool covered[kSub] = {};
             uint32_t q_n = 0, q_lit0 = 0, q_lit = 0, q_off = 0, q_mcode = 0, q_op = 0;
             // ---- fast path: minimal serial walk, then everything else for all candidates at once (cj_match.hpp) ----

@@ -95,10 +95,13 @@ __device__ __forceinline__ uint64_t bp_scan64(uint64_t v, uint64_t& total) {
 // ---------------------------------------------------------------------------------------------------------------------
 // K1
 template <class G>
-__global__ __launch_bounds__(64) void big_mark_kernel(BigParse a) {
+__global__ __launch_bounds__(64) void big_mark_kernel(BigParse a0) {
+    BigParse a = a0;
+    uint32_t piece_index = blockIdx.x;
+    if (a0.jobs != nullptr) { const uint2 pm = a0.piece_map[blockIdx.x]; a = a0.jobs[pm.x]; piece_index = pm.y; }
     const uint32_t P = a.piece, sub = P / 64u;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t p = blockIdx.x, lane = lane_id();
+    const uint32_t p = piece_index, lane = lane_id();
     const uint32_t B = a.start + p * P;
     const uint32_t E = a.iend - B > P ? B + P : a.iend;         // piece = [B, E)
     uint32_t* s_bits = reinterpret_cast<uint32_t*>(smem + bp_lds_in(P));
@@ -194,7 +197,8 @@ __global__ __launch_bounds__(64) void big_mark_kernel(BigParse a) {
 // write the entries out in parallel.  An entry beyond the first 64 bytes of its piece (a sequence longer than that crosses
 // the piece's start) takes the walk through global memory, as does a piece the chain jumps over.
 template <class G>
-__global__ __launch_bounds__(64) void big_thread_kernel(BigParse a) {
+__global__ __launch_bounds__(64) void big_thread_kernel(BigParse a0) {
+    const BigParse a = a0.jobs != nullptr ? a0.jobs[blockIdx.x] : a0;
     __shared__ uint32_t s_next[64 * 64];
     __shared__ uint32_t s_ent[64], s_fe[64];
     const uint32_t P = a.piece, sub = P / 64u, lane = lane_id();
@@ -268,10 +272,13 @@ __device__ __forceinline__ void bp_chain(const BigParse& a, uint32_t p, uint32_t
 // ---------------------------------------------------------------------------------------------------------------------
 // K3
 template <class G>
-__global__ __launch_bounds__(64) void big_count_kernel(BigParse a) {
+__global__ __launch_bounds__(64) void big_count_kernel(BigParse a0) {
+    BigParse a = a0;
+    uint32_t piece_index = blockIdx.x;
+    if (a0.jobs != nullptr) { const uint2 pm = a0.piece_map[blockIdx.x]; a = a0.jobs[pm.x]; piece_index = pm.y; }
     const uint32_t P = a.piece;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t p = blockIdx.x, lane = lane_id();
+    const uint32_t p = piece_index, lane = lane_id();
     const uint32_t B = a.start + p * P;
     const uint32_t E = a.iend - B > P ? B + P : a.iend;
     const uint32_t whi = a.iend - B > P + kBpSlack ? B + P + kBpSlack : a.iend;
@@ -303,7 +310,8 @@ __global__ __launch_bounds__(64) void big_count_kernel(BigParse a) {
 }
 
 // K4: totals[2p], totals[2p+1] -> exclusive prefix; status[2..3] = total sequences (lo, hi), status[4..5] = total output
-__global__ __launch_bounds__(64) void big_scan_kernel(BigParse a) {
+__global__ __launch_bounds__(64) void big_scan_kernel(BigParse a0) {
+    const BigParse a = a0.jobs != nullptr ? a0.jobs[blockIdx.x] : a0;
     const uint32_t lane = lane_id();
     uint64_t run_c = 0, run_o = 0;
     for (uint32_t p0 = 0; p0 < a.np; p0 += 64u) {
@@ -324,10 +332,13 @@ __global__ __launch_bounds__(64) void big_scan_kernel(BigParse a) {
 // K5: validation + absolute sync points.  status[1] |= 1 on any violation; status[6..7] = decoded size (set by the lane
 // that meets the last sequence)
 template <class G>
-__global__ __launch_bounds__(64) void big_emit_kernel(BigParse a) {
+__global__ __launch_bounds__(64) void big_emit_kernel(BigParse a0) {
+    BigParse a = a0;
+    uint32_t piece_index = blockIdx.x;
+    if (a0.jobs != nullptr) { const uint2 pm = a0.piece_map[blockIdx.x]; a = a0.jobs[pm.x]; piece_index = pm.y; }
     const uint32_t P = a.piece;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t p = blockIdx.x, lane = lane_id();
+    const uint32_t p = piece_index, lane = lane_id();
     const uint32_t B = a.start + p * P;
     const uint32_t E = a.iend - B > P ? B + P : a.iend;
     const uint32_t whi = a.iend - B > P + kBpSlack ? B + P + kBpSlack : a.iend;
@@ -362,8 +373,11 @@ __global__ __launch_bounds__(64) void big_emit_kernel(BigParse a) {
 // K6: slab s = output [s * 65536, min((s+1) * 65536, total)).  The decoder of a slab walks whole sync groups (8
 // sequences): from the last sync point at or before the slab's first byte to the end of the group that holds its last
 // byte; what lies outside the slab is clipped there.
-__global__ __launch_bounds__(256) void big_slab_kernel(BigSlabs d) {
-    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+__global__ __launch_bounds__(256) void big_slab_kernel(BigSlabs d0, const BigSlabs* jobs, const uint2* slab_job, uint32_t n_all) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n_all) return;
+    const BigSlabs d = jobs != nullptr ? jobs[slab_job[t].x] : d0;
+    const uint32_t s = jobs != nullptr ? slab_job[t].y : t;
     if (s >= d.n_slabs) return;
     const uint64_t S = (uint64_t)s * 65536ull;
     const uint64_t Eo = S + 65536ull < d.total ? S + 65536ull : d.total;
@@ -383,11 +397,11 @@ __global__ __launch_bounds__(256) void big_slab_kernel(BigSlabs d) {
     const uint32_t in_hi = k1 + 1u < d.n_sync ? d.sync[k1 + 1u].x : d.iend;
     d.in_off[s] = d.in_base_off + in_lo;
     d.in_len[s] = in_hi - in_lo;
-    d.out_off[s] = S;
-    d.out_cap[s] = Eo - S;
+    d.out_off[s] = d.out_base_off + S;
+    d.out_cap[s] = S;                                       // (the decoder's slab mode: the slab's first output position in its stream)
     d.result[s] = (int64_t)(Eo - S);
-    d.meta[s] = make_uint2(nrec, 0u);
-    d.first[s] = make_uint2(k0, in_lo);
+    d.meta[s] = make_uint2(nrec, (s + 1u == d.n_slabs ? d.iend : in_hi + 64u) - in_lo);      // the stream's end relative to the slab's input; only the last slab needs the true one
+    d.first[s] = make_uint2(d.sync_index_base + k0, in_lo);
     atomicMax(d.max_rec, nrec);
 }
 
@@ -406,6 +420,26 @@ void run(const BigParse& a, hipStream_t s) {
 
 }  // namespace
 
+template <class G>
+void run_many(const BigParse& hdr, uint32_t n_jobs, uint32_t n_pieces, uint32_t max_piece, hipStream_t s) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(big_mark_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bp_lds_all(kBigPieceLarge));
+    hipLaunchKernelGGL(big_mark_kernel<G>, dim3(n_pieces), dim3(64), bp_lds_all(max_piece), s, hdr);
+    hipLaunchKernelGGL(big_thread_kernel<G>, dim3(n_jobs), dim3(64), 0, s, hdr);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(big_count_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bp_lds_in(kBigPieceLarge));
+    hipLaunchKernelGGL(big_count_kernel<G>, dim3(n_pieces), dim3(64), bp_lds_in(max_piece), s, hdr);
+    hipLaunchKernelGGL(big_scan_kernel, dim3(n_jobs), dim3(64), 0, s, hdr);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(big_emit_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bp_lds_in(kBigPieceLarge));
+    hipLaunchKernelGGL(big_emit_kernel<G>, dim3(n_pieces), dim3(64), bp_lds_in(max_piece), s, hdr);
+}
+
+void launch_big_parse_many(const BigParse* jobs, uint32_t n_jobs, const uint2* piece_map, uint32_t n_pieces, uint32_t max_piece, int codec, hipStream_t s) {
+    if (n_jobs == 0 || n_pieces == 0) return;
+    BigParse hdr = {};
+    hdr.jobs = jobs; hdr.piece_map = piece_map;
+    if (codec == CJ_CODEC_SNAPPY_RAW) run_many<SnappyGrammar>(hdr, n_jobs, n_pieces, max_piece, s);
+    else run_many<Lz4Grammar>(hdr, n_jobs, n_pieces, max_piece, s);
+}
+
 void launch_big_parse(const BigParse& a, int codec, hipStream_t s) {
     if (a.np == 0) return;
     if (codec == CJ_CODEC_SNAPPY_RAW) run<SnappyGrammar>(a, s);
@@ -414,7 +448,12 @@ void launch_big_parse(const BigParse& a, int codec, hipStream_t s) {
 
 void launch_big_slabs(const BigSlabs& d, hipStream_t s) {
     if (d.n_slabs == 0) return;
-    hipLaunchKernelGGL(big_slab_kernel, dim3((d.n_slabs + 255u) / 256u), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(big_slab_kernel, dim3((d.n_slabs + 255u) / 256u), dim3(256), 0, s, d, (const BigSlabs*)nullptr, (const uint2*)nullptr, d.n_slabs);
+}
+
+void launch_big_slabs_many(const BigSlabs* jobs, const uint2* slab_job, uint32_t n_slabs, hipStream_t s) {
+    if (n_slabs == 0) return;
+    hipLaunchKernelGGL(big_slab_kernel, dim3((n_slabs + 255u) / 256u), dim3(256), 0, s, BigSlabs{}, jobs, slab_job, n_slabs);
 }
 
 }  // namespace cj

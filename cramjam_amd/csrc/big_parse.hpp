@@ -25,6 +25,8 @@ struct BigParse {
     uint64_t* lane_op;       // np * 64
     uint64_t* totals;        // np * 2 (count, bytes) -> exclusive prefix after the scan
     uint2* sync;             // absolute (ip, op) of every 8th sequence; iend / 16 + 2 entries cover any stream
+    const BigParse* jobs;    // several streams in one run of launches (launch_big_parse_many): the kernels' argument is a header —
+    const uint2* piece_map;  // block b works on piece piece_map[b].y of jobs[piece_map[b].x]; nullptr = this struct is the one stream
     uint32_t* status;        // 16 words, zeroed: [0] chain did not end at the input's end, [1] violation, [2,3] sequences,
                              // [4,5] output bytes counted, [6,7] decoded size, [8] last sequence seen
 };
@@ -35,6 +37,8 @@ struct BigSlabs {
     uint64_t n_seq, total;   // sequences, decoded bytes
     uint32_t iend;
     uint64_t in_base_off;    // offset of stream position 0 from the batch's in_base
+    uint64_t out_base_off;   // offset of the stream's first output byte from the batch's out_base
+    uint32_t sync_index_base;// index of sync[0] in the array the decoder is given (several streams share one launch)
     uint32_t n_slabs;
     uint64_t* in_off; uint64_t* in_len; uint64_t* out_off; uint64_t* out_cap; int64_t* result;
     uint2* meta;             // ParseMeta {records, 0}
@@ -43,6 +47,11 @@ struct BigSlabs {
 };
 
 void launch_big_parse(const BigParse& a, int codec, hipStream_t s);
+// jobs / piece_map: device arrays (n_jobs structs; n_pieces entries); max_piece = the largest piece size among the jobs
+void launch_big_parse_many(const BigParse* jobs, uint32_t n_jobs, const uint2* piece_map, uint32_t n_pieces, uint32_t max_piece, int codec, hipStream_t s);
 void launch_big_slabs(const BigSlabs& d, hipStream_t s);
+// jobs: device array; slab_job[i] = {job, slab index in that job} for every slab of the chunk list; the jobs' array pointers are
+// already offset to their first slab
+void launch_big_slabs_many(const BigSlabs* jobs, const uint2* slab_job, uint32_t n_slabs, hipStream_t s);
 
 }  // namespace cj

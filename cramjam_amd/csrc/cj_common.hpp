@@ -61,6 +61,7 @@ int64_t large_lz4_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap
 int64_t large_lz4_frame_blocks(const uint8_t* in, size_t n, uint8_t* out, size_t cap);      // <= large_split_max() bytes
 int64_t large_snappy_frame(const uint8_t* in, size_t n, uint8_t* out, size_t cap);           // <= large_split_max() bytes
 size_t large_split_max();
+int large_lz4_decompress_many(size_t nj, const uint8_t* const* ins, const size_t* lens, uint8_t* const* outs, const size_t* caps, int64_t* result);
 int64_t large_decompress(int codec, uint32_t flags, const uint8_t* in, size_t n, uint8_t* out, size_t cap);
 void launch_lz4_decode_lds2_slabs(const BatchArgs& a, const void* sync, const void* meta, void* tabs, uint32_t* counter,
                                   const void* first, uint32_t stream_len, uint32_t* done, void* cross, uint32_t tab_stride,

@@ -520,30 +520,45 @@ int64_t cj_lz4_frame_decompress(const uint8_t* in, size_t n, uint8_t* out, size_
     const size_t nb = f.blocks.size();
     if (nb > 0xFFFFFFF0ull) return CJ_E_BAD_ARG;
     uint64_t total = 0;
-    // A few large independent blocks (the lz4 command line's 4 MiB default, 256 KiB / 1 MiB frames): as chunks of a batch each
-    // would be one serial stream on one wavefront (0.035 GB/s per block); instead every block goes through the large-stream
-    // path of its own (large.hip: parallel parse + slab decoder), one after the other.  With many such blocks the batch has
-    // enough wavefronts in flight and stays faster.
+    // Independent blocks above 64 KiB (the lz4 command line's 4 MiB default, 256 KiB / 1 MiB frames): as chunks of a batch each
+    // would be one serial stream on one wavefront (0.035 GB/s per block); instead all blocks go through the large-stream
+    // path together (large.hip: one parallel parse over the pieces of all blocks, one slab decoder launch over all slabs).
     bool big_done = false;
-    // estimate, µs: nb calls of ≈0.45 ms + 10 GB/s each, against one wavefront working ≈35 MB/s through the largest block
-    const bool few_big = f.block_max > 65536 && (uint64_t)nb * (450u + f.block_max / 10000u) < f.block_max / 35u;
+    const bool few_big = f.block_max > 65536;
     if (nb > 0 && few_big && out != nullptr && f.indep) {
         uint64_t bound = 0;
         for (const Lz4Block& b : f.blocks) bound += (b.word & 0x80000000u) ? (b.word & 0x7FFFFFFFu) : f.block_max;
         if (bound <= cap) {                                                    // (else: the generic path knows the writer's error order)
-            for (const Lz4Block& b : f.blocks) {
+            // every compressed block decodes to its slot (where it would lie if every block before it decoded to block_max
+            // bytes); the parse runs over all blocks at once; then the output is closed up where a block came out shorter
+            // (only the last one does in frames liblz4 writes) and the stored blocks are copied in
+            std::vector<const uint8_t*> ins; std::vector<size_t> lens, caps; std::vector<uint8_t*> outs;
+            std::vector<uint64_t> slots(nb);
+            uint64_t slot = 0;
+            for (size_t i = 0; i < nb; i++) {
+                const Lz4Block& b = f.blocks[i];
                 const uint32_t sz = b.word & 0x7FFFFFFFu;
-                if (b.word & 0x80000000u) std::memcpy(out + total, in + b.src_off, sz);
-                else {
-                    const int64_t r = cj::large_decompress(CJ_CODEC_LZ4_BLOCK, 0u, in + b.src_off, sz, out + total, f.block_max);
-                    if (r == CJ_E_NO_DEVICE || r == CJ_E_OOM) return r;
-                    if (r < 0) return CJ_E_LZ4F_DECOMPRESS;
-                    total += (uint64_t)r;
-                    continue;
-                }
-                total += sz;
+                slots[i] = slot;
+                if (b.word & 0x80000000u) slot += sz;
+                else { ins.push_back(in + b.src_off); lens.push_back(sz); outs.push_back(out + slot); caps.push_back(f.block_max); slot += f.block_max; }
             }
-            big_done = true;
+            std::vector<int64_t> rj(ins.size());
+            const int rc = ins.empty() ? 0 : cj::large_lz4_decompress_many(ins.size(), ins.data(), lens.data(), outs.data(), caps.data(), rj.data());
+            if (rc == 0) {
+                size_t k = 0;
+                for (size_t i = 0; i < nb; i++) {
+                    const Lz4Block& b = f.blocks[i];
+                    uint64_t got;
+                    if (b.word & 0x80000000u) { got = b.word & 0x7FFFFFFFu; std::memmove(out + total, in + b.src_off, got); }
+                    else {
+                        if (rj[k] < 0) return CJ_E_LZ4F_DECOMPRESS;
+                        got = (uint64_t)rj[k++];
+                        if (slots[i] != total) std::memmove(out + total, out + slots[i], got);
+                    }
+                    total += got;
+                }
+                big_done = true;
+            } else if (rc != CJ_E_BAD_ARG) return rc;
         }
     }
     if (nb > 0 && !big_done) {

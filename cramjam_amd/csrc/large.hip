@@ -424,7 +424,7 @@ int64_t large_decompress(int codec, uint32_t flags, const uint8_t* in, size_t n,
     uint8_t* b = (uint8_t*)e->d_big.p;
     HIP_TRY(hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
     HIP_TRY(hipMemsetAsync(b + o_status, 0, 64, s), CJ_E_NO_DEVICE);
-    BigParse bp;
+    BigParse bp = {};
     bp.in = d_in + skip; bp.iend = iend; bp.start = (uint32_t)start; bp.piece = piece; bp.np = np; bp.cap = cap64;
     bp.bits = (uint32_t*)(b + o_bits); bp.merge = (uint32_t*)(b + o_merge); bp.exitp = (uint32_t*)(b + o_exit); bp.next_tab = (uint32_t*)(b + o_next); bp.fe_tab = (uint32_t*)(b + o_fe);
     bp.entry = (uint2*)(b + o_entry); bp.lane_idx = (uint32_t*)(b + o_lidx); bp.lane_op = (uint64_t*)(b + o_lop);
@@ -452,7 +452,7 @@ int64_t large_decompress(int codec, uint32_t flags, const uint8_t* in, size_t n,
     uint64_t* d_meta = (uint64_t*)e->d_meta.p;
     HIP_TRY(hipMemsetAsync(d_meta + r_misc, 0, (rows - r_misc) * 8, s), CJ_E_NO_DEVICE);
     BigSlabs sd;
-    sd.sync = bp.sync; sd.n_sync = n_sync; sd.n_seq = n_seq; sd.total = total; sd.iend = iend; sd.in_base_off = skip; sd.n_slabs = n_slabs;
+    sd.sync = bp.sync; sd.n_sync = n_sync; sd.n_seq = n_seq; sd.total = total; sd.iend = iend; sd.in_base_off = skip; sd.out_base_off = 0; sd.sync_index_base = 0; sd.n_slabs = n_slabs;
     sd.in_off = d_meta; sd.in_len = d_meta + n_slabs; sd.out_off = d_meta + 2 * (size_t)n_slabs; sd.out_cap = d_meta + 3 * (size_t)n_slabs;
     sd.result = (int64_t*)(d_meta + 4 * (size_t)n_slabs); sd.meta = (uint2*)(d_meta + r_meta); sd.first = (uint2*)(d_meta + r_first);
     sd.max_rec = (uint32_t*)(d_meta + r_misc);
@@ -479,6 +479,157 @@ int64_t large_decompress(int codec, uint32_t flags, const uint8_t* in, size_t n,
     for (uint32_t i = 0; i < n_slabs; i++)
         if (res[i] < 0) return corrupt;                     // the decoder's stall guard: cannot happen for a stream the parse accepted
     return (int64_t)total;
+}
+
+// Several LZ4 blocks (no size prefix), each a large stream of its own — the blocks of an LZ4 frame with large independent
+// blocks (frame.hip).  The parse kernels run over the pieces of ALL blocks at once (launch_big_parse_many) and the decoder
+// over the slabs of all blocks (every block's first slab has no predecessor); the host waits twice in total.  result[j] = decoded size or
+// CJ_E_CORRUPT; returns 0, or a CJ_E_* that concerns the call as a whole (CJ_E_BAD_ARG: not for this path).
+int large_lz4_decompress_many(size_t nj, const uint8_t* const* ins, const size_t* lens, uint8_t* const* outs, const size_t* caps, int64_t* result) {
+    cj_engine* e = default_engine();
+    if (!e) return CJ_E_NO_DEVICE;
+    if (nj == 0) return 0;
+    struct Job { size_t in_off, meta_off, out_off; BigSlabs sd; uint64_t n_seq, total; uint32_t n_sync, n_slabs; };
+    std::vector<Job> jobs(nj);
+    std::vector<BigParse> bps(nj);
+    std::vector<uint2> pmap;
+    size_t in_total = 0, big_total = 0;
+    uint32_t max_piece = kBigPieceSmall;
+    std::vector<size_t> big_off(nj);
+    // the blocks of one frame lie in ONE host buffer, a few header bytes apart: one copy to the device instead of one per block
+    const uint8_t* span_lo = ins[0]; const uint8_t* span_hi = ins[0] + lens[0];
+    size_t sum_len = 0;
+    for (size_t j = 0; j < nj; j++) { span_lo = std::min(span_lo, ins[j]); span_hi = std::max(span_hi, ins[j] + lens[j]); sum_len += lens[j]; }
+    const bool one_span = (size_t)(span_hi - span_lo) <= sum_len + sum_len / 8 + 4096;
+    size_t slab_bound = 0;                                                 // the descriptors of the decoder's chunk list reuse the tail of the parse scratch
+    for (size_t j = 0; j < nj; j++) slab_bound += (caps[j] + 65535) / 65536;
+    for (size_t j = 0; j < nj; j++) {
+        if (lens[j] == 0 || lens[j] > 0x7FFFFFF0ull || caps[j] == 0 || caps[j] > 0x7E000000ull) return CJ_E_BAD_ARG;
+        BigParse& bp = bps[j];
+        bp = BigParse{};
+        bp.iend = (uint32_t)lens[j]; bp.start = 0; bp.cap = caps[j];
+        bp.piece = bp.iend < kBigPieceSwitch ? kBigPieceSmall : kBigPieceLarge;
+        bp.np = (bp.iend + bp.piece - 1) / bp.piece;
+        max_piece = std::max(max_piece, bp.piece);
+        for (uint32_t p = 0; p < bp.np; p++) pmap.push_back(make_uint2((uint32_t)j, p));
+        jobs[j].in_off = one_span ? (size_t)(ins[j] - span_lo) : in_total; in_total += (lens[j] + 64 + 255) & ~(size_t)255;
+        const size_t np = bp.np;
+        big_off[j] = big_total;
+        big_total += (((np * (bp.piece / 8)) + 255) & ~(size_t)255) + 6 * ((np * 256 + 255) & ~(size_t)255) + ((np * 8 + 255) & ~(size_t)255)
+                   + ((np * 512 + 255) & ~(size_t)255) + ((np * 16 + 255) & ~(size_t)255) + ((((size_t)bp.iend / 16 + 2) * 8 + 255) & ~(size_t)255);
+    }
+    std::lock_guard<std::mutex> lock(e->mu);
+    HIP_TRY(hipSetDevice(e->device), CJ_E_NO_DEVICE);
+    hipStream_t s = e->stream;
+    const size_t o_status = big_total, o_jobs = o_status + 64 * nj, o_pmap = (o_jobs + nj * sizeof(BigParse) + 255) & ~(size_t)255;
+    if (!e->d_in.reserve((one_span ? (size_t)(span_hi - span_lo) : in_total) + 64) || !e->d_big.reserve(o_status + std::max(o_pmap - o_status + pmap.size() * 8, ((nj * sizeof(BigSlabs) + 255) & ~(size_t)255) + slab_bound * 8) + 64)) return CJ_E_OOM;
+    uint8_t* d_in = (uint8_t*)e->d_in.p;
+    uint8_t* b = (uint8_t*)e->d_big.p;
+    uint32_t* d_status = (uint32_t*)(b + o_status);                      // nj * 16 words, contiguous: one copy back
+    HIP_TRY(hipMemsetAsync(d_status, 0, 64 * nj, s), CJ_E_NO_DEVICE);
+    for (size_t j = 0; j < nj; j++) {
+        BigParse& bp = bps[j];
+        const size_t np = bp.np;
+        size_t off = big_off[j];
+        const auto region = [&off](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+        bp.in = d_in + jobs[j].in_off;
+        bp.bits = (uint32_t*)(b + region(np * (bp.piece / 8))); bp.merge = (uint32_t*)(b + region(np * 256)); bp.exitp = (uint32_t*)(b + region(np * 256));
+        bp.next_tab = (uint32_t*)(b + region(np * 256)); bp.fe_tab = (uint32_t*)(b + region(np * 256)); bp.entry = (uint2*)(b + region(np * 8));
+        bp.lane_idx = (uint32_t*)(b + region(np * 256)); bp.lane_op = (uint64_t*)(b + region(np * 512)); bp.totals = (uint64_t*)(b + region(np * 16));
+        bp.sync = (uint2*)(b + region(((size_t)bp.iend / 16 + 2) * 8)); bp.status = d_status + 16 * j;
+        if (!one_span) HIP_TRY(hipMemcpyAsync(d_in + jobs[j].in_off, ins[j], lens[j], hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
+    }
+    if (one_span) HIP_TRY(hipMemcpyAsync(d_in, span_lo, (size_t)(span_hi - span_lo), hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
+    HIP_TRY(hipMemcpyAsync(b + o_jobs, bps.data(), nj * sizeof(BigParse), hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
+    HIP_TRY(hipMemcpyAsync(b + o_pmap, pmap.data(), pmap.size() * 8, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
+    launch_big_parse_many((const BigParse*)(b + o_jobs), (uint32_t)nj, (const uint2*)(b + o_pmap), (uint32_t)pmap.size(), max_piece, CJ_CODEC_LZ4_BLOCK, s);
+    HIP_TRY(hipGetLastError(), CJ_E_NO_DEVICE);
+    std::vector<uint32_t> st(16 * nj);
+    HIP_TRY(hipMemcpyAsync(st.data(), d_status, 64 * nj, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
+    HIP_TRY(hipStreamSynchronize(s), CJ_E_NO_DEVICE);
+
+    // the slabs of all blocks form ONE chunk list for the decoder (every block's first slab has no predecessor)
+    size_t n_slabs = 0, out_total = 0;
+    for (size_t j = 0; j < nj; j++) {
+        Job& J = jobs[j];
+        const uint32_t* t = st.data() + 16 * j;
+        J.n_slabs = 0; J.total = 0;
+        if (t[0] != 0 || t[1] != 0 || t[8] != 1) { result[j] = CJ_E_CORRUPT; continue; }
+        J.n_seq = ((uint64_t)t[3] << 32) | t[2]; J.total = ((uint64_t)t[7] << 32) | t[6];
+        result[j] = (int64_t)J.total;
+        if (J.total == 0) continue;
+        J.n_sync = (uint32_t)((J.n_seq + kSyncEvery - 1) / kSyncEvery);
+        J.n_slabs = (uint32_t)((J.total + 65535) / 65536);
+        J.meta_off = n_slabs; n_slabs += J.n_slabs;                       // index of the block's first slab
+        J.out_off = out_total; out_total += (J.total + 256 + 255) & ~(size_t)255;
+    }
+    // outputs that follow each other in the caller's buffer (the blocks of a frame, all full but the last): same layout on the
+    // device, one copy back
+    bool out_contig = true;
+    {
+        const uint8_t* expect = nullptr;
+        for (size_t j = 0; j < nj; j++) {
+            if (jobs[j].n_slabs == 0) { if (result[j] < 0) out_contig = false; continue; }
+            if (expect != nullptr && outs[j] != expect) out_contig = false;
+            expect = outs[j] + jobs[j].total;
+        }
+        if (out_contig) { out_total = 0; for (size_t j = 0; j < nj; j++) if (jobs[j].n_slabs) { jobs[j].out_off = out_total; out_total += jobs[j].total; } }
+    }
+    if (n_slabs == 0) return 0;
+    if (n_slabs > 0xFFFFFFF0ull) return CJ_E_BAD_ARG;
+    const size_t r_misc = 7 * n_slabs, r_done = r_misc + 2, rows = r_done + (n_slabs + 1) / 2 + 1;
+    if (!e->d_meta.reserve(rows * 8) || !e->d_out.reserve(out_total + 256)) return CJ_E_OOM;
+    uint64_t* m = (uint64_t*)e->d_meta.p;
+    HIP_TRY(hipMemsetAsync(m + r_misc, 0, (rows - r_misc) * 8, s), CJ_E_NO_DEVICE);
+    const uint2* sync_base = reinterpret_cast<const uint2*>(b);
+    std::vector<BigSlabs> sds(nj);
+    std::vector<uint2> slab_job(n_slabs);
+    for (size_t j = 0; j < nj; j++) {
+        Job& J = jobs[j];
+        BigSlabs& sd = sds[j];
+        sd = BigSlabs{};
+        if (J.n_slabs == 0) continue;
+        const size_t f = J.meta_off;
+        sd.sync = bps[j].sync; sd.n_sync = J.n_sync; sd.n_seq = J.n_seq; sd.total = J.total; sd.iend = bps[j].iend; sd.in_base_off = J.in_off;
+        sd.out_base_off = J.out_off; sd.sync_index_base = (uint32_t)(bps[j].sync - sync_base); sd.n_slabs = J.n_slabs;
+        sd.in_off = m + f; sd.in_len = m + n_slabs + f; sd.out_off = m + 2 * n_slabs + f; sd.out_cap = m + 3 * n_slabs + f;
+        sd.result = (int64_t*)(m + 4 * n_slabs + f); sd.meta = (uint2*)(m + 5 * n_slabs) + f; sd.first = (uint2*)(m + 6 * n_slabs) + f;
+        sd.max_rec = (uint32_t*)(m + r_misc);
+        for (uint32_t i = 0; i < J.n_slabs; i++) slab_job[f + i] = make_uint2((uint32_t)j, i);
+    }
+    // the descriptors and the slab -> block map travel in the parse scratch (the verdict words and the job structs are done with)
+    const size_t o_sds = o_status, o_sj = (o_sds + nj * sizeof(BigSlabs) + 255) & ~(size_t)255;
+    HIP_TRY(hipMemcpyAsync(b + o_sds, sds.data(), nj * sizeof(BigSlabs), hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
+    HIP_TRY(hipMemcpyAsync(b + o_sj, slab_job.data(), n_slabs * 8, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
+    launch_big_slabs_many((const BigSlabs*)(b + o_sds), (const uint2*)(b + o_sj), (uint32_t)n_slabs, s);
+    HIP_TRY(hipGetLastError(), CJ_E_NO_DEVICE);
+    uint32_t max_rec = 0;
+    HIP_TRY(hipMemcpyAsync(&max_rec, m + r_misc, 4, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
+    HIP_TRY(hipStreamSynchronize(s), CJ_E_NO_DEVICE);
+
+    if (e->n_cu == 0) HIP_TRY(hipDeviceGetAttribute(&e->n_cu, hipDeviceAttributeMultiprocessorCount, e->device), CJ_E_NO_DEVICE);
+    const uint32_t grid = (uint32_t)std::min<size_t>(2u * (size_t)e->n_cu, n_slabs);
+    const uint32_t cross_stride = 3u * ((max_rec + 63u) & ~63u), tab_stride = 4u * ((max_rec + 63u) & ~63u);
+    const size_t tab_bytes = (size_t)grid * tab_stride * 16, cross_bytes = (size_t)grid * cross_stride * 16;
+    if (!e->d_bigtab.reserve(tab_bytes + cross_bytes + (size_t)grid * (tab_stride + 512u) * 4)) return CJ_E_OOM;
+    BatchArgs a;
+    fill_args(a, 0u, n_slabs, d_in, m, m + n_slabs, (uint8_t*)e->d_out.p, m + 2 * n_slabs, m + 3 * n_slabs, (int64_t*)(m + 4 * n_slabs));
+    launch_lz4_decode_lds2_slabs(a, sync_base, m + 5 * n_slabs, e->d_bigtab.p, (uint32_t*)(m + r_misc) + 1, m + 6 * n_slabs, 0u,
+                                 (uint32_t*)(m + r_done), (uint8_t*)e->d_bigtab.p + tab_bytes, tab_stride, cross_stride, grid, s, CJ_CODEC_LZ4_BLOCK);
+    HIP_TRY(hipGetLastError(), CJ_E_NO_DEVICE);
+    std::vector<int64_t> res(n_slabs);
+    HIP_TRY(hipMemcpyAsync(res.data(), m + 4 * n_slabs, n_slabs * 8, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
+    if (out_contig) {
+        for (size_t j = 0; j < nj; j++)
+            if (jobs[j].n_slabs) { HIP_TRY(hipMemcpyAsync(outs[j], e->d_out.p, out_total, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE); break; }
+    } else {
+        for (size_t j = 0; j < nj; j++)
+            if (jobs[j].n_slabs) HIP_TRY(hipMemcpyAsync(outs[j], (uint8_t*)e->d_out.p + jobs[j].out_off, jobs[j].total, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
+    }
+    HIP_TRY(hipStreamSynchronize(s), CJ_E_NO_DEVICE);
+    for (size_t j = 0; j < nj; j++)
+        for (uint32_t i = 0; i < jobs[j].n_slabs; i++) if (res[jobs[j].meta_off + i] < 0) result[j] = CJ_E_CORRUPT;
+    return 0;
 }
 
 }  // namespace cj

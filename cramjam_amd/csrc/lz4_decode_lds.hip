@@ -566,6 +566,9 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             if (c >= a.n_chunks) break;
         }
         const ParseMeta pm = meta[c];
+        // kSlab: does this chunk have a predecessor whose completion it may have to wait for?  (large streams: out_cap[c] holds the
+        // slab's first output position IN ITS STREAM — several streams may share one launch; linked frames: block 0 has none)
+        const bool has_prev = kSlab && (sl.rel ? c > 0u : a.out_cap[c] != 0ull);
         if constexpr (kLinked) {
             if (pm.in_skip & kRouteStored) {                 // stored block: its bytes ARE the window (history for the next block)
                 const uint32_t len = (uint32_t)a.result[c];
@@ -597,7 +600,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 __syncthreads();
                 CJ_TRACE_T0(4);                                            // stores acknowledged
                 if (tid == 0) {
-                    if (c > 0u) while (__hip_atomic_load(&sl.done[c - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
+                    if (has_prev) while (__hip_atomic_load(&sl.done[c - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
                     if (wt_tail) {                           // a chunk whose size is not a multiple of 16 ended with plain byte stores
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -624,8 +627,10 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         if (pm.nseq == 0u) { publish(); continue; }          // error, empty, or routed to another kernel
         const uint32_t nseq = pm.nseq;
         const uint32_t U = (uint32_t)a.result[c];            // decoded size, 1..65536
-        const uint8_t* in = a.in_base + a.in_off[c] + pm.in_skip;
-        const uint32_t iend = (uint32_t)a.in_len[c] - pm.in_skip;
+        const bool slab_meta = kSlab && !sl.rel;            // large streams: meta[c].in_skip = the stream's end relative to this slab's input
+        const uint32_t in_skip = slab_meta ? 0u : pm.in_skip;
+        const uint8_t* in = a.in_base + a.in_off[c] + in_skip;
+        const uint32_t iend = (uint32_t)a.in_len[c] - in_skip;
         const uint8_t* in_al = in - (reinterpret_cast<uintptr_t>(in) & 3u);
         const uint8_t* last_dw = in_al + ((((uint32_t)(reinterpret_cast<uintptr_t>(in) & 3u)) + iend - 1u) & ~3u);
         // offset (relative to in) up to which reads are safe: the end of the 16 B granule holding the last input byte
@@ -653,9 +658,9 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         if constexpr (kSlab) {
             using G = typename std::conditional<kCodec == CJ_CODEC_SNAPPY_RAW, SnappyGrammar, Lz4Grammar>::type;
             const uint32_t in_lo = frames[c].y;
-            const uint32_t s_iend = sl.rel ? iend : n_frames - in_lo;     // the stream's end, relative to this slab's input
+            const uint32_t s_iend = sl.rel ? iend : pm.in_skip;           // the stream's end, relative to this slab's input
             const uint64_t S = a.out_off[c];
-            const int64_t op_bias = sl.rel ? 0 : (int64_t)S;
+            const int64_t op_bias = sl.rel ? 0 : (int64_t)a.out_cap[c];   // the stream's sync points count output from the stream's start; S is the slab's place in the output BUFFER
             const auto rd = [&](uint32_t p) { return staged ? lds_ld32(a_in + p) : ld32u(in + p); };
             uint4* cross = sl.cross + (size_t)blockIdx.x * sl.cross_stride;
             for (uint32_t sp = tid; sp < nsp; sp += kL2Threads) {
@@ -1189,7 +1194,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 }
                 if (++spins > kSpinLimit) {
                     if constexpr (kSlab) {                         // a long wait is legitimate while the previous slab is still running
-                        if (c > 0u && !prev_seen) {
+                        if (has_prev && !prev_seen) {
                             uint32_t f = 0;
                             if (lane == 0) f = __hip_atomic_load(&sl.done[c - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             prev_seen = rdlane(f, 0) != 0u;

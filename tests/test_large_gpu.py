@@ -340,3 +340,27 @@ def test_large_streams_under_concurrent_load():
     for t in ths: t.start()
     for t in ths: t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("bs_code", [5, 6, 7])
+def test_lz4_frames_with_large_independent_blocks(bs_code):
+    """LZ4F block sizes above 64 KiB (256 KiB, 1 MiB, 4 MiB): all compressed blocks of the frame go through the large-stream
+    path together; stored blocks (incompressible stretches) lie between them; damage is reported like the oracle does"""
+    rnd = random.Random(bs_code)
+    text = b"".join(b"%d bottles of beer on the wall, %d bottles of beer\n" % (rnd.randrange(977), rnd.randrange(1013)) for _ in range(30000))
+    bs = {5: 256 << 10, 6: 1 << 20, 7: 4 << 20}[bs_code]
+    data = (text + rnd.randbytes(bs + 1000) + b"".join(oracle.synth_v1(PIECE, i) for i in range(12)) + text[:70000] + rnd.randbytes(3 * bs // 2) + text[:12345])
+    for flags in (0, 2 | 4):                               # plain; block checksums + content size
+        r, frame = oracle.lz4_frame_compress(data, bs_code, flags)
+        assert bytes(cramjam.lz4.decompress(frame)) == data
+        out = np.zeros(len(data), dtype=np.uint8)
+        assert cramjam.lz4.decompress_into(frame, out) == len(data) and out.tobytes() == data
+        for t in range(10):
+            b = bytearray(frame); i = rnd.randrange(7, len(b)); b[i] ^= 1 << rnd.randrange(8)
+            if t % 3 == 0: b = b[:rnd.randrange(8, len(b))]
+            er, eo = oracle.lz4_frame_decompress(bytes(b), len(data) + (4 << 20))
+            try:
+                got = bytes(cramjam.lz4.decompress(bytes(b)))
+                assert er >= 0 and got == eo[:er], (bs_code, flags, t, er)
+            except cramjam.DecompressionError:
+                assert er < 0, (bs_code, flags, t, er)

@@ -61,7 +61,10 @@ int64_t large_lz4_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap
 int64_t large_lz4_frame_blocks(const uint8_t* in, size_t n, uint8_t* out, size_t cap);      // <= large_split_max() bytes
 int64_t large_snappy_frame(const uint8_t* in, size_t n, uint8_t* out, size_t cap);           // <= large_split_max() bytes
 size_t large_split_max();
-int large_lz4_decompress_many(size_t nj, const uint8_t* const* ins, const size_t* lens, uint8_t* const* outs, const size_t* caps, int64_t* result);
+int large_decompress_many(::cj_engine* e, int codec, size_t nj, const uint8_t* const* ins, const size_t* lens, const size_t* starts, uint8_t* const* outs, const size_t* caps, int64_t* result);
+// the large chunks of a host batch: prologue on the host, then large_decompress_many; result[i] set for every listed chunk
+int large_decompress_listed(::cj_engine* e, int codec, uint32_t flags, size_t n_listed, const size_t* idx, const uint8_t* const* in_ptrs, const size_t* in_lens,
+                            uint8_t* const* out_ptrs, const size_t* out_caps, int64_t* result);
 int64_t large_decompress(int codec, uint32_t flags, const uint8_t* in, size_t n, uint8_t* out, size_t cap);
 void launch_lz4_decode_lds2_slabs(const BatchArgs& a, const void* sync, const void* meta, void* tabs, uint32_t* counter,
                                   const void* first, uint32_t stream_len, uint32_t* done, void* cross, uint32_t tab_stride,

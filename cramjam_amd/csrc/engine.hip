@@ -415,6 +415,30 @@ int cj_batch_host(cj_engine* e, cj_codec codec, cj_op op, uint32_t flags, size_t
     if (!e || (n && (!in_ptrs || !in_lens || !out_ptrs || !out_caps || !result))) return CJ_E_BAD_ARG;
     if (n == 0) return 0;
     if (n > 0xFFFFFFF0ull) return CJ_E_BAD_ARG;
+    // decompress: chunks above 64 KiB (by input or by capacity) would each be one serial stream on one wavefront; up to
+    // 256 MiB of them take the large-stream path together (large.hip) and the rest of the batch follows as usual
+    if (op == CJ_OP_DECOMPRESS && n > 1 && !(flags & (CJ_FLAG_FORCE_WAVE_PER_CHUNK | CJ_FLAG_FORCE_LANE_PER_CHUNK | CJ_FLAG_FORCE_LDS_PER_CHUNK))) {
+        std::vector<size_t> big, rest;
+        size_t big_bytes = 0;
+        for (size_t i = 0; i < n; i++) {
+            const bool is_big = in_ptrs[i] && out_ptrs[i] && (in_lens[i] > kLargeMin || (codec == CJ_CODEC_SNAPPY_RAW
+                                    ? cj_snappy_raw_decompress_len(in_ptrs[i], in_lens[i]) > (int64_t)kLargeMin
+                                    : (out_caps[i] > kLargeMin && in_lens[i] > 4096)));
+            if (is_big) { big.push_back(i); big_bytes += in_lens[i]; } else rest.push_back(i);
+        }
+        if (!big.empty() && big_bytes <= (256u << 20)) {
+            const int rc = cj::large_decompress_listed(e, codec, flags, big.size(), big.data(), in_ptrs, in_lens, out_ptrs, out_caps, result);
+            if (rc != 0) return rc;
+            if (rest.empty()) return 0;
+            std::vector<const uint8_t*> ip(rest.size()); std::vector<size_t> il(rest.size()), oc(rest.size()); std::vector<uint8_t*> opp(rest.size());
+            std::vector<int64_t> rr(rest.size());
+            for (size_t k = 0; k < rest.size(); k++) { ip[k] = in_ptrs[rest[k]]; il[k] = in_lens[rest[k]]; opp[k] = out_ptrs[rest[k]]; oc[k] = out_caps[rest[k]]; }
+            const int rc2 = cj_batch_host(e, codec, op, flags, rest.size(), ip.data(), il.data(), opp.data(), oc.data(), rr.data());
+            if (rc2 != 0) return rc2;
+            for (size_t k = 0; k < rest.size(); k++) result[rest[k]] = rr[k];
+            return 0;
+        }
+    }
     std::lock_guard<std::mutex> lock(e->mu);
     HIP_TRY(hipSetDevice(e->device), CJ_E_NO_DEVICE);
 

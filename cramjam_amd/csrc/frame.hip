@@ -543,7 +543,7 @@ int64_t cj_lz4_frame_decompress(const uint8_t* in, size_t n, uint8_t* out, size_
                 else { ins.push_back(in + b.src_off); lens.push_back(sz); outs.push_back(out + slot); caps.push_back(f.block_max); slot += f.block_max; }
             }
             std::vector<int64_t> rj(ins.size());
-            const int rc = ins.empty() ? 0 : cj::large_lz4_decompress_many(ins.size(), ins.data(), lens.data(), outs.data(), caps.data(), rj.data());
+            const int rc = ins.empty() ? 0 : cj::large_decompress_many(e, CJ_CODEC_LZ4_BLOCK, ins.size(), ins.data(), lens.data(), nullptr, outs.data(), caps.data(), rj.data());
             if (rc == 0) {
                 size_t k = 0;
                 for (size_t i = 0; i < nb; i++) {

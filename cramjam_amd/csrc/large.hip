@@ -364,6 +364,47 @@ size_t large_split_max() { return kSplitMax; }
 // (lz4_decode_lds.hip, kSlab).  Error codes and capacity rules are those of the single-chunk kernels (lz4_block_prologue,
 // snappy_parse_kernel's header checks), applied here on the host.
 // =====================================================================================================================
+// The checks in front of the decoder (lz4_block_prologue / the Snappy length header), on the host.  false: `early` is the
+// call's result (an error, or 0 for an empty block); true: decode in[skip ..], element stream from `start`, capacity cap64.
+static bool large_prologue(int codec, uint32_t flags, const uint8_t* in, size_t n, size_t cap, uint64_t& skip, uint64_t& start, uint64_t& cap64, int64_t& early) {
+    const bool snappy = codec == CJ_CODEC_SNAPPY_RAW;
+    skip = 0; start = 0; cap64 = cap;
+    if (!snappy) {
+        if (flags & CJ_FLAG_LZ4_SIZE_PREFIX) {
+            if (n < 4) { early = CJ_E_NO_PREFIX; return false; }
+            uint32_t u; std::memcpy(&u, in, 4);
+            const int32_t size = (int32_t)u;
+            if (size < 0) { early = CJ_E_NEG_PREFIX; return false; }
+            if ((uint32_t)size > 0x7E000000u) { early = CJ_E_PREFIX_TOO_BIG; return false; }
+            if ((uint64_t)size > cap64) { early = CJ_E_OUT_TOO_SMALL; return false; }
+            skip = 4; cap64 = (uint64_t)size;
+        } else {
+            if (cap64 > 0xFFFFFFFFull || (int32_t)(uint32_t)cap64 < 0) { early = CJ_E_NEG_PREFIX; return false; }
+            if ((uint32_t)cap64 > 0x7E000000u) { early = CJ_E_PREFIX_TOO_BIG; return false; }
+        }
+        if (n - skip > 0x7FFFFFF0ull) { early = CJ_E_CORRUPT; return false; }
+        if (cap64 == 0) { early = (n - skip == 1 && in[skip] == 0) ? 0 : (int64_t)CJ_E_CORRUPT; return false; }
+        if (n - skip == 0) { early = CJ_E_CORRUPT; return false; }
+    } else {
+        if (n == 0) { early = CJ_E_SNAPPY_EMPTY; return false; }
+        if (n > 0x7FFFFFF0ull) { early = CJ_E_SNAPPY_CORRUPT; return false; }
+        uint64_t ulen = 0; uint32_t shift = 0, i = 0, hdr = 0; bool ok = false;
+        while (hdr < n && i < 10u) {
+            const uint32_t b = in[hdr++];
+            if (b < 0x80u) { if (!(i == 9u && b > 1u)) { ulen |= (uint64_t)b << shift; ok = true; } break; }
+            ulen |= (uint64_t)(b & 0x7fu) << shift;
+            shift += 7; i += 1;
+        }
+        if (!ok) { early = CJ_E_SNAPPY_HEADER; return false; }
+        if (ulen > 0xFFFFFFFFull) { early = CJ_E_SNAPPY_TOO_BIG; return false; }
+        if (ulen > cap64) { early = CJ_E_SNAPPY_BUF_SMALL; return false; }
+        if (ulen == 0) { early = hdr == n ? 0 : (int64_t)CJ_E_SNAPPY_CORRUPT; return false; }
+        if (hdr == n) { early = CJ_E_SNAPPY_CORRUPT; return false; }
+        start = hdr; cap64 = ulen;
+    }
+    return true;
+}
+
 static std::vector<uint32_t>* g_dbg_sync = nullptr;       // set by cj_debug_big_parse only (single-threaded test hook)
 static uint64_t g_dbg_nseq = 0;
 
@@ -373,38 +414,9 @@ int64_t large_decompress(int codec, uint32_t flags, const uint8_t* in, size_t n,
     const bool snappy = codec == CJ_CODEC_SNAPPY_RAW;
     const int64_t corrupt = snappy ? CJ_E_SNAPPY_CORRUPT : CJ_E_CORRUPT;
     uint64_t skip = 0, start = 0, cap64 = cap;
-    if (!snappy) {
-        if (flags & CJ_FLAG_LZ4_SIZE_PREFIX) {
-            if (n < 4) return CJ_E_NO_PREFIX;
-            uint32_t u; std::memcpy(&u, in, 4);
-            const int32_t size = (int32_t)u;
-            if (size < 0) return CJ_E_NEG_PREFIX;
-            if ((uint32_t)size > 0x7E000000u) return CJ_E_PREFIX_TOO_BIG;
-            if ((uint64_t)size > cap64) return CJ_E_OUT_TOO_SMALL;
-            skip = 4; cap64 = (uint64_t)size;
-        } else {
-            if (cap64 > 0xFFFFFFFFull || (int32_t)(uint32_t)cap64 < 0) return CJ_E_NEG_PREFIX;
-            if ((uint32_t)cap64 > 0x7E000000u) return CJ_E_PREFIX_TOO_BIG;
-        }
-        if (n - skip > 0x7FFFFFF0ull) return CJ_E_CORRUPT;
-        if (cap64 == 0) return (n - skip == 1 && in[skip] == 0) ? 0 : (int64_t)CJ_E_CORRUPT;
-        if (n - skip == 0) return CJ_E_CORRUPT;
-    } else {
-        if (n == 0) return CJ_E_SNAPPY_EMPTY;
-        if (n > 0x7FFFFFF0ull) return CJ_E_SNAPPY_CORRUPT;
-        uint64_t ulen = 0; uint32_t shift = 0, i = 0, hdr = 0; bool ok = false;
-        while (hdr < n && i < 10u) {
-            const uint32_t b = in[hdr++];
-            if (b < 0x80u) { if (!(i == 9u && b > 1u)) { ulen |= (uint64_t)b << shift; ok = true; } break; }
-            ulen |= (uint64_t)(b & 0x7fu) << shift;
-            shift += 7; i += 1;
-        }
-        if (!ok) return CJ_E_SNAPPY_HEADER;
-        if (ulen > 0xFFFFFFFFull) return CJ_E_SNAPPY_TOO_BIG;
-        if (ulen > cap64) return CJ_E_SNAPPY_BUF_SMALL;
-        if (ulen == 0) return hdr == n ? 0 : (int64_t)CJ_E_SNAPPY_CORRUPT;
-        if (hdr == n) return CJ_E_SNAPPY_CORRUPT;
-        start = hdr; cap64 = ulen;
+    {
+        int64_t early = 0;
+        if (!large_prologue(codec, flags, in, n, cap, skip, start, cap64, early)) return early;
     }
     const uint32_t iend = (uint32_t)(n - skip);
     const uint32_t piece = iend < kBigPieceSwitch ? kBigPieceSmall : kBigPieceLarge;
@@ -481,12 +493,14 @@ int64_t large_decompress(int codec, uint32_t flags, const uint8_t* in, size_t n,
     return (int64_t)total;
 }
 
-// Several LZ4 blocks (no size prefix), each a large stream of its own — the blocks of an LZ4 frame with large independent
-// blocks (frame.hip).  The parse kernels run over the pieces of ALL blocks at once (launch_big_parse_many) and the decoder
+// Several streams (LZ4 blocks without their size prefix / Snappy raw streams with starts[j] = the first element's position),
+// each a large stream of its own — the blocks of an LZ4 frame with large independent blocks (frame.hip), the large chunks of
+// a host batch (engine.hip).  The parse kernels run over the pieces of ALL blocks at once (launch_big_parse_many) and the decoder
 // over the slabs of all blocks (every block's first slab has no predecessor); the host waits twice in total.  result[j] = decoded size or
 // CJ_E_CORRUPT; returns 0, or a CJ_E_* that concerns the call as a whole (CJ_E_BAD_ARG: not for this path).
-int large_lz4_decompress_many(size_t nj, const uint8_t* const* ins, const size_t* lens, uint8_t* const* outs, const size_t* caps, int64_t* result) {
-    cj_engine* e = default_engine();
+int large_decompress_many(cj_engine* e, int codec, size_t nj, const uint8_t* const* ins, const size_t* lens, const size_t* starts, uint8_t* const* outs, const size_t* caps, int64_t* result) {
+    const int64_t corrupt = codec == CJ_CODEC_SNAPPY_RAW ? CJ_E_SNAPPY_CORRUPT : CJ_E_CORRUPT;
+    if (!e) e = default_engine();
     if (!e) return CJ_E_NO_DEVICE;
     if (nj == 0) return 0;
     struct Job { size_t in_off, meta_off, out_off; BigSlabs sd; uint64_t n_seq, total; uint32_t n_sync, n_slabs; };
@@ -504,12 +518,12 @@ int large_lz4_decompress_many(size_t nj, const uint8_t* const* ins, const size_t
     size_t slab_bound = 0;                                                 // the descriptors of the decoder's chunk list reuse the tail of the parse scratch
     for (size_t j = 0; j < nj; j++) slab_bound += (caps[j] + 65535) / 65536;
     for (size_t j = 0; j < nj; j++) {
-        if (lens[j] == 0 || lens[j] > 0x7FFFFFF0ull || caps[j] == 0 || caps[j] > 0x7E000000ull) return CJ_E_BAD_ARG;
+        if (lens[j] == 0 || lens[j] > 0x7FFFFFF0ull || caps[j] == 0 || caps[j] > 0xFFFFFFFFull || (starts && starts[j] >= lens[j])) return CJ_E_BAD_ARG;
         BigParse& bp = bps[j];
         bp = BigParse{};
-        bp.iend = (uint32_t)lens[j]; bp.start = 0; bp.cap = caps[j];
+        bp.iend = (uint32_t)lens[j]; bp.start = starts ? (uint32_t)starts[j] : 0u; bp.cap = caps[j];
         bp.piece = bp.iend < kBigPieceSwitch ? kBigPieceSmall : kBigPieceLarge;
-        bp.np = (bp.iend + bp.piece - 1) / bp.piece;
+        bp.np = (bp.iend - bp.start + bp.piece - 1) / bp.piece;
         max_piece = std::max(max_piece, bp.piece);
         for (uint32_t p = 0; p < bp.np; p++) pmap.push_back(make_uint2((uint32_t)j, p));
         jobs[j].in_off = one_span ? (size_t)(ins[j] - span_lo) : in_total; in_total += (lens[j] + 64 + 255) & ~(size_t)255;
@@ -542,7 +556,7 @@ int large_lz4_decompress_many(size_t nj, const uint8_t* const* ins, const size_t
     if (one_span) HIP_TRY(hipMemcpyAsync(d_in, span_lo, (size_t)(span_hi - span_lo), hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
     HIP_TRY(hipMemcpyAsync(b + o_jobs, bps.data(), nj * sizeof(BigParse), hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
     HIP_TRY(hipMemcpyAsync(b + o_pmap, pmap.data(), pmap.size() * 8, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
-    launch_big_parse_many((const BigParse*)(b + o_jobs), (uint32_t)nj, (const uint2*)(b + o_pmap), (uint32_t)pmap.size(), max_piece, CJ_CODEC_LZ4_BLOCK, s);
+    launch_big_parse_many((const BigParse*)(b + o_jobs), (uint32_t)nj, (const uint2*)(b + o_pmap), (uint32_t)pmap.size(), max_piece, codec, s);
     HIP_TRY(hipGetLastError(), CJ_E_NO_DEVICE);
     std::vector<uint32_t> st(16 * nj);
     HIP_TRY(hipMemcpyAsync(st.data(), d_status, 64 * nj, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
@@ -554,7 +568,7 @@ int large_lz4_decompress_many(size_t nj, const uint8_t* const* ins, const size_t
         Job& J = jobs[j];
         const uint32_t* t = st.data() + 16 * j;
         J.n_slabs = 0; J.total = 0;
-        if (t[0] != 0 || t[1] != 0 || t[8] != 1) { result[j] = CJ_E_CORRUPT; continue; }
+        if (t[0] != 0 || t[1] != 0 || t[8] != 1) { result[j] = corrupt; continue; }
         J.n_seq = ((uint64_t)t[3] << 32) | t[2]; J.total = ((uint64_t)t[7] << 32) | t[6];
         result[j] = (int64_t)J.total;
         if (J.total == 0) continue;
@@ -615,7 +629,7 @@ int large_lz4_decompress_many(size_t nj, const uint8_t* const* ins, const size_t
     BatchArgs a;
     fill_args(a, 0u, n_slabs, d_in, m, m + n_slabs, (uint8_t*)e->d_out.p, m + 2 * n_slabs, m + 3 * n_slabs, (int64_t*)(m + 4 * n_slabs));
     launch_lz4_decode_lds2_slabs(a, sync_base, m + 5 * n_slabs, e->d_bigtab.p, (uint32_t*)(m + r_misc) + 1, m + 6 * n_slabs, 0u,
-                                 (uint32_t*)(m + r_done), (uint8_t*)e->d_bigtab.p + tab_bytes, tab_stride, cross_stride, grid, s, CJ_CODEC_LZ4_BLOCK);
+                                 (uint32_t*)(m + r_done), (uint8_t*)e->d_bigtab.p + tab_bytes, tab_stride, cross_stride, grid, s, codec);
     HIP_TRY(hipGetLastError(), CJ_E_NO_DEVICE);
     std::vector<int64_t> res(n_slabs);
     HIP_TRY(hipMemcpyAsync(res.data(), m + 4 * n_slabs, n_slabs * 8, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
@@ -628,7 +642,27 @@ int large_lz4_decompress_many(size_t nj, const uint8_t* const* ins, const size_t
     }
     HIP_TRY(hipStreamSynchronize(s), CJ_E_NO_DEVICE);
     for (size_t j = 0; j < nj; j++)
-        for (uint32_t i = 0; i < jobs[j].n_slabs; i++) if (res[jobs[j].meta_off + i] < 0) result[j] = CJ_E_CORRUPT;
+        for (uint32_t i = 0; i < jobs[j].n_slabs; i++) if (res[jobs[j].meta_off + i] < 0) result[j] = corrupt;
+    return 0;
+}
+
+// The large chunks idx[0 .. n_listed) of a host batch (cj_batch_host): the checks in front of the decoder on the host, then all
+// of them together through large_decompress_many.
+int large_decompress_listed(cj_engine* e, int codec, uint32_t flags, size_t n_listed, const size_t* idx, const uint8_t* const* in_ptrs,
+                            const size_t* in_lens, uint8_t* const* out_ptrs, const size_t* out_caps, int64_t* result) {
+    std::vector<const uint8_t*> ins; std::vector<size_t> lens, starts, caps, which; std::vector<uint8_t*> outs;
+    for (size_t k = 0; k < n_listed; k++) {
+        const size_t i = idx[k];
+        uint64_t skip, start, cap64; int64_t early = 0;
+        if (!large_prologue(codec, flags, in_ptrs[i], in_lens[i], out_caps[i], skip, start, cap64, early)) { result[i] = early; continue; }
+        ins.push_back(in_ptrs[i] + skip); lens.push_back(in_lens[i] - skip); starts.push_back(start); outs.push_back(out_ptrs[i]); caps.push_back(cap64);
+        which.push_back(i);
+    }
+    if (ins.empty()) return 0;
+    std::vector<int64_t> r(ins.size());
+    const int rc = large_decompress_many(e, codec, ins.size(), ins.data(), lens.data(), starts.data(), outs.data(), caps.data(), r.data());
+    if (rc != 0) return rc;
+    for (size_t k = 0; k < which.size(); k++) result[which[k]] = r[k];
     return 0;
 }
 

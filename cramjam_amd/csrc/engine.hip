@@ -426,7 +426,7 @@ int cj_batch_host(cj_engine* e, cj_codec codec, cj_op op, uint32_t flags, size_t
                                     : (out_caps[i] > kLargeMin && in_lens[i] > 4096)));
             if (is_big) { big.push_back(i); big_bytes += in_lens[i]; } else rest.push_back(i);
         }
-        if (!big.empty() && big_bytes <= (256u << 20)) {
+        if (!big.empty() && big.size() <= 512 && big_bytes <= (256u << 20)) {      // (per-chunk host work: not for thousands of chunks)
             const int rc = cj::large_decompress_listed(e, codec, flags, big.size(), big.data(), in_ptrs, in_lens, out_ptrs, out_caps, result);
             if (rc != 0) return rc;
             if (rest.empty()) return 0;

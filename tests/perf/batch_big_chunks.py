@@ -1,6 +1,6 @@
 """A host batch of chunks above 64 KiB through Engine.batch_host (decompress): they take the large-stream path together."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import oracle
 from cramjam_amd import _native as N
 parts = [oracle.synth_v1(65536, i) for i in range(64)]

@@ -1,7 +1,7 @@
 """A batch of 64 KiB chunks of text-like data (log lines: deep match chains) through the batch decoder; run under
 rocprofv3 --kernel-trace --stats to read the decoder kernel's time (match forwarding)."""
 import os, sys, random, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import oracle
 from cramjam_amd import _native as N
 rnd = random.Random(1)

@@ -2,7 +2,7 @@
 """Fingerprint of the GPU encoders' output on a fixed corpus (sha256 over all compressed chunks) + throughput.
 Used to check that a restructured matcher still emits byte-identical streams.  GPU only."""
 import hashlib, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import oracle
 from cramjam_amd import _native as N
 

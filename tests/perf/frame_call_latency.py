@@ -1,6 +1,6 @@
 """Latency of ONE framed compress / decompress call by size (host bytes in, Buffer out).  GPU only."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import oracle, cramjam_amd as cj
 def lat(fn, reps=15):
     fn(); best = 1e9

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Host-boundary (PCIe-inclusive) rates of the framed single-buffer API on one MI355X.  GPU only."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import oracle
 import cramjam_amd as cj
 

@@ -2,7 +2,7 @@
 """PCIe-inclusive rate of the host-buffer batch path: times the cj_batch_host C call itself
 (pack into pinned staging -> H2D -> kernels -> D2H -> scatter), marshalling excluded."""
 import ctypes as C, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import oracle
 from cramjam_amd import _native as N

@@ -1,7 +1,7 @@
 """One large LZ4 block whose matches cross every 64 KiB slab boundary (synth chunks shifted by 1000 bytes), decompressed
 through the single-buffer API.  Run under rocprofv3 --kernel-trace --stats for the per-kernel split."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import oracle
 import cramjam_amd as cj
 mb = int(os.environ.get("MB", "64"))

@@ -1,6 +1,6 @@
 """Single-buffer decompress rates of ONE large stream for data of different dependency shape (GPU only)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import oracle, cramjam_amd as cramjam
 PIECE = 65536
 def run(name, data, codec="lz4"):
@@ -27,8 +27,8 @@ log = b"".join(b"2026-09-28T12:%02d:%02d.%03d INFO worker-%d request id=%08x pat
 run("log lines", log); run("log lines", log, "snappy")
 js = b"".join(json.dumps({"id": i, "name": "user%d" % rnd.randrange(1000), "tags": ["a", "b", rnd.choice("xyz")], "score": rnd.random()}).encode() + b"\n" for i in range(300000))
 run("JSON lines", js); run("JSON lines", js, "snappy")
-src = b"".join(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cramjam_amd", "csrc", f), "rb").read()
-               for f in sorted(os.listdir(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cramjam_amd", "csrc")))
+src = b"".join(open(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "cramjam_amd", "csrc", f), "rb").read()
+               for f in sorted(os.listdir(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "cramjam_amd", "csrc")))
                if f.endswith((".hip", ".hpp", ".cpp"))) * 12
 run("C++ source", src); run("C++ source", src, "snappy")
 run("random (stored)", random.Random(1).randbytes(32 << 20)); run("random (stored)", random.Random(1).randbytes(32 << 20), "snappy")

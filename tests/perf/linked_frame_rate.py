@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import oracle, cramjam_amd as cj
 mb = 64
 parts = [oracle.synth_v1(65536, i) for i in range(64)]

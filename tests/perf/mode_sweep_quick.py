@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Latency / throughput of LZ4 decode over batch sizes for the default pipeline and the forced mappings (GPU only)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import oracle
 from cramjam_amd import _native as N

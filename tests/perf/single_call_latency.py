@@ -1,6 +1,6 @@
 """Latency of ONE call of the four raw entry points by buffer size (host bytes in, Buffer out).  GPU only."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import oracle, cramjam_amd as cj
 def lat(fn, reps=20):
     fn(); best = 1e9

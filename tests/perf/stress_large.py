@@ -2,7 +2,7 @@
 streams of different shapes through the default engine (one after the other: the engine serialises them) while another
 thread keeps a second engine busy with batches on its own stream.  Every byte is checked.  GPU only."""
 import os, sys, threading, time, random
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import oracle, cramjam_amd as cj
 from cramjam_amd import _native as N
 SECONDS = float(os.environ.get("SECONDS", "20"))

@@ -309,7 +309,7 @@ def test_random_hand_made_lz4_streams_across_slabs():
 def test_large_streams_under_concurrent_load():
     """the slab decoder's hand-over between workgroups (completion flags, write-through stores, acquire) under uneven load:
     host threads decompress large streams of different shapes while another thread keeps a second engine busy with batches
-    on its own HIP stream; every byte is checked (tools/stress_large.py is the long version)"""
+    on its own HIP stream; every byte is checked (tests/perf/stress_large.py is the long version)"""
     import threading, time
     from cramjam_amd import _native as N
     rnd = random.Random(5)

@@ -20,7 +20,16 @@ namespace cj {
 #define CJ_HASH_BITS 13
 #endif
 constexpr uint32_t kHashBits = CJ_HASH_BITS;
-constexpr uint32_t kHashSize = 1u << kHashBits;
+// slots actually kept per wave: any count <= 2^kHashBits (the 32-bit hash is scaled onto [0, kHashSlots) with a
+// multiply-high, so the load stays uniform for counts that are not a power of two)
+#ifndef CJ_HASH_SLOTS
+#define CJ_HASH_SLOTS (1u << CJ_HASH_BITS)
+#endif
+constexpr uint32_t kHashSize = CJ_HASH_SLOTS;
+__device__ __forceinline__ uint32_t hash_slot(uint32_t v) {
+    if constexpr ((kHashSize & (kHashSize - 1u)) == 0u) return (v * 2654435761u) >> (32 - kHashBits);
+    else return __umulhi(v * 2654435761u, kHashSize);
+}
 // waves per encoder block: keep the block's tables within the 64 KiB static-LDS limit
 constexpr int kEncWaves = 1;   // one wave per block: 160 KiB / 16 KiB = 10 resident waves per CU (4-wave blocks would round down to 8)
 constexpr int kEncThreads = 64 * kEncWaves;
@@ -38,7 +47,7 @@ __device__ __forceinline__ void ht_clear(uint16_t* ht) {
 constexpr uint32_t kPreStep = CJ_PRE_STEP;
 __device__ __forceinline__ void ht_preindex(const uint8_t* in, uint16_t* ht, uint32_t q0) {
     for (uint32_t p = lane_id() * kPreStep; p < q0; p += 64u * kPreStep) {
-        const uint32_t h = (ld32u(in + p) * 2654435761u) >> (32 - kHashBits);
+        const uint32_t h = hash_slot(ld32u(in + p));
         ht[h] = (uint16_t)p;
     }
 }
@@ -165,7 +174,7 @@ __device__ __forceinline__ void probe_round(const uint8_t* in, const uint16_t* h
         uint32_t c = 0;
         ok[j] = false;
         if (my <= last_start) {
-            const uint32_t h = (v[j] * 2654435761u) >> (32 - kHashBits);
+            const uint32_t h = hash_slot(v[j]);
             r.hslot[j] = h;
             c = (my & 0xFFFF0000u) | ht[h];
             if (c >= my) c -= 65536u;       // slot belongs to the previous 64 KiB lap (or is stale)

@@ -104,7 +104,36 @@ def run_frames(cases, seed, verbose=False):
     return bad
 
 
+def run_compress(cases, seed, verbose=False):
+    """the compressors on random sizes (clustered around the 16 KiB / 64 KiB piece boundaries and their multiples): the oracle's
+    decoders must give the input back from the block, raw and both framed outputs"""
+    rnd.seed(seed)
+    t0 = time.time(); done = 0; bad = []
+    pool = b"".join(d for _, d in shapes())
+    while done < cases and not bad:
+        base = rnd.choice((0, 16384, 32768, 49152, 65536, 131072, 196608, 262144, 1 << 20, rnd.randrange(1 << 22)))
+        n = max(0, base + rnd.randrange(-40, 41)) if rnd.randrange(3) else rnd.randrange(1 << rnd.randrange(1, 23))
+        o = rnd.randrange(max(1, len(pool) - n)) if n < len(pool) else 0
+        data = (pool[o:o + n] if rnd.randrange(5) else rnd.randbytes(n))[:n]
+        n = len(data)
+        b = bytes(cj.lz4.compress_block(data, store_size=False))
+        if oracle.lz4_decompress_raw(b, n) != (n, data) and n: bad.append(("lz4 block", n))
+        b = bytes(cj.snappy.compress_raw(data))
+        if oracle.snappy_decompress(b) != (n, data): bad.append(("snappy raw", n))
+        b = bytes(cj.lz4.compress(data))
+        if oracle.lz4_frame_decompress(b) != (n, data): bad.append(("lz4 frame", n))
+        b = bytes(cj.snappy.compress(data))
+        if oracle.snappy_frame_decompress(b) != (n, data): bad.append(("snappy framed", n))
+        done += 4
+        if verbose and done % 400 == 0: print("compress: cases %d, %.0f s" % (done, time.time() - t0), flush=True)
+    return bad
+
+
 if __name__ == "__main__":
+    if os.environ.get("COMPRESS"):
+        bad = run_compress(int(os.environ.get("CASES", "600")), int(os.environ.get("SEED", "1")), verbose=True)
+        print("mismatches:", bad)
+        sys.exit(1 if bad else 0)
     if os.environ.get("FRAMES"):
         bad = run_frames(int(os.environ.get("CASES", "600")), int(os.environ.get("SEED", "1")), verbose=True)
         print("mismatches:", bad)

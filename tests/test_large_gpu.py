@@ -375,3 +375,4 @@ def test_mutation_fuzz_of_large_streams():
     mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
     assert mod.run(1000, 11) == []
     assert mod.run_frames(600, 12) == []
+    assert mod.run_compress(2000, 13) == []

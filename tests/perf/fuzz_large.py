@@ -129,7 +129,42 @@ def run_compress(cases, seed, verbose=False):
     return bad
 
 
+def run_batch(cases, seed, verbose=False):
+    """batches of mutated chunks of 1 B .. 64 KiB through Engine.batch_host, default pipeline and each forced mapping: the
+    oracle's verdict per chunk and its bytes where it accepts"""
+    from cramjam_amd import _native as N
+    rnd.seed(seed)
+    t0 = time.time(); done = 0; bad = []
+    pool = b"".join(d for _, d in shapes())
+    eng = N.Engine(0)
+    while done < cases and not bad:
+        codec = rnd.choice((N.CODEC_LZ4_BLOCK, N.CODEC_SNAPPY_RAW))
+        lz = codec == N.CODEC_LZ4_BLOCK
+        streams, caps, want = [], [], []
+        for _ in range(rnd.choice((1, 7, 300, 2500))):
+            n = rnd.randrange(1, 65537) if rnd.randrange(3) else 65536
+            o = rnd.randrange(len(pool) - n)
+            data = pool[o:o + n] if rnd.randrange(6) else rnd.randbytes(n)
+            blob = (oracle.lz4_compress_raw if lz else oracle.snappy_compress)(data)[1]
+            m = mutate(blob)[0] if rnd.randrange(8) and len(blob) > 8 else blob
+            cap = n if rnd.randrange(5) else rnd.randrange(1, 65537)
+            streams.append(m); caps.append(cap)
+            want.append(oracle.lz4_decompress_raw(m, cap) if lz else oracle.snappy_decompress(m, cap))
+        flag = rnd.choice((0, 0, N.FLAG_FORCE_WAVE_PER_CHUNK, N.FLAG_FORCE_LANE_PER_CHUNK if lz else 0, N.FLAG_FORCE_LDS_PER_CHUNK))
+        res, outs = eng.batch_host(codec, N.OP_DECOMPRESS, flag, streams, caps)
+        for i, ((er, eo), r, o) in enumerate(zip(want, res, outs)):
+            if (er < 0) != (r < 0) or (er >= 0 and (r != er or o != eo)): bad.append(("lz4" if lz else "snappy", flag, i, len(streams), er, r)); break
+        done += len(streams)
+        if verbose: print("batch: cases %d, %.0f s" % (done, time.time() - t0), flush=True)
+    eng.close()
+    return bad
+
+
 if __name__ == "__main__":
+    if os.environ.get("BATCH"):
+        bad = run_batch(int(os.environ.get("CASES", "600")), int(os.environ.get("SEED", "1")), verbose=True)
+        print("mismatches:", bad)
+        sys.exit(1 if bad else 0)
     if os.environ.get("COMPRESS"):
         bad = run_compress(int(os.environ.get("CASES", "600")), int(os.environ.get("SEED", "1")), verbose=True)
         print("mismatches:", bad)

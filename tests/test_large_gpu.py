@@ -376,3 +376,4 @@ def test_mutation_fuzz_of_large_streams():
     assert mod.run(1000, 11) == []
     assert mod.run_frames(600, 12) == []
     assert mod.run_compress(2000, 13) == []
+    assert mod.run_batch(20000, 14) == []

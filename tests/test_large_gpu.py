@@ -2,6 +2,7 @@
 64 KiB pieces, compress them as a batch and join the pieces' streams into one valid block.  The judge is the oracle's
 decoder (the reference's bar for compressed output: it must decode losslessly — reference tests/test_variants.py
 round trips); sizes and ratios are checked against a batch of independent 64 KiB chunks."""
+import os
 import random
 
 import numpy as np

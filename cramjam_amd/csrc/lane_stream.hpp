@@ -35,22 +35,37 @@ struct LaneStream {
 // aligned 16 B loads, 8 lines per load instruction) and the data is written to the lanes' rings.
 // (Measured alternative: issuing in one round and committing in the next with a 512 B ring halves occupancy —
 // 33 KiB of LDS per wave — and ran slower: 8.6 ms vs 3.6 ms for 100 k chunks.)
-__device__ __forceinline__ void refill_round(LaneStream& st, bool want, uint32_t wave_ring) {
-    const uint32_t lane = lane_id(), piece = lane & 7u;
+// What a lane needs to know about the 8 lanes it fetches for (lane t = 8 r + lane / 8 in step r): their stream base and
+// end never change, so they are exchanged once per kernel instead of once per round (5 -> 1 ds_bpermute per step).
+struct RefillPlan { uint32_t blo[8], bhi[8], end[8]; };
+__device__ __forceinline__ RefillPlan refill_plan(const LaneStream& st) {
+    RefillPlan p;
+    const uint32_t lane = lane_id();
     const uint32_t blo = (uint32_t)(uintptr_t)st.base, bhi = (uint32_t)((uintptr_t)st.base >> 32);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int t = 8 * r + (int)(lane >> 3);
+        p.blo[r] = (uint32_t)__shfl((int)blo, t); p.bhi[r] = (uint32_t)__shfl((int)bhi, t); p.end[r] = (uint32_t)__shfl((int)st.end, t);
+    }
+    return p;
+}
+
+__device__ __forceinline__ void refill_round(LaneStream& st, bool want, uint32_t wave_ring, const RefillPlan& plan) {
+    const uint32_t lane = lane_id(), piece = lane & 7u;
+    const uint32_t mine = st.hi | (want ? 1u : 0u);                    // hi is a multiple of 128
+    uint32_t th[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) th[r] = (uint32_t)__shfl((int)mine, 8 * r + (int)(lane >> 3));
     uint4 v[8];
     uint32_t dsta[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const int t = 8 * r + (int)(lane >> 3);
-        const uint32_t t_want = (uint32_t)__shfl((int)want, t), t_hi = (uint32_t)__shfl((int)st.hi, t);
-        const uint32_t t_end = (uint32_t)__shfl((int)st.end, t);
-        const uint32_t t_blo = (uint32_t)__shfl((int)blo, t), t_bhi = (uint32_t)__shfl((int)bhi, t);
-        const uint32_t off = t_hi + 16u * piece;
+        const uint32_t off = (th[r] & ~1u) + 16u * piece;
         v[r] = make_uint4(0, 0, 0, 0);
         dsta[r] = 0xffffffffu;
-        if (t_want && off < t_end) {
-            const uint8_t* src = reinterpret_cast<const uint8_t*>(((uint64_t)t_bhi << 32) | t_blo) + off;
+        if ((th[r] & 1u) && off < plan.end[r]) {
+            const uint8_t* src = reinterpret_cast<const uint8_t*>(((uint64_t)plan.bhi[r] << 32) | plan.blo[r]) + off;
             v[r] = *reinterpret_cast<const uint4*>(src);               // 16 B aligned, never crosses into a page past the stream
             dsta[r] = wave_ring + (uint32_t)t * kRingStride + (off & (kRingBytes - 1u));
         }

@@ -81,6 +81,7 @@ __global__ __launch_bounds__(64 * kParseWaves) void lz4_parse_kernel(BatchArgs a
     st.end = done ? 0u : mis + (uint32_t)n64;
     st.ring = wave_ring + lane * kRingStride;
     const uint32_t iend = st.end;
+    const RefillPlan plan = refill_plan(st);
     uint2* csync = sync + (size_t)c * kSyncPitch;
 
     uint32_t ip = mis, op = 0, nseq = 0;
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(64 * kParseWaves) void lz4_parse_kernel(BatchArgs a
             const bool want = !done && st.hi < iend && (st.hi - st.lo < kRingBytes || ip >= st.lo + 128u);
             const bool urgent = want && ip + 48u > st.hi;
             if (ballot64(urgent) == 0ull) break;
-            refill_round(st, want, wave_ring);
+            refill_round(st, want, wave_ring, plan);
         }
         if (!done) {
             // one sequence; mirrors lz4_lane_walk<false> with reads through the line cache

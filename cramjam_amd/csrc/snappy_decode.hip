@@ -280,6 +280,7 @@ __global__ __launch_bounds__(64 * kParseWaves) void snappy_parse_kernel(BatchArg
     st.end = done ? 0u : mis + (uint32_t)n64 - hdr;
     st.ring = wave_ring + lane * kRingStride;
     const uint32_t iend = st.end;
+    const RefillPlan plan = refill_plan(st);
     uint2* csync = sync + (size_t)c * kSyncPitch;
     const auto rd = [&st](uint32_t p) { return st.ld32(p); };
 
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(64 * kParseWaves) void snappy_parse_kernel(BatchArg
             const bool want = !done && st.hi < iend && (st.hi - st.lo < kRingBytes || ip >= st.lo + 128u);
             const bool urgent = want && ip + 48u > st.hi;
             if (ballot64(urgent) == 0ull) break;
-            refill_round(st, want, wave_ring);
+            refill_round(st, want, wave_ring, plan);
         }
         if (!done) {
             if ((nrec % kSyncEvery) == 0u) {

@@ -2,15 +2,16 @@
 // A wave-load with 64 unrelated addresses costs ~2.3k cycles here (64 separate line requests, measured), and a lane
 // touches each 128 B line ~16 times; so instead the wavefront refills the caches cooperatively — 8 lanes fetch one
 // lane's next 128 B line with aligned 16 B loads, 8 lines per load instruction — and the per-sequence reads become
-// LDS reads.  Lane rings are 260 B apart so that lanes reading the same ring offset hit different banks.
+// LDS reads.  Lane rings are 272 B apart (16 B aligned: a fetched piece is one ds_write_b128).
 #pragma once
 #include "lz4_lane_walk.hpp"
 
 namespace cj {
 
-constexpr uint32_t kParseWaves = 2;                    // waves per block (ring storage 2 x 64 x 260 B = 33 KiB static LDS)
+constexpr uint32_t kParseWaves = 2;                    // waves per block (ring storage 2 x 64 x 272 B = 34 KiB static LDS)
 constexpr uint32_t kRingBytes = 256;                   // two 128 B lines per lane
-constexpr uint32_t kRingStride = kRingBytes + 4;       // +4: lanes reading the same ring offset hit different banks
+constexpr uint32_t kRingStride = kRingBytes + 16;      // 16 B aligned rings (one ds_write_b128 per fetched piece); the lanes read at unrelated
+                                                       // offsets anyway, so the exact skew between rings does not matter for bank conflicts
 
 struct LaneStream {
     const uint8_t* base;    // 128 B aligned address at or below the first stream byte
@@ -73,8 +74,9 @@ __device__ __forceinline__ void refill_round(LaneStream& st, bool want, uint32_t
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         if (dsta[r] != 0xffffffffu) {
-            asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:4\n\tds_write_b32 %0, %3 offset:8\n\t"
-                         "ds_write_b32 %0, %4 offset:12" :: "v"(dsta[r]), "v"(v[r].x), "v"(v[r].y), "v"(v[r].z), "v"(v[r].w) : "memory");
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 q = {v[r].x, v[r].y, v[r].z, v[r].w};
+            asm volatile("ds_write_b128 %0, %1" :: "v"(dsta[r]), "v"(q) : "memory");
         }
     }
     if (want) {

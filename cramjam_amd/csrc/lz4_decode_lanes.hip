@@ -35,8 +35,7 @@ __global__ __launch_bounds__(64) void lz4_decode_lanes_kernel(BatchArgs a) {
 // 256-byte line cache in LDS.  A wave-load with 64 unrelated addresses costs ~2.3k cycles here (64 separate
 // line requests, measured), and a lane touches each 128 B line ~16 times; so instead the wavefront refills
 // the caches cooperatively — 8 lanes fetch one lane's next 128 B line with aligned 16 B loads, 8 lines per
-// load instruction — and the per-sequence reads become LDS reads.  Lane rings are 260 B apart so that
-// lanes reading the same ring offset hit different banks.
+// load instruction — and the per-sequence reads become LDS reads (lane_stream.hpp).
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * kParseWaves) void lz4_parse_kernel(BatchArgs a, uint2* sync, ParseMeta* meta) {
     __shared__ __attribute__((aligned(16))) uint8_t rings[kParseWaves * 64 * kRingStride];

@@ -472,17 +472,36 @@ __device__ __forceinline__ DW<ND> gl_ld_vec(const uint8_t* g) {
     return r;
 }
 
+// The same for a source that needs no shift (exact pointer): lds_store_tier<T> stores source bytes < n <= T only, and with a
+// zero shift those come from the first T / 4 dwords — the two dwords after them only feed bytes that are never stored.  So T
+// bytes = T / 16 dwordx4 loads are enough: one scattered load instead of two for the 16-byte tier, two instead of three for 32
+// (D2 is bound by the address unit's ~1 cycle per lane per scattered load instruction, not by latency: requesting the next
+// batch's bytes a batch ahead made it slower, 22.7 k -> 28 k cycles per chunk, because it took a third instruction per record).
+template <int T>
+__device__ __forceinline__ DW<T / 4 + 2> gl_ld_exact(const uint8_t* g) {
+    DW<T / 4 + 2> r;
+#pragma unroll
+    for (int i = 0; i < T / 4; i += 4) {
+        uint4 v;
+        __builtin_memcpy(&v, g + 4 * i, 16);
+        r.w[i] = v.x; r.w[i + 1] = v.y; r.w[i + 2] = v.z; r.w[i + 3] = v.w;
+    }
+    r.w[T / 4] = 0u; r.w[T / 4 + 1] = 0u;
+    return r;
+}
+
 // kLinked (LZ4 frames with linked blocks, frame.hip): the workgroup takes a whole FRAME (frames[f] = first block index,
 // block count) and walks its blocks in order; the LDS holds TWO 64 KiB windows, the block being decoded and the previous
 // block (every non-last block of such a frame decodes to exactly 64 KiB — the host checks that before it launches this
 // path), so a match that reaches back past the start of its block reads final bytes from the other window.
 constexpr uint32_t kL2LinkedBytes = 2u * 65536u + 8192u + 384u;        // 139 648 B: one workgroup per CU
 
-#ifdef CJ_L2_WAVES_PER_EU
-#define CJ_L2_ATTR __attribute__((amdgpu_waves_per_eu(CJ_L2_WAVES_PER_EU, CJ_L2_WAVES_PER_EU)))
-#else
-#define CJ_L2_ATTR
+// two workgroups of eight wavefronts per CU = four wavefronts per SIMD: the register allocator must stay within 128 VGPRs
+// (without the attribute it sees only the 512-thread bound and may take more, which silently halves the residency)
+#ifndef CJ_L2_WAVES_PER_EU
+#define CJ_L2_WAVES_PER_EU 4
 #endif
+#define CJ_L2_ATTR __attribute__((amdgpu_waves_per_eu(CJ_L2_WAVES_PER_EU, CJ_L2_WAVES_PER_EU)))
 // kSlab (large.hip: ONE large stream): chunk c is the 64 KiB slab c of the stream's OUTPUT.  Its records are cut from the
 // stream's absolute sync points (frames[c] = {first sync index, stream position of that sync point}; n_frames = stream
 // length): sequences that begin before the slab or end after it are clipped, and the part of a match whose source lies
@@ -647,7 +666,19 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             const uint4* src = reinterpret_cast<const uint4*>(in - mis);
             uint4* dst = reinterpret_cast<uint4*>(s_out);
             const uint32_t nvec = staged ? (mis + iend + 15u) >> 4 : 0u;
-            for (uint32_t i = tid; i < nvec; i += kL2Threads) dst[i] = src[i];
+            // five loads in flight per thread (a 40 KiB chunk is 5 x 512 vectors): written as one load and one store per
+            // iteration the compiler waits for every load before the next one — five dependent round trips per chunk
+            for (uint32_t i0 = tid; i0 < nvec; i0 += 5u * kL2Threads) {
+                const uint32_t last = nvec - 1u;
+                const uint32_t i1 = i0 + kL2Threads, i2 = i0 + 2u * kL2Threads, i3 = i0 + 3u * kL2Threads, i4 = i0 + 4u * kL2Threads;
+                const uint4 v0 = src[i0], v1 = src[i1 < last ? i1 : last], v2 = src[i2 < last ? i2 : last],
+                            v3 = src[i3 < last ? i3 : last], v4 = src[i4 < last ? i4 : last];
+                dst[i0] = v0;
+                if (i1 < nvec) dst[i1] = v1;
+                if (i2 < nvec) dst[i2] = v2;
+                if (i3 < nvec) dst[i3] = v3;
+                if (i4 < nvec) dst[i4] = v4;
+            }
         }
         __syncthreads();
         CJ_PHASE_MARK(0);
@@ -941,10 +972,10 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 const uint32_t tier = wave_tier(step, step > 0u);
                 if (step > 0u) {
                     const uint8_t* g = in + src;
-                    if (src + 4u * (tier / 4u + 2u) <= safe_end) {      // the vector loads stay inside the chunk's last granule
-                        if (tier <= 16u) lds_store_tier<16>(gl_ld_vec<6>(g), a_out + dst, 0u, step, dm);
-                        else if (tier <= 32u) lds_store_tier<32>(gl_ld_vec<10>(g), a_out + dst, 0u, step, dm);
-                        else lds_store_tier<64>(gl_ld_vec<18>(g), a_out + dst, 0u, step, dm);
+                    if (src + tier <= safe_end) {                       // the vector loads stay inside the chunk's last granule
+                        if (tier <= 16u) lds_store_tier<16>(gl_ld_exact<16>(g), a_out + dst, 0u, step, dm);
+                        else if (tier <= 32u) lds_store_tier<32>(gl_ld_exact<32>(g), a_out + dst, 0u, step, dm);
+                        else lds_store_tier<64>(gl_ld_exact<64>(g), a_out + dst, 0u, step, dm);
                     } else {                                            // last few sequences of the chunk: clamped dwords
                         const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(g) & 3u);
                         const uint8_t* ga = g - sh;
@@ -1003,7 +1034,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                     while (ballot64(n > 0u)) {                 // <=16 bytes per pass (register budget: this sits inside D3's loop; 32-byte
                         const uint32_t step = n < 16u ? n : 16u;   // passes measured no faster); the output buffer is padded, over-reads are harmless
                         if (step > 0u) {
-                            lds_store_tier<16>(gl_ld_vec<6>(g), a_out + dst, 0u, step, dm);
+                            lds_store_tier<16>(gl_ld_exact<16>(g), a_out + dst, 0u, step, dm);
                             bits_set(s_bits, dst, dst + step);
                             n -= step; g += step; dst += step;
                         }

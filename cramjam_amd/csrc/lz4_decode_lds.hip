@@ -134,6 +134,39 @@ __device__ __forceinline__ void lds_copy_tier(uint32_t tier, uint32_t dst, uint3
     else lds_store_tier<64>(lds_ld_aligned18(sa), dst, sh, n, dm);
 }
 
+// ---- sparse exact copy (D3) --------------------------------------------------------------------------------
+// D3 copies with a handful of lanes active: the matches that became ready in this poll.  gfx950 executes LDS accesses at any
+// byte alignment for about one extra cycle per ACTIVE misaligned lane (tools/lds_unaligned_probe.hip: +64 cycles with 64
+// lanes, +16 with 16, +4 with 4), so there a copy of m <= 32 bytes is the first and the last 8 (16, 4) bytes of the match —
+// overlapping in the middle — read and stored at their exact addresses: 2-4 reads and 2-4 stores instead of the 6-10 aligned
+// dword reads, byte shifts and 10-14 head / dword / tail stores of lds_store_tier (which is built for 64 active lanes, D2).
+// [src, src + m) is final and does not overlap [dst, dst + m); up to 7 bytes past the source may be read (never stored).
+__device__ __forceinline__ void lds_copy_sparse(uint32_t dst, uint32_t src, uint32_t m) {
+    if (m > 16u) {
+        uint64_t r0, r1, r2, r3;
+        const uint32_t s2 = src + m - 16u, d2 = dst + m - 16u;
+        asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %5\n\tds_read_b64 %3, %5 offset:8\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(src), "v"(s2) : "memory");
+        asm volatile("ds_write_b64 %0, %2\n\tds_write_b64 %0, %3 offset:8\n\tds_write_b64 %1, %4\n\tds_write_b64 %1, %5 offset:8"
+                     :: "v"(dst), "v"(d2), "v"(r0), "v"(r1), "v"(r2), "v"(r3) : "memory");
+    } else if (m >= 8u) {
+        uint64_t r0, r1;
+        const uint32_t s2 = src + m - 8u, d2 = dst + m - 8u;
+        asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r0), "=&v"(r1) : "v"(src), "v"(s2) : "memory");
+        asm volatile("ds_write_b64 %0, %2\n\tds_write_b64 %1, %3" :: "v"(dst), "v"(d2), "v"(r0), "v"(r1) : "memory");
+    } else if (m >= 4u) {
+        uint64_t r0;
+        asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r0) : "v"(src) : "memory");
+        const uint32_t lo = (uint32_t)r0, hi = (uint32_t)(r0 >> (8u * (m - 4u)));
+        asm volatile("ds_write_b32 %0, %2\n\tds_write_b32 %1, %3" :: "v"(dst), "v"(dst + m - 4u), "v"(lo), "v"(hi) : "memory");
+    } else {                                               // 1..3 bytes (Snappy copies)
+        uint32_t r;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(src) : "memory");
+        if (m & 2u) asm volatile("ds_write_b16 %0, %1" :: "v"(dst), "v"(r) : "memory");
+        if (m & 1u) asm volatile("ds_write_b8 %0, %1" :: "v"(dst + (m & 2u)), "v"(r >> (8u * (m & 2u))) : "memory");
+    }
+}
+
 __device__ __forceinline__ uint32_t wave_tier(uint32_t n, bool active) {       // wave-uniform tier for the active lanes
     if (ballot64(active && n > 32u)) return 64u;
     if (ballot64(active && n > 16u)) return 32u;
@@ -1115,10 +1148,8 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 }
                 const uint64_t rm = ballot64(ready);
                 if (rm != 0ull) {
-                    const uint32_t tier = ballot64(ready && m > 16u) ? 32u : 16u;
                     if (ready) {
-                        if (tier == 16u) lds_store_tier<16>(lds_ld_aligned6(asrc & ~3u), a_out + dst, asrc & 3u, m, dm);
-                        else lds_store_tier<32>(lds_ld_aligned10(asrc & ~3u), a_out + dst, asrc & 3u, m, dm);
+                        lds_copy_sparse(a_out + dst, asrc, m);
                         asm volatile("ds_or_b32 %0, %1\n\tds_or_b32 %0, %2 offset:4" :: "v"(qa), "v"(qm0), "v"(qm1) : "memory");
                         pending = false;
                     }

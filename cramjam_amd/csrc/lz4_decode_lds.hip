@@ -695,6 +695,8 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         //      reads are LDS reads; D2 re-reads the literal bytes from global memory (L2 hits) because it overwrites
         //      the window while other lanes still need their sources ----
         const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(in) & 15u);
+        // this thread's first sync point (D1) is requested together with the chunk's bytes: one round trip instead of two
+        const uint2 p_first = csync[tid < nsp ? tid : 0u];
         {
             const uint4* src = reinterpret_cast<const uint4*>(in - mis);
             uint4* dst = reinterpret_cast<uint4*>(s_out);
@@ -728,7 +730,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             const auto rd = [&](uint32_t p) { return staged ? lds_ld32(a_in + p) : ld32u(in + p); };
             uint4* cross = sl.cross + (size_t)blockIdx.x * sl.cross_stride;
             for (uint32_t sp = tid; sp < nsp; sp += kL2Threads) {
-                const uint2 p = csync[sp];
+                const uint2 p = sp == tid ? p_first : csync[sp];
                 uint32_t ip = p.x - in_lo;
                 int64_t op = (int64_t)(uint64_t)p.y - op_bias;          // may be negative: the group starts before the slab
                 uint32_t sq = sp * kSyncEvery, near = 0;
@@ -782,7 +784,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             // Snappy: a record = optional literal element + optional copy element (snappy_records.hpp)
             const auto rd = [a_in](uint32_t p) { return lds_ld32(a_in + p); };
             for (uint32_t sp = tid; sp < nsp; sp += kL2Threads) {
-                const uint2 p = csync[sp];
+                const uint2 p = sp == tid ? p_first : csync[sp];
                 uint32_t ip = p.x, op = p.y;
                 uint32_t s = sp * kSyncEvery;
                 uint32_t near = 0;
@@ -796,7 +798,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             }
         } else
         for (uint32_t sp = tid; sp < nsp; sp += kL2Threads) {
-            const uint2 p = csync[sp];
+            const uint2 p = sp == tid ? p_first : csync[sp];
             uint32_t ip = p.x, op = p.y;
             uint32_t s = sp * kSyncEvery, near = 0;
             for (uint32_t j = 0; j < kSyncEvery && s < nseq; j++, s++) {

@@ -991,7 +991,10 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         for (uint32_t base = wave * 64u; base < nrec_all; base += kL2Threads) {
             const uint4 rec = rec_nx;
             rec_nx = make_uint4(0, 0, 0, 0);
-            if (base + kL2Threads + lane < nrec_all) rec_nx = table[base + kL2Threads + lane];
+            {   // the wave's last batch requests its FIRST batch again: D3 starts on it without another round trip
+                const uint32_t nb = base + kL2Threads < nrec_all ? base + kL2Threads : wave * 64u;
+                if (nb + lane < nrec_all) rec_nx = table[nb + lane];
+            }
             uint32_t n = rec.y, src = rec.x, dst = rec.z - rec.y;
             uint64_t lm = ballot64(n >= kLongRun);
             while (lm) {
@@ -1096,8 +1099,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         uint32_t ndef = 0, dpos = 0;
         bool pass2 = false;
         if constexpr (kSlab) dlist = sl.defer + (size_t)blockIdx.x * sl.defer_stride + (size_t)wave * (sl.defer_stride / 8u);
-        rec_nx = make_uint4(0, 0, 0, 0);
-        if (wave * 64u + lane < nrec_all) rec_nx = table[wave * 64u + lane];
+        // rec_nx = the wave's first batch (requested by D2's last iteration, or by D2's prologue if the wave has no batch)
         for (uint32_t base = wave * 64u;; base += kL2Threads) {
             uint4 rec;
             uint32_t ridx = base + lane;

@@ -618,6 +618,11 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             if (c >= a.n_chunks) break;
         }
         const ParseMeta pm = meta[c];
+        // the chunk's descriptors in ONE round trip: left to itself the compiler waits for pm.nseq (the early-out below) before it
+        // even requests the others, and the chunk's bytes are a third dependent round trip behind those
+        const uint64_t d_in_off = a.in_off[c], d_in_len = a.in_len[c], d_out_off = a.out_off[c];
+        const uint64_t d_result = (uint64_t)a.result[c];
+        asm volatile("" :: "v"(pm.nseq), "v"(pm.in_skip), "v"((uint32_t)d_in_off), "v"((uint32_t)d_in_len), "v"((uint32_t)d_out_off), "v"((uint32_t)d_result));
         // kSlab: does this chunk have a predecessor whose completion it may have to wait for?  (large streams: out_cap[c] holds the
         // slab's first output position IN ITS STREAM — several streams may share one launch; linked frames: block 0 has none)
         const bool has_prev = kSlab && (sl.rel ? c > 0u : a.out_cap[c] != 0ull);
@@ -678,16 +683,16 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         }
         if (pm.nseq == 0u) { publish(); continue; }          // error, empty, or routed to another kernel
         const uint32_t nseq = pm.nseq;
-        const uint32_t U = (uint32_t)a.result[c];            // decoded size, 1..65536
+        const uint32_t U = (uint32_t)d_result;               // decoded size, 1..65536
         const bool slab_meta = kSlab && !sl.rel;            // large streams: meta[c].in_skip = the stream's end relative to this slab's input
         const uint32_t in_skip = slab_meta ? 0u : pm.in_skip;
-        const uint8_t* in = a.in_base + a.in_off[c] + in_skip;
-        const uint32_t iend = (uint32_t)a.in_len[c] - in_skip;
+        const uint8_t* in = a.in_base + d_in_off + in_skip;
+        const uint32_t iend = (uint32_t)d_in_len - in_skip;
         const uint8_t* in_al = in - (reinterpret_cast<uintptr_t>(in) & 3u);
         const uint8_t* last_dw = in_al + ((((uint32_t)(reinterpret_cast<uintptr_t>(in) & 3u)) + iend - 1u) & ~3u);
         // offset (relative to in) up to which reads are safe: the end of the 16 B granule holding the last input byte
         const uint32_t safe_end = ((((uint32_t)(reinterpret_cast<uintptr_t>(in) & 15u)) + iend + 15u) & ~15u) - (uint32_t)(reinterpret_cast<uintptr_t>(in) & 15u);
-        uint8_t* out = a.out_base + a.out_off[c];
+        uint8_t* out = a.out_base + d_out_off;
         const uint2* csync = kSlab ? sync + frames[c].x : sync + (size_t)c * kSyncPitch;
         const uint32_t nsp = (nseq + kSyncEvery - 1u) / kSyncEvery;
         const bool staged = !kSlab || iend <= kLdsInMax;   // kSlab: a slab inside a long literal run may span more input than the window holds
@@ -702,18 +707,22 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             uint4* dst = reinterpret_cast<uint4*>(s_out);
             const uint32_t nvec = staged ? (mis + iend + 15u) >> 4 : 0u;
             // five loads in flight per thread (a 40 KiB chunk is 5 x 512 vectors): written as one load and one store per
-            // iteration the compiler waits for every load before the next one — five dependent round trips per chunk
-            for (uint32_t i0 = tid; i0 < nvec; i0 += 5u * kL2Threads) {
+            // iteration the compiler waits for every load before the next one — five dependent round trips per chunk.  The
+            // first group is straight-line code (a loop header would make the compiler wait for the sync point requested
+            // above before it issues the group's loads); longer chunks continue in the loop.
+            const auto group = [&](uint32_t i0) {
                 const uint32_t last = nvec - 1u;
                 const uint32_t i1 = i0 + kL2Threads, i2 = i0 + 2u * kL2Threads, i3 = i0 + 3u * kL2Threads, i4 = i0 + 4u * kL2Threads;
-                const uint4 v0 = src[i0], v1 = src[i1 < last ? i1 : last], v2 = src[i2 < last ? i2 : last],
+                const uint4 v0 = src[i0 < last ? i0 : last], v1 = src[i1 < last ? i1 : last], v2 = src[i2 < last ? i2 : last],
                             v3 = src[i3 < last ? i3 : last], v4 = src[i4 < last ? i4 : last];
-                dst[i0] = v0;
+                if (i0 < nvec) dst[i0] = v0;
                 if (i1 < nvec) dst[i1] = v1;
                 if (i2 < nvec) dst[i2] = v2;
                 if (i3 < nvec) dst[i3] = v3;
                 if (i4 < nvec) dst[i4] = v4;
-            }
+            };
+            if (nvec > 0u) group(tid);
+            for (uint32_t i0 = tid + 5u * kL2Threads; i0 < nvec; i0 += 5u * kL2Threads) group(i0);
         }
         __syncthreads();
         CJ_PHASE_MARK(0);

@@ -588,6 +588,10 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
     const bool prof = (a.flags & 0x1000u) != 0;
     unsigned long long t_prev = prof ? __builtin_readcyclecounter() : 0ull;
     uint32_t fr_first = 0, fr_n = 0, fr_k = 0;               // kLinked: current frame and position in it
+    // batches: thread 0 claims the NEXT chunk right after the current one is known, so the atomic's round trip runs under the
+    // descriptor loads instead of in front of them (slabs are claimed when they are started: their order matters)
+    uint32_t next_c = 0;
+    if constexpr (!kLinked && !kSlab) { if (tid == 0) next_c = atomicAdd(counter, 1u); }
 
     for (;;) {
         uint32_t c;
@@ -610,12 +614,13 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             for (uint32_t i = tid; i < 2048u; i += kL2Threads) s_bits[i] = 0u;
             __syncthreads();                                 // also: the previous block's D4 has finished reading its window
         } else {
-            if (tid == 0) { *s_chunk = atomicAdd(counter, 1u); *s_fail = 0u; *s_ncross = 0u; *s_nextra = 0u; *s_small = 0u; *s_prevok = 0u; }
+            if (tid == 0) { *s_chunk = kSlab ? atomicAdd(counter, 1u) : next_c; *s_fail = 0u; *s_ncross = 0u; *s_nextra = 0u; *s_small = 0u; *s_prevok = 0u; }
             for (uint32_t i = tid; i < 2048u; i += kL2Threads) s_bits[i] = 0u;
             __syncthreads();
             c = *s_chunk;
             __syncthreads();                                 // everyone has read s_chunk before thread 0 can overwrite it
             if (c >= a.n_chunks) break;
+            if constexpr (!kSlab) { if (tid == 0) next_c = atomicAdd(counter, 1u); }
         }
         const ParseMeta pm = meta[c];
         // the chunk's descriptors in ONE round trip: left to itself the compiler waits for pm.nseq (the early-out below) before it

@@ -27,7 +27,12 @@ struct LaneStream {
                          : "=&v"(w0), "=&v"(w1) : "v"(a0), "v"(a1) : "memory");
             return __builtin_amdgcn_alignbyte(w1, w0, p & 3u);
         }
-        return ld_le_tail(base, p, end);                                // outside the window (long literal run, stream tail)
+        // outside the window (long literal run, stream tail): a global read.  It waits for its own data here, inside the branch:
+        // otherwise the compiler puts a vmcnt(0) wait on the common path after the branch, where it also waits for the sync point
+        // store of the step (vmcnt counts stores) — a store round trip every eighth step for nothing.
+        const uint32_t v = ld_le_tail(base, p, end);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0) only
+        return v;
     }
     __device__ __forceinline__ uint32_t ld8(uint32_t p) const { return ld32(p) & 0xffu; }
 };

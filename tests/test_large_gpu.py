@@ -370,7 +370,7 @@ def test_lz4_frames_with_large_independent_blocks(bs_code):
 def test_mutation_fuzz_of_large_streams():
     """tests/perf/fuzz_large.py (bit flips, 0xFF runs, truncation, insertions, swapped words on four data shapes): every
     verdict and every accepted byte equals the oracle's; the same for LZ4 frames and Snappy framing.  120 000 raw and
-    80 000 framed cases of it ran clean in round 1 (profiles/r01/v11_fuzz_large.txt)."""
+    80 000 framed cases of it ran clean in round 1 (profiles/r01/fuzz_and_stress.txt)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("fuzz_large", os.path.join(os.path.dirname(__file__), "perf", "fuzz_large.py"))
     mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)

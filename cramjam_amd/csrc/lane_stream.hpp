@@ -35,6 +35,16 @@ struct LaneStream {
         return v;
     }
     __device__ __forceinline__ uint32_t ld8(uint32_t p) const { return ld32(p) & 0xffu; }
+    // the straight-line form for the parse kernels' common case: is [p, p + 4) cached, and the 4 bytes at p read from the ring
+    // whether or not it is (the address never leaves the lane's ring; the value only means something if in_window(p))
+    __device__ __forceinline__ bool in_window(uint32_t p) const { return p >= lo && p + 4u <= hi && p + 4u <= end; }
+    __device__ __forceinline__ uint32_t ring32(uint32_t p) const {
+        const uint32_t a0 = ring + (p & (kRingBytes - 4u)), a1 = ring + ((p + 4u) & (kRingBytes - 4u));
+        uint32_t w0, w1;
+        asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(w0), "=&v"(w1) : "v"(a0), "v"(a1) : "memory");
+        return __builtin_amdgcn_alignbyte(w1, w0, p & 3u);
+    }
 };
 
 // One wave-convergent refill round: every lane that has room fetches its next 128 B line (8 lanes per line,

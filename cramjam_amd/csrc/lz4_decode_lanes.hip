@@ -103,6 +103,33 @@ __global__ __launch_bounds__(64 * kParseWaves) void lz4_parse_kernel(BatchArgs a
                 if (slot < kSyncStride) csync[slot] = make_uint2(ip - mis, op);
             }
             nseq += 1;
+        }
+        // ---- the common case as straight-line code: token and offset both in the line cache, length extensions of at most one
+        //      byte, not near the end of the block, match valid.  Nothing is committed unless all of that holds; every other
+        //      sequence (and every error) takes the general walk below from the same state.  The general walk alone is ~235
+        //      instructions per step, half of them scalar mask bookkeeping for its ~30 conditional blocks, and the kernel is
+        //      bound by exactly that ----
+        bool fast_ok = false;
+        if (!done) {
+            const uint32_t t4 = st.ring32(ip);
+            const uint32_t token = t4 & 0xffu, e1 = (t4 >> 8) & 0xffu;
+            const bool x1 = (token >> 4) == 15u;
+            const uint32_t lit = (token >> 4) + (x1 ? e1 : 0u);
+            const uint32_t ip1 = ip + 1u + (x1 ? 1u : 0u), ip2 = ip1 + lit;
+            const bool w1 = st.in_window(ip), w2 = ip2 + 4u <= st.hi && ip2 + 4u <= iend;
+            const uint32_t o4 = st.ring32(ip2);
+            const uint32_t offset = o4 & 0xffffu, mc = token & 15u, e2 = (o4 >> 16) & 0xffu;
+            const bool x2 = mc == 15u;
+            const uint32_t mlen = mc + (x2 ? e2 : 0u) + 4u;
+            const uint32_t ip3 = ip2 + 2u + (x2 ? 1u : 0u);
+            const uint32_t op2 = op + lit;
+            // rem_in >= lit + 8 implies every bound the general walk checks while it reads one-byte extensions
+            fast_ok = w1 && w2 && !(x1 && e1 == 255u) && !(x2 && e2 == 255u)
+                      && cap - op >= lit + 12u && iend - ip1 >= lit + 8u
+                      && offset != 0u && offset <= op2 + hist && cap - op2 >= mlen + 5u;
+            if (fast_ok) { ip = ip3; op = op2 + mlen; }
+        }
+        if (!done && !fast_ok) {
             bool bad = false, last = false;
             const uint32_t t4 = st.ld32(ip);
             const uint32_t token = t4 & 0xffu;

@@ -234,6 +234,10 @@ void launch_snappy_decode_lanes(const BatchArgs& a, const void* lists, uint32_t 
 // kSyncEvery records for the workgroup-per-chunk LDS decoder; chunks that decoder cannot take (capacity or input
 // too large, too few / too many records) are flagged kRouteWave for the wave kernel.
 // ---------------------------------------------------------------------------------------------------
+#ifndef CJ_SN_PARSE_AHEAD
+#define CJ_SN_PARSE_AHEAD 32u
+#endif
+constexpr uint32_t kSnParseAhead = CJ_SN_PARSE_AHEAD;   // cached bytes a lane must have ahead of its position before a step (24: 2.78 ms, 32: 2.79, 40: 2.83, 48: 2.89)
 __global__ __launch_bounds__(64 * kParseWaves) void snappy_parse_kernel(BatchArgs a, uint2* sync, ParseMeta* meta) {
     __shared__ __attribute__((aligned(16))) uint8_t rings[kParseWaves * 64 * kRingStride];
     const uint32_t c = blockIdx.x * (64u * kParseWaves) + threadIdx.x;
@@ -289,7 +293,7 @@ __global__ __launch_bounds__(64 * kParseWaves) void snappy_parse_kernel(BatchArg
         if (!done && ip >= st.hi) st.lo = st.hi = ip & ~127u;      // jumped past the window (long literal): re-anchor
         for (;;) {
             const bool want = !done && st.hi < iend && (st.hi - st.lo < kRingBytes || ip >= st.lo + 128u);
-            const bool urgent = want && ip + 48u > st.hi;
+            const bool urgent = want && ip + kSnParseAhead > st.hi;
             if (ballot64(urgent) == 0ull) break;
             refill_round(st, want, wave_ring, plan);
         }

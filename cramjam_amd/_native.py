@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcramjam_hip.so")
+LIB_PATH = os.environ.get("CJ_HIP_LIB") or os.path.join(_HERE, "libcramjam_hip.so")   # CJ_HIP_LIB: a tuning variant (tools/build_variant.sh)
 
 CODEC_LZ4_BLOCK, CODEC_SNAPPY_RAW = 0, 1
 OP_DECOMPRESS, OP_COMPRESS = 0, 1

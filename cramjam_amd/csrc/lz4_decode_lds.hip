@@ -54,6 +54,13 @@ __device__ __forceinline__ uint32_t lds_ld32(uint32_t a) {
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
     return v;
 }
+// 4 bytes at ANY byte address through two ALIGNED dwords + v_alignbyte: an unaligned ds_read is replayed once per active lane
+// (~64 LDS cycles per wave-instruction with a full wave), this pair costs 4 when conflict-free.  D1 walks the token chain with it.
+__device__ __forceinline__ uint32_t lds_ld32a(uint32_t a) {
+    uint64_t v;
+    asm volatile("ds_read2_b32 %0, %1 offset1:1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a & ~3u) : "memory");
+    return __builtin_amdgcn_alignbyte((uint32_t)(v >> 32), (uint32_t)v, a & 3u);
+}
 __device__ __forceinline__ uint2 lds_ld64(uint32_t a) {
     uint2 v;
     asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:4\n\ts_waitcnt lgkmcnt(0)"
@@ -741,7 +748,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             const uint32_t s_iend = sl.rel ? iend : pm.in_skip;           // the stream's end, relative to this slab's input
             const uint64_t S = a.out_off[c];
             const int64_t op_bias = sl.rel ? 0 : (int64_t)a.out_cap[c];   // the stream's sync points count output from the stream's start; S is the slab's place in the output BUFFER
-            const auto rd = [&](uint32_t p) { return staged ? lds_ld32(a_in + p) : ld32u(in + p); };
+            const auto rd = [&](uint32_t p) { return staged ? lds_ld32a(a_in + p) : ld32u(in + p); };
             uint4* cross = sl.cross + (size_t)blockIdx.x * sl.cross_stride;
             for (uint32_t sp = tid; sp < nsp; sp += kL2Threads) {
                 const uint2 p = sp == tid ? p_first : csync[sp];
@@ -796,7 +803,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         } else
         if constexpr (kCodec == CJ_CODEC_SNAPPY_RAW) {
             // Snappy: a record = optional literal element + optional copy element (snappy_records.hpp)
-            const auto rd = [a_in](uint32_t p) { return lds_ld32(a_in + p); };
+            const auto rd = [a_in](uint32_t p) { return lds_ld32a(a_in + p); };
             for (uint32_t sp = tid; sp < nsp; sp += kL2Threads) {
                 const uint2 p = sp == tid ? p_first : csync[sp];
                 uint32_t ip = p.x, op = p.y;
@@ -816,7 +823,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             uint32_t ip = p.x, op = p.y;
             uint32_t s = sp * kSyncEvery, near = 0;
             for (uint32_t j = 0; j < kSyncEvery && s < nseq; j++, s++) {
-                const uint32_t t4 = lds_ld32(a_in + ip);           // token + 3 following bytes (may over-read: harmless)
+                const uint32_t t4 = lds_ld32a(a_in + ip);           // token + 3 following bytes (may over-read: harmless)
                 const uint32_t token = t4 & 0xffu;
                 ip += 1;
                 uint32_t lit = token >> 4;
@@ -829,7 +836,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 ip += lit; op += lit;
                 uint32_t w = 0, mlen = 0;
                 if (s + 1u < nseq) {
-                    const uint32_t o4 = lds_ld32(a_in + ip);
+                    const uint32_t o4 = lds_ld32a(a_in + ip);
                     const uint32_t offset = o4 & 0xffffu;
                     ip += 2;
                     mlen = token & 15u;
@@ -1113,6 +1120,150 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         uint32_t ndef = 0, dpos = 0;
         bool pass2 = false;
         if constexpr (kSlab) dlist = sl.defer + (size_t)blockIdx.x * sl.defer_stride + (size_t)wave * (sl.defer_stride / 8u);
+        // ---- D3, batches of independent chunks: the poll step as ONE hand-scheduled block.  The resolver is bound by how long a
+        //      trip round the poll loop takes (the dependency chain is 21-33 levels deep on the benchmark data and every level
+        //      costs a producer's publish + a consumer's poll + its copy), and the loop below this one compiles to ~100
+        //      instructions per trip, most of them mask bookkeeping.  Here a trip is: bitmap words of the waiting lanes (exec =
+        //      waiting), ready test (two v_bfi + v_or + v_cmpx), and for the ready lanes the copy as first + last 8 (4) bytes at
+        //      their exact addresses — few lanes are active, and gfx950 charges a misaligned DS access per ACTIVE lane —, the
+        //      publish (two ds_or) and the mask update: ~12 instructions when nothing is ready, ~35 with copies.
+        //      Lanes outside the fast shape (longer than 32 bytes, self-overlapping, 1-3 bytes) keep the general path.
+        if constexpr (!kSlab && !kLinked) {
+            for (uint32_t base = wave * 64u; base < nrec_all; base += kL2Threads) {
+                const uint4 rec = rec_nx;
+                rec_nx = make_uint4(0, 0, 0, 0);
+                if (base + kL2Threads + lane < nrec_all) rec_nx = table[base + kL2Threads + lane];
+                const uint32_t dst = rec.z, off = rec.w & 0xffffu, m = rec.w >> 16;
+                const uint32_t src = dst - off;
+                const uint32_t need = off < m ? off : m;
+                bool pending = m > 0u;
+                const bool fast = pending && m >= 4u && m <= 32u && off >= m;
+                uint32_t pa = 0, pm0 = 0, pm1 = 0, qa = 0, qm0 = 0, qm1 = 0;
+                if (fast) {
+                    const uint32_t sh = src & 31u, e = sh + need;
+                    pa = (uint32_t)(uintptr_t)(s_bits + (src >> 5));
+                    pm0 = (e >= 32u ? ~0u : ((1u << e) - 1u)) & (~0u << sh);
+                    pm1 = e > 32u ? ((1u << (e - 32u)) - 1u) : 0u;
+                    const uint32_t dh = dst & 31u, de = dh + m;
+                    qa = (uint32_t)(uintptr_t)(s_bits + (dst >> 5));
+                    qm0 = (de >= 32u ? ~0u : ((1u << de) - 1u)) & (~0u << dh);
+                    qm1 = de > 32u ? ((1u << (de - 32u)) - 1u) : 0u;
+                }
+                // copy plan: pieces at [0] and [m - 8] (m >= 8; 8 bytes each), or [0] and [m - 4] (m < 8; 4 bytes each); m > 16: also [8], [m - 16]
+                const uint32_t as0 = a_out + src, ad0 = a_out + dst;
+                const uint32_t o1 = m >= 8u ? m - 8u : m - 4u, o3 = m > 16u ? m - 16u : 0u;
+                const uint32_t as1 = as0 + o1, ad1 = ad0 + o1, as3 = as0 + o3, ad3 = ad0 + o3;
+                uint64_t mp = ballot64(fast);                                  // fast lanes still waiting
+                const uint64_t mA = ballot64(fast && m > 16u), mB = ballot64(fast && m >= 8u), mC = ballot64(fast && m < 8u);
+                const bool any_slow = ballot64(pending && !fast) != 0ull;
+                bool spend = pending && !fast;
+                uint32_t spins = 0;
+                while (mp != 0ull || (any_slow && ballot64(spend) != 0ull)) {
+                    if (mp != 0ull) {
+                        uint32_t w0, w1, t0, t1, c0, c1;
+                        uint64_t r0, r1, r2, r3, sv, sr, st;
+                        asm volatile(
+                            "s_mov_b64 %[sv], exec\n\t"
+                            "s_mov_b64 exec, %[mp]\n\t"
+                            "ds_read_b32 %[w0], %[pa]\n\t"
+                            "ds_read_b32 %[w1], %[pa] offset:4\n\t"
+                            "s_waitcnt lgkmcnt(0)\n\t"
+                            "v_bfi_b32 %[t0], %[w0], 0, %[pm0]\n\t"              // pm0 & ~w0: needed bits that are not set yet
+                            "v_bfi_b32 %[t1], %[w1], 0, %[pm1]\n\t"
+                            "v_or_b32 %[t0], %[t0], %[t1]\n\t"
+                            "v_cmpx_eq_u32 0, %[t0]\n\t"                         // exec = ready lanes
+                            "s_cbranch_execz 1f\n\t"
+                            "s_mov_b64 %[sr], exec\n\t"
+                            "s_and_b64 exec, %[sr], %[mB]\n\t"                   // 8..32 bytes: first and last 8
+                            "ds_read_b64 %[r0], %[as0]\n\t"
+                            "ds_read_b64 %[r1], %[as1]\n\t"
+                            "s_and_b64 exec, %[sr], %[mA]\n\t"                   // 17..32: the two middle pieces
+                            "ds_read_b64 %[r2], %[as0] offset:8\n\t"
+                            "ds_read_b64 %[r3], %[as3]\n\t"
+                            "s_and_b64 exec, %[sr], %[mC]\n\t"                   // 4..7 bytes: first and last 4
+                            "ds_read_b32 %[c0], %[as0]\n\t"
+                            "ds_read_b32 %[c1], %[as1]\n\t"
+                            "s_waitcnt lgkmcnt(0)\n\t"
+                            "ds_write_b32 %[ad0], %[c0]\n\t"
+                            "ds_write_b32 %[ad1], %[c1]\n\t"
+                            "s_and_b64 exec, %[sr], %[mA]\n\t"
+                            "ds_write_b64 %[ad0], %[r2] offset:8\n\t"
+                            "ds_write_b64 %[ad3], %[r3]\n\t"
+                            "s_and_b64 exec, %[sr], %[mB]\n\t"
+                            "ds_write_b64 %[ad0], %[r0]\n\t"
+                            "ds_write_b64 %[ad1], %[r1]\n\t"
+                            "s_mov_b64 exec, %[sr]\n\t"
+                            "ds_or_b32 %[qa], %[qm0]\n\t"                        // publish: behind the copy's writes in the wave's DS queue
+                            "ds_or_b32 %[qa], %[qm1] offset:4\n\t"
+                            "s_andn2_b64 %[mp], %[mp], %[sr]\n"
+                            "1:\n\t"
+                            "s_mov_b64 exec, %[sv]"
+                            : [mp] "+s"(mp), [sv] "=&s"(sv), [sr] "=&s"(sr), [st] "=&s"(st), [w0] "=&v"(w0), [w1] "=&v"(w1), [t0] "=&v"(t0), [t1] "=&v"(t1),
+                              [c0] "=&v"(c0), [c1] "=&v"(c1), [r0] "=&v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3)
+                            : [pa] "v"(pa), [pm0] "v"(pm0), [pm1] "v"(pm1), [qa] "v"(qa), [qm0] "v"(qm0), [qm1] "v"(qm1),
+                              [as0] "v"(as0), [as1] "v"(as1), [as3] "v"(as3), [ad0] "v"(ad0), [ad1] "v"(ad1), [ad3] "v"(ad3),
+                              [mA] "s"(mA), [mB] "s"(mB), [mC] "s"(mC)
+                            : "memory", "vcc", "scc");
+                    }
+                    if (any_slow) {
+                        bool sready = false;
+                        if (spend) sready = bits_ready(s_bits, src, src + need);
+                        if (sready && m <= 64u && off >= m && m >= 4u) {
+                            lds_store_tier<64>(lds_ld_aligned18(as0 & ~3u), ad0, as0 & 3u, m, dm);
+                            bits_set(s_bits, dst, dst + m);
+                            spend = false;
+                        } else if (sready && m < kLongRun) {
+                            const uint8_t* sp = s_out + src;
+                            if (off >= 8u) {
+                                uint32_t k = 0;
+                                for (; k + 8u <= m; k += 8u) {
+                                    uint8_t t[8];
+#pragma unroll
+                                    for (int q = 0; q < 8; q++) t[q] = sp[k + q];
+#pragma unroll
+                                    for (int q = 0; q < 8; q++) s_out[dst + k + q] = t[q];
+                                }
+                                for (; k < m; k++) s_out[dst + k] = sp[k];
+                            } else {
+                                for (uint32_t k = 0; k < m; k++) s_out[dst + k] = sp[k];
+                            }
+                            bits_set(s_bits, dst, dst + m);
+                            spend = false;
+                        }
+                        uint64_t longm = ballot64(sready && m >= kLongRun);
+                        while (longm) {
+                            const uint32_t l = ctz64(longm);
+                            longm &= longm - 1ull;
+                            const uint32_t lmm = rdlane(m, l), lo = rdlane(off, l), ld = rdlane(dst, l);
+                            const uint8_t* sb = s_out + (ld - lo);
+                            if (lo == 1u || lo == 2u || lo == 4u) {
+                                const uint32_t h = (0u - ld) & 15u, hh = h < lmm ? h : lmm;
+                                if (lane < hh) s_out[ld + lane] = sb[lane % lo];
+                                uint32_t wv = 0;
+#pragma unroll
+                                for (uint32_t i = 0; i < 4u; i++) wv |= (uint32_t)sb[(hh + i) % lo] << (8u * i);
+                                const uint32_t nv = (lmm - hh) >> 4;
+                                uint4* dv = reinterpret_cast<uint4*>(s_out + ld + hh);
+                                for (uint32_t q = lane; q < nv; q += 64u) dv[q] = make_uint4(wv, wv, wv, wv);
+                                const uint32_t t0 = hh + (nv << 4);
+                                if (t0 + lane < lmm) s_out[ld + t0 + lane] = sb[(t0 + lane) % lo];
+                            } else {
+                                uint32_t rr = lane, step = 64u;
+                                if (lo <= 64u) { rr = lane % lo; step = 64u % lo; }
+                                for (uint32_t k = lane; k < lmm; k += 64u) {
+                                    s_out[ld + k] = sb[lo >= lmm ? k : rr];
+                                    rr += step;
+                                    if (rr >= lo) rr -= lo;
+                                }
+                            }
+                            wave_bits_set(s_bits, ld, ld + lmm);
+                            if (lane == l) spend = false;
+                        }
+                    }
+                    if (++spins > kSpinLimit) { *s_fail = 1u; break; }
+                }
+            }
+        } else
         // rec_nx = the wave's first batch (requested by D2's last iteration, or by D2's prologue if the wave has no batch)
         for (uint32_t base = wave * 64u;; base += kL2Threads) {
             uint4 rec;

@@ -55,6 +55,8 @@ def lib():
             ("cjo_lz4_frame_decompress", i64, [u8p, sz, u8p, sz]),
             ("cjo_synth_v1", None, [u8p, sz, C.c_uint64, C.c_uint64]),
             ("cjo_batch_run", C.c_int, [C.c_int, C.c_int, sz, u8p, u8p, u8p, u8p, sz, u8p]),
+            ("cjo_batch_run_reps", C.c_int, [C.c_int, C.c_int, C.c_int, sz, u8p, u8p, u8p, u8p, sz, u8p]),
+            ("cjo_have_liblz4", C.c_int, []),
         ]:
             f = getattr(L, name)
             f.restype, f.argtypes = res, args

@@ -8,9 +8,12 @@
  *    releases the GIL around each call, /root/reference/src/lz4.rs:84,126, src/snappy.rs:57,75,
  *    so a thread pool over chunks is the reference's best multi-core configuration).
  */
+#define _GNU_SOURCE
 #include "cj_oracle.h"
+#include <dlfcn.h>
 #include <pthread.h>
 #include <stdatomic.h>
+#include <stdlib.h>
 #include <string.h>
 
 static inline uint64_t splitmix64(uint64_t* s) {
@@ -43,40 +46,84 @@ void cjo_synth_v1(uint8_t* dst, size_t S, uint64_t index, uint64_t seed) {
     }
 }
 
+/* liblz4's own decoder, when the host has the library (same C code lineage the reference executes through lz4-sys):
+ * resolved once with dlopen, never linked.  op 4 below; -1 for every chunk when it is absent. */
+typedef int (*lz4_safe_fn)(const char*, char*, int, int);
+static lz4_safe_fn g_lz4_safe;
+static int g_lz4_tried;
+static lz4_safe_fn liblz4_decoder(void) {
+    if (!g_lz4_tried) {
+        static const char* names[] = { "liblz4.so.1", "/lib/x86_64-linux-gnu/liblz4.so.1", "/opt/conda/lib/liblz4.so.1", "liblz4.so" };
+        for (unsigned k = 0; k < sizeof names / sizeof names[0] && !g_lz4_safe; k++) {
+            void* h = dlopen(names[k], RTLD_NOW | RTLD_LOCAL);
+            if (h) g_lz4_safe = (lz4_safe_fn)dlsym(h, "LZ4_decompress_safe");
+        }
+        g_lz4_tried = 1;
+    }
+    return g_lz4_safe;
+}
+int cjo_have_liblz4(void) { return liblz4_decoder() != 0; }
+
+/* A pool that lives for the whole call: `reps` passes over the batch, the threads are created ONCE and meet at a barrier
+ * between passes (round 1 created and joined 255 threads per 33 ms pass and reported a tenth of what the cores can do). */
 typedef struct {
-    int op; size_t n; const uint8_t* in_base; const uint64_t* in_off; const uint64_t* in_len;
-    uint8_t* out_base; size_t out_stride; int64_t* res; atomic_size_t next;
+    int op, reps; size_t n; const uint8_t* in_base; const uint64_t* in_off; const uint64_t* in_len;
+    uint8_t* out_base; size_t out_stride; int64_t* res; atomic_size_t* next; pthread_barrier_t* bar; int use_bar;
 } job_t;
 
 static void* worker(void* p) {
     job_t* j = (job_t*)p;
-    for (;;) {
-        size_t i = atomic_fetch_add(&j->next, 16);
-        if (i >= j->n) break;
-        size_t e = i + 16 < j->n ? i + 16 : j->n;
-        for (; i < e; i++) {
-            const uint8_t* in = j->in_base + j->in_off[i];
-            uint8_t* out = j->out_base + i * j->out_stride;
-            size_t n = (size_t)j->in_len[i];
-            switch (j->op) {
-            case 0: j->res[i] = cjo_lz4_decompress_raw(in, n, out, j->out_stride); break;
-            case 1: j->res[i] = cjo_lz4_compress_raw(in, n, out, j->out_stride); break;
-            case 2: j->res[i] = cjo_snappy_decompress(in, n, out, j->out_stride); break;
-            default: j->res[i] = cjo_snappy_compress(in, n, out, j->out_stride); break;
+    lz4_safe_fn lz4 = j->op == 4 ? liblz4_decoder() : 0;
+    for (int r = 0; r < j->reps; r++) {
+        for (;;) {
+            size_t i = atomic_fetch_add(&j->next[r], 8);
+            if (i >= j->n) break;
+            size_t e = i + 8 < j->n ? i + 8 : j->n;
+            for (; i < e; i++) {
+                const uint8_t* in = j->in_base + j->in_off[i];
+                uint8_t* out = j->out_base + i * j->out_stride;
+                size_t n = (size_t)j->in_len[i];
+                switch (j->op) {
+                case 0: j->res[i] = cjo_lz4_decompress_raw(in, n, out, j->out_stride); break;
+                case 1: j->res[i] = cjo_lz4_compress_raw(in, n, out, j->out_stride); break;
+                case 2: j->res[i] = cjo_snappy_decompress(in, n, out, j->out_stride); break;
+                case 3: j->res[i] = cjo_snappy_compress(in, n, out, j->out_stride); break;
+                default: j->res[i] = lz4 ? lz4((const char*)in, (char*)out, (int)n, (int)j->out_stride) : -1; break;
+                }
             }
         }
+        if (j->use_bar) pthread_barrier_wait(j->bar);      /* pass r is complete before anyone overwrites its outputs */
     }
     return 0;
 }
 
+int cjo_batch_run_reps(int op, int threads, int reps, size_t n_chunks, const uint8_t* in_base, const uint64_t* in_off,
+                       const uint64_t* in_len, uint8_t* out_base, size_t out_stride, int64_t* res) {
+    if (threads < 1) threads = 1;
+    if (threads > 1024) threads = 1024;
+    if (reps < 1) reps = 1;
+    atomic_size_t* next = (atomic_size_t*)calloc((size_t)reps, sizeof(atomic_size_t));
+    pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
+    if (!next || !th) { free(next); free(th); return -1; }
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, 0, (unsigned)threads);
+    job_t j = { op, reps, n_chunks, in_base, in_off, in_len, out_base, out_stride, res, next, &bar, threads > 1 };
+    int started = 1;
+    for (int t = 1; t < threads; t++) {
+        if (pthread_create(&th[t], 0, worker, &j) != 0) break;
+        started++;
+    }
+    if (started != threads) {                 /* could not start the pool: the barrier would never open */
+        j.use_bar = 0; j.reps = 1;
+    }
+    worker(&j);
+    for (int t = 1; t < started; t++) pthread_join(th[t], 0);
+    pthread_barrier_destroy(&bar);
+    free(next); free(th);
+    return started == threads ? 0 : -2;
+}
+
 int cjo_batch_run(int op, int threads, size_t n_chunks, const uint8_t* in_base, const uint64_t* in_off,
                   const uint64_t* in_len, uint8_t* out_base, size_t out_stride, int64_t* res) {
-    job_t j = { op, n_chunks, in_base, in_off, in_len, out_base, out_stride, res, 0 };
-    if (threads < 1) threads = 1;
-    if (threads > 256) threads = 256;
-    pthread_t th[256];
-    for (int t = 1; t < threads; t++) pthread_create(&th[t], 0, worker, &j);
-    worker(&j);
-    for (int t = 1; t < threads; t++) pthread_join(th[t], 0);
-    return 0;
+    return cjo_batch_run_reps(op, threads, 1, n_chunks, in_base, in_off, in_len, out_base, out_stride, res);
 }

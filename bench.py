@@ -4,20 +4,31 @@
 One "step" = one pass of the hot path over the whole device-resident batch: N chunks of 64 KiB
 (synth-v1) compressed with the reference's C code family (system liblz4
 LZ4_compress_default; falls back to this engine's own GPU encoder if the library is absent), already in
-HBM when the timed region starts, decoded by one launch of lz4_decode_kernel into distinct outputs.
-Weak scaling: every GPU owns `--chunks` chunks (independent units, no data-path collective).
+HBM when the timed region starts, decoded by ONE batch submission (parse kernel -> workgroup-per-chunk LDS
+decoder -> wave kernel on routed chunks, all on the engine's stream) into distinct outputs.
+
+`--gpus N` runs N ranks, one per GPU (the script re-launches itself under torch.distributed.run when it was
+started plainly; the driver's own torchrun command works as well).  Weak scaling: rank r owns the chunks with
+global index i = k*N + r (round-robin, no data-path collective); with N > 1 every GPU holds 125 000 chunks
+(8 x 125 000 = BASELINE configs[3]), with N = 1 100 000 (configs[1]).
+
+`--workload mixed256k` is BASELINE configs[4]: 256 KiB chunks, even chunk indices LZ4-block / odd Snappy-raw,
+one engine (= one HIP stream) per codec per GPU running concurrently.
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task description):
-  value     = uncompressed GB/s over all ranks (sum of bytes / max wall time over ranks)
-  roofline  = algorithmic bytes (compressed read + uncompressed written) per launch / mean launch
-              duration measured with HIP events on the engine's stream, vs the 8 TB/s HBM peak
-  cpu_baseline = the CPU oracle (scalar C restatement of liblz4's decoder) on this host's cores over a
-              bounded sample of the same chunks (rank 0, N=1 only)
+  value        = uncompressed GB/s over all ranks (sum of bytes / max wall time over ranks)
+  roofline     = algorithmic bytes (compressed read + uncompressed written) per step / mean step duration measured
+                 with HIP events on the engine's stream, vs the 8 TB/s HBM peak; `traffic` = HBM bytes per step from
+                 two extra rocprofv3 passes of this same command (--pmc FETCH_SIZE / --pmc WRITE_SIZE), or null
+  cpu_baseline = CPU decoders on this host's cores over the same unique chunks (rank 0, N=1 only): the oracle's C
+                 restatement ("port") and, when the host has it, liblz4's LZ4_decompress_safe ("liblz4"), each with
+                 all cores and with one
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -30,16 +41,20 @@ HBM_PEAK = 8.0e12   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--in-flight", type=int, default=1, help="batches in flight: step k is submitted to engine k mod N (own stream, outputs, results)")
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--chunks", type=int, default=100_000, help="chunks per GPU (BASELINE configs[1]: 100k x 64 KiB)")
-    ap.add_argument("--chunk-bytes", type=int, default=65536)
-    ap.add_argument("--unique", type=int, default=8192, help="distinct chunks generated; replicated device-side")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--chunks", type=int, default=None, help="chunks per GPU (default: 100 000 at --gpus 1 = configs[1]; 125 000 at --gpus N = configs[3] at N=8; mixed256k: 16 384)")
+    ap.add_argument("--chunk-bytes", type=int, default=None)
+    ap.add_argument("--unique", type=int, default=8192, help="distinct chunks generated per GPU; replicated device-side to distinct addresses")
     ap.add_argument("--codec", default="lz4", choices=["lz4", "snappy"])
-    ap.add_argument("--op", default="decompress", choices=["decompress", "compress"])
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--op", default="decompress", choices=["decompress", "compress", "roundtrip"],
+                    help="roundtrip = one compress + one decompress of the batch per step (configs[2] with --codec snappy)")
+    ap.add_argument("--workload", default="default", choices=["default", "mixed256k"])
+    ap.add_argument("--in-flight", type=int, default=1, help="batches in flight: step k is submitted to engine k mod N (own stream, outputs, results)")
+    ap.add_argument("--cpu-seconds", type=float, default=16.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic", default="auto", choices=["auto", "on", "off"],
+                    help="HBM bytes per step from two extra rocprofv3 --pmc passes of this command (auto: only for the default 1-GPU workload)")
     ap.add_argument("--compressor", default="auto", choices=["auto", "liblz4", "gpu"])
     ap.add_argument("--phase-profile", action="store_true", help="debug: per-phase cycle counters of the LDS decoder")
     ap.add_argument("--lz4-mode", default="auto", choices=["auto", "wave", "lane", "lds"],
@@ -59,58 +74,61 @@ def load_liblz4():
     return None, None
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    import numpy as np
+def relaunch(args):
+    """`python bench.py --gpus N` started plainly: become N ranks under torch.distributed.run (one per GPU)."""
+    import socket
     import torch
-    import torch.distributed as dist
-    from cramjam_amd import _native as N
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus:
+        raise SystemExit("bench.py --gpus %d needs %d visible GPUs, found %d (no silent fallback to fewer)" % (args.gpus, args.gpus, have))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    use_dist = world > 1 or os.environ.get("CJ_FORCE_DIST") == "1"
-    if use_dist:
-        dist.init_process_group("nccl", device_id=dev)
-    L = N.lib()
-    eng = N.Engine(local)
 
-    S, U, NCH = args.chunk_bytes, min(args.unique, args.chunks), args.chunks
-    codec = N.CODEC_LZ4_BLOCK if args.codec == "lz4" else N.CODEC_SNAPPY_RAW
-    dec = args.op == "decompress"
+class Batch:
+    """one codec's device-resident batch on one engine: inputs, descriptors, outputs"""
+    pass
 
-    # ---- workload: U unique synth-v1 chunks generated on the device ----
+
+def build_batch(N, L, eng, dev, codec, op_dec, S, U, NCH, first_index, compressor, torch, np):
+    """U unique synth-v1 chunks (indices first_index ..) generated on the device, compressed (decompress workloads),
+    replicated device-side to NCH chunks at distinct addresses.  Returns a Batch."""
+    b = Batch()
+    b.codec, b.dec, b.S, b.U, b.NCH, b.eng = codec, op_dec, S, U, NCH, eng
     raw = torch.empty(U * S, dtype=torch.uint8, device=dev)
-    N.check(L.cj_bench_synth_v1(raw.data_ptr(), S, S, 0, U, 0x5EED, None))
+    N.check(L.cj_bench_synth_v1(raw.data_ptr(), S, S, first_index, U, 0x5EED, None))
     torch.cuda.synchronize()
-
+    b.raw = raw
     bound = L.cj_lz4_block_compress_bound(S, 0) if codec == N.CODEC_LZ4_BLOCK else L.cj_snappy_raw_max_compress_len(S)
     stride_c = (bound + 15) & ~15
-    comp_name = None
-    raw_h = None
-    if dec or not args.no_cpu_baseline:
-        raw_h = raw.cpu().numpy()
-    if dec:
-        lz4lib, comp_name = (None, None)
-        if codec == N.CODEC_LZ4_BLOCK and args.compressor in ("auto", "liblz4"):
-            lz4lib, comp_name = load_liblz4()
+    b.stride_c = stride_c
+    b.comp_name = None
+    b.raw_h = None
+    reps = (NCH + U - 1) // U
+    ids = np.arange(NCH, dtype=np.uint64)
+    if op_dec:
+        b.raw_h = raw.cpu().numpy()
+        lz4lib = None
+        if codec == N.CODEC_LZ4_BLOCK and compressor in ("auto", "liblz4"):
+            lz4lib, b.comp_name = load_liblz4()
         if lz4lib is not None:
             from concurrent.futures import ThreadPoolExecutor
             comp_h = np.zeros(U * stride_c, dtype=np.uint8)
             clen = np.zeros(U, dtype=np.uint64)
 
             def work(i):
-                r = lz4lib.LZ4_compress_default(raw_h.ctypes.data + i * S, comp_h.ctypes.data + i * stride_c, S, stride_c)
+                r = lz4lib.LZ4_compress_default(b.raw_h.ctypes.data + i * S, comp_h.ctypes.data + i * stride_c, S, stride_c)
                 assert r > 0
                 clen[i] = r
             with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as ex:
                 list(ex.map(work, range(U)))
         else:
-            comp_name = "cramjam_amd GPU encoder (%s)" % args.codec
+            b.comp_name = "cramjam_amd GPU encoder (%s)" % ("lz4" if codec == N.CODEC_LZ4_BLOCK else "snappy")
             comp_d = torch.zeros(U * stride_c, dtype=torch.uint8, device=dev)
             meta = torch.tensor(np.concatenate([np.arange(U, dtype=np.uint64) * S, np.full(U, S, np.uint64),
                                                 np.arange(U, dtype=np.uint64) * stride_c, np.full(U, stride_c, np.uint64),
@@ -135,55 +153,128 @@ def main():
             n = int(clen[i])
             packed_h[int(uoff[i]):int(uoff[i]) + n] = comp_h[i * stride_c:i * stride_c + n]
         del comp_h
+        b.packed_h, b.uoff, b.clen = packed_h, uoff, clen
         packed = torch.from_numpy(packed_h).to(dev)
-        reps = (NCH + U - 1) // U
-        cin = packed.repeat(reps)                      # reps distinct copies in HBM
-        ids = np.arange(NCH, dtype=np.uint64)
+        b.cin = packed.repeat(reps)                      # reps distinct copies in HBM
         in_off = (ids // U) * np.uint64(packed_total) + uoff[ids % U]
         in_len = clen[ids % U].astype(np.uint64)
         out_off = ids * np.uint64(S)
         out_cap = np.full(NCH, S, np.uint64)
-        out = torch.empty(NCH * S, dtype=torch.uint8, device=dev)
-        in_ptr = cin.data_ptr()
-        bytes_in = int(in_len.sum()); bytes_out = NCH * S
+        b.out = torch.empty(NCH * S, dtype=torch.uint8, device=dev)
+        b.bytes_in, b.bytes_out = int(in_len.sum()), NCH * S
     else:
-        reps = (NCH + U - 1) // U
-        cin = raw.repeat(reps)
-        ids = np.arange(NCH, dtype=np.uint64)
+        b.cin = raw.repeat(reps)
         in_off = ids * np.uint64(S)
         in_len = np.full(NCH, S, np.uint64)
         out_off = ids * np.uint64(stride_c)
         out_cap = np.full(NCH, stride_c, np.uint64)
-        out = torch.empty(NCH * stride_c, dtype=torch.uint8, device=dev)
-        in_ptr = cin.data_ptr()
-        bytes_in = NCH * S; bytes_out = None
-    meta = torch.from_numpy(np.concatenate([in_off, in_len, out_off, out_cap, np.zeros(NCH, np.uint64)]).view(np.int64)).to(dev)
-    mp = meta.data_ptr()
+        b.out = torch.empty(NCH * stride_c, dtype=torch.uint8, device=dev)
+        b.bytes_in, b.bytes_out = NCH * S, None
+    b.meta = torch.from_numpy(np.concatenate([in_off, in_len, out_off, out_cap, np.zeros(NCH, np.uint64)]).view(np.int64)).to(dev)
+    return b
+
+
+def batch_call(N, b, flags, op=None):
+    mp = b.meta.data_ptr()
+    op = (N.OP_DECOMPRESS if b.dec else N.OP_COMPRESS) if op is None else op
+    return (b.codec, op, flags, b.NCH, b.cin.data_ptr(), mp, mp + 8 * b.NCH, b.out.data_ptr(), mp + 16 * b.NCH, mp + 24 * b.NCH, mp + 32 * b.NCH)
+
+
+def verify_decoded(N, L, b, torch, dev):
+    res = b.meta[4 * b.NCH:].cpu().numpy()
+    assert (res == b.S).all(), "decode status/length mismatch: %s" % res[res != b.S][:8]
+    mism = torch.zeros(1, dtype=torch.int64, device=dev)
+    N.check(L.cj_bench_compare(b.out.data_ptr(), b.meta.data_ptr() + 16 * b.NCH, b.raw.data_ptr(), b.S, b.U, b.S, b.NCH, mism.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert int(mism.item()) == 0, "%d chunks decoded wrong" % int(mism.item())
+
+
+def main():
+    args = parse()
+    in_torchrun = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if not in_torchrun and args.gpus > 1:
+        relaunch(args)
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d — launch one rank per GPU (python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d), "
+                         "or run `python bench.py --gpus %d` plainly and let it launch the ranks" % (args.gpus, world, args.gpus, args.gpus, args.gpus))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from cramjam_amd import _native as N
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
+    if local >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d has no GPU (LOCAL_RANK %d, %d visible)" % (rank, local, torch.cuda.device_count()))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    use_dist = world > 1 or os.environ.get("CJ_FORCE_DIST") == "1"
+    if use_dist:
+        dist.init_process_group("nccl", device_id=dev)
+    L = N.lib()
+    eng = N.Engine(local)
+
+    mixed = args.workload == "mixed256k"
+    S = args.chunk_bytes or (262144 if mixed else 65536)
+    NCH = args.chunks or (16384 if mixed else (100_000 if world == 1 else 125_000))
+    U = min(args.unique, NCH)
+    if mixed:
+        U = min(U, 2048)
+    codec = N.CODEC_LZ4_BLOCK if args.codec == "lz4" else N.CODEC_SNAPPY_RAW
+    dec = args.op in ("decompress", "roundtrip")
     mode_flag = {"auto": 0, "wave": N.FLAG_FORCE_WAVE_PER_CHUNK, "lane": N.FLAG_FORCE_LANE_PER_CHUNK,
                  "lds": N.FLAG_FORCE_LDS_PER_CHUNK}[args.lz4_mode] | (0x1000 if args.phase_profile else 0)
-    a = (codec, N.OP_DECOMPRESS if dec else N.OP_COMPRESS, mode_flag, NCH, in_ptr, mp, mp + 8 * NCH, out.data_ptr(), mp + 16 * NCH,
-         mp + 24 * NCH, mp + 32 * NCH)
+
+    # ---- workload: distinct synth-v1 chunk indices per rank (rank r generates indices r*U .. r*U+U-1) ----
+    first_index = rank * U
+    batches = []
+    if mixed:
+        # chunk i of this GPU: even -> LZ4 block, odd -> Snappy raw; one engine (stream) per codec
+        eng2 = N.Engine(local)
+        batches.append(build_batch(N, L, eng, dev, N.CODEC_LZ4_BLOCK, True, S, U, NCH - NCH // 2, first_index, args.compressor, torch, np))
+        batches.append(build_batch(N, L, eng2, dev, N.CODEC_SNAPPY_RAW, True, S, U, NCH // 2, first_index + (1 << 32), args.compressor, torch, np))
+    else:
+        batches.append(build_batch(N, L, eng, dev, codec, dec, S, U, NCH, first_index, args.compressor, torch, np))
+    b0 = batches[0]
+    rt = None
+    if args.op == "roundtrip":
+        # configs[2]: compress the decoded batch again in the same step (the raw chunks are the compress input)
+        rt = build_batch(N, L, eng, dev, codec, False, S, U, NCH, first_index, args.compressor, torch, np)
     torch.cuda.synchronize()
 
-    # more than one batch in flight: extra engines (streams) with their own output and result buffers, same inputs
-    lanes = [(eng, a, out, meta)]
+    calls = [(b.eng, batch_call(N, b, mode_flag)) for b in batches]
+    # more than one batch in flight (single-codec workloads): extra engines with their own output and result buffers, same inputs
+    lanes = [calls]
+    extra = []
     for _ in range(1, max(1, args.in_flight)):
+        if mixed:
+            break
         e2 = N.Engine(local)
-        out2 = torch.empty_like(out)
-        meta2 = meta.clone()
+        out2 = torch.empty_like(b0.out)
+        meta2 = b0.meta.clone()
         mp2 = meta2.data_ptr()
-        lanes.append((e2, a[:4] + (in_ptr, mp2, mp2 + 8 * NCH, out2.data_ptr(), mp2 + 16 * NCH, mp2 + 24 * NCH, mp2 + 32 * NCH), out2, meta2))
+        a0 = calls[0][1]
+        lanes.append([(e2, a0[:5] + (mp2, mp2 + 8 * NCH, out2.data_ptr(), mp2 + 16 * NCH, mp2 + 24 * NCH, mp2 + 32 * NCH))])
+        extra.append((out2, meta2))
     torch.cuda.synchronize()
+
+    single = len(lanes) == 1 and len(calls) == 1 and rt is None
 
     def run_steps(k):
-        if len(lanes) == 1:
-            return eng.batch_device_timed(*a, k)       # K launches on the engine stream, HIP events around them
+        if single:
+            return eng.batch_device_timed(*calls[0][1], k)       # K submissions on the engine stream, HIP events around them
         t = time.perf_counter()
         for i in range(k):
-            e_, a_, _, _ = lanes[i % len(lanes)]
-            e_.batch_device(*a_)
-        for e_, _, _, _ in lanes:
-            e_.sync()
+            for e_, a_ in lanes[i % len(lanes)]:
+                e_.batch_device(*a_)                               # asynchronous: the codecs' streams run concurrently
+            if rt is not None:
+                eng.batch_device(*batch_call(N, rt, 0))
+        for ln in lanes:
+            for e_, _ in ln:
+                e_.sync()
         return (time.perf_counter() - t) * 1e3 / k
 
     # ---- warmup, then EXACTLY K timed steps between barrier+synchronize on both sides ----
@@ -208,60 +299,78 @@ def main():
         print("LDS decoder cycles/chunk: S0 %d  D1 %d  D2 %d  D3 %d  D4 %d  (blocks %d)" % (ph[0] // nb, ph[1] // nb, ph[2] // nb, ph[3] // nb, ph[4] // nb, nb), file=sys.stderr)
 
     # ---- verify at full size: every chunk's result and every output byte ----
-    res = meta[4 * NCH:].cpu().numpy()
+    bytes_in = sum(b.bytes_in for b in batches)
     if dec:
-        for _, _, out_k, meta_k in lanes[:min(len(lanes), args.steps + args.warmup)]:
-            res_k = meta_k[4 * NCH:].cpu().numpy()
-            assert (res_k == S).all(), "decode status/length mismatch: %s" % res_k[res_k != S][:8]
+        for b in batches:
+            verify_decoded(N, L, b, torch, dev)
+        for out2, meta2 in extra[:max(0, min(len(extra), args.steps + args.warmup - 1))]:
+            res_k = meta2[4 * NCH:].cpu().numpy()
+            assert (res_k == S).all()
             mism = torch.zeros(1, dtype=torch.int64, device=dev)
-            N.check(L.cj_bench_compare(out_k.data_ptr(), mp + 16 * NCH, raw.data_ptr(), S, U, S, NCH, mism.data_ptr(), None))
+            N.check(L.cj_bench_compare(out2.data_ptr(), meta2.data_ptr() + 16 * NCH, b0.raw.data_ptr(), S, U, S, NCH, mism.data_ptr(), None))
             torch.cuda.synchronize()
-            assert int(mism.item()) == 0, "%d chunks decoded wrong" % int(mism.item())
+            assert int(mism.item()) == 0
+        bytes_out = sum(b.bytes_out for b in batches)
         ratio = bytes_out / bytes_in
+        algo = bytes_in + bytes_out
     else:
+        res = b0.meta[4 * NCH:].cpu().numpy()
         assert (res > 0).all()
         bytes_out = int(res.sum())
         ratio = bytes_in / bytes_out
-    unc_bytes = NCH * S
+        algo = bytes_in + bytes_out
+    if rt is not None:
+        res = rt.meta[4 * NCH:].cpu().numpy()
+        assert (res > 0).all(), "compress half of the round trip failed"
+        algo += rt.bytes_in + int(res.sum())
+    unc_bytes = sum(b.NCH for b in batches) * S
 
     from cramjam_amd.shard import aggregate
     wall_max, total_unc = aggregate(dist if use_dist else None, dev, wall, unc_bytes)
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and dec:
-        cpu = cpu_baseline(args, codec, raw_h, S, U, packed_h, uoff, clen)
+    default_case = (not mixed and dec and rt is None and args.codec == "lz4" and S == 65536 and args.lz4_mode == "auto" and args.in_flight == 1)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and dec and not mixed:
+        cpu = cpu_baseline(args, codec, b0)
+    traffic = None
+    if rank == 0 and world == 1 and (args.traffic == "on" or (args.traffic == "auto" and default_case)) and not os.environ.get("CJ_BENCH_CHILD"):
+        traffic = measure_traffic()
 
     if rank == 0:
-        # HBM traffic from PMC counters cannot be sampled inside this process; it is measured with separate
-        # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command and summarised by
-        # tools/pmc_summary.py.  Reported only when the committed summary matches this exact workload.
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc", "hbm_traffic_lz4_decode_100k_x_64k.json")))
-            if dec and args.codec == "lz4" and NCH == 100_000 and S == 65536 and args.lz4_mode == "auto":
-                traffic = tj["total_hbm_bytes_per_step"]
-        except (OSError, ValueError, KeyError):
-            pass
-        algo = bytes_in + (bytes_out if bytes_out is not None else 0)
         achieved = algo / (kernel_ms * 1e-3)
+        if mixed:
+            metric = "uncompressed GB/s (mixed LZ4-block + Snappy-raw decomp, %d KiB chunks)" % (S // 1024)
+            workload = "mixed: even chunks lz4-block / odd snappy-raw decompress, %d x %d B synth-v1 chunks per GPU, one stream per codec, device-resident" % (NCH, S)
+            kernel = "lz4_parse_kernel+lz4_decode_lds2_kernel | snappy_parse_kernel+lz4_decode_lds2_kernel<snappy> (concurrent streams)"
+        else:
+            metric = ("uncompressed GB/s (LZ4-block decomp, 64 KiB chunks)" if (dec and rt is None and args.codec == "lz4" and S == 65536)
+                      else "uncompressed GB/s (%s %s, %d B chunks)" % (args.codec, args.op, S))
+            workload = "%s-block %s, %d x %d B synth-v1 chunks per GPU, device-resident" % (args.codec, args.op, NCH, S)
+            if dec and args.codec == "lz4":
+                kernel = {"auto": "lz4_parse_kernel+lz4_decode_lds2_kernel", "lds": "lz4_parse_kernel+lz4_decode_lds2_kernel",
+                          "wave": "lz4_decode_kernel", "lane": "lz4_decode_lanes_kernel"}[args.lz4_mode]
+            elif dec:
+                kernel = "snappy_parse_kernel+lz4_decode_lds2_kernel<snappy>"
+            else:
+                kernel = "%s_encode_kernel" % args.codec
+            if rt is not None:
+                kernel += "+%s_encode_kernel" % args.codec
         line = {
-            "metric": "uncompressed GB/s (LZ4-block decomp, 64 KiB chunks)" if (dec and args.codec == "lz4" and S == 65536)
-                      else "uncompressed GB/s (%s %s, %d B chunks)" % (args.codec, args.op, S),
+            "metric": metric,
             "value": total_unc / (wall_max / args.steps) / 1e9,
             "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall_max / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%s-block %s, %d x %d B synth-v1 chunks per GPU, device-resident" % (args.codec, args.op, NCH, S),
-                       "chunks_per_gpu": NCH, "chunk_bytes": S, "unique_chunks": U, "ratio": round(ratio, 4),
-                       "compressed_by": comp_name, "batches_in_flight": len(lanes), "sharding": "chunk i -> gpu (i mod N), no collective",
+            "config": {"workload": workload, "chunks_per_gpu": NCH, "chunk_bytes": S, "unique_chunks": U, "ratio": round(ratio, 4),
+                       "compressed_by": " | ".join(sorted({b.comp_name for b in batches if b.comp_name})) or None,
+                       "batches_in_flight": len(lanes),
+                       "sharding": "chunk i -> gpu (i mod N), no collective; rank r generates synth-v1 indices r*%d .. r*%d+%d" % (U, U, U - 1),
                        "verified": "all results + all output bytes compared on device"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": traffic,
-                         "kernel": {"auto": "lz4_parse_kernel+lz4_decode_lds2_kernel", "lds": "lz4_parse_kernel+lz4_decode_lds2_kernel", "wave": "lz4_decode_kernel",
-                                    "lane": "lz4_decode_lanes_kernel"}[args.lz4_mode] if (dec and args.codec == "lz4") else ("snappy_parse_kernel+lz4_decode_lds2_kernel<snappy>" if (dec and args.lz4_mode in ("auto", "lds")) else "%s_%s_kernel" % (args.codec, "decode" if dec else "encode")),
-                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo},
+                         "frac": achieved / HBM_PEAK, "traffic": traffic["total"] if traffic else None,
+                         "traffic_detail": traffic, "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
@@ -269,30 +378,132 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, codec, raw_h, S, U, packed_h, uoff, clen):
-    """CPU oracle (oracle/: scalar C restatement of LZ4_decompress_safe / snap's decoder), all host cores,
-    bounded sample: the U unique chunks, repeated until ~cpu-seconds elapsed."""
+def usable_cores():
+    """threads worth starting on this host: logical CPUs, limited by the affinity mask and by a cgroup CPU quota (a
+    container with 256 visible CPUs and a quota of 8 runs 256 threads at 8 cores' worth after the first burst)"""
+    n = os.cpu_count() or 1
+    note = "%d logical CPUs" % n
+    try:
+        aff = len(os.sched_getaffinity(0))
+        if aff < n:
+            n, note = aff, note + ", affinity %d" % aff
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = (None if txt[0] == "max" else float(txt[0])), float(txt[1])
+            else:
+                quota, period = float(txt[0]), float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                quota = None if quota <= 0 else quota
+            if quota is not None:
+                q = max(1, int(quota / period + 0.999))
+                note += ", cgroup quota %.1f CPUs" % (quota / period)
+                n = min(n, q)
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n, note
+
+
+def cpu_baseline(args, codec, b):
+    """CPU decoders over the U unique chunks of this run, ONE persistent thread pool per leg (oracle/synth_batch_oracle.c):
+    the oracle's C restatement (kind "port") and the host's liblz4 when present (kind "liblz4"; LZ4 only), each with all
+    cores and with one.  The top-level fields are the port on all cores; `legs` lists everything."""
     import numpy as np
     import oracle
     OL = oracle.lib()
-    cores = os.cpu_count() or 1
-    threads = min(cores, 256)
+    S, U = b.S, b.U
+    cores, cores_note = usable_cores()
     out = np.empty(U * S, dtype=np.uint8)
     res = np.zeros(U, dtype=np.int64)
-    off = np.ascontiguousarray(uoff, dtype=np.uint64)
-    ln = np.ascontiguousarray(clen, dtype=np.uint64)
-    op = 0 if codec == 0 else 2
-    done = 0
-    t0 = time.perf_counter()
-    while True:
-        OL.cjo_batch_run(op, threads, U, packed_h.ctypes.data, off.ctypes.data, ln.ctypes.data, out.ctypes.data, S, res.ctypes.data)
-        done += 1
+    off = np.ascontiguousarray(b.uoff, dtype=np.uint64)
+    ln = np.ascontiguousarray(b.clen, dtype=np.uint64)
+    lz4 = codec == 0
+    plan = [("port", 0 if lz4 else 2, cores, 0.35), ("port", 0 if lz4 else 2, 1, 0.15)]
+    if lz4 and OL.cjo_have_liblz4():
+        plan += [("liblz4", 4, cores, 0.35), ("liblz4", 4, 1, 0.15)]
+    scale = args.cpu_seconds / sum(p[3] for p in plan)
+    legs = []
+    for kind, op, threads, share in plan:
+        n1 = U if threads > 1 else min(U, 256)          # one thread: a slice of the chunks is enough for a calibration pass
+        t0 = time.perf_counter()
+        OL.cjo_batch_run_reps(op, threads, 1, n1, b.packed_h.ctypes.data, off.ctypes.data, ln.ctypes.data, out.ctypes.data, S, res.ctypes.data)
+        t1 = time.perf_counter() - t0
+        reps = max(1, min(100000, int(share * scale / max(t1, 1e-6))))
+        res[:] = 0
+        t0 = time.perf_counter()
+        rc = OL.cjo_batch_run_reps(op, threads, reps, n1, b.packed_h.ctypes.data, off.ctypes.data, ln.ctypes.data, out.ctypes.data, S, res.ctypes.data)
         el = time.perf_counter() - t0
-        if el >= args.cpu_seconds or done >= 2000:
-            break
-    assert (res == S).all() and (out == raw_h).all(), "cpu oracle disagrees with generator"
-    return {"value": done * U * S / el / 1e9, "unit": "GB/s", "cores": threads, "kind": "port",
-            "sample": "%d x %d unique %d B chunks (same inputs as the GPU run), %.1f s" % (done, U, S, el)}
+        assert rc == 0 and (res[:n1] == S).all() and (out[:n1 * S] == b.raw_h[:n1 * S]).all(), "cpu decoder (%s) disagrees with the generator" % kind
+        legs.append({"kind": kind, "cores": threads, "value": reps * n1 * S / el / 1e9, "unit": "GB/s",
+                     "sample": "%d passes x %d unique %d B chunks (same inputs as the GPU run), one thread pool, %.1f s" % (reps, n1, S, el)})
+    top = dict(legs[0])
+    top["host"] = cores_note
+    top["legs"] = legs
+    return top
+
+
+def measure_traffic():
+    """HBM bytes per step of THIS command, measured now: two child runs under rocprofv3 (--pmc FETCH_SIZE, --pmc WRITE_SIZE —
+    separate passes, the TCC block cannot hold both), 2 timed steps each, summed over every kernel of a step.
+    Corrections as /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes: KiB -> B; FETCH_SIZE x2 on gfx950 (wide coalesced
+    reads are tallied at half their bytes); WRITE_SIZE as is (calibrated in round 1 on the decoder's exact output size).
+    Returns None when rocprofv3 is missing or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    steps, warm = 2, 1
+    base = [a for a in sys.argv[1:]]
+    encodes = any(a in ("compress", "roundtrip") for a in base)
+    for flag in ("--steps", "--warmup", "--cpu-seconds", "--traffic"):
+        while flag in base:
+            i = base.index(flag)
+            del base[i:i + 2]
+    child = [sys.executable, os.path.abspath(__file__)] + base + ["--steps", str(steps), "--warmup", str(warm), "--no-cpu-baseline", "--traffic", "off"]
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="cj_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            env = dict(os.environ, CJ_BENCH_CHILD="1", TMPDIR="/tmp")
+            r = subprocess.run([prof, "--pmc", ctr, "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            per = {}
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") != ctr:
+                        continue
+                    k = row["Kernel_Name"].split("(")[0]
+                    if "cj::" not in k:                      # the library's kernels only (the bench utilities live in an anonymous namespace)
+                        continue
+                    if "encode" in k and not encodes:        # input preparation with the GPU encoder is not part of a step
+                        continue
+                    per.setdefault(k, []).append(float(row["Counter_Value"]))
+            out[ctr] = per
+    except (OSError, subprocess.SubprocessError):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    launches = steps + warm
+    detail, total = {}, 0.0
+    for k in sorted(set(out["FETCH_SIZE"]) | set(out["WRITE_SIZE"])):
+        f, w = out["FETCH_SIZE"].get(k, []), out["WRITE_SIZE"].get(k, [])
+        # dispatches per step of this kernel = samples / launches (e.g. the routed wave kernel: one per step)
+        rd = sum(f) / launches * 1024.0 * 2.0
+        wr = sum(w) / launches * 1024.0
+        detail[k] = {"hbm_read_bytes": rd, "hbm_write_bytes": wr}
+        total += rd + wr
+    return {"total": total, "unit": "bytes per step", "kernels": detail,
+            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate child runs of this command (%d steps + %d warmup each); KiB->B, FETCH_SIZE x2 (gfx950)" % (steps, warm)}
 
 
 if __name__ == "__main__":

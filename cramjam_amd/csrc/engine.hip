@@ -520,7 +520,15 @@ int64_t cj_lz4_block_compress(const uint8_t* in, size_t n, uint8_t* out, size_t 
 int64_t cj_lz4_block_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap, int size_prepended) {
     // one large stream (by its input, or by the output size it announces): parsed and decoded slab-parallel (large.hip)
     uint64_t announced = cap;
-    if (size_prepended && in && n >= 4) { uint32_t u; std::memcpy(&u, in, 4); if ((int32_t)u >= 0 && u <= cap) announced = u; }
+    if (size_prepended && in && n >= 4) {
+        uint32_t u; std::memcpy(&u, in, 4);
+        if ((int32_t)u >= 0 && u <= cap) {
+            announced = u;
+            // an LZ4 length byte stands for at most 255 bytes: a block cannot decode to more than 255 n + 64 — a prefix that
+            // announces more belongs to a stream whose decode fails; answer without staging gigabytes for it
+            if (announced > 255ull * (uint64_t)n + 64ull) return CJ_E_CORRUPT;
+        }
+    }
     if ((n > kLargeMin || announced > kLargeMin) && in && out)
         return cj::large_decompress(CJ_CODEC_LZ4_BLOCK, size_prepended ? CJ_FLAG_LZ4_SIZE_PREFIX : 0u, in, n, out, cap);
     return single(CJ_CODEC_LZ4_BLOCK, CJ_OP_DECOMPRESS, size_prepended ? CJ_FLAG_LZ4_SIZE_PREFIX : 0u, in, n, out, cap);
@@ -532,6 +540,12 @@ int64_t cj_snappy_raw_compress(const uint8_t* in, size_t n, uint8_t* out, size_t
 }
 
 int64_t cj_snappy_raw_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap) {
+    // a 3-byte copy element stands for at most 64 bytes: n bytes cannot decode to more than 22 n + 64 — a preamble that
+    // announces more (and fits the caller's buffer) belongs to a stream whose decode fails
+    if (in && n > 0) {
+        const int64_t dn = cj_snappy_raw_decompress_len(in, n);
+        if (dn > 0 && (uint64_t)dn <= cap && (uint64_t)dn > 22ull * (uint64_t)n + 64ull) return CJ_E_SNAPPY_CORRUPT;
+    }
     if (in && out && (n > kLargeMin || (n > 0 && cj_snappy_raw_decompress_len(in, n) > (int64_t)kLargeMin)))
         return cj::large_decompress(CJ_CODEC_SNAPPY_RAW, 0u, in, n, out, cap);
     return single(CJ_CODEC_SNAPPY_RAW, CJ_OP_DECOMPRESS, 0u, in, n, out, cap);

@@ -423,9 +423,16 @@ int64_t cj_lz4_frame_decompress_bound(const uint8_t* in, size_t n) {
     if (err) return err;
     if (f.skippable) return 0;
     if (f.late_err) return f.late_err;
-    if (f.csize) return (int64_t)f.content_size;
+    // what the blocks can produce at most: a stored block its own size, a compressed block of c bytes at most 255 c + 64 (an
+    // LZ4 length byte stands for at most 255 bytes) and never more than the frame's block size.  The announced content size
+    // is attacker-controlled: it bounds the result from above, it never raises it (a 19-byte frame announcing 2^46 bytes
+    // used to make the caller allocate that; values >= 2^63 turned into bogus negative "error codes")
     uint64_t total = 0;
-    for (const Lz4Block& b : f.blocks) total += (b.word & 0x80000000u) ? (b.word & 0x7FFFFFFFu) : f.block_max;
+    for (const Lz4Block& b : f.blocks) {
+        const uint64_t c = b.word & 0x7FFFFFFFu;
+        total += (b.word & 0x80000000u) ? c : std::min<uint64_t>(f.block_max, 255ull * c + 64ull);
+    }
+    if (f.csize && f.content_size < total) return (int64_t)f.content_size;
     return (int64_t)total;
 }
 
@@ -639,6 +646,7 @@ int64_t cj_lz4_frame_decompress(const uint8_t* in, size_t n, uint8_t* out, size_
         // first failure in stream order: malformed block, then the writer running out of room
         for (size_t i = 0; i < nb; i++) {
             if (res[i] < 0) return CJ_E_LZ4F_DECOMPRESS;
+            if (f.csize && total + (uint64_t)res[i] > f.content_size) return CJ_E_LZ4F_CONTENT_SIZE;      // more than the header announced (LZ4F: ERROR_frameSize_wrong)
             if (out != nullptr && total + (uint64_t)res[i] > cap) return CJ_E_FRAME_WRITE;
             total += (uint64_t)res[i];
         }

@@ -27,6 +27,7 @@
 #include <unistd.h>
 #include <mutex>
 #include <new>
+#include <stdexcept>
 #include <thread>
 #include <unordered_map>
 #include <utility>
@@ -39,6 +40,38 @@ namespace {
 
 PyObject* CompressionError = nullptr;
 PyObject* DecompressionError = nullptr;
+
+// ---- C++ exceptions never cross into CPython ----------------------------------------------------------------
+// Allocation of an attacker-sized result (std::bad_alloc / std::length_error from ByteVec, make_result, the block pool)
+// used to unwind through the interpreter's frames and end the process in std::terminate.  Every method the module
+// exports now runs under Guarded<>, which turns them into Python exceptions (the reference raises too), and the GIL
+// is released through a scope object, so that unwinding out of a GIL-free region re-acquires it first.
+struct NoGil {
+    PyThreadState* st;
+    NoGil() : st(PyEval_SaveThread()) {}
+    ~NoGil() { PyEval_RestoreThread(st); }
+    NoGil(const NoGil&) = delete;
+    NoGil& operator=(const NoGil&) = delete;
+};
+#undef Py_BEGIN_ALLOW_THREADS
+#undef Py_END_ALLOW_THREADS
+#define Py_BEGIN_ALLOW_THREADS { NoGil cj_nogil_scope_;
+#define Py_END_ALLOW_THREADS }
+
+PyObject* translate_cxx_exception() {           // inside a catch (...) block, GIL held
+    try { throw; }
+    catch (const std::bad_alloc&) { return PyErr_NoMemory(); }
+    catch (const std::length_error&) { PyErr_SetString(PyExc_ValueError, "requested size is too large"); }
+    catch (const std::exception& e) { PyErr_SetString(PyExc_RuntimeError, e.what()); }
+    catch (...) { PyErr_SetString(PyExc_RuntimeError, "cramjam_amd: unknown C++ exception"); }
+    return nullptr;
+}
+template <auto F> struct Guarded;
+template <class... A, PyObject* (*F)(A...)> struct Guarded<F> {
+    static PyObject* call(A... a) {
+        try { return F(a...); } catch (...) { return translate_cxx_exception(); }
+    }
+};
 
 // Result buffers are written completely by the device copy, so they are allocated WITHOUT value initialisation (a
 // zero-filled 64 MiB std::vector costs ~20 ms of single-threaded page faults + memset — 5x the whole GPU round trip);
@@ -113,11 +146,17 @@ void prefault(uint8_t* p, size_t n) {
     for (auto& x : th) x.join();
 }
 
-ByteVec make_result(size_t n) {             // n uninitialised, pre-faulted bytes
+// n uninitialised bytes; pre-faulted only when the size is one the input can actually produce (`plausible`): a 5-byte
+// stream announcing 4 GiB must not make 16 threads touch 4 GiB before the first block has been looked at
+ByteVec make_result(size_t n, bool plausible = true) {
     ByteVec v(n);
-    prefault(v.data(), n);
+    if (plausible) prefault(v.data(), n);
     return v;
 }
+// upper bounds of what n compressed bytes can decode to: an LZ4 length byte stands for at most 255 bytes, a 3-byte
+// Snappy copy element for at most 64
+inline bool lz4_size_plausible(uint64_t out, uint64_t in_len) { return out <= 255ull * in_len + 64ull; }
+inline bool snappy_size_plausible(uint64_t out, uint64_t in_len) { return out <= 22ull * in_len + 64ull; }
 
 // ------------------------------------------------------------------------------------------
 // Buffer  (reference src/io.rs:370-684)
@@ -485,17 +524,17 @@ int Buffer_getbuffer(BufferObject* self, Py_buffer* view, int flags) {
 }
 
 PyMethodDef Buffer_methods[] = {
-    {"len", (PyCFunction)Buffer_len, METH_NOARGS, "Length of the underlying buffer"},
-    {"write", (PyCFunction)Buffer_write, METH_O, "Write some bytes to the buffer"},
-    {"read", (PyCFunction)Buffer_read, METH_VARARGS | METH_KEYWORDS, "Read from the buffer at its current position"},
-    {"readinto", (PyCFunction)Buffer_readinto, METH_O, "Read from the buffer into a bytes-like object"},
-    {"seek", (PyCFunction)Buffer_seek, METH_VARARGS | METH_KEYWORDS, "Seek; whence 0 start, 1 current, 2 end"},
-    {"seekable", (PyCFunction)Buffer_seekable, METH_NOARGS, "Always True"},
-    {"tell", (PyCFunction)Buffer_tell, METH_NOARGS, "Current position"},
-    {"set_len", (PyCFunction)Buffer_set_len, METH_O, "Set the length; truncates or zero-fills"},
-    {"truncate", (PyCFunction)Buffer_truncate, METH_NOARGS, "Truncate the buffer"},
-    {"get_view_reference", (PyCFunction)Buffer_get_view_reference, METH_NOARGS, "Object this Buffer views, or None"},
-    {"get_view_reference_count", (PyCFunction)Buffer_get_view_reference_count, METH_NOARGS, "Refcount of the viewed object, or None"},
+    {"len", (PyCFunction)Guarded<Buffer_len>::call, METH_NOARGS, "Length of the underlying buffer"},
+    {"write", (PyCFunction)Guarded<Buffer_write>::call, METH_O, "Write some bytes to the buffer"},
+    {"read", (PyCFunction)Guarded<Buffer_read>::call, METH_VARARGS | METH_KEYWORDS, "Read from the buffer at its current position"},
+    {"readinto", (PyCFunction)Guarded<Buffer_readinto>::call, METH_O, "Read from the buffer into a bytes-like object"},
+    {"seek", (PyCFunction)Guarded<Buffer_seek>::call, METH_VARARGS | METH_KEYWORDS, "Seek; whence 0 start, 1 current, 2 end"},
+    {"seekable", (PyCFunction)Guarded<Buffer_seekable>::call, METH_NOARGS, "Always True"},
+    {"tell", (PyCFunction)Guarded<Buffer_tell>::call, METH_NOARGS, "Current position"},
+    {"set_len", (PyCFunction)Guarded<Buffer_set_len>::call, METH_O, "Set the length; truncates or zero-fills"},
+    {"truncate", (PyCFunction)Guarded<Buffer_truncate>::call, METH_NOARGS, "Truncate the buffer"},
+    {"get_view_reference", (PyCFunction)Guarded<Buffer_get_view_reference>::call, METH_NOARGS, "Object this Buffer views, or None"},
+    {"get_view_reference_count", (PyCFunction)Guarded<Buffer_get_view_reference_count>::call, METH_NOARGS, "Refcount of the viewed object, or None"},
     {nullptr, nullptr, 0, nullptr}};
 
 PySequenceMethods Buffer_as_sequence = {(lenfunc)Buffer_sq_length, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
@@ -546,7 +585,7 @@ PyObject* lz4_decompress_block(PyObject*, PyObject* args, PyObject* kw) {       
     int64_t r;
     if (has) {
         // Some(n): no prefix expected, capacity n, the returned Buffer keeps length n (not truncated, zero tail)
-        buf = make_result(n);
+        buf = make_result(n, lz4_size_plausible(n, (uint64_t)in.len));
         Py_BEGIN_ALLOW_THREADS
         r = cj_lz4_block_decompress(in.ptr, (size_t)in.len, buf.data(), n, 0);
         Py_END_ALLOW_THREADS
@@ -557,6 +596,8 @@ PyObject* lz4_decompress_block(PyObject*, PyObject* args, PyObject* kw) {       
         int64_t size = cj_lz4_block_prefixed_len(in.ptr, (size_t)in.len);
         if (size < 0) return raise_code(DecompressionError, size);
         if (size > 0x7E000000ll) return raise_code(DecompressionError, size > 0x7FFFFFFFll ? CJ_E_NEG_PREFIX : CJ_E_PREFIX_TOO_BIG);
+        // (a prefix no block of this length can fulfil: the decode would fail, say so without allocating gigabytes)
+        if (!lz4_size_plausible((uint64_t)size, (uint64_t)in.len)) return raise_code(DecompressionError, CJ_E_CORRUPT);
         buf = make_result((size_t)size);
         Py_BEGIN_ALLOW_THREADS
         r = cj_lz4_block_decompress(in.ptr, (size_t)in.len, buf.data(), (size_t)size, 1);
@@ -653,6 +694,7 @@ PyObject* snappy_decompress_raw(PyObject*, PyObject* args, PyObject* kw) {      
     if (in.len == 0) return raise_code(DecompressionError, CJ_E_SNAPPY_EMPTY);
     int64_t n = cj_snappy_raw_decompress_len(in.ptr, (size_t)in.len);
     if (n < 0) return raise_code(DecompressionError, n);
+    if (!snappy_size_plausible((uint64_t)n, (uint64_t)in.len)) return raise_code(DecompressionError, CJ_E_SNAPPY_CORRUPT);
     ByteVec buf = make_result((size_t)n);
     int64_t r;
     Py_BEGIN_ALLOW_THREADS
@@ -989,15 +1031,15 @@ PyObject* File_repr(FileObject* self) {
     return PyUnicode_FromFormat("cramjam.File<path=%s, len=%zd>", self->path->c_str(), n);
 }
 PyMethodDef File_methods[] = {
-    {"write", (PyCFunction)File_write, METH_O, "Write some bytes to the file, where input data can be anything in BytesType"},
-    {"read", (PyCFunction)File_read, METH_VARARGS | METH_KEYWORDS, "Read from the file in its current position, returns bytes (n_bytes=None)"},
-    {"readinto", (PyCFunction)File_readinto, METH_O, "Read from the file in its current position, into a BytesType object."},
-    {"seek", (PyCFunction)File_seek, METH_VARARGS | METH_KEYWORDS, "Seek to a position within the file (position, whence=None)"},
-    {"seekable", (PyCFunction)File_seekable, METH_NOARGS, "Whether the file is seekable; always True."},
-    {"tell", (PyCFunction)File_tell, METH_NOARGS, "Give the current position of the file."},
-    {"set_len", (PyCFunction)File_set_len, METH_O, "Set the length of the file (truncates or null-byte fills)."},
-    {"truncate", (PyCFunction)File_truncate, METH_NOARGS, "Truncate the file."},
-    {"len", (PyCFunction)File_len, METH_NOARGS, "Length of the file in bytes"},
+    {"write", (PyCFunction)Guarded<File_write>::call, METH_O, "Write some bytes to the file, where input data can be anything in BytesType"},
+    {"read", (PyCFunction)Guarded<File_read>::call, METH_VARARGS | METH_KEYWORDS, "Read from the file in its current position, returns bytes (n_bytes=None)"},
+    {"readinto", (PyCFunction)Guarded<File_readinto>::call, METH_O, "Read from the file in its current position, into a BytesType object."},
+    {"seek", (PyCFunction)Guarded<File_seek>::call, METH_VARARGS | METH_KEYWORDS, "Seek to a position within the file (position, whence=None)"},
+    {"seekable", (PyCFunction)Guarded<File_seekable>::call, METH_NOARGS, "Whether the file is seekable; always True."},
+    {"tell", (PyCFunction)Guarded<File_tell>::call, METH_NOARGS, "Give the current position of the file."},
+    {"set_len", (PyCFunction)Guarded<File_set_len>::call, METH_O, "Set the length of the file (truncates or null-byte fills)."},
+    {"truncate", (PyCFunction)Guarded<File_truncate>::call, METH_NOARGS, "Truncate the file."},
+    {"len", (PyCFunction)Guarded<File_len>::call, METH_NOARGS, "Length of the file in bytes"},
     {nullptr, nullptr, 0, nullptr}};
 PySequenceMethods File_as_sequence = {};
 PyNumberMethods File_as_number = {};
@@ -1012,9 +1054,19 @@ struct CompressorObject {
     PyObject_HEAD
     int codec;                   // 0 snappy, 1 lz4
     bool finished, started, content_checksum;
+    bool busy;                   // a flush()/finish() of this object is running with the GIL released
     int level;
     ByteVec* pending;
     cj::Xxh32* hash;
+};
+// pyo3 guards &mut self with a borrow flag and raises "Already borrowed" on re-entry (src/io.rs:761-814 take &mut self);
+// without it a second thread calling compress()/flush() during the GPU call would reallocate the vector being read
+struct CompressorBorrow {
+    CompressorObject* o; bool ok;
+    explicit CompressorBorrow(CompressorObject* c) : o(c), ok(!c->busy) {
+        if (ok) o->busy = true; else PyErr_SetString(PyExc_RuntimeError, "Already borrowed");
+    }
+    ~CompressorBorrow() { if (ok) o->busy = false; }
 };
 
 extern PyTypeObject SnappyCompressorType, Lz4CompressorType, SnappyDecompressorType, Lz4DecompressorType;
@@ -1022,7 +1074,7 @@ extern PyTypeObject SnappyCompressorType, Lz4CompressorType, SnappyDecompressorT
 PyObject* Compressor_new_common(PyTypeObject* type, int codec) {
     CompressorObject* self = (CompressorObject*)type->tp_alloc(type, 0);
     if (!self) return nullptr;
-    self->codec = codec; self->finished = false; self->started = false; self->content_checksum = true; self->level = -1;
+    self->codec = codec; self->finished = false; self->started = false; self->content_checksum = true; self->level = -1; self->busy = false;
     self->pending = new ByteVec();
     self->hash = new cj::Xxh32(0);
     return (PyObject*)self;
@@ -1054,6 +1106,8 @@ PyObject* Compressor_compress(CompressorObject* self, PyObject* input) {        
         PyErr_SetString(CompressionError, "Compressor looks to have been consumed via `finish()`. please create a new compressor instance.");
         return nullptr;
     }
+    CompressorBorrow borrow(self);
+    if (!borrow.ok) return nullptr;
     Bytes in;
     if (!get_bytes(input, in)) return nullptr;
     self->pending->insert(self->pending->end(), in.ptr, in.ptr + in.len);
@@ -1099,6 +1153,8 @@ int64_t compressor_emit(CompressorObject* self, ByteVec& out, bool finish) {
 }
 
 PyObject* Compressor_flush(CompressorObject* self, PyObject*) {                        // src/io.rs:796-814
+    CompressorBorrow borrow(self);
+    if (!borrow.ok) return nullptr;
     ByteVec out;
     if (!self->finished) {
         int64_t r;
@@ -1111,6 +1167,8 @@ PyObject* Compressor_flush(CompressorObject* self, PyObject*) {                 
 }
 
 PyObject* Compressor_finish(CompressorObject* self, PyObject*) {                       // src/io.rs:773-794
+    CompressorBorrow borrow(self);
+    if (!borrow.ok) return nullptr;
     ByteVec out;
     if (!self->finished) {
         int64_t r;
@@ -1124,9 +1182,9 @@ PyObject* Compressor_finish(CompressorObject* self, PyObject*) {                
 }
 
 PyMethodDef Compressor_methods[] = {
-    {"compress", (PyCFunction)Compressor_compress, METH_O, "Compress input into the current compressor's stream."},
-    {"flush", (PyCFunction)Compressor_flush, METH_NOARGS, "Flush and return current compressed stream"},
-    {"finish", (PyCFunction)Compressor_finish, METH_NOARGS, "Consume the current compressor state and return the compressed stream"},
+    {"compress", (PyCFunction)Guarded<Compressor_compress>::call, METH_O, "Compress input into the current compressor's stream."},
+    {"flush", (PyCFunction)Guarded<Compressor_flush>::call, METH_NOARGS, "Flush and return current compressed stream"},
+    {"finish", (PyCFunction)Guarded<Compressor_finish>::call, METH_NOARGS, "Consume the current compressor state and return the compressed stream"},
     {nullptr, nullptr, 0, nullptr}};
 
 struct DecompressorObject {                                                            // src/lib.rs:298-394
@@ -1196,10 +1254,10 @@ int Decompressor_bool(DecompressorObject* self) { return !self->finished && !sel
 PyObject* Decompressor_repr(DecompressorObject* self) { return PyUnicode_FromFormat("Decompressor<len=%zu>", self->finished ? (size_t)0 : self->inner->size()); }
 
 PyMethodDef Decompressor_methods[] = {
-    {"decompress", (PyCFunction)Decompressor_decompress, METH_O, "Decompress this input into the inner buffer."},
-    {"flush", (PyCFunction)Decompressor_flush, METH_NOARGS, "Flush and return current decompressed stream."},
-    {"finish", (PyCFunction)Decompressor_finish, METH_NOARGS, "Consume the current Decompressor state and return the decompressed stream"},
-    {"len", (PyCFunction)Decompressor_len, METH_NOARGS, "Length of internal buffer containing decompressed data."},
+    {"decompress", (PyCFunction)Guarded<Decompressor_decompress>::call, METH_O, "Decompress this input into the inner buffer."},
+    {"flush", (PyCFunction)Guarded<Decompressor_flush>::call, METH_NOARGS, "Flush and return current decompressed stream."},
+    {"finish", (PyCFunction)Guarded<Decompressor_finish>::call, METH_NOARGS, "Consume the current Decompressor state and return the decompressed stream"},
+    {"len", (PyCFunction)Guarded<Decompressor_len>::call, METH_NOARGS, "Length of internal buffer containing decompressed data."},
     {nullptr, nullptr, 0, nullptr}};
 PySequenceMethods Decompressor_as_sequence = {};
 PyNumberMethods Decompressor_as_number = {};
@@ -1237,28 +1295,28 @@ bool ready_stream_types() {
 }
 
 PyMethodDef lz4_methods[] = {
-    {"compress", (PyCFunction)lz4_compress, METH_VARARGS | METH_KEYWORDS, "LZ4 (frame) compression (data, level=None, output_len=None)"},
-    {"decompress", (PyCFunction)lz4_decompress, METH_VARARGS | METH_KEYWORDS, "LZ4 (frame) decompression (data, output_len=None)"},
-    {"compress_into", (PyCFunction)lz4_compress_into, METH_VARARGS | METH_KEYWORDS, "Compress (frame) directly into an output buffer (input, output, level=None)"},
-    {"decompress_into", (PyCFunction)lz4_decompress_into, METH_VARARGS | METH_KEYWORDS, "Decompress (frame) directly into an output buffer (input, output)"},
-    {"decompress_block", (PyCFunction)lz4_decompress_block, METH_VARARGS | METH_KEYWORDS, "LZ4 block decompression (data, output_len=None)"},
-    {"compress_block", (PyCFunction)lz4_compress_block, METH_VARARGS | METH_KEYWORDS, "LZ4 block compression (data, output_len=None, mode=None, acceleration=None, compression=None, store_size=None)"},
-    {"decompress_block_into", (PyCFunction)lz4_decompress_block_into, METH_VARARGS | METH_KEYWORDS, "LZ4 block decompression into a pre-allocated buffer (input, output, output_len=None)"},
-    {"compress_block_into", (PyCFunction)lz4_compress_block_into, METH_VARARGS | METH_KEYWORDS, "LZ4 block compression into a pre-allocated buffer"},
-    {"compress_block_bound", (PyCFunction)lz4_compress_block_bound, METH_O, "Size of a buffer guaranteed to hold the block-compressed result"},
+    {"compress", (PyCFunction)Guarded<lz4_compress>::call, METH_VARARGS | METH_KEYWORDS, "LZ4 (frame) compression (data, level=None, output_len=None)"},
+    {"decompress", (PyCFunction)Guarded<lz4_decompress>::call, METH_VARARGS | METH_KEYWORDS, "LZ4 (frame) decompression (data, output_len=None)"},
+    {"compress_into", (PyCFunction)Guarded<lz4_compress_into>::call, METH_VARARGS | METH_KEYWORDS, "Compress (frame) directly into an output buffer (input, output, level=None)"},
+    {"decompress_into", (PyCFunction)Guarded<lz4_decompress_into>::call, METH_VARARGS | METH_KEYWORDS, "Decompress (frame) directly into an output buffer (input, output)"},
+    {"decompress_block", (PyCFunction)Guarded<lz4_decompress_block>::call, METH_VARARGS | METH_KEYWORDS, "LZ4 block decompression (data, output_len=None)"},
+    {"compress_block", (PyCFunction)Guarded<lz4_compress_block>::call, METH_VARARGS | METH_KEYWORDS, "LZ4 block compression (data, output_len=None, mode=None, acceleration=None, compression=None, store_size=None)"},
+    {"decompress_block_into", (PyCFunction)Guarded<lz4_decompress_block_into>::call, METH_VARARGS | METH_KEYWORDS, "LZ4 block decompression into a pre-allocated buffer (input, output, output_len=None)"},
+    {"compress_block_into", (PyCFunction)Guarded<lz4_compress_block_into>::call, METH_VARARGS | METH_KEYWORDS, "LZ4 block compression into a pre-allocated buffer"},
+    {"compress_block_bound", (PyCFunction)Guarded<lz4_compress_block_bound>::call, METH_O, "Size of a buffer guaranteed to hold the block-compressed result"},
     {nullptr, nullptr, 0, nullptr}};
 
 PyMethodDef snappy_methods[] = {
-    {"compress", (PyCFunction)snappy_compress, METH_VARARGS | METH_KEYWORDS, "Snappy (framed) compression (data, output_len=None)"},
-    {"decompress", (PyCFunction)snappy_decompress, METH_VARARGS | METH_KEYWORDS, "Snappy (framed) decompression (data, output_len=None)"},
-    {"compress_into", (PyCFunction)snappy_compress_into, METH_VARARGS | METH_KEYWORDS, "Compress (framed) directly into an output buffer"},
-    {"decompress_into", (PyCFunction)snappy_decompress_into, METH_VARARGS | METH_KEYWORDS, "Decompress (framed) directly into an output buffer"},
-    {"decompress_raw", (PyCFunction)snappy_decompress_raw, METH_VARARGS | METH_KEYWORDS, "Snappy raw decompression (data, output_len=None)"},
-    {"compress_raw", (PyCFunction)snappy_compress_raw, METH_VARARGS | METH_KEYWORDS, "Snappy raw compression (data, output_len=None)"},
-    {"compress_raw_into", (PyCFunction)snappy_compress_raw_into, METH_VARARGS | METH_KEYWORDS, "Compress raw format directly into an output buffer"},
-    {"decompress_raw_into", (PyCFunction)snappy_decompress_raw_into, METH_VARARGS | METH_KEYWORDS, "Decompress raw format directly into an output buffer"},
-    {"compress_raw_max_len", (PyCFunction)snappy_compress_raw_max_len, METH_O, "Max compressed length for snappy raw compression"},
-    {"decompress_raw_len", (PyCFunction)snappy_decompress_raw_len, METH_O, "Decompressed length of the given raw data"},
+    {"compress", (PyCFunction)Guarded<snappy_compress>::call, METH_VARARGS | METH_KEYWORDS, "Snappy (framed) compression (data, output_len=None)"},
+    {"decompress", (PyCFunction)Guarded<snappy_decompress>::call, METH_VARARGS | METH_KEYWORDS, "Snappy (framed) decompression (data, output_len=None)"},
+    {"compress_into", (PyCFunction)Guarded<snappy_compress_into>::call, METH_VARARGS | METH_KEYWORDS, "Compress (framed) directly into an output buffer"},
+    {"decompress_into", (PyCFunction)Guarded<snappy_decompress_into>::call, METH_VARARGS | METH_KEYWORDS, "Decompress (framed) directly into an output buffer"},
+    {"decompress_raw", (PyCFunction)Guarded<snappy_decompress_raw>::call, METH_VARARGS | METH_KEYWORDS, "Snappy raw decompression (data, output_len=None)"},
+    {"compress_raw", (PyCFunction)Guarded<snappy_compress_raw>::call, METH_VARARGS | METH_KEYWORDS, "Snappy raw compression (data, output_len=None)"},
+    {"compress_raw_into", (PyCFunction)Guarded<snappy_compress_raw_into>::call, METH_VARARGS | METH_KEYWORDS, "Compress raw format directly into an output buffer"},
+    {"decompress_raw_into", (PyCFunction)Guarded<snappy_decompress_raw_into>::call, METH_VARARGS | METH_KEYWORDS, "Decompress raw format directly into an output buffer"},
+    {"compress_raw_max_len", (PyCFunction)Guarded<snappy_compress_raw_max_len>::call, METH_O, "Max compressed length for snappy raw compression"},
+    {"decompress_raw_len", (PyCFunction)Guarded<snappy_decompress_raw_len>::call, METH_O, "Decompressed length of the given raw data"},
     {nullptr, nullptr, 0, nullptr}};
 
 PyModuleDef lz4_def = {PyModuleDef_HEAD_INIT, "cramjam_amd.lz4", "LZ4 block de/compression on MI355X", -1, lz4_methods};

@@ -187,7 +187,13 @@ int  cj_engine_device(const cj_engine* e);
  * chunk i reads  in_base + in_off[i] .. + in_len[i]   and writes  out_base + out_off[i] .. + out_cap[i];
  * result[i] = bytes produced (>= 0) or CJ_E_* (< 0); one bad chunk never affects another.
  * hip_stream: a hipStream_t (NULL = the engine's own stream).  Asynchronous: returns after enqueue;
- * call cj_engine_sync (or synchronise the stream yourself) before reading results. */
+ * call cj_engine_sync (or synchronise the stream yourself) before reading results.
+ * Input addressing: chunks may start at any byte alignment, but the kernels fetch the stream with aligned vector loads —
+ * the 16-byte granules that hold a chunk's first and last byte are read whole (up to 15 bytes before in_base + in_off[i]
+ * and up to 15 bytes past its end; never used, never written).  Both granules must therefore lie inside the device
+ * allocation: true for every chunk of a buffer that comes from hipMalloc / a caching allocator (allocations start on
+ * 256-byte boundaries and are padded to their granule), NOT for a chunk that begins or ends flush with a page the
+ * caller carved up itself.  cj_batch_host pads to 16 bytes on its own staging buffers. */
 int cj_batch_device(cj_engine* e, cj_codec codec, cj_op op, uint32_t flags, size_t n_chunks,
                     const uint8_t* in_base, const uint64_t* in_off, const uint64_t* in_len,
                     uint8_t* out_base, const uint64_t* out_off, const uint64_t* out_cap,

@@ -255,3 +255,49 @@ def test_file_obj_api(tmp_path):
     assert File(str(tmp_path / "sink.txt")).read() == b"456789bc!!"
     with pytest.raises(TypeError):
         cramjam.lz4.compress_block(ap)                    # block functions need bytes in memory (the reference panics here)
+
+
+# ---- hostile sizes must raise, never abort the interpreter (round-1 advisor finding: uncaught std::bad_alloc /
+#      std::length_error used to reach std::terminate).  No GPU needed: every case fails before any device work. ----
+def _run_snippet(code):
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r)\n%s" % (ROOT, code)], capture_output=True, text=True, timeout=120)
+    return r
+
+
+def test_hostile_sizes_raise_python_exceptions():
+    code = r'''
+import struct, cramjam_amd as cj
+ok = 0
+# LZ4 frame: FLG=0x68 (version 01, independent blocks, content size present), BD=0x40, content_size=2**46, valid header checksum
+import ctypes
+hdr = bytes([0x04, 0x22, 0x4D, 0x18, 0x68, 0x40]) + struct.pack("<Q", 1 << 46)
+from cramjam_amd import _native as N
+try:
+    cj.lz4.decompress(hdr + b"\x00" + b"\x00\x00\x00\x00")
+except Exception as e:
+    ok += 1
+try:
+    cj.lz4.decompress_block(b"abc", output_len=2**63)
+except (MemoryError, ValueError, OverflowError, RuntimeError, cj.DecompressionError) as e:
+    ok += 1
+try:
+    cj.Buffer().set_len(2**62)
+except (MemoryError, ValueError, OverflowError) as e:
+    ok += 1
+try:
+    cj.snappy.decompress_raw(b"\xff\xff\xff\xff\x0f")          # a 5-byte stream announcing 4 GiB
+except cj.DecompressionError as e:
+    ok += 1
+try:
+    cj.lz4.decompress_block(struct.pack("<I", 0x7E000000) + b"\x00")   # prefix announcing 2 GiB for a 1-byte block
+except cj.DecompressionError as e:
+    ok += 1
+print("survived", ok)
+'''
+    r = _run_snippet(code)
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+    assert "survived 5" in r.stdout, (r.stdout, r.stderr[-2000:])

@@ -129,13 +129,14 @@ static int64_t parse_header(const uint8_t* in, size_t n, FrameInfo* fi) {
     return (int64_t)fi->hdr_len;
 }
 
-/* upper bound of the decoded size from headers alone (content size when present, else blocks x max block size) */
+/* upper bound of the decoded size from the headers alone: what the blocks can produce at most (a stored block its size, a
+ * compressed block of c bytes min(block size, 255 c + 64): an LZ4 length byte stands for at most 255 bytes), capped by the
+ * announced content size when there is one — the announcement never raises the bound (it is attacker-controlled) */
 int64_t cjo_lz4_frame_decompress_bound(const uint8_t* in, size_t n) {
     if (n >= 8 && (rd32(in) & 0xFFFFFFF0u) == 0x184D2A50u) return 0;       /* skippable frame first: decoder yields nothing */
     FrameInfo fi;
     int64_t h = parse_header(in, n, &fi);
     if (h < 0) return h;
-    if (fi.csize) return (int64_t)fi.content_size;
     const size_t B = block_max(fi.bs_code);
     size_t pos = (size_t)h;
     uint64_t total = 0;
@@ -146,9 +147,11 @@ int64_t cjo_lz4_frame_decompress_bound(const uint8_t* in, size_t n) {
         size_t sz = w & 0x7FFFFFFFu;
         if (sz > B) return CJO_E_LZ4F_BLOCK_SIZE;
         if (n - pos < sz + (fi.bsum ? 4u : 0u)) return CJO_E_LZ4F_INCOMPLETE;
-        total += (w & 0x80000000u) ? sz : B;
+        uint64_t most = 255ull * sz + 64ull;
+        total += (w & 0x80000000u) ? sz : (most < B ? most : B);
         pos += sz + (fi.bsum ? 4 : 0);
     }
+    if (fi.csize && fi.content_size < total) return (int64_t)fi.content_size;
     return (int64_t)total;
 }
 

@@ -33,13 +33,7 @@ constexpr int kBlockThreads = 64 * kWavesPerBlock;
 void launch_lz4_decode(const BatchArgs& a, hipStream_t s);        // one wavefront per chunk
 void launch_lz4_decode_lanes(const BatchArgs& a, hipStream_t s);  // one lane per chunk
 // parse (lane per chunk) + decode (workgroup per chunk, LDS-resident window); sync/meta are engine scratch
-void launch_lz4_classify(const BatchArgs& a, void* meta, void* lists, uint32_t lane_share, uint32_t wave_share, hipStream_t s);
 void launch_lz4_parse(const BatchArgs& a, void* sync, void* meta, hipStream_t s);
-void launch_lz4_parse_wave(const BatchArgs& a, void* sync, void* meta, hipStream_t s);
-void launch_lz4_parse_spec(const BatchArgs& a, void* sync, void* meta, hipStream_t s);      // wavefront per chunk, 64 segments parsed at once      // wavefront per chunk: small / medium batches
-void launch_lz4_decode_lanes_listed(const BatchArgs& a, const void* lists, uint32_t lane_share, hipStream_t s);
-void launch_lz4_decode_listed(const BatchArgs& a, const void* lists, uint32_t wave_share, hipStream_t s);   // wave kernel on the classify kernel's early wave share
-void launch_lz4_decode_lds(const BatchArgs& a, const void* sync, const void* meta, hipStream_t s);
 void launch_lz4_decode_routed(const BatchArgs& a, const void* meta, hipStream_t s);   // wave kernel on chunks the parse kernel routed to it
 // variant 2: persistent grid (2 workgroups per CU), record tables in the global scratch `tabs`, chunk indices from *counter
 // codec: CJ_CODEC_LZ4_BLOCK or CJ_CODEC_SNAPPY_RAW (only the record expansion D1 differs)
@@ -47,13 +41,14 @@ void launch_lz4_decode_lds2(const BatchArgs& a, const void* sync, const void* me
 // linked LZ4-frame blocks: one workgroup walks the blocks of a frame in order, previous block kept as a second LDS window
 void launch_lz4_decode_lds2_linked(const BatchArgs& a, const void* sync, const void* meta, void* tabs, uint32_t* counter,
                                    const void* frames, uint32_t n_frames, uint32_t grid, hipStream_t s);
+// parse + decode in ONE kernel: the segmented parse runs inside the workgroup on the staged chunk; meta[c] = kRouteWave for chunks it leaves to the wave kernel
+void launch_lz4_decode_fused(const BatchArgs& a, void* meta, void* tabs, uint32_t* counter, uint32_t grid, hipStream_t s, int codec = 0);
 size_t lz4_lds2_tab_bytes(uint32_t grid);
 size_t lz4_lds_scratch_sync_bytes(size_t n_chunks);
 size_t lz4_lds_scratch_meta_bytes(size_t n_chunks);
 void launch_lz4_encode(const BatchArgs& a, hipStream_t s);
 void launch_snappy_decode(const BatchArgs& a, hipStream_t s);                                   // one wavefront per chunk
-void launch_snappy_decode_skipping(const BatchArgs& a, const void* meta, hipStream_t s);         // ... except chunks flagged for the lane kernel
-void launch_snappy_decode_lanes(const BatchArgs& a, const void* lists, uint32_t lane_share, hipStream_t s);   // one lane per chunk (all, or the listed share)
+void launch_snappy_decode_lanes(const BatchArgs& a, hipStream_t s);                            // one lane per chunk
 void launch_snappy_parse(const BatchArgs& a, void* sync, void* meta, hipStream_t s);
 // large.hip: one large buffer cut into pieces that are compressed as a batch and joined into one stream
 int64_t large_snappy_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap);
@@ -69,8 +64,6 @@ int64_t large_decompress(int codec, uint32_t flags, const uint8_t* in, size_t n,
 void launch_lz4_decode_lds2_slabs(const BatchArgs& a, const void* sync, const void* meta, void* tabs, uint32_t* counter,
                                   const void* first, uint32_t stream_len, uint32_t* done, void* cross, uint32_t tab_stride,
                                   uint32_t cross_stride, uint32_t grid, hipStream_t s, int codec, bool rel = false);
-void launch_snappy_parse_spec(const BatchArgs& a, void* sync, void* meta, hipStream_t s);  // wavefront per chunk, 64 segments parsed at once
-void launch_snappy_parse_wave(const BatchArgs& a, void* sync, void* meta, hipStream_t s);  // wavefront per chunk: small / medium batches           // parse + LDS pipeline, like launch_lz4_parse
 void launch_snappy_decode_routed(const BatchArgs& a, const void* meta, hipStream_t s);       // wave kernel on chunks the parse kernel routed to it
 void launch_snappy_encode(const BatchArgs& a, hipStream_t s);
 

@@ -77,10 +77,8 @@ struct cj_engine {
     std::mutex mu;                 // serialises host-batch staging on this engine
     cj::DevBuf d_in, d_out, d_meta;
     std::mutex scratch_mu;         // LZ4 parse->decode scratch (sync points, per-chunk meta), reused across calls
-    cj::DevBuf d_sync, d_pmeta, d_lanelist;   // d_lanelist: [0] = count, [16..] = chunk indices
+    cj::DevBuf d_sync, d_pmeta, d_lanelist;   // d_lanelist: word [2] = the workgroup decoder's chunk counter
     hipEvent_t scratch_free = nullptr;    // recorded after the last kernel that reads the scratch
-    hipStream_t aux = nullptr, aux2 = nullptr;   // the lane- / wave-kernel shares of a large LZ4-decode batch run here, concurrently
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
     cj::PinnedBuf h_in, h_out;
     std::vector<uint64_t> h_meta;
     cj::DevBuf d_frame;            // frame.hip: assembled / staged framed stream

@@ -22,177 +22,66 @@ void cj::fill_args(cj::BatchArgs& a, uint32_t flags, size_t n, const uint8_t* in
 
 namespace {
 
-int launch_slice(cj_engine* e, cj_codec codec, cj_op op, const cj::BatchArgs& a, hipStream_t s) {
-    if (codec == CJ_CODEC_LZ4_BLOCK) {
-        if (op == CJ_OP_DECOMPRESS) {
-            static const size_t lds_min = [] {
-                const char* v = std::getenv("CJ_LDS_MIN_CHUNKS");
-                return v ? (size_t)std::strtoull(v, nullptr, 10) : (size_t)CJ_LDS_MIN_CHUNKS;
-            }();
-            int mode = a.n_chunks >= lds_min ? 2 : 0;          // 0 wave, 1 lane, 2 parse + {LDS workgroup | wave} per chunk
-            if (a.flags & CJ_FLAG_FORCE_WAVE_PER_CHUNK) mode = 0;
-            if (a.flags & CJ_FLAG_FORCE_LANE_PER_CHUNK) mode = 1;
-            if (a.flags & CJ_FLAG_FORCE_LDS_PER_CHUNK) mode = 2;
-            if (mode == 0) cj::launch_lz4_decode(a, s);
-            else if (mode == 1) cj::launch_lz4_decode_lanes(a, s);
-            else {
-                std::lock_guard<std::mutex> lock(e->scratch_mu);
-                static const uint32_t lane_share = [] {
-                    const char* v = std::getenv("CJ_LANE_SHARE");      // n/20 of the short-sequence chunks go to the lane kernel
-                    long x = v ? std::strtol(v, nullptr, 10) : CJ_LANE_SHARE_DEFAULT;
-                    return (uint32_t)(x < 0 ? 0 : x > 20 ? 20 : x);
-                }();
-                static const uint32_t wave_share = [] {
-                    const char* v = std::getenv("CJ_WAVE_SHARE");
-                    long x = v ? std::strtol(v, nullptr, 10) : CJ_WAVE_SHARE_DEFAULT;
-                    return (uint32_t)(x < 0 ? 0 : x > 20 ? 20 : x);
-                }();
-                const size_t list_bytes = 16 + (size_t)a.n_chunks * 8;
-                const bool grow = cj::lz4_lds_scratch_sync_bytes(a.n_chunks) > e->d_sync.cap ||
-                                  cj::lz4_lds_scratch_meta_bytes(a.n_chunks) > e->d_pmeta.cap || list_bytes > e->d_lanelist.cap;
-                if (grow && e->scratch_free) HIP_TRY(hipEventSynchronize(e->scratch_free), CJ_E_NO_DEVICE);
-                if (!e->d_sync.reserve(cj::lz4_lds_scratch_sync_bytes(a.n_chunks)) ||
-                    !e->d_pmeta.reserve(cj::lz4_lds_scratch_meta_bytes(a.n_chunks)) || !e->d_lanelist.reserve(list_bytes)) return CJ_E_OOM;
-                if (!e->scratch_free) {
-                    HIP_TRY(hipEventCreateWithFlags(&e->scratch_free, hipEventDisableTiming), CJ_E_NO_DEVICE);
-                    HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming), CJ_E_NO_DEVICE);
-                    HIP_TRY(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming), CJ_E_NO_DEVICE);
-                    HIP_TRY(hipEventCreateWithFlags(&e->ev_join2, hipEventDisableTiming), CJ_E_NO_DEVICE);
-                    HIP_TRY(hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking), CJ_E_NO_DEVICE);
-                    HIP_TRY(hipStreamCreateWithFlags(&e->aux2, hipStreamNonBlocking), CJ_E_NO_DEVICE);
-                } else HIP_TRY(hipStreamWaitEvent(s, e->scratch_free, 0), CJ_E_NO_DEVICE);   // previous user of the scratch
-                uint32_t* lists = (uint32_t*)e->d_lanelist.p;
-                HIP_TRY(hipMemsetAsync(lists, 0, 16, s), CJ_E_NO_DEVICE);
-                // 1. classify (no parsing): pick the lane- and wave-kernel shares by compression ratio, build compact lists
-                cj::launch_lz4_classify(a, e->d_pmeta.p, lists, lane_share, wave_share, s);
-                // 2. fork: three kernels with three different bottlenecks run concurrently — lane kernel (HBM traffic of
-                //    random match reads), wave kernel (dependent-latency chain), parse + LDS decoder (instruction issue / LDS)
-                const bool forked = lane_share + wave_share > 0;
-                if (forked) HIP_TRY(hipEventRecord(e->ev_fork, s), CJ_E_NO_DEVICE);
-                if (lane_share > 0) {
-                    HIP_TRY(hipStreamWaitEvent(e->aux, e->ev_fork, 0), CJ_E_NO_DEVICE);
-                    cj::launch_lz4_decode_lanes_listed(a, lists, lane_share, e->aux);
-                    HIP_TRY(hipEventRecord(e->ev_join, e->aux), CJ_E_NO_DEVICE);
-                }
-                if (wave_share > 0) {
-                    HIP_TRY(hipStreamWaitEvent(e->aux2, e->ev_fork, 0), CJ_E_NO_DEVICE);
-                    cj::launch_lz4_decode_listed(a, lists, wave_share, e->aux2);
-                    HIP_TRY(hipEventRecord(e->ev_join2, e->aux2), CJ_E_NO_DEVICE);
-                }
-                // validate, size, count sequences, route: a wavefront per chunk is the faster front end below ~6 k chunks
-                // (≈0.9 ms per chunk but one chunk per wave), a lane per chunk above (3.5 ms flat, 64 chunks per wave)
-                static const size_t wave_parse_max = [] {
-                    const char* v = std::getenv("CJ_WAVE_PARSE_MAX");
-                    return v ? (size_t)std::strtoull(v, nullptr, 10) : (size_t)CJ_WAVE_PARSE_MAX_DEFAULT;
-                }();
-                static const size_t spec_parse_max = [] {
-                    const char* v = std::getenv("CJ_SPEC_PARSE_MAX");
-                    return v ? (size_t)std::strtoull(v, nullptr, 10) : (size_t)CJ_SPEC_PARSE_MAX_DEFAULT;
-                }();
-                if (a.n_chunks < spec_parse_max) cj::launch_lz4_parse_spec(a, e->d_sync.p, e->d_pmeta.p, s);
-                else if (a.n_chunks < wave_parse_max) cj::launch_lz4_parse_wave(a, e->d_sync.p, e->d_pmeta.p, s);
-                else cj::launch_lz4_parse(a, e->d_sync.p, e->d_pmeta.p, s);
-                static const int lds_variant = [] { const char* v = std::getenv("CJ_LDS_VARIANT"); return v ? std::atoi(v) : 2; }();
-                if (lds_variant == 2) {
-                    if (e->n_cu == 0) HIP_TRY(hipDeviceGetAttribute(&e->n_cu, hipDeviceAttributeMultiprocessorCount, e->device), CJ_E_NO_DEVICE);
-                    const uint32_t grid = 2u * (uint32_t)e->n_cu;
-                    if (!e->d_tab.reserve(cj::lz4_lds2_tab_bytes(grid))) return CJ_E_OOM;
-                    cj::launch_lz4_decode_lds2(a, e->d_sync.p, e->d_pmeta.p, e->d_tab.p, lists + 2, grid, s);
-                } else
-                cj::launch_lz4_decode_lds(a, e->d_sync.p, e->d_pmeta.p, s);      // many short sequences
-                cj::launch_lz4_decode_routed(a, e->d_pmeta.p, s);                // few long runs / oversize chunks
-                if (lane_share > 0) HIP_TRY(hipStreamWaitEvent(s, e->ev_join, 0), CJ_E_NO_DEVICE);   // 3. join
-                if (wave_share > 0) HIP_TRY(hipStreamWaitEvent(s, e->ev_join2, 0), CJ_E_NO_DEVICE);
-                HIP_TRY(hipEventRecord(e->scratch_free, s), CJ_E_NO_DEVICE);
-            }
-        } else cj::launch_lz4_encode(a, s);
-    } else if (codec == CJ_CODEC_SNAPPY_RAW) {
-        if (op == CJ_OP_DECOMPRESS) {
-            static const size_t big_min = [] {
-                const char* v = std::getenv("CJ_LDS_MIN_CHUNKS");
-                return v ? (size_t)std::strtoull(v, nullptr, 10) : (size_t)CJ_LDS_MIN_CHUNKS;
-            }();
-            static const uint32_t sn_share = [] {
-                const char* v = std::getenv("CJ_SNAPPY_LANE_SHARE");
-                long x = v ? std::strtol(v, nullptr, 10) : CJ_SNAPPY_LANE_SHARE_DEFAULT;
-                return (uint32_t)(x < 0 ? 0 : x > 20 ? 20 : x);
-            }();
-            // large batches: 3 = parse + LDS workgroup decoder (+ wave kernel on routed chunks), the same pipeline as LZ4;
-            // 2 = the earlier classify + lane-kernel pipeline (CJ_SNAPPY_PIPELINE=lanes), kept for comparison
-            static const bool lanes_pipeline = [] { const char* v = std::getenv("CJ_SNAPPY_PIPELINE"); return v && std::string(v) == "lanes"; }();
-            int mode = a.n_chunks >= big_min ? (lanes_pipeline ? (sn_share > 0 ? 2 : 0) : 3) : 0;
-            if (a.flags & CJ_FLAG_FORCE_WAVE_PER_CHUNK) mode = 0;
-            if (a.flags & CJ_FLAG_FORCE_LANE_PER_CHUNK) mode = 1;
-            if (a.flags & CJ_FLAG_FORCE_LDS_PER_CHUNK) mode = 3;
-            if (mode == 0) cj::launch_snappy_decode(a, s);
-            else if (mode == 1) cj::launch_snappy_decode_lanes(a, nullptr, 0, s);
-            else if (mode == 3) {
-                std::lock_guard<std::mutex> lock(e->scratch_mu);
-                const size_t list_bytes = 16 + (size_t)a.n_chunks * 8;
-                const bool grow = cj::lz4_lds_scratch_sync_bytes(a.n_chunks) > e->d_sync.cap ||
-                                  cj::lz4_lds_scratch_meta_bytes(a.n_chunks) > e->d_pmeta.cap || list_bytes > e->d_lanelist.cap;
-                if (grow && e->scratch_free) HIP_TRY(hipEventSynchronize(e->scratch_free), CJ_E_NO_DEVICE);
-                if (!e->d_sync.reserve(cj::lz4_lds_scratch_sync_bytes(a.n_chunks)) ||
-                    !e->d_pmeta.reserve(cj::lz4_lds_scratch_meta_bytes(a.n_chunks)) || !e->d_lanelist.reserve(list_bytes)) return CJ_E_OOM;
-                if (!e->scratch_free) {
-                    HIP_TRY(hipEventCreateWithFlags(&e->scratch_free, hipEventDisableTiming), CJ_E_NO_DEVICE);
-                    HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming), CJ_E_NO_DEVICE);
-                    HIP_TRY(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming), CJ_E_NO_DEVICE);
-                    HIP_TRY(hipEventCreateWithFlags(&e->ev_join2, hipEventDisableTiming), CJ_E_NO_DEVICE);
-                    HIP_TRY(hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking), CJ_E_NO_DEVICE);
-                    HIP_TRY(hipStreamCreateWithFlags(&e->aux2, hipStreamNonBlocking), CJ_E_NO_DEVICE);
-                } else HIP_TRY(hipStreamWaitEvent(s, e->scratch_free, 0), CJ_E_NO_DEVICE);
-                uint32_t* lists = (uint32_t*)e->d_lanelist.p;
-                HIP_TRY(hipMemsetAsync(lists, 0, 16, s), CJ_E_NO_DEVICE);                                   // [2] = the decoder's chunk counter
-                HIP_TRY(hipMemsetAsync(e->d_pmeta.p, 0, cj::lz4_lds_scratch_meta_bytes(a.n_chunks), s), CJ_E_NO_DEVICE);   // no chunk is pre-routed
-                if (e->n_cu == 0) HIP_TRY(hipDeviceGetAttribute(&e->n_cu, hipDeviceAttributeMultiprocessorCount, e->device), CJ_E_NO_DEVICE);
-                const uint32_t grid = 2u * (uint32_t)e->n_cu;
-                if (!e->d_tab.reserve(cj::lz4_lds2_tab_bytes(grid))) return CJ_E_OOM;
-                static const size_t sn_wave_parse_max = [] {
-                    const char* v = std::getenv("CJ_WAVE_PARSE_MAX");
-                    return v ? (size_t)std::strtoull(v, nullptr, 10) : (size_t)CJ_WAVE_PARSE_MAX_DEFAULT;
-                }();
-                static const size_t sn_spec_parse_max = [] {
-                    const char* v = std::getenv("CJ_SPEC_PARSE_MAX");
-                    return v ? (size_t)std::strtoull(v, nullptr, 10) : (size_t)CJ_SPEC_PARSE_MAX_DEFAULT;
-                }();
-                if (a.n_chunks < sn_spec_parse_max) cj::launch_snappy_parse_spec(a, e->d_sync.p, e->d_pmeta.p, s);
-                else if (a.n_chunks < sn_wave_parse_max) cj::launch_snappy_parse_wave(a, e->d_sync.p, e->d_pmeta.p, s);
-                else cj::launch_snappy_parse(a, e->d_sync.p, e->d_pmeta.p, s);
-                cj::launch_lz4_decode_lds2(a, e->d_sync.p, e->d_pmeta.p, e->d_tab.p, lists + 2, grid, s, CJ_CODEC_SNAPPY_RAW);
-                cj::launch_snappy_decode_routed(a, e->d_pmeta.p, s);
-                HIP_TRY(hipEventRecord(e->scratch_free, s), CJ_E_NO_DEVICE);
-            } else {
-                // large batch: mid-ratio chunks (many short elements) go to the lane kernel on the auxiliary stream, the
-                // rest (and the long-run chunks, which the wave kernel copies 16 B/lane) stay on the wave kernel
-                std::lock_guard<std::mutex> lock(e->scratch_mu);
-                const size_t list_bytes = 16 + (size_t)a.n_chunks * 8;
-                const bool grow = cj::lz4_lds_scratch_meta_bytes(a.n_chunks) > e->d_pmeta.cap || list_bytes > e->d_lanelist.cap;
-                if (grow && e->scratch_free) HIP_TRY(hipEventSynchronize(e->scratch_free), CJ_E_NO_DEVICE);
-                if (!e->d_pmeta.reserve(cj::lz4_lds_scratch_meta_bytes(a.n_chunks)) || !e->d_lanelist.reserve(list_bytes)) return CJ_E_OOM;
-                if (!e->scratch_free) {
-                    HIP_TRY(hipEventCreateWithFlags(&e->scratch_free, hipEventDisableTiming), CJ_E_NO_DEVICE);
-                    HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming), CJ_E_NO_DEVICE);
-                    HIP_TRY(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming), CJ_E_NO_DEVICE);
-                    HIP_TRY(hipEventCreateWithFlags(&e->ev_join2, hipEventDisableTiming), CJ_E_NO_DEVICE);
-                    HIP_TRY(hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking), CJ_E_NO_DEVICE);
-                    HIP_TRY(hipStreamCreateWithFlags(&e->aux2, hipStreamNonBlocking), CJ_E_NO_DEVICE);
-                } else HIP_TRY(hipStreamWaitEvent(s, e->scratch_free, 0), CJ_E_NO_DEVICE);
-                uint32_t* lists = (uint32_t*)e->d_lanelist.p;
-                HIP_TRY(hipMemsetAsync(lists, 0, 16, s), CJ_E_NO_DEVICE);
-                cj::launch_lz4_classify(a, e->d_pmeta.p, lists, sn_share, 0, s);     // codec independent: looks at sizes only
-                HIP_TRY(hipEventRecord(e->ev_fork, s), CJ_E_NO_DEVICE);
-                HIP_TRY(hipStreamWaitEvent(e->aux, e->ev_fork, 0), CJ_E_NO_DEVICE);
-                cj::launch_snappy_decode_lanes(a, lists, sn_share, e->aux);
-                HIP_TRY(hipEventRecord(e->ev_join, e->aux), CJ_E_NO_DEVICE);
-                cj::launch_snappy_decode_skipping(a, e->d_pmeta.p, s);
-                HIP_TRY(hipStreamWaitEvent(s, e->ev_join, 0), CJ_E_NO_DEVICE);
-                HIP_TRY(hipEventRecord(e->scratch_free, s), CJ_E_NO_DEVICE);
-            }
-        } else cj::launch_snappy_encode(a, s);
+// scratch of the workgroup decoders (per-chunk verdicts, the chunk counter, record tables), shared by every call on the
+// engine: a call waits (on the stream) for the previous user before it overwrites them
+int lds_scratch(cj_engine* e, const cj::BatchArgs& a, hipStream_t s, bool with_sync) {
+    const size_t list_bytes = 16 + (size_t)a.n_chunks * 8;
+    const size_t sync_bytes = with_sync ? cj::lz4_lds_scratch_sync_bytes(a.n_chunks) : 0;
+    const bool grow = sync_bytes > e->d_sync.cap || cj::lz4_lds_scratch_meta_bytes(a.n_chunks) > e->d_pmeta.cap || list_bytes > e->d_lanelist.cap;
+    if (grow && e->scratch_free) HIP_TRY(hipEventSynchronize(e->scratch_free), CJ_E_NO_DEVICE);
+    if (!e->d_sync.reserve(sync_bytes) || !e->d_pmeta.reserve(cj::lz4_lds_scratch_meta_bytes(a.n_chunks)) || !e->d_lanelist.reserve(list_bytes)) return CJ_E_OOM;
+    if (!e->scratch_free) HIP_TRY(hipEventCreateWithFlags(&e->scratch_free, hipEventDisableTiming), CJ_E_NO_DEVICE);
+    else HIP_TRY(hipStreamWaitEvent(s, e->scratch_free, 0), CJ_E_NO_DEVICE);   // previous user of the scratch
+    HIP_TRY(hipMemsetAsync(e->d_lanelist.p, 0, 16, s), CJ_E_NO_DEVICE);        // [2] = the decoder's chunk counter
+    if (e->n_cu == 0) HIP_TRY(hipDeviceGetAttribute(&e->n_cu, hipDeviceAttributeMultiprocessorCount, e->device), CJ_E_NO_DEVICE);
+    if (!e->d_tab.reserve(cj::lz4_lds2_tab_bytes(2u * (uint32_t)e->n_cu))) return CJ_E_OOM;
+    return 0;
+}
+
+// LZ4 block / Snappy raw decode of a batch of independent chunks:
+//   up to CJ_FUSED_MAX_CHUNKS chunks   parse + decode in ONE kernel (two persistent workgroups per CU: segmented parse on the staged
+//                      chunk, records, literals, matches through the LDS window)
+//   larger batches     lane-per-chunk parse kernel (validation + sync points in memory) -> the same workgroup decoder: with every
+//                      CU's LDS pipe saturated by the resolver the in-kernel parse's dependent LDS reads cost more than a second
+//                      pass over the input (100 k chunks: 18 ms fused, 10.6 ms with the parse kernel)
+//   then               the wavefront-per-chunk kernel on what the parse left over (errors, chunks above 64 KiB, few long runs)
+//   flags              CJ_FLAG_FORCE_WAVE_PER_CHUNK / _LANE_PER_CHUNK: one mapping for every chunk (tests, comparisons)
+int launch_decode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a, hipStream_t s) {
+    const bool lz4 = codec == CJ_CODEC_LZ4_BLOCK;
+    int mode = 2;
+    if (a.flags & CJ_FLAG_FORCE_WAVE_PER_CHUNK) mode = 0;
+    if (a.flags & CJ_FLAG_FORCE_LANE_PER_CHUNK) mode = 1;
+    if (a.flags & CJ_FLAG_FORCE_LDS_PER_CHUNK) mode = 2;
+    if (mode == 0) { if (lz4) cj::launch_lz4_decode(a, s); else cj::launch_snappy_decode(a, s); return 0; }
+    if (mode == 1) { if (lz4) cj::launch_lz4_decode_lanes(a, s); else cj::launch_snappy_decode_lanes(a, s); return 0; }
+    const bool fused = a.n_chunks <= (uint32_t)CJ_FUSED_MAX_CHUNKS;
+    std::lock_guard<std::mutex> lock(e->scratch_mu);
+    const int rc = lds_scratch(e, a, s, !fused);
+    if (rc != 0) return rc;
+    uint32_t* lists = (uint32_t*)e->d_lanelist.p;
+    const uint32_t grid = 2u * (uint32_t)e->n_cu;
+    if (fused) {
+        cj::launch_lz4_decode_fused(a, e->d_pmeta.p, e->d_tab.p, lists + 2, grid, s, codec);
     } else {
-        return CJ_E_BAD_ARG;
+        HIP_TRY(hipMemsetAsync(e->d_pmeta.p, 0, cj::lz4_lds_scratch_meta_bytes(a.n_chunks), s), CJ_E_NO_DEVICE);   // no chunk is pre-routed
+        // validate, size, count sequences, sync points, route
+        if (lz4) cj::launch_lz4_parse(a, e->d_sync.p, e->d_pmeta.p, s);
+        else cj::launch_snappy_parse(a, e->d_sync.p, e->d_pmeta.p, s);
+        cj::launch_lz4_decode_lds2(a, e->d_sync.p, e->d_pmeta.p, e->d_tab.p, lists + 2, grid, s, codec);
     }
+    if (lz4) cj::launch_lz4_decode_routed(a, e->d_pmeta.p, s);                // few long runs / oversize chunks / errors
+    else cj::launch_snappy_decode_routed(a, e->d_pmeta.p, s);
+    HIP_TRY(hipEventRecord(e->scratch_free, s), CJ_E_NO_DEVICE);
+    return 0;
+}
+
+int launch_slice(cj_engine* e, cj_codec codec, cj_op op, const cj::BatchArgs& a, hipStream_t s) {
+    if (codec != CJ_CODEC_LZ4_BLOCK && codec != CJ_CODEC_SNAPPY_RAW) return CJ_E_BAD_ARG;
+    if (op == CJ_OP_DECOMPRESS) {
+        const int rc = launch_decode(e, codec, a, s);
+        if (rc != 0) return rc;
+    } else if (codec == CJ_CODEC_LZ4_BLOCK) cj::launch_lz4_encode(a, s);
+    else cj::launch_snappy_encode(a, s);
     HIP_TRY(hipGetLastError(), CJ_E_NO_DEVICE);
     return 0;
 }
@@ -357,11 +246,6 @@ void cj_engine_destroy(cj_engine* e) {
     e->d_in.release(); e->d_out.release(); e->d_meta.release(); e->d_sync.release(); e->d_pmeta.release(); e->d_lanelist.release(); e->d_frame.release(); e->d_tab.release(); e->d_big.release(); e->d_bigtab.release();
     e->h_in.release(); e->h_out.release();
     if (e->scratch_free) (void)hipEventDestroy(e->scratch_free);
-    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
-    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
-    if (e->ev_join2) (void)hipEventDestroy(e->ev_join2);
-    if (e->aux) (void)hipStreamDestroy(e->aux);
-    if (e->aux2) (void)hipStreamDestroy(e->aux2);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }

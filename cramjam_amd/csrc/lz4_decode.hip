@@ -86,15 +86,9 @@ __device__ __forceinline__ int64_t lz4_wave_decode(const uint8_t* in, uint32_t n
     return bad ? (int64_t)CJ_E_CORRUPT : (int64_t)op;
 }
 
-// route: nullptr = decode every chunk; else only chunks the parse kernel flagged kRouteWave.
-// list/count: when non-null, wave i decodes chunk list[i] for i < *count (the classify kernel's early wave share).
-__global__ __launch_bounds__(kBlockThreads) void lz4_decode_kernel(BatchArgs a, const ParseMeta* route,
-                                                                   const uint32_t* list, const uint32_t* count) {
-    uint32_t chunk = uni(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
-    if (list != nullptr) {
-        if (chunk >= *count) return;
-        chunk = uni(list[chunk]);
-    }
+// route: nullptr = decode every chunk; else only chunks the parse stage flagged kRouteWave.
+__global__ __launch_bounds__(kBlockThreads) void lz4_decode_kernel(BatchArgs a, const ParseMeta* route) {
+    const uint32_t chunk = uni(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
     if (chunk >= a.n_chunks) return;
     if (route != nullptr && (route[chunk].in_skip & kRouteWave) == 0u) return;
     const uint8_t* in = a.in_base + a.in_off[chunk];
@@ -124,206 +118,6 @@ __global__ __launch_bounds__(kBlockThreads) void lz4_decode_kernel(BatchArgs a, 
 
     const int64_t r = lz4_wave_decode(in, (uint32_t)n64, out, (uint32_t)cap64, 0u);
     if (lane_id() == 0) a.result[chunk] = r;
-}
-
-// ---------------------------------------------------------------------------------------------------
-// lz4_parse_wave_kernel — the parse stage for SMALL and medium batches: one wavefront per chunk, the token chain walked
-// wave-uniformly on the scalar unit out of the register window (no copies), two further 256 B rows always in flight.
-// Same outputs and routing rules as lz4_parse_kernel (lane per chunk): decoded size or error, sequence count, an
-// (ip, op) sync point every kSyncEvery sequences.  A lane-per-chunk walk retires 64 chunks per instruction but each
-// lane needs ~3.5 ms for a 64 KiB chunk whatever the batch size; a wave walks one chunk in ~0.9 ms, so below
-// ~6 k chunks (and for every single-buffer call) this kernel is the faster front end for the LDS decoder
-// (measured: 1 chunk 1.0 vs 1.7 ms for the plain wave decoder, 4 096 chunks 2.2 vs 3.2 ms with the lane parse).
-// ---------------------------------------------------------------------------------------------------
-struct ParseWindow : InWindow {
-    uint32_t p0, p1;            // rows for wpos + 512 and wpos + 768, requested ahead of need
-    __device__ __forceinline__ void anchor_pf(uint32_t pos) {
-        anchor(pos);
-        p0 = load_row(wpos + 512u);
-        p1 = load_row(wpos + 768u);
-    }
-    __device__ __forceinline__ void ensure_pf(uint32_t pos) {
-        const uint32_t q = pos - wpos;
-        if (q >= 256u) {
-            if (q < 504u) { w0 = w1; w1 = p0; p0 = p1; wpos += 256u; p1 = load_row(wpos + 768u); }
-            else anchor_pf(pos);
-        }
-    }
-    __device__ __forceinline__ uint32_t fetch32_any_pf(uint32_t pos) {
-        if (pos - wpos > 500u) anchor_pf(pos);
-        return fetch32(pos);
-    }
-};
-
-__global__ __launch_bounds__(kBlockThreads) void lz4_parse_wave_kernel(BatchArgs a, uint2* sync, ParseMeta* meta) {
-    const uint32_t c = uni(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
-    if (c >= a.n_chunks) return;
-    if ((meta[c].in_skip & kRouteLane) != 0u) return;          // handed to the lane kernel by the classify kernel
-    const uint8_t* in = a.in_base + a.in_off[c];
-    const uint8_t* const in0 = in;
-    uint64_t n64 = a.in_len[c], cap64 = a.out_cap[c];
-    ParseMeta pm = {0u, 0u};
-    int64_t r = lz4_block_prologue(a.flags, in, n64, cap64);
-    bool walk = false;
-    if (r == 0) {
-        const uint32_t cap0 = (uint32_t)cap64, iend0 = (uint32_t)n64;
-        if (cap0 == 0) r = (iend0 == 1 && in[0] == 0) ? 0 : (int64_t)CJ_E_CORRUPT;
-        else if (iend0 == 0) r = CJ_E_CORRUPT;
-        else if (cap0 > kLdsOutMax || iend0 > kLdsInMax) pm.in_skip = kRouteWave;      // too big for the LDS window
-        else walk = true;
-    }
-    if (walk) {
-        const uint32_t cap = (uint32_t)cap64;
-        uint2* csync = sync + (size_t)c * kSyncPitch;
-        ParseWindow w;
-        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(in) & 3u);
-        w.base = in - mis;
-        w.iend = mis + (uint32_t)n64;
-        w.anchor_pf(mis);
-        const uint32_t iend = w.iend;
-        uint32_t ip = mis, op = 0, nseq = 0;
-        bool bad = false;
-        for (;;) {
-            if ((nseq % kSyncEvery) == 0u) {
-                const uint32_t slot = nseq / kSyncEvery;
-                if (slot < kSyncStride && lane_id() == 0) csync[slot] = make_uint2(ip - mis, op);
-            }
-            nseq += 1;
-            w.ensure_pf(ip);
-            const uint32_t t4 = w.fetch32(ip);
-            const uint32_t token = t4 & 0xffu;
-            ip += 1;
-            uint32_t lit = token >> 4;                              // iend <= kLdsInMax: 32 bits suffice
-            if (lit == 15u) {
-                if (ip + 15u >= iend) { bad = true; break; }
-                uint32_t b = (t4 >> 8) & 0xffu;
-                ip += 1; lit += b;
-                if (ip + 15u > iend) { bad = true; break; }
-                while (b == 255u) {
-                    b = w.fetch32_any_pf(ip) & 0xffu;
-                    ip += 1; lit += b;
-                    if (ip + 15u > iend) { bad = true; break; }
-                }
-                if (bad) break;
-            }
-            const uint32_t rem_out = cap - op, rem_in = iend - ip;
-            if (rem_out < lit + 12u || rem_in < lit + 8u) {
-                if (rem_in != lit || rem_out < lit) bad = true;
-                else op += lit;
-                break;
-            }
-            ip += lit; op += lit;
-            const uint32_t o4 = w.fetch32_any_pf(ip);
-            const uint32_t offset = o4 & 0xffffu;
-            ip += 2;
-            uint32_t mlen = token & 15u;
-            if (mlen == 15u) {
-                uint32_t b = (o4 >> 16) & 0xffu;
-                ip += 1; mlen += b;
-                if (ip + 4u > iend) { bad = true; break; }
-                while (b == 255u) {
-                    b = w.fetch32_any_pf(ip) & 0xffu;
-                    ip += 1; mlen += b;
-                    if (ip + 4u > iend) { bad = true; break; }
-                }
-                if (bad) break;
-            }
-            mlen += 4u;
-            if (offset == 0u || offset > op) { bad = true; break; }
-            if (cap - op < mlen + 5u) { bad = true; break; }
-            op += mlen;
-        }
-        if (bad) r = CJ_E_CORRUPT;
-        else {
-            r = (int64_t)op;
-            if (r > 0) {
-                if ((nseq + kSyncEvery - 1u) / kSyncEvery > kSyncStride || nseq < kLdsMinSeq) pm.in_skip = kRouteWave;
-                else { pm.nseq = nseq; pm.in_skip = (uint32_t)(in - in0); }
-            }
-        }
-    }
-    if (lane_id() == 0) {
-        a.result[c] = r;
-        meta[c] = pm;
-    }
-}
-
-// Snappy counterpart (records instead of sequences; grammar in snappy_records.hpp): same outputs as snappy_parse_kernel
-__global__ __launch_bounds__(kBlockThreads) void snappy_parse_wave_kernel(BatchArgs a, uint2* sync, ParseMeta* meta) {
-    const uint32_t c = uni(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
-    if (c >= a.n_chunks) return;
-    if ((meta[c].in_skip & kRouteLane) != 0u) return;
-    const uint8_t* in = a.in_base + a.in_off[c];
-    const uint64_t n64 = a.in_len[c], cap64 = a.out_cap[c];
-    ParseMeta pm = {0u, 0u};
-    int64_t r = 0;
-    uint32_t dn = 0, hdr = 0;
-    bool walk = false;
-    if (n64 == 0) r = CJ_E_SNAPPY_EMPTY;
-    else if (n64 > 0xFFFFFFF0ull) r = CJ_E_SNAPPY_CORRUPT;
-    else {
-        uint64_t ulen = 0;
-        uint32_t shift = 0, i = 0;
-        bool ok = false;
-        while (hdr < (uint32_t)n64 && i < 10u) {
-            const uint32_t b = in[hdr];
-            hdr += 1;
-            if (b < 0x80u) { if (!(i == 9u && b > 1u)) { ulen |= (uint64_t)b << shift; ok = true; } break; }
-            ulen |= (uint64_t)(b & 0x7fu) << shift;
-            shift += 7; i += 1;
-        }
-        if (!ok) r = CJ_E_SNAPPY_HEADER;
-        else if (ulen > 0xFFFFFFFFull) r = CJ_E_SNAPPY_TOO_BIG;
-        else if (ulen > cap64) r = CJ_E_SNAPPY_BUF_SMALL;
-        else if (ulen == 0) r = (hdr == (uint32_t)n64) ? 0 : (int64_t)CJ_E_SNAPPY_CORRUPT;
-        else if (ulen > kLdsOutMax || n64 - hdr > kLdsInMax) pm.in_skip = kRouteWave;
-        else { dn = (uint32_t)ulen; walk = true; }
-    }
-    if (walk) {
-        uint2* csync = sync + (size_t)c * kSyncPitch;
-        ParseWindow w;
-        const uint8_t* body = in + hdr;
-        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(body) & 3u);
-        w.base = body - mis;
-        w.iend = mis + (uint32_t)n64 - hdr;
-        w.anchor_pf(mis);
-        const uint32_t iend = w.iend;
-        const auto rd = [&w](uint32_t p) { return w.fetch32_any_pf(p); };
-        uint32_t ip = mis, op = 0, nrec = 0;
-        bool bad = false;
-        while (ip < iend) {
-            if ((nrec % kSyncEvery) == 0u) {
-                const uint32_t slot = nrec / kSyncEvery;
-                if (slot < kSyncStride && lane_id() == 0) csync[slot] = make_uint2(ip - mis, op);
-            }
-            nrec += 1;
-            w.ensure_pf(ip);
-            SnRecord rec;
-            if (snappy_record_step(rd, ip, op, iend, dn, rec) != 0) { bad = true; break; }
-        }
-        if (bad || op != dn) r = CJ_E_SNAPPY_CORRUPT;
-        else {
-            r = (int64_t)dn;
-            if ((nrec + kSyncEvery - 1u) / kSyncEvery > kSyncStride || nrec < kLdsMinSeq) pm.in_skip = kRouteWave;
-            else { pm.nseq = nrec; pm.in_skip = hdr; }
-        }
-    }
-    if (lane_id() == 0) {
-        a.result[c] = r;
-        meta[c] = pm;
-    }
-}
-
-void launch_snappy_parse_wave(const BatchArgs& a, void* sync, void* meta, hipStream_t s) {
-    if (a.n_chunks == 0) return;
-    dim3 grid((a.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlockThreads);
-    hipLaunchKernelGGL(snappy_parse_wave_kernel, grid, block, 0, s, a, (uint2*)sync, (ParseMeta*)meta);
-}
-
-void launch_lz4_parse_wave(const BatchArgs& a, void* sync, void* meta, hipStream_t s) {
-    if (a.n_chunks == 0) return;
-    dim3 grid((a.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlockThreads);
-    hipLaunchKernelGGL(lz4_parse_wave_kernel, grid, block, 0, s, a, (uint2*)sync, (ParseMeta*)meta);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -369,21 +163,14 @@ void launch_lz4_frame_chain(const uint8_t* in, const uint64_t* blk_off, const ui
 void launch_lz4_decode(const BatchArgs& a, hipStream_t s) {
     if (a.n_chunks == 0) return;
     dim3 grid((a.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlockThreads);
-    hipLaunchKernelGGL(lz4_decode_kernel, grid, block, 0, s, a, (const ParseMeta*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+    hipLaunchKernelGGL(lz4_decode_kernel, grid, block, 0, s, a, (const ParseMeta*)nullptr);
 }
 
 void launch_lz4_decode_routed(const BatchArgs& a, const void* meta, hipStream_t s) {
     if (a.n_chunks == 0) return;
     dim3 grid((a.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlockThreads);
-    hipLaunchKernelGGL(lz4_decode_kernel, grid, block, 0, s, a, (const ParseMeta*)meta, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+    hipLaunchKernelGGL(lz4_decode_kernel, grid, block, 0, s, a, (const ParseMeta*)meta);
 }
 
-void launch_lz4_decode_listed(const BatchArgs& a, const void* lists, uint32_t wave_share, hipStream_t s) {
-    if (a.n_chunks == 0 || wave_share == 0) return;
-    const uint64_t maxn = ((uint64_t)a.n_chunks + kLaneShareDen - 1u) / kLaneShareDen * wave_share;
-    dim3 grid((unsigned)((maxn + kWavesPerBlock - 1) / kWavesPerBlock)), block(kBlockThreads);
-    const uint32_t* l = (const uint32_t*)lists;
-    hipLaunchKernelGGL(lz4_decode_kernel, grid, block, 0, s, a, (const ParseMeta*)nullptr, l + 4 + a.n_chunks, l + 1);
-}
 
 }  // namespace cj

@@ -47,8 +47,7 @@ __global__ __launch_bounds__(64 * kParseWaves) void lz4_parse_kernel(BatchArgs a
     const uint32_t c = blockIdx.x * (64u * kParseWaves) + threadIdx.x;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     const uint32_t wave_ring = (uint32_t)(uintptr_t)rings + wave * 64u * kRingStride;
-    // chunks the classify kernel already handed to the lane kernel (meta pre-marked kRouteLane) are not ours
-    const bool exists = c < a.n_chunks && (meta[c < a.n_chunks ? c : 0].in_skip & kRouteLane) == 0u;
+    const bool exists = c < a.n_chunks;
 
     // ---- per-lane setup (same prologue / special cases as the other mappings) ----
     const uint8_t* in0 = nullptr; const uint8_t* in = nullptr;
@@ -199,74 +198,10 @@ __global__ __launch_bounds__(64 * kParseWaves) void lz4_parse_kernel(BatchArgs a
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// lz4_classify_kernel — one thread per chunk, no parsing: picks the share of the batch that the lane-per-chunk
-// kernel decodes on the auxiliary stream while parse + LDS decode run on the main one.  Only chunks whose
-// compression ratio says "many short sequences" (neither RLE-like nor incompressible) are eligible — long-run
-// chunks are ~5x faster through the wave kernel, and only the parse kernel can tell those apart exactly.
-// The choice affects speed only; every kernel decodes any valid chunk identically.
-// ---------------------------------------------------------------------------------------------------
-// lists: [0] = lane-kernel count, [1] = wave-kernel count, lane list at lists + 4, wave list at lists + 4 + n_chunks
-__global__ __launch_bounds__(256) void lz4_classify_kernel(BatchArgs a, ParseMeta* meta, uint32_t* lists,
-                                                           uint32_t lane_share, uint32_t wave_share) {
-    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t lane = lane_id();
-    bool to_lane = false, to_wave = false;
-    if (c < a.n_chunks) {
-        const uint64_t n = a.in_len[c], cap = a.out_cap[c];
-        // ratio between 1.05 and 5, and small enough that a lane is a sensible unit of work
-        const bool eligible = cap <= kLdsOutMax && n * 20u < cap * 19u && n * 5u > cap;
-        const uint32_t slot = c % kLaneShareDen;
-        to_lane = eligible && slot < lane_share;
-        to_wave = eligible && !to_lane && slot < lane_share + wave_share;
-        ParseMeta pm = {0u, (to_lane || to_wave) ? kRouteLane : 0u};
-        meta[c] = pm;
-    }
-    uint32_t* lane_list = lists + 4;
-    uint32_t* wave_list = lists + 4 + a.n_chunks;
-    const uint64_t ml = ballot64(to_lane), mw = ballot64(to_wave);
-    const uint64_t below = (1ull << lane) - 1ull;
-    if (ml != 0ull) {
-        uint32_t pos = 0;
-        if (lane == 0) pos = atomicAdd(&lists[0], (uint32_t)__builtin_popcountll(ml));
-        pos = rdlane(pos, 0);
-        if (to_lane) lane_list[pos + (uint32_t)__builtin_popcountll(ml & below)] = c;
-    }
-    if (mw != 0ull) {
-        uint32_t pos = 0;
-        if (lane == 0) pos = atomicAdd(&lists[1], (uint32_t)__builtin_popcountll(mw));
-        pos = rdlane(pos, 0);
-        if (to_wave) wave_list[pos + (uint32_t)__builtin_popcountll(mw & below)] = c;
-    }
-}
-
-// lane-per-chunk decode of the chunks in `list` (compact, so every wavefront is full)
-__global__ __launch_bounds__(64) void lz4_decode_lanes_listed_kernel(BatchArgs a, const uint32_t* list, const uint32_t* count) {
-    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
-    if (i >= *count) return;
-    const uint32_t c = list[i];
-    const uint8_t* in = a.in_base + a.in_off[c];
-    uint64_t n64 = a.in_len[c];
-    uint8_t* out = a.out_base + a.out_off[c];
-    uint64_t cap64 = a.out_cap[c];
-    const int64_t status = lz4_block_prologue(a.flags, in, n64, cap64);
-    if (status != 0) { a.result[c] = status; return; }
-    const uint32_t cap = (uint32_t)cap64, iend = (uint32_t)n64;
-    if (cap == 0) { a.result[c] = (iend == 1 && in[0] == 0) ? 0 : (int64_t)CJ_E_CORRUPT; return; }
-    if (iend == 0) { a.result[c] = CJ_E_CORRUPT; return; }
-    a.result[c] = lz4_lane_walk<true>(in, iend, out, cap, nullptr, 0, nullptr);
-}
-
 void launch_lz4_decode_lanes(const BatchArgs& a, hipStream_t s) {
     if (a.n_chunks == 0) return;
     dim3 grid((a.n_chunks + 63u) / 64u), block(64);
     hipLaunchKernelGGL(lz4_decode_lanes_kernel, grid, block, 0, s, a);
-}
-
-void launch_lz4_classify(const BatchArgs& a, void* meta, void* lists, uint32_t lane_share, uint32_t wave_share, hipStream_t s) {
-    if (a.n_chunks == 0) return;
-    dim3 grid((a.n_chunks + 255u) / 256u), block(256);
-    hipLaunchKernelGGL(lz4_classify_kernel, grid, block, 0, s, a, (ParseMeta*)meta, (uint32_t*)lists, lane_share, wave_share);
 }
 
 void launch_lz4_parse(const BatchArgs& a, void* sync, void* meta, hipStream_t s) {
@@ -274,15 +209,6 @@ void launch_lz4_parse(const BatchArgs& a, void* sync, void* meta, hipStream_t s)
     const uint32_t per_block = 64u * kParseWaves;
     dim3 grid((a.n_chunks + per_block - 1u) / per_block), block(per_block);
     hipLaunchKernelGGL(lz4_parse_kernel, grid, block, 0, s, a, (uint2*)sync, (ParseMeta*)meta);
-}
-
-void launch_lz4_decode_lanes_listed(const BatchArgs& a, const void* lists, uint32_t lane_share, hipStream_t s) {
-    if (a.n_chunks == 0 || lane_share == 0) return;
-    // upper bound of listed chunks: ceil(n/20) * share
-    const uint64_t maxn = ((uint64_t)a.n_chunks + kLaneShareDen - 1u) / kLaneShareDen * lane_share;
-    dim3 grid((unsigned)((maxn + 63u) / 64u)), block(64);
-    const uint32_t* l = (const uint32_t*)lists;
-    hipLaunchKernelGGL(lz4_decode_lanes_listed_kernel, grid, block, 0, s, a, l + 4, l);
 }
 
 }  // namespace cj

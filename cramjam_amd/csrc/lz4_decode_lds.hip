@@ -1,25 +1,28 @@
-// lz4_decode_lds.hip — LZ4 *block* decoder, one WORKGROUP (16 wavefronts) per chunk, with the whole
-// 64 KiB output window, the compressed chunk, a sequence table and a ready bitmap resident in LDS
-// (160 KiB/CU on gfx950).
+// lz4_decode_lds.hip — the WORKGROUP decoder: LZ4 *block* / Snappy *raw* decoding with the chunk's 64 KiB output window
+// resident in LDS (160 KiB/CU on gfx950), two persistent workgroups of eight wavefronts per CU.
+// Same results as the other mappings (reference call sites /root/reference/src/lz4.rs:88,90,164,168, src/snappy.rs:57,106).
 //
-// Runs after lz4_parse_kernel (lz4_decode_lanes.hip), which validated the stream, computed the decoded
-// size and left an (ip, op) sync point every 8 sequences.  Same results as the other mappings
-// (reference call sites /root/reference/src/lz4.rs:88,90,164,168).
-//
-// Why: with one wave/lane per chunk every match copy is a dependent read of the chunk's own earlier
-// output somewhere in the last 64 KiB — an HBM round trip of a 128 B line for ~18 useful bytes.  Here
-// the history never leaves the CU: HBM sees exactly the algorithmic bytes (compressed chunk in with
-// 16 B/lane coalesced loads, 64 KiB out with 16 B/lane coalesced stores; PMC-verified), and the serial
-// token chain is broken by the sync points.  Phases per chunk (cycles measured on the benchmark data):
-//   S0  4.4k  stage compressed bytes into LDS, clear the ready bitmap
-//   D1 10.0k  one thread per sync point re-walks 8 sequences in LDS and writes 16 B sequence records
-//   D2 11.2k  literals: one lane per sequence, aligned-dword reads + one wait + head/dword/tail stores
-//   D3 60.5k  matches: one lane per sequence, copied as soon as the ready bitmap covers its source bytes;
-//             the earliest unresolved match is always ready, so the spin is deadlock-free (and bounded);
-//             runs >= 512 B are copied cooperatively by the whole wavefront
-//   D4  1.5k  stream the finished window to HBM
-// D3 is instruction-issue bound (the dependency DAG is ~25 levels x 100-500 matches; only ~4 of 64 lanes
-// are ready per poll); DESIGN.md §5.1 lists the restructurings that were measured and lost.
+// Why: with one wave/lane per chunk every match copy is a dependent read of the chunk's own earlier output somewhere in
+// the last 64 KiB — an HBM round trip of a 128 B line for ~18 useful bytes.  Here the history never leaves the CU.
+// Phases per chunk (cycles measured on the benchmark data with two workgroups per CU, profiles/r02):
+//   S0   8.8 k  stage the compressed chunk in the still unused window (16 B/lane loads), clear the ready bitmap
+//   P   (batches up to CJ_FUSED_MAX_CHUNKS chunks, lz4_decode_fused_kernel) the parse stage itself: 256 lanes walk 256 segments
+//               of the staged chunk, the true path is stitched, validated and written as 16 B records (fused_parse below)
+//   D1  12.5 k  (larger batches, after lz4_parse_kernel / snappy_parse_kernel) one thread per sync point re-walks 8 sequences
+//               in LDS (aligned dword pairs + v_alignbyte) and writes their records to the workgroup's table
+//   D1f         match forwarding for chunks of near matches (deep dependency chains), see below
+//   D2   22 k   literals: one lane per sequence, global -> window, head / dword / tail stores, ready bits set
+//   D3   52 k   matches: one lane per sequence, copied as soon as the ready bitmap covers its source bytes (the earliest
+//               unresolved match is always ready: deadlock-free); one hand-scheduled poll step for the common shape
+//   D4   2.3 k  stream the finished window to HBM (non-temporal 16 B stores)
+// What bounds it (profiles/r02/experiments): the LDS PIPE.  A sparse copy costs the pipe a few cycles per INSTRUCTION whatever
+// the number of active lanes (tools/lds_throughput_probe.hip: ds_read_b64 2.4, ds_write_b64 6.5, ds_or_b32 4.2 with 4 lanes;
+// a misaligned access lanes + 1), the resolver issues ~14 of them per poll round for ~4 ready matches, and with two
+// workgroups per CU in D3 the pipe is saturated — which is also why every dependent LDS read of the other phases takes
+// ~700 cycles.  Shortening the poll loop's instruction stream (3x), deeper prefetch in D2 or keeping every match of a thread
+// in flight changed nothing or lost; DESIGN.md §5.1 has the numbers.
+// The slab mode (one large stream: chunk c = slab c of its output) and the linked mode (LZ4 frames with linked blocks: the
+// previous block stays in a second window) share the body.
 #include "lz4_lane_walk.hpp"
 #include "snappy_records.hpp"
 #include "parse_grammar.hpp"
@@ -27,21 +30,11 @@
 
 namespace cj {
 
-#ifndef CJ_LDS_THREADS
-#define CJ_LDS_THREADS 1024
-#endif
-constexpr uint32_t kLdsThreads = CJ_LDS_THREADS;
-constexpr uint32_t kOffOut = 0;
-constexpr uint32_t kOffBits = 65536;                 // 2048 x u32: one ready bit per output byte
-constexpr uint32_t kOffIn = kOffBits + 8192;         // compressed bytes, then the record table
-constexpr uint32_t kLdsBytes = 163840;               // all 160 KiB, one dynamic region (no static LDS: keeps the base 16 B aligned)
-constexpr uint32_t kOffVars = kLdsBytes - 384;       // [0] fail flag, [4] work counter, [64,128) dummy bytes, [128,384) dummy dwords
-constexpr uint32_t kInTableBytes = kOffVars - kOffIn;
 constexpr uint32_t kLongRun = 512;                   // runs at least this long are copied by the whole wavefront
 constexpr uint32_t kSpinLimit = 1u << 18;
 
-// record: x = literal source (LDS byte offset inside s_in), y = literal length, z = match destination
-//         (= op after literals), w = offset | match length << 16 (0 on the final, literal-only sequence)
+// record: x = literal source (position in the compressed stream), y = literal length, z = match destination
+//         (= op after literals), w = offset | match length << 16 (0 = no match: LZ4's final sequence, a Snappy literal)
 
 // ---- unaligned LDS accessors ------------------------------------------------------------------
 // gfx950 executes ds_read_b32/ds_write_b32 at any byte alignment (tools/lds_unaligned_probe.hip:
@@ -232,244 +225,12 @@ __device__ unsigned long long g_lds_phase_cycles[8];
         }                                                                               \
     } while (0)
 
-__global__ __launch_bounds__(kLdsThreads) void lz4_decode_lds_kernel(BatchArgs a, const uint2* sync, const ParseMeta* meta) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t* s_out = smem + kOffOut;
-    uint32_t* s_bits = reinterpret_cast<uint32_t*>(smem + kOffBits);
-    uint8_t* s_in = smem + kOffIn;
-
-    const uint32_t a_out = (uint32_t)(uintptr_t)s_out, a_in = (uint32_t)(uintptr_t)s_in;   // LDS byte offsets
-    const Dummies dm = {(uint32_t)(uintptr_t)(smem + kOffVars + 64u) + (threadIdx.x & 63u),
-                        (uint32_t)(uintptr_t)(smem + kOffVars + 128u) + 4u * (threadIdx.x & 63u)};
-
-    const uint32_t c = blockIdx.x;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const ParseMeta pm = meta[c];
-    if (pm.nseq == 0u) return;                           // error, empty, or already decoded by the parse kernel
-    const uint32_t nseq = pm.nseq;
-    const uint32_t U = (uint32_t)a.result[c];            // decoded size, 1..65536
-    const uint8_t* in = a.in_base + a.in_off[c] + pm.in_skip;
-    const uint32_t iend = (uint32_t)a.in_len[c] - pm.in_skip;
-    uint8_t* out = a.out_base + a.out_off[c];
-
-    const bool prof = (a.flags & 0x1000u) != 0;
-    unsigned long long t_prev = prof ? __builtin_readcyclecounter() : 0ull;
-
-    // sync point of this thread for the first slab: issued now so its global-load latency hides behind S0
-    const uint2* csync = sync + (size_t)c * kSyncPitch;
-    const uint32_t nsp = (nseq + kSyncEvery - 1u) / kSyncEvery;
-    uint2 sp_first = make_uint2(0, 0);
-    if (tid < nsp) sp_first = csync[tid];
-
-    // ---- S0: stage the compressed chunk (16 B aligned loads), clear the bitmap ----
-    const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(in) & 15u);
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(in - mis);
-        uint4* dst = reinterpret_cast<uint4*>(s_in);
-        const uint32_t nvec = (mis + iend + 15u) >> 4;
-        for (uint32_t i = tid; i < nvec; i += kLdsThreads) dst[i] = src[i];
-        for (uint32_t i = tid; i < 2048u; i += kLdsThreads) s_bits[i] = 0u;
-    }
-    const uint32_t tb_off = (mis + iend + 15u) & ~15u;
-    uint4* table = reinterpret_cast<uint4*>(s_in + tb_off);
-    const uint32_t tcap = (kInTableBytes - tb_off) >> 4;                 // records that fit
-    const uint32_t sp_per_slab = tcap / kSyncEvery;                      // >= 1 by construction (iend <= kLdsInMax)
-    uint32_t* s_fail = reinterpret_cast<uint32_t*>(smem + kOffVars);
-    uint32_t* s_next = reinterpret_cast<uint32_t*>(smem + kOffVars + 4u);   // next unclaimed record of the current slab
-    if (tid == 0) { *s_fail = 0u; s_next[1] = 0u; s_next[2] = 0u; }
-    __syncthreads();
-    CJ_PHASE_MARK(0);
-
-    for (uint32_t sp0 = 0; sp0 < nsp; sp0 += sp_per_slab) {
-        const uint32_t sp1 = min(nsp, sp0 + sp_per_slab);
-        const uint32_t seq0 = sp0 * kSyncEvery;
-        const uint32_t nrec = min(nseq, sp1 * kSyncEvery) - seq0;
-
-        // ---- D1: expand sync points into sequence records ----
-        for (uint32_t sp = sp0 + tid; sp < sp1; sp += kLdsThreads) {
-            const uint2 p = sp == tid ? sp_first : csync[sp];
-            uint32_t ip = p.x + mis, op = p.y;
-            uint32_t s = sp * kSyncEvery;
-            for (uint32_t j = 0; j < kSyncEvery && s < nseq; j++, s++) {
-                const uint32_t t4 = lds_ld32(a_in + ip);           // token + 3 following bytes (may over-read: harmless)
-                const uint32_t token = t4 & 0xffu;
-                ip += 1;
-                uint32_t lit = token >> 4;
-                if (lit == 15u) {
-                    uint32_t b = (t4 >> 8) & 0xffu;
-                    ip += 1; lit += b;
-                    while (b == 255u) { b = lds_ld8(a_in + ip); ip += 1; lit += b; }
-                }
-                const uint32_t lit_src = ip;
-                ip += lit; op += lit;
-                uint32_t w = 0;
-                uint32_t mlen = 0;
-                if (s + 1u < nseq) {
-                    const uint32_t o4 = lds_ld32(a_in + ip);
-                    const uint32_t offset = o4 & 0xffffu;
-                    ip += 2;
-                    mlen = token & 15u;
-                    if (mlen == 15u) {
-                        uint32_t b = (o4 >> 16) & 0xffu;
-                        ip += 1; mlen += b;
-                        while (b == 255u) { b = lds_ld8(a_in + ip); ip += 1; mlen += b; }
-                    }
-                    mlen += 4u;
-                    w = offset | (mlen << 16);
-                }
-                table[s - seq0] = make_uint4(lit_src, lit, op, w);
-                op += mlen;
-            }
-        }
-        if (tid == 0) *s_next = 0u;
-        __syncthreads();
-        CJ_PHASE_MARK(1);
-
-        // ---- D2: literals, one lane per sequence, dependency-free and dense ----
-        for (uint32_t base = wave * 64u; base < nrec; base += kLdsThreads) {
-            const uint32_t r = base + lane;
-            uint4 rec = make_uint4(0, 0, 0, 0);
-            if (r < nrec) rec = table[r];
-            uint32_t n = rec.y, src = a_in + rec.x, dst = rec.z - rec.y;
-            // very long runs (incompressible data) are copied by the whole wavefront
-            uint64_t lm = ballot64(n >= kLongRun);
-            while (lm) {
-                const uint32_t l = ctz64(lm);
-                lm &= lm - 1ull;
-                const uint32_t ln = rdlane(n, l), ls = rdlane(src, l), ld = rdlane(dst, l);
-                for (uint32_t k = lane; k < ln; k += 64u) lds_st8(a_out + ld + k, lds_ld8(ls + k));
-                wave_bits_set(s_bits, ld, ld + ln);
-                if (lane == l) n = 0;
-            }
-            while (ballot64(n > 0u)) {                         // <=64 bytes per pass
-                const uint32_t step = n < 64u ? n : 64u;
-                const uint32_t tier = wave_tier(step, step > 0u);
-                if (step > 0u) {
-                    lds_copy_tier(tier, a_out + dst, src, step, dm);
-                    bits_set(s_bits, dst, dst + step);
-                    n -= step; src += step; dst += step;
-                }
-            }
-        }
-        __syncthreads();
-        CJ_PHASE_MARK(2);
-
-        // ---- D3: matches, one lane per sequence, dependency-exact through the ready bitmap.  Waves take batches of 64
-        //      consecutive sequences round-robin; a lane copies its match as soon as the bitmap says its source bytes
-        //      are final.  The earliest unresolved match is always ready, so the spin is deadlock-free (and bounded).
-        //      The loop is instruction-issue bound (~650 sparse iterations per chunk, ~4 ready lanes each), so
-        //      everything that does not change per poll is hoisted: the two bitmap words + masks that decide
-        //      readiness and the two words + masks that publish the result are computed once per batch.
-        for (uint32_t base = wave * 64u; base < nrec; base += kLdsThreads) {
-            const uint32_t r = base + lane;
-            uint4 rec = make_uint4(0, 0, 0, 0);
-            if (r < nrec) rec = table[r];
-            const uint32_t dst = rec.z, off = rec.w & 0xffffu, m = rec.w >> 16;
-            const uint32_t src = dst - off;
-            const uint32_t need = off < m ? off : m;          // distinct source bytes
-            bool pending = m > 0u;
-            // fast lanes: source window and destination both fit two bitmap words and the copy is a plain tier copy
-            const bool fast = pending && m <= 32u && off >= m;
-            uint32_t pa = 0, pm0 = 0, pm1 = 0, qa = 0, qm0 = 0, qm1 = 0;
-            if (fast) {
-                const uint32_t sh = src & 31u, e = sh + need;                 // bits [sh, e) of the 64-bit window at word src>>5
-                pa = (uint32_t)(uintptr_t)(s_bits + (src >> 5));
-                pm0 = (e >= 32u ? ~0u : ((1u << e) - 1u)) & (~0u << sh);
-                pm1 = e > 32u ? ((1u << (e - 32u)) - 1u) : 0u;
-                const uint32_t dh = dst & 31u, de = dh + m;
-                qa = (uint32_t)(uintptr_t)(s_bits + (dst >> 5));
-                qm0 = (de >= 32u ? ~0u : ((1u << de) - 1u)) & (~0u << dh);
-                qm1 = de > 32u ? ((1u << (de - 32u)) - 1u) : 0u;
-            }
-            const bool any_slow = ballot64(pending && !fast) != 0ull;
-            uint32_t spins = 0;
-            while (ballot64(pending) != 0ull) {
-                bool ready = false;
-                if (pending && fast) {
-                    const uint2 w = lds_ld64(pa);
-                    ready = ((w.x & pm0) == pm0) && ((w.y & pm1) == pm1);
-                }
-                const uint64_t rm = ballot64(ready);
-                if (rm != 0ull) {
-                    const uint32_t tier = ballot64(ready && m > 16u) ? 32u : 16u;
-                    if (ready) {
-                        if (tier == 16u) lds_store_tier<16>(lds_ld_aligned6((a_out + src) & ~3u), a_out + dst, src & 3u, m, dm);
-                        else lds_store_tier<32>(lds_ld_aligned10((a_out + src) & ~3u), a_out + dst, src & 3u, m, dm);
-                        // publish: the copy's DS writes were issued before these DS atomics by the same wave (in order)
-                        asm volatile("ds_or_b32 %0, %1\n\tds_or_b32 %0, %2 offset:4" :: "v"(qa), "v"(qm0), "v"(qm1) : "memory");
-                        pending = false;
-                    }
-                }
-                if (any_slow) {
-                    // rare shapes: self-overlapping matches, matches longer than 32 bytes, RLE-like long runs
-                    bool sready = false;
-                    if (pending && !fast) sready = bits_ready(s_bits, src, src + need);
-                    if (sready && m < kLongRun) {
-                        if (off >= 8u) {
-                            uint32_t k = 0;
-                            for (; k + 8u <= m; k += 8u) {
-                                uint8_t t[8];
-#pragma unroll
-                                for (int q = 0; q < 8; q++) t[q] = s_out[src + k + q];
-#pragma unroll
-                                for (int q = 0; q < 8; q++) s_out[dst + k + q] = t[q];
-                            }
-                            for (; k < m; k++) s_out[dst + k] = s_out[src + k];
-                        } else {
-                            for (uint32_t k = 0; k < m; k++) s_out[dst + k] = s_out[src + k];
-                        }
-                        bits_set(s_bits, dst, dst + m);
-                        pending = false;
-                    }
-                    uint64_t longm = ballot64(sready && m >= kLongRun);     // RLE-like: whole wavefront, 64 bytes per step
-                    while (longm) {
-                        const uint32_t l = ctz64(longm);
-                        longm &= longm - 1ull;
-                        const uint32_t lm = rdlane(m, l), lo = rdlane(off, l), ld = rdlane(dst, l);
-                        const uint32_t ls = ld - lo;
-                        uint32_t rr = lane, step = 64u;
-                        if (lo <= 64u) { rr = lane % lo; step = 64u % lo; }
-                        for (uint32_t k = lane; k < lm; k += 64u) {           // periodic read: sources are the lo bytes before ld
-                            s_out[ld + k] = s_out[ls + (lo >= lm ? k : rr)];
-                            rr += step;
-                            if (rr >= lo) rr -= lo;
-                        }
-                        wave_bits_set(s_bits, ld, ld + lm);
-                        if (lane == l) pending = false;
-                    }
-                }
-                if (++spins > kSpinLimit) { *s_fail = 1u; break; }
-            }
-        }
-        __syncthreads();
-        CJ_PHASE_MARK(3);
-    }
-
-    // ---- D4: stream the window out (16 B per lane), exact tail ----
-    {
-        const uint32_t nvec = U >> 4;
-        const uint4* src = reinterpret_cast<const uint4*>(s_out);
-        for (uint32_t i = tid; i < nvec; i += kLdsThreads) st16u(out + 16u * i, src[i]);
-        for (uint32_t i = (nvec << 4) + tid; i < U; i += kLdsThreads) out[i] = s_out[i];
-    }
-    __syncthreads();
-    CJ_PHASE_MARK(4);
-    if (prof && tid == 0) {
-        atomicAdd(&g_lds_phase_cycles[5], 1ull);
-        atomicAdd(&g_lds_phase_cycles[6], (unsigned long long)s_next[1]);
-        atomicAdd(&g_lds_phase_cycles[7], (unsigned long long)s_next[2]);
-    }
-    if (tid == 0 && *s_fail) a.result[c] = CJ_E_CORRUPT;    // cannot happen for a stream the parse kernel accepted
-}
-
 // =====================================================================================================
-// Variant 2: TWO workgroups per CU.  The kernel above keeps the compressed chunk and the record table in LDS next
-// to the output window, which fills the CU's 160 KiB with ONE chunk — and its longest phase (D3) is bound by the
-// latency of the match-dependency chain, not by issue or LDS bandwidth, so most of the CU idles.  Here only what
-// must be in LDS stays there (output window + ready bitmap, 72.4 KiB): the compressed bytes are read straight
-// from global memory (each byte is consumed once, by D1's token walk or D2's literal copy) and the record table
-// lives in a per-workgroup global scratch slot that is written once and read twice with coalesced 16 B accesses
-// (L2-resident: the grid is persistent, 2 slots per CU).  Two chunks per CU then overlap each other's latency.
+// TWO workgroups per CU: only what must be in LDS stays there (output window + ready bitmap, 72.4 KiB).  The compressed
+// bytes are staged in the still unused window for the token walk and read again from global memory (L2 hits) for the
+// literal copies, and the record table lives in a per-workgroup global scratch slot that is written once and read twice
+// with coalesced 16 B accesses (L2-resident: the grid is persistent, 2 slots per CU).  Two chunks per CU overlap each
+// other's latency (one chunk per CU with everything in LDS — round 1's first version — ran at 385 GB/s against 508).
 // Workgroups are persistent and pull chunk indices from a global counter.
 // =====================================================================================================
 #ifndef CJ_L2_THREADS
@@ -530,6 +291,214 @@ __device__ __forceinline__ DW<T / 4 + 2> gl_ld_exact(const uint8_t* g) {
     return r;
 }
 
+// =====================================================================================================
+// The PARSE STAGE INSIDE the decoder (kFused): no separate parse kernel, no sync points in memory, the compressed chunk is
+// read from HBM once.  S0 has staged the chunk in LDS; 256 lanes then walk 256 SEGMENTS of it at once — the segmented
+// speculative walk of parse_spec.hip (one wavefront per chunk there) on four wavefronts:
+//   P1a  lane l starts at the guessed position l * seg and walks its own segment, marking every position it visits
+//        (one bit per input byte, in the ready bitmap's space: it is not needed before D2);
+//   P1b  it walks on through the following segments until it steps on a marked position: from there its path IS that
+//        segment owner's path (the next-element function depends on the bytes only); merge[l] = that position;
+//   P2   the true path = lane 0's piece, then the piece of the lane it merged into, ...: a pointer chain over the lanes,
+//        marked from lane 0 by pointer doubling (8 rounds for 256 lanes) instead of 256 dependent hops;
+//   P3   the lanes on the chain count the sequences and output bytes of their piece, an exclusive scan over the lanes
+//        gives every piece its first sequence index and output position;
+//   P4   they walk their piece once more with the true (index, output position): the decoder's own validation rules
+//        (the same Lz4Grammar / SnappyGrammar functions as the parse kernels) and the 16-byte records of D1, written
+//        straight to the workgroup's record table.
+// Anything that is not a clean chunk of 256..8192 sequences (any violation, too few or too many sequences) is handed to
+// the wavefront-per-chunk kernel, which decodes every valid chunk and names every error exactly: returns false then.
+// =====================================================================================================
+constexpr uint32_t kFusedLanes = 256;
+constexpr uint32_t kFusedAux = 6u * kFusedLanes * 4u;              // merge, next, mark, entry, count, bytes: 6 KiB behind the decoder's LDS
+
+__device__ __forceinline__ uint32_t wave_excl_scan_add32(uint32_t v, uint32_t& total) {
+    const uint32_t lane = lane_id();
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)x, d, 64);
+        if (lane >= (uint32_t)d) x += t;
+    }
+    total = rdlane(x, 63);
+    return x - v;
+}
+
+// One element at position ip, straight-line: the common LZ4 sequence (length extensions of at most one byte, not within 8 bytes of
+// the end) costs two LDS round trips and ~25 instructions; G::at — the general function with its loops — runs only where a lane
+// meets anything else (a wavefront walks at the pace of its slowest lane: the general function alone is ~1.4 k cycles per step).
+template <class G, class Rd>
+__device__ __forceinline__ bool walk_step(const Rd& rd, uint32_t ip, uint32_t iend, Seq& s) {
+    if constexpr (std::is_same<G, Lz4Grammar>::value) {
+        const uint32_t t4 = rd(ip);
+        const uint32_t token = t4 & 0xffu, e1 = (t4 >> 8) & 0xffu;
+        const bool x1 = (token >> 4) == 15u;
+        const uint32_t lit = (token >> 4) + (x1 ? e1 : 0u);
+        const uint32_t ip1 = ip + 1u + (x1 ? 1u : 0u), ip2 = ip1 + lit;
+        const uint32_t o4 = rd(ip2 < iend ? ip2 : ip);
+        const uint32_t mc = token & 15u, e2 = (o4 >> 16) & 0xffu;
+        const bool x2 = mc == 15u;
+        // rem_in >= lit + 8 keeps every bound G::at checks while it reads one-byte extensions
+        const bool fast = !(x1 && e1 == 255u) && !(x2 && e2 == 255u) && ip1 + 16u <= iend && iend - ip1 >= lit + 8u;
+        if (ballot64(!fast) == 0ull) {
+            s.lit = lit; s.lit_at = ip1; s.last = false; s.offset = o4 & 0xffffu;
+            s.mlen = mc + (x2 ? e2 : 0u) + 4u;
+            s.next = ip2 + 2u + (x2 ? 1u : 0u);
+            return true;
+        }
+        bool ok = true;
+        if (fast) {
+            s.lit = lit; s.lit_at = ip1; s.last = false; s.offset = o4 & 0xffffu;
+            s.mlen = mc + (x2 ? e2 : 0u) + 4u;
+            s.next = ip2 + 2u + (x2 ? 1u : 0u);
+        } else ok = G::at(rd, ip, iend, s);
+        return ok;
+    } else {
+        return G::at(rd, ip, iend, s);
+    }
+}
+
+// a_in: LDS address of stream position 0; aux: kFusedAux bytes of LDS; bits: 8 KiB, zeroed; table: the record table.
+// On success: nseq_out / U_out, *near_out += matches with an offset below kFwdNear.  Every thread of the workgroup calls it.
+template <class G, uint32_t kThreads>
+__device__ __forceinline__ bool fused_parse(uint32_t a_in, uint32_t iend, uint32_t cap, uint32_t* bits, uint32_t* aux, uint4* table,
+                                            uint32_t* s_near, uint32_t& nseq_out, uint32_t& U_out) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t* s_merge = aux;
+    uint32_t* s_next = aux + kFusedLanes;
+    uint32_t* s_mark = aux + 2u * kFusedLanes;
+    uint32_t* s_entry = aux + 3u * kFusedLanes;
+    uint32_t* s_tot = aux + 4u * kFusedLanes;            // [0..8): per-wave totals (count, bytes); [16..24): verdict words
+    const uint32_t a_bits = (uint32_t)(uintptr_t)bits;
+    const auto rd = [a_in](uint32_t q) { return lds_ld32a(a_in + q); };
+    const bool plane = tid < kFusedLanes;                  // the parse lanes (wavefronts 0-3); everyone takes the barriers
+
+    uint32_t nl = (iend + 63u) / 64u;
+    nl = nl > kFusedLanes ? kFusedLanes : nl;
+    const uint32_t seg = (((iend + nl - 1u) / nl + 3u) & ~3u) | 4u;          // 4 x odd: the lanes' start positions spread over the banks
+    const bool active = plane && tid < nl && tid * seg < iend;
+    const uint32_t seg_end = (tid + 1u) * seg;
+    if (tid < 32u) s_tot[tid] = 0u;
+
+    // ---- P1a ----
+    uint32_t p = active ? tid * seg : kPosEnd;
+    if (plane) {
+        while (ballot64(p < seg_end && p < iend) != 0ull) {
+            if (p < seg_end && p < iend) {
+                asm volatile("ds_or_b32 %0, %1" :: "v"(a_bits + 4u * (p >> 5)), "v"(1u << (p & 31u)) : "memory");
+                Seq sq;
+                p = walk_step<G>(rd, p, iend, sq) ? sq.next : kPosErr;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- P1b ----
+    uint32_t merge_pos = p;
+    if (plane) {
+        bool going = active && p < iend;
+        while (ballot64(going) != 0ull) {
+            if (going) {
+                uint32_t w;
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(a_bits + 4u * (p >> 5)) : "memory");
+                if ((w >> (p & 31u)) & 1u) { merge_pos = p; going = false; }
+                else {
+                    Seq sq;
+                    p = walk_step<G>(rd, p, iend, sq) ? sq.next : kPosErr;
+                    if (p >= iend) { merge_pos = p; going = false; }
+                }
+            }
+        }
+        if (active && merge_pos >= iend && merge_pos != kPosEnd) merge_pos = kPosErr;
+        const uint32_t nx0 = merge_pos < iend ? merge_pos / seg : tid;       // a piece that ends the stream points at itself
+        s_merge[tid] = merge_pos;
+        s_next[tid] = active ? nx0 : tid;
+        s_mark[tid] = tid == 0u ? 1u : 0u;
+        s_entry[tid] = 0u;
+    }
+    __syncthreads();
+    // ---- P2: mark the chain from lane 0 by pointer doubling ----
+    for (uint32_t round = 0; round < 8u; round++) {
+        uint32_t n1 = 0, n2 = 0;
+        if (plane) {
+            n1 = s_next[tid];
+            if (s_mark[tid]) s_mark[n1] = 1u;
+            n2 = s_next[n1];
+        }
+        __syncthreads();
+        if (plane) s_next[tid] = n2;
+        __syncthreads();
+    }
+    bool on_chain = false;
+    if (plane) {
+        on_chain = active && s_mark[tid] != 0u;
+        if (on_chain && merge_pos < iend) s_entry[merge_pos / seg] = merge_pos;
+    }
+    __syncthreads();
+    const uint32_t entry = plane ? s_entry[tid] : 0u;       // lane 0 enters at 0
+    const uint32_t piece_end = merge_pos;
+
+    // ---- P3: count ----
+    uint32_t cnt = 0, outb = 0;
+    if (plane) {
+        uint32_t q = on_chain ? entry : kPosEnd;
+        while (ballot64(q < iend && q != piece_end) != 0ull) {
+            if (q < iend && q != piece_end) {
+                Seq sq;
+                if (walk_step<G>(rd, q, iend, sq)) { cnt += 1; outb += sq.lit + sq.mlen; q = sq.next; }
+                else q = kPosErr;
+            }
+        }
+    }
+    uint32_t base_idx = 0, base_op = 0;
+    if (plane) {
+        uint32_t tc, tb;
+        base_idx = wave_excl_scan_add32(cnt, tc);
+        base_op = wave_excl_scan_add32(outb, tb);
+        if (lane == 0) { s_tot[wave] = tc; s_tot[4u + wave] = tb; }
+    }
+    __syncthreads();
+    if (plane) {
+        for (uint32_t w = 0; w < wave; w++) { base_idx += s_tot[w]; base_op += s_tot[4u + w]; }
+    }
+    const uint32_t total_seq = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
+    // (a valid chunk's pieces add up to at most `cap` output bytes; a wild count is caught by the checks of P4)
+    if (total_seq < kLdsMinSeq || total_seq > kSyncStride * kSyncEvery) return false;       // uniform: too few / too many sequences for this decoder
+
+    // ---- P4: validate + write the records ----
+    if (plane) {
+        bool bad = false, saw_last = false;
+        uint32_t final_op = 0, near = 0;
+        uint32_t q = on_chain ? entry : kPosEnd, idx = base_idx, op = base_op;
+        while (ballot64(q < iend && q != piece_end && !bad) != 0ull) {
+            if (q < iend && q != piece_end && !bad) {
+                Seq sq;
+                bool fin = false;
+                uint32_t op2 = op;
+                if (!walk_step<G>(rd, q, iend, sq) || !G::check(sq, op2, cap, fin) || idx >= total_seq) bad = true;
+                else {
+                    const uint32_t dst = op + sq.lit;
+                    const uint32_t w = sq.mlen == 0u ? 0u : ((sq.offset & 0xffffu) | (sq.mlen << 16));       // (a Snappy stream may END with a copy)
+                    table[idx] = make_uint4(sq.lit_at, sq.lit, dst, w);
+                    near += (w != 0u && sq.offset < 4096u) ? 1u : 0u;
+                    op = op2;
+                    if (fin) { final_op = op; saw_last = true; q = kPosEnd; }
+                    else { q = sq.next; idx += 1; }
+                }
+            }
+        }
+        if (near) atomicAdd(s_near, near);
+        if (on_chain && (bad || piece_end == kPosErr)) atomicOr(&s_tot[16], 1u);
+        if (on_chain && saw_last) { atomicAdd(&s_tot[17], 1u); s_tot[18] = final_op; s_tot[19] = idx + 1u; }
+    }
+    __syncthreads();
+    const uint32_t op_end = s_tot[18];
+    if (s_tot[16] != 0u || s_tot[17] != 1u || s_tot[19] != total_seq || !G::result_ok(op_end, cap) || op_end == 0u) return false;
+    nseq_out = total_seq;
+    U_out = op_end;
+    return true;
+}
+
+
 // kLinked (LZ4 frames with linked blocks, frame.hip): the workgroup takes a whole FRAME (frames[f] = first block index,
 // block count) and walks its blocks in order; the LDS holds TWO 64 KiB windows, the block being decoded and the previous
 // block (every non-last block of such a frame decodes to exactly 64 KiB — the host checks that before it launches this
@@ -572,7 +541,7 @@ constexpr uint32_t kSlabPatience = CJ_SLAB_PATIENCE;
 // rel = 1 (LZ4 frames with linked blocks, frame.hip): chunk c is block c of the frame — its sync points are its own (ip, op
 // relative to the block), the stream length is the block's, a STORED block is copied; history = the blocks before it.
 
-template <int kCodec, bool kLinked, bool kSlab>
+template <int kCodec, bool kLinked, bool kSlab, bool kFused = false>
 __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync, const ParseMeta* meta, uint4* tabs, uint32_t* counter,
                                           const uint2* frames, uint32_t n_frames, const SlabArgs& sl) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -629,12 +598,51 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             if (c >= a.n_chunks) break;
             if constexpr (!kSlab) { if (tid == 0) next_c = atomicAdd(counter, 1u); }
         }
-        const ParseMeta pm = meta[c];
+        ParseMeta pm = {1u, 0u};                            // kFused: nothing has looked at the chunk yet
+        if constexpr (!kFused) pm = meta[c];
         // the chunk's descriptors in ONE round trip: left to itself the compiler waits for pm.nseq (the early-out below) before it
         // even requests the others, and the chunk's bytes are a third dependent round trip behind those
         const uint64_t d_in_off = a.in_off[c], d_in_len = a.in_len[c], d_out_off = a.out_off[c];
-        const uint64_t d_result = (uint64_t)a.result[c];
+        const uint64_t d_result = kFused ? a.out_cap[c] : (uint64_t)a.result[c];      // kFused: the capacity (the parse computes the size)
         asm volatile("" :: "v"(pm.nseq), "v"(pm.in_skip), "v"((uint32_t)d_in_off), "v"((uint32_t)d_in_len), "v"((uint32_t)d_out_off), "v"((uint32_t)d_result));
+        uint32_t f_cap = 0;                                  // kFused: output capacity (LZ4) / announced length (Snappy) handed to the parse
+        if constexpr (kFused) {
+            // the prologue of the parse kernels: size prefix / length preamble, the special cases, what this decoder cannot hold.
+            // Everything that is not a plain chunk goes to the wavefront-per-chunk kernel (it names every error exactly).
+            ParseMeta* meta_w = const_cast<ParseMeta*>(meta);
+            const uint8_t* in0 = a.in_base + d_in_off;
+            uint64_t n64 = d_in_len, cap64 = d_result;
+            bool route = false;
+            uint32_t skip = 0;
+            if constexpr (kCodec == CJ_CODEC_SNAPPY_RAW) {
+                uint64_t ulen = 0;
+                uint32_t shift = 0, i = 0, hdr = 0;
+                bool ok = false;
+                if (n64 == 0 || n64 > 0xFFFFFFF0ull) route = true;
+                else {
+                    const uint32_t h0 = ld32u(in0), h1 = ld32u(in0 + 4);         // (padded: reads past a tiny chunk stay in its granule... see cramjam_hip.h)
+                    while (hdr < (uint32_t)n64 && i < 5u) {
+                        const uint32_t bb = (hdr < 4u ? h0 >> (8u * hdr) : h1 >> (8u * (hdr - 4u))) & 0xffu;
+                        hdr += 1;
+                        if (bb < 0x80u) { ulen |= (uint64_t)bb << shift; ok = true; break; }
+                        ulen |= (uint64_t)(bb & 0x7fu) << shift;
+                        shift += 7; i += 1;
+                    }
+                    if (!ok || ulen > 0xFFFFFFFFull || ulen > cap64 || ulen == 0 || ulen > kLdsOutMax || n64 - hdr > kLdsInMax || hdr == (uint32_t)n64) route = true;
+                    skip = hdr; cap64 = ulen;
+                }
+            } else {
+                const uint8_t* inp = in0;
+                if (lz4_block_prologue(a.flags, inp, n64, cap64) != 0) route = true;
+                else {
+                    skip = (uint32_t)(inp - in0);
+                    if (cap64 == 0 || n64 == 0 || cap64 > kLdsOutMax || n64 > kLdsInMax) route = true;
+                }
+            }
+            if (route) { if (tid == 0) meta_w[c] = ParseMeta{0u, kRouteWave}; continue; }
+            pm.in_skip = skip;
+            f_cap = (uint32_t)cap64;
+        }
         // kSlab: does this chunk have a predecessor whose completion it may have to wait for?  (large streams: out_cap[c] holds the
         // slab's first output position IN ITS STREAM — several streams may share one launch; linked frames: block 0 has none)
         const bool has_prev = kSlab && (sl.rel ? c > 0u : a.out_cap[c] != 0ull);
@@ -694,8 +702,8 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             }
         }
         if (pm.nseq == 0u) { publish(); continue; }          // error, empty, or routed to another kernel
-        const uint32_t nseq = pm.nseq;
-        const uint32_t U = (uint32_t)d_result;               // decoded size, 1..65536
+        uint32_t nseq = pm.nseq;                             // kFused: set by the parse below
+        uint32_t U = (uint32_t)d_result;                     // decoded size, 1..65536
         const bool slab_meta = kSlab && !sl.rel;            // large streams: meta[c].in_skip = the stream's end relative to this slab's input
         const uint32_t in_skip = slab_meta ? 0u : pm.in_skip;
         const uint8_t* in = a.in_base + d_in_off + in_skip;
@@ -713,7 +721,8 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         //      the window while other lanes still need their sources ----
         const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(in) & 15u);
         // this thread's first sync point (D1) is requested together with the chunk's bytes: one round trip instead of two
-        const uint2 p_first = csync[tid < nsp ? tid : 0u];
+        uint2 p_first = make_uint2(0u, 0u);
+        if constexpr (!kFused) p_first = csync[tid < nsp ? tid : 0u];
         {
             const uint4* src = reinterpret_cast<const uint4*>(in - mis);
             uint4* dst = reinterpret_cast<uint4*>(s_out);
@@ -741,7 +750,20 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
 
         // ---- D1: expand sync points into sequence records (LDS -> global table) ----
         const uint32_t a_in = a_out + mis;
+        if constexpr (kFused) {
+            using G = typename std::conditional<kCodec == CJ_CODEC_SNAPPY_RAW, SnappyGrammar, Lz4Grammar>::type;
+            const bool ok = fused_parse<G, kL2Threads>(a_in, iend, f_cap, s_bits, reinterpret_cast<uint32_t*>(smem + kL2Bytes), table, s_small, nseq, U);
+            ParseMeta* meta_w = const_cast<ParseMeta*>(meta);
+            if (!ok) { if (tid == 0) meta_w[c] = ParseMeta{0u, kRouteWave}; continue; }      // (uniform)
+            if (tid == 0) { meta_w[c] = ParseMeta{0u, 0u}; a.result[c] = (int64_t)U; }
+            for (uint32_t i = tid; i < 2048u; i += kL2Threads) s_bits[i] = 0u;                // the walk's marks: a bitmap again
+            __syncthreads();
+            CJ_PHASE_MARK(1);
+        }
         uint32_t nrec_all = nseq;                            // kSlab: + the internal remainders of cross matches (extra records)
+        if constexpr (kFused) {
+            // (the records are in the table already)
+        } else
         if constexpr (kSlab) {
             using G = typename std::conditional<kCodec == CJ_CODEC_SNAPPY_RAW, SnappyGrammar, Lz4Grammar>::type;
             const uint32_t in_lo = frames[c].y;
@@ -1472,6 +1494,25 @@ __global__ __launch_bounds__(kL2Threads) __attribute__((amdgpu_waves_per_eu(4, 4
     lds2_body<kCodec, false, true>(a, sync, meta, tabs, counter, first, stream_len, sl);
 }
 
+// parse + decode in one kernel (batches of independent chunks).  meta: written here (kRouteWave for the chunks left to the wave kernel)
+template <int kCodec>
+__global__ __launch_bounds__(kL2Threads) CJ_L2_ATTR void lz4_decode_fused_kernel(BatchArgs a, ParseMeta* meta, uint4* tabs, uint32_t* counter) {
+    lds2_body<kCodec, false, false, true>(a, nullptr, meta, tabs, counter, nullptr, 0u, SlabArgs{nullptr, nullptr, 0u, 0u, 0u, nullptr, 0u});
+}
+
+void launch_lz4_decode_fused(const BatchArgs& a, void* meta, void* tabs, uint32_t* counter, uint32_t grid, hipStream_t s, int codec) {
+    if (a.n_chunks == 0) return;
+    constexpr uint32_t bytes = kL2Bytes + kFusedAux;
+    static_assert(2u * bytes <= 163840u, "two workgroups per CU");
+    if (codec == CJ_CODEC_SNAPPY_RAW) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_fused_kernel<CJ_CODEC_SNAPPY_RAW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        hipLaunchKernelGGL((lz4_decode_fused_kernel<CJ_CODEC_SNAPPY_RAW>), dim3(grid), dim3(kL2Threads), bytes, s, a, (ParseMeta*)meta, (uint4*)tabs, counter);
+        return;
+    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_fused_kernel<CJ_CODEC_LZ4_BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    hipLaunchKernelGGL((lz4_decode_fused_kernel<CJ_CODEC_LZ4_BLOCK>), dim3(grid), dim3(kL2Threads), bytes, s, a, (ParseMeta*)meta, (uint4*)tabs, counter);
+}
+
 size_t lz4_lds2_tab_bytes(uint32_t grid) { return (size_t)grid * kL2TabRecords * sizeof(uint4); }
 
 void launch_lz4_decode_lds2(const BatchArgs& a, const void* sync, const void* meta, void* tabs, uint32_t* counter,
@@ -1522,13 +1563,6 @@ void launch_lz4_decode_lds2_slabs(const BatchArgs& a, const void* sync, const vo
                        (const uint2*)sync, (const ParseMeta*)meta, (uint4*)tabs, counter, (const uint2*)first, stream_len, sl);
 }
 
-void launch_lz4_decode_lds(const BatchArgs& a, const void* sync, const void* meta, hipStream_t s) {
-    if (a.n_chunks == 0) return;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_lds_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);   // per device; cheap
-    hipLaunchKernelGGL(lz4_decode_lds_kernel, dim3(a.n_chunks), dim3(kLdsThreads), kLdsBytes, s, a,
-                       (const uint2*)sync, (const ParseMeta*)meta);
-}
 
 }  // namespace cj
 #ifdef CJ_SLAB_TRACE

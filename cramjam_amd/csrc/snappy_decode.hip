@@ -13,13 +13,11 @@
 
 namespace cj {
 
-// skip: when non-null, chunks flagged kRouteLane there belong to the lane kernel (large-batch pipeline);
-// only_routed: decode only the chunks the parse kernel flagged kRouteWave (parse + LDS pipeline)
-__global__ __launch_bounds__(kBlockThreads) void snappy_decode_kernel(BatchArgs a, const ParseMeta* skip, int only_routed) {
+// route: nullptr = decode every chunk; else only chunks the parse stage flagged kRouteWave
+__global__ __launch_bounds__(kBlockThreads) void snappy_decode_kernel(BatchArgs a, const ParseMeta* route) {
     const uint32_t chunk = uni(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
     if (chunk >= a.n_chunks) return;
-    if (skip != nullptr && (skip[chunk].in_skip & kRouteLane) != 0u) return;
-    if (only_routed && (skip[chunk].in_skip & kRouteWave) == 0u) return;
+    if (route != nullptr && (route[chunk].in_skip & kRouteWave) == 0u) return;
     const uint8_t* in = a.in_base + a.in_off[chunk];
     const uint64_t n64 = a.in_len[chunk];
     uint8_t* out = a.out_base + a.out_off[chunk];
@@ -193,13 +191,8 @@ __device__ __forceinline__ int64_t snappy_lane_walk(const uint8_t* in, uint64_t 
     return (int64_t)dn;
 }
 
-// list/count: when non-null, lane i decodes chunk list[i] for i < *count
-__global__ __launch_bounds__(64) void snappy_decode_lanes_kernel(BatchArgs a, const uint32_t* list, const uint32_t* count) {
-    uint32_t c = blockIdx.x * 64u + threadIdx.x;
-    if (list != nullptr) {
-        if (c >= *count) return;
-        c = list[c];
-    }
+__global__ __launch_bounds__(64) void snappy_decode_lanes_kernel(BatchArgs a) {
+    const uint32_t c = blockIdx.x * 64u + threadIdx.x;
     if (c >= a.n_chunks) return;
     a.result[c] = snappy_lane_walk(a.in_base + a.in_off[c], a.in_len[c], a.out_base + a.out_off[c], a.out_cap[c]);
 }
@@ -207,25 +200,13 @@ __global__ __launch_bounds__(64) void snappy_decode_lanes_kernel(BatchArgs a, co
 void launch_snappy_decode(const BatchArgs& a, hipStream_t s) {
     if (a.n_chunks == 0) return;
     dim3 grid((a.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlockThreads);
-    hipLaunchKernelGGL(snappy_decode_kernel, grid, block, 0, s, a, (const ParseMeta*)nullptr, 0);
+    hipLaunchKernelGGL(snappy_decode_kernel, grid, block, 0, s, a, (const ParseMeta*)nullptr);
 }
 
-void launch_snappy_decode_skipping(const BatchArgs& a, const void* meta, hipStream_t s) {
-    if (a.n_chunks == 0) return;
-    dim3 grid((a.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlockThreads);
-    hipLaunchKernelGGL(snappy_decode_kernel, grid, block, 0, s, a, (const ParseMeta*)meta, 0);
-}
 
-void launch_snappy_decode_lanes(const BatchArgs& a, const void* lists, uint32_t lane_share, hipStream_t s) {
+void launch_snappy_decode_lanes(const BatchArgs& a, hipStream_t s) {
     if (a.n_chunks == 0) return;
-    if (lists == nullptr) {
-        hipLaunchKernelGGL(snappy_decode_lanes_kernel, dim3((a.n_chunks + 63u) / 64u), dim3(64), 0, s, a, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
-        return;
-    }
-    if (lane_share == 0) return;
-    const uint64_t maxn = ((uint64_t)a.n_chunks + kLaneShareDen - 1u) / kLaneShareDen * lane_share;
-    const uint32_t* l = (const uint32_t*)lists;
-    hipLaunchKernelGGL(snappy_decode_lanes_kernel, dim3((unsigned)((maxn + 63u) / 64u)), dim3(64), 0, s, a, l + 4, l);
+    hipLaunchKernelGGL(snappy_decode_lanes_kernel, dim3((a.n_chunks + 63u) / 64u), dim3(64), 0, s, a);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -243,7 +224,7 @@ __global__ __launch_bounds__(64 * kParseWaves) void snappy_parse_kernel(BatchArg
     const uint32_t c = blockIdx.x * (64u * kParseWaves) + threadIdx.x;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     const uint32_t wave_ring = (uint32_t)(uintptr_t)rings + wave * 64u * kRingStride;
-    const bool exists = c < a.n_chunks && (meta[c < a.n_chunks ? c : 0].in_skip & kRouteLane) == 0u;
+    const bool exists = c < a.n_chunks;
 
     const uint8_t* in = nullptr;
     uint64_t n64 = 0, cap64 = 0;
@@ -354,7 +335,7 @@ void launch_snappy_parse(const BatchArgs& a, void* sync, void* meta, hipStream_t
 void launch_snappy_decode_routed(const BatchArgs& a, const void* meta, hipStream_t s) {
     if (a.n_chunks == 0) return;
     dim3 grid((a.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlockThreads);
-    hipLaunchKernelGGL(snappy_decode_kernel, grid, block, 0, s, a, (const ParseMeta*)meta, 1);
+    hipLaunchKernelGGL(snappy_decode_kernel, grid, block, 0, s, a, (const ParseMeta*)meta);
 }
 
 }  // namespace cj

@@ -29,6 +29,9 @@
 extern "C" {
 #endif
 
+/* the library is built with -fvisibility=hidden: exactly the functions declared here are exported */
+#define CJ_API __attribute__((visibility("default")))
+
 #define CJ_ABI_VERSION 1
 
 /* ---- error codes ---- */
@@ -62,12 +65,12 @@ extern "C" {
 #define CJ_E_BAD_ARG           (-101)
 #define CJ_E_OOM               (-102) /* device or pinned-host allocation failed */
 
-const char* cj_strerror(int64_t code);
+CJ_API const char* cj_strerror(int64_t code);
 /* text of the last HIP runtime error seen by the calling thread ("" if none) */
-const char* cj_last_hip_error(void);
-int cj_abi_version(void);
+CJ_API const char* cj_last_hip_error(void);
+CJ_API int cj_abi_version(void);
 /* number of visible HIP devices (0 if none / runtime unusable) */
-int cj_device_count(void);
+CJ_API int cj_device_count(void);
 
 /* =====================================================================================
  * Single-buffer entry points — exactly what a pyo3/Rust host would bind in place of the
@@ -82,65 +85,65 @@ int cj_device_count(void);
 
 /* src/lz4.rs:228  libcramjam::lz4::block::compress_bound(len, Some(prepend))
  * = LZ4_compressBound(len) (+4 when prepend); 0 when len > 0x7E000000. Pure arithmetic, no device. */
-size_t cj_lz4_block_compress_bound(size_t len, int prepend);
+CJ_API size_t cj_lz4_block_compress_bound(size_t len, int prepend);
 
 /* src/lz4.rs:127,206  libcramjam::lz4::block::compress_into(in, out, level, accel, prepend)
  * level/accel: -1 = None.  The reference forwards them but libcramjam always runs the DEFAULT
  * mode, so they do not change the output; accepted and ignored here too.  prepend: -1 = None -> 1. */
-int64_t cj_lz4_block_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap,
+CJ_API int64_t cj_lz4_block_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap,
                               int level, int accel, int prepend);
 
 /* src/lz4.rs:88,164,168  libcramjam::lz4::block::decompress_into(in, out, Some(size_prepended))
  * size_prepended=1: u32-LE length prefix expected, decode capacity = that length;
  * size_prepended=0: raw block, decode capacity = cap.  Returns decoded byte count. */
-int64_t cj_lz4_block_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap, int size_prepended);
+CJ_API int64_t cj_lz4_block_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap, int size_prepended);
 
 /* src/lz4.rs:90  libcramjam::lz4::block::decompress_vec reads this before allocating:
  * the u32-LE prefix, or CJ_E_NO_PREFIX when n < 4. Pure arithmetic, no device. */
-int64_t cj_lz4_block_prefixed_len(const uint8_t* in, size_t n);
+CJ_API int64_t cj_lz4_block_prefixed_len(const uint8_t* in, size_t n);
 
 /* src/snappy.rs:114  snap::raw::max_compress_len(len) = 32 + len + len/6 (0 = too big). No device. */
-size_t cj_snappy_raw_max_compress_len(size_t len);
+CJ_API size_t cj_snappy_raw_max_compress_len(size_t len);
 /* src/snappy.rs:121  snap::raw::decompress_len(in): varint preamble; 0 for empty input. No device. */
-int64_t cj_snappy_raw_decompress_len(const uint8_t* in, size_t n);
+CJ_API int64_t cj_snappy_raw_decompress_len(const uint8_t* in, size_t n);
 /* src/snappy.rs:75,97  libcramjam::snappy::raw::compress(in, out); needs cap >= max_compress_len(n) */
-int64_t cj_snappy_raw_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap);
+CJ_API int64_t cj_snappy_raw_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap);
 /* src/snappy.rs:57,106 libcramjam::snappy::raw::decompress(in, out); needs cap >= decompress_len(in) */
-int64_t cj_snappy_raw_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap);
+CJ_API int64_t cj_snappy_raw_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap);
 
 /* ---- Snappy FRAMING format: a stream of independent <= 64 KiB pieces, each with a masked
  * CRC-32C; pieces are de/compressed and checksummed on the GPU as one batch. ---- */
 /* upper bound of cj_snappy_frame_compress's output: 10 + 8 * ceil(n / 65536) + n (0 for n == 0). No device. */
-size_t cj_snappy_frame_max_compress_len(size_t n);
+CJ_API size_t cj_snappy_frame_max_compress_len(size_t n);
 /* src/snappy.rs:38,82  libcramjam::snappy::compress (snap read::FrameEncoder): stream identifier + one chunk per
  * 65536 input bytes, stored uncompressed when it does not shrink by 1/8; empty input -> empty output. */
-int64_t cj_snappy_frame_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap);
+CJ_API int64_t cj_snappy_frame_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap);
 /* decoded length of a framed stream from its chunk headers alone (what a caller allocates before
  * cj_snappy_frame_decompress), or the first header-level error. No device. */
-int64_t cj_snappy_frame_decompress_len(const uint8_t* in, size_t n);
+CJ_API int64_t cj_snappy_frame_decompress_len(const uint8_t* in, size_t n);
 /* src/snappy.rs:24,88  libcramjam::snappy::decompress (snap read::FrameDecoder): errors are reported in stream
  * order like the sequential decoder would (block error, checksum, output full, then header errors).
  * out == NULL: validate only — decode and checksum on the device, return the decoded length or the first error. */
-int64_t cj_snappy_frame_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap);
+CJ_API int64_t cj_snappy_frame_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap);
 
 /* ---- LZ4 FRAME format: blocks de/compressed on the GPU — independent-block and single-block
  * frames as one batch, linked-block frames by a chain kernel; XXH32 frame checksums on a concurrent host thread. ---- */
 /* upper bound of cj_lz4_frame_compress's output: 15 + 4 * ceil(n / 65536) + n. No device. */
-size_t cj_lz4_frame_compress_bound(size_t n);
+CJ_API size_t cj_lz4_frame_compress_bound(size_t n);
 /* src/lz4.rs:43,56  libcramjam::lz4::compress(input, output, level) (lz4 crate EncoderBuilder -> LZ4F): 64 KiB blocks,
  * content checksum, no content size — like the reference — but INDEPENDENT blocks (the reference links them) and one
  * matcher for every `level` (the reference's default level 4 is LZ4HC): any LZ4F decoder reads the result. */
-int64_t cj_lz4_frame_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap, int level);
+CJ_API int64_t cj_lz4_frame_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap, int level);
 /* only the block sequence of such a frame (u32 size word + data per 64 KiB of input; no header, EndMark or checksum):
  * what a streaming encoder (reference src/lz4.rs:231-292 `Compressor`) emits per flush.  cap >= n + 4 * ceil(n / 65536). */
-int64_t cj_lz4_frame_compress_blocks(const uint8_t* in, size_t n, uint8_t* out, size_t cap);
+CJ_API int64_t cj_lz4_frame_compress_blocks(const uint8_t* in, size_t n, uint8_t* out, size_t cap);
 /* upper bound of the decoded size from the headers alone (content size if stored, else blocks x max block size), or the
  * first header-level error. No device. */
-int64_t cj_lz4_frame_decompress_bound(const uint8_t* in, size_t n);
+CJ_API int64_t cj_lz4_frame_decompress_bound(const uint8_t* in, size_t n);
 /* src/lz4.rs:28,63  libcramjam::lz4::decompress (lz4 crate Decoder -> LZ4F_decompress): all block sizes, linked and
  * independent blocks, block / content checksums, content size; stops after the first frame like the crate's Decoder.
  * out == NULL: validate only (block structure and block decode; the content checksum needs the bytes on the host). */
-int64_t cj_lz4_frame_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap);
+CJ_API int64_t cj_lz4_frame_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap);
 
 /* =====================================================================================
  * Batch extension (no reference equivalent: the reference API is one buffer per call; a GPU only
@@ -154,34 +157,21 @@ typedef enum { CJ_OP_DECOMPRESS = 0, CJ_OP_COMPRESS = 1 } cj_op;
 
 /* flags */
 #define CJ_FLAG_LZ4_SIZE_PREFIX 1u   /* lz4: blocks carry / get the u32-LE length prefix (store_size) */
-/* Decode kernel-mapping overrides (tuning/testing; results are identical).  Default (batches of at least
- * CJ_LDS_MIN_CHUNKS chunks, env override): "parse, then per chunk either the workgroup decoder with the 64 KiB output
- * window resident in LDS (many short sequences) or the wavefront-per-chunk decoder (few long runs, chunks > 64 KiB)". */
+/* decode mapping overrides (tests and comparisons; results are identical): one wavefront per chunk, one lane per chunk, or
+ * the workgroup decoder for every chunk it can take.  Default: the workgroup decoder, the wave kernel for what it leaves over */
 #define CJ_FLAG_FORCE_WAVE_PER_CHUNK 0x100u
 #define CJ_FLAG_FORCE_LANE_PER_CHUNK 0x200u
 #define CJ_FLAG_FORCE_LDS_PER_CHUNK  0x400u
-#define CJ_LDS_MIN_CHUNKS 1
-/* below this many chunks the parse stage runs one WAVEFRONT per chunk (≈0.9 ms per 64 KiB chunk, independent of the
- * batch size but one chunk per wave: 2.2 ms for 4 096 chunks), above it one LANE per chunk (3.5 ms flat, 64 chunks per
- * wave: 3.2 ms for 4 096, 4.5 ms for 16 384); env CJ_WAVE_PARSE_MAX overrides */
-#define CJ_WAVE_PARSE_MAX_DEFAULT 6144
-/* LZ4: below this many chunks the parse stage walks 64 segments of each chunk at once (parse_spec.hip); env
- * CJ_SPEC_PARSE_MAX overrides, 0 disables */
-#define CJ_SPEC_PARSE_MAX_DEFAULT 8192
-/* share (n/20) of the short-sequence chunks of such a batch that is decoded by the lane-per-chunk kernel on an
- * internal auxiliary stream, concurrently with the LDS workgroup decoder (env CJ_LANE_SHARE overrides; 0 = off) */
-#define CJ_LANE_SHARE_DEFAULT 0
+/* decode batches up to this many chunks run parse + decode as ONE kernel (the segmented parse inside the workgroup decoder:
+ * 1 chunk 0.16 ms instead of 0.25, 8 192 chunks 348 instead of 178 GB/s); above, a lane-per-chunk parse kernel in front of the
+ * decoder is cheaper per chunk (measured crossover between 16 384 and 32 768 chunks, profiles/r02) */
+#define CJ_FUSED_MAX_CHUNKS 24576
 /* decode batches larger than this are submitted in slices of this many chunks (env CJ_SLICE_CHUNKS) */
 #define CJ_SLICE_CHUNKS_DEFAULT 131072
-/* Snappy: share (n/20) of the mid-ratio chunks of a large batch decoded by the lane-per-chunk kernel, concurrently
- * with the wavefront-per-chunk kernel (env CJ_SNAPPY_LANE_SHARE; 0 = wave kernel only) */
-#define CJ_SNAPPY_LANE_SHARE_DEFAULT 20   /* measured 116 / 170 / 206 / 228 GB/s for shares 0 / 10 / 14 / 20 on synth-v1 */
-/* likewise the share decoded by the wavefront-per-chunk kernel on a second auxiliary stream (env CJ_WAVE_SHARE) */
-#define CJ_WAVE_SHARE_DEFAULT 0   /* measured: any wave share slows the batch (441 -> 355 -> 294 GB/s for 0/1/2): its waves steal issue slots from the issue-bound LDS decoder */
 
-int  cj_engine_create(int device, cj_engine** out);
-void cj_engine_destroy(cj_engine* e);
-int  cj_engine_device(const cj_engine* e);
+CJ_API int  cj_engine_create(int device, cj_engine** out);
+CJ_API void cj_engine_destroy(cj_engine* e);
+CJ_API int  cj_engine_device(const cj_engine* e);
 
 /* Device-resident batch: every pointer is a DEVICE pointer on the engine's GPU.
  * chunk i reads  in_base + in_off[i] .. + in_len[i]   and writes  out_base + out_off[i] .. + out_cap[i];
@@ -194,32 +184,47 @@ int  cj_engine_device(const cj_engine* e);
  * allocation: true for every chunk of a buffer that comes from hipMalloc / a caching allocator (allocations start on
  * 256-byte boundaries and are padded to their granule), NOT for a chunk that begins or ends flush with a page the
  * caller carved up itself.  cj_batch_host pads to 16 bytes on its own staging buffers. */
-int cj_batch_device(cj_engine* e, cj_codec codec, cj_op op, uint32_t flags, size_t n_chunks,
+CJ_API int cj_batch_device(cj_engine* e, cj_codec codec, cj_op op, uint32_t flags, size_t n_chunks,
                     const uint8_t* in_base, const uint64_t* in_off, const uint64_t* in_len,
                     uint8_t* out_base, const uint64_t* out_off, const uint64_t* out_cap,
                     int64_t* result, void* hip_stream);
-int cj_engine_sync(cj_engine* e);
+CJ_API int cj_engine_sync(cj_engine* e);
 
 /* Host batch: host pointers; the engine packs inputs into pinned staging, copies H2D, runs the
  * kernels, copies D2H and scatters.  Synchronous. result[i] as above. */
-int cj_batch_host(cj_engine* e, cj_codec codec, cj_op op, uint32_t flags, size_t n_chunks,
+CJ_API int cj_batch_host(cj_engine* e, cj_codec codec, cj_op op, uint32_t flags, size_t n_chunks,
                   const uint8_t* const* in_ptrs, const size_t* in_lens,
                   uint8_t* const* out_ptrs, const size_t* out_caps, int64_t* result);
 
 /* Timing aid for benchmarks: runs the same device batch `reps` times on the engine stream between
  * two hipEvents and returns the mean kernel time per rep in milliseconds (< 0 on error). */
-double cj_batch_device_timed(cj_engine* e, cj_codec codec, cj_op op, uint32_t flags, size_t n_chunks,
+CJ_API double cj_batch_device_timed(cj_engine* e, cj_codec codec, cj_op op, uint32_t flags, size_t n_chunks,
                              const uint8_t* in_base, const uint64_t* in_off, const uint64_t* in_len,
                              uint8_t* out_base, const uint64_t* out_off, const uint64_t* out_cap,
                              int64_t* result, int reps);
 
 /* Thin device-memory helpers so C / ctypes callers need no HIP binding of their own. */
-void* cj_device_alloc(cj_engine* e, size_t bytes);
-void  cj_device_free(cj_engine* e, void* p);
-int   cj_memcpy_h2d(cj_engine* e, void* dst_dev, const void* src_host, size_t bytes);
-int   cj_memcpy_d2h(cj_engine* e, void* dst_host, const void* src_dev, size_t bytes);
-int   cj_memcpy_d2d(cj_engine* e, void* dst_dev, const void* src_dev, size_t bytes);
-int   cj_memset_dev(cj_engine* e, void* dst_dev, int value, size_t bytes);
+CJ_API void* cj_device_alloc(cj_engine* e, size_t bytes);
+CJ_API void  cj_device_free(cj_engine* e, void* p);
+CJ_API int   cj_memcpy_h2d(cj_engine* e, void* dst_dev, const void* src_host, size_t bytes);
+CJ_API int   cj_memcpy_d2h(cj_engine* e, void* dst_host, const void* src_dev, size_t bytes);
+CJ_API int   cj_memcpy_d2d(cj_engine* e, void* dst_dev, const void* src_dev, size_t bytes);
+CJ_API int   cj_memset_dev(cj_engine* e, void* dst_dev, int value, size_t bytes);
+
+/* ---- test and benchmark utilities exported next to the engine (NOT part of the drop-in ABI: cramjam_amd/csrc/bench_util.hip
+ *      and debug counters of the decoders) ---- */
+/* n chunks of S bytes at d_out + i*stride = synth-v1(S, first_index + i, seed), generated on the device */
+CJ_API int cj_bench_synth_v1(void* d_out, uint64_t stride, uint64_t S, uint64_t first_index, uint64_t n, uint64_t seed, void* stream);
+/* *d_mismatches += chunks i in [0, n) with got[got_off[i] .. +S) != want[(i % n_unique)*want_stride .. +S) */
+CJ_API int cj_bench_compare(const void* d_got, const uint64_t* d_got_off, const void* d_want, uint64_t want_stride,
+                            uint32_t n_unique, uint64_t S, uint32_t n, void* d_mismatches, void* stream);
+/* per-phase cycle counters of the workgroup decoder (flag bit 0x1000 of a device batch): S0, D1, D2, D3, D4, chunks */
+CJ_API int cj_debug_lds_phase_cycles(unsigned long long* out8, int reset);
+CJ_API long long cj_debug_forwarded_chunks(int reset);            /* chunks / slabs that went through the forwarding phase */
+CJ_API unsigned long long cj_debug_linked_lds_frames(void);       /* linked-block LZ4 frames decoded by the two-window decoder */
+/* large-stream path with its parse stage's absolute sync points handed back (tests compare them with a serial walk) */
+CJ_API int64_t cj_debug_big_parse(int codec, uint32_t flags, const uint8_t* in, size_t n, uint8_t* out, size_t cap,
+                                  uint32_t* sync_pairs, size_t max_pairs, uint64_t* n_seq);
 
 #ifdef __cplusplus
 }

@@ -197,9 +197,9 @@ def test_device_batch_synth_roundtrip(eng, chunk, mapping):
 
 
 def test_default_pipeline_mixed_large_batch(eng):
-    """>= CJ_LDS_MIN_CHUNKS chunks through the DEFAULT path: parse kernel routes every chunk to the LDS workgroup
-    decoder (many short sequences) or the wave decoder (few long runs, oversize, tiny); malformed chunks must
-    fail alone.  Every result and byte is compared with the oracle."""
+    """A batch through the DEFAULT path (up to CJ_FUSED_MAX_CHUNKS chunks: parse + decode in one kernel): every chunk goes to
+    the LDS workgroup decoder (many short sequences) or the wave decoder (few long runs, oversize, tiny); malformed chunks
+    must fail alone.  Every result and byte is compared with the oracle."""
     import random
     rnd = random.Random(11)
     kinds = []
@@ -237,7 +237,7 @@ def test_default_pipeline_mixed_large_batch(eng):
 
 
 def test_default_pipeline_mixed_large_batch_snappy(eng):
-    """Snappy twin of the test above: classify by ratio -> lane kernel (aux stream) || wave kernel."""
+    """Snappy twin of the test above."""
     import random
     rnd = random.Random(12)
     uniq = []

@@ -11,7 +11,7 @@ OBJS=""
 for f in $R/cramjam_amd/build/*.o; do
   b=$(basename $f .o)
   if echo " $SRCS " | grep -q " $b.hip "; then
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $FLAGS -c $R/cramjam_amd/csrc/$b.hip -o $R/cramjam_amd/variants/obj_$NAME/$b.o
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-function $FLAGS -c $R/cramjam_amd/csrc/$b.hip -o $R/cramjam_amd/variants/obj_$NAME/$b.o
     OBJS="$OBJS $R/cramjam_amd/variants/obj_$NAME/$b.o"
   else
     OBJS="$OBJS $f"

@@ -1,23 +1,31 @@
-# Round-end evidence run (on the GPU box): gpu tests, default bench line, rocprofv3 kernel stats of the same command,
-# FETCH_SIZE / WRITE_SIZE passes (separate, as the MI355X guide prescribes) and the secondary-path bench lines.
+# Round-end evidence run (on the GPU box): gpu tests, the default bench line (it measures its HBM traffic itself with two
+# rocprofv3 --pmc child runs), rocprofv3 kernel stats of the same command, SQ / LDS counters, and the secondary-path bench lines.
 # Outputs land in gpurun_out/<tag>/; copy the summaries into profiles/rNN/.
-TAG=${1:-v7}
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
 O=gpurun_out/$TAG; rm -rf $O; mkdir -p $O
-timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 | tee $O/pytest_gpu.txt
-python bench.py > $O/bench.json 2> $O/bench.err; tail -c 700 $O/bench.json; echo
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --no-cpu-baseline > $O/stats.log 2>&1
+timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -3 | tee $O/pytest_gpu.txt
+python bench.py > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json; echo
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --no-cpu-baseline --traffic off > $O/stats.log 2>&1
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv; head -8 $O/kernel_stats.csv
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python bench.py --no-cpu-baseline --steps 3 --warmup 1 > $O/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python bench.py --no-cpu-baseline --steps 3 --warmup 1 > $O/write.log 2>&1
-cp $(find $O/fetch -name "*counter_collection.csv" | head -1) $O/fetch_size_counter_collection.csv
-cp $(find $O/write -name "*counter_collection.csv" | head -1) $O/write_size_counter_collection.csv
-python tools/pmc_summary.py $O/fetch_size_counter_collection.csv $O/write_size_counter_collection.csv $O/hbm_traffic.json > /dev/null
-python -c "
-import json; d=json.load(open('$O/hbm_traffic.json')); print({k:(round(v['hbm_read_bytes']/1e9,2),round(v['hbm_write_bytes']/1e9,2)) for k,v in d['kernels'].items()}, d['total_hbm_bytes_per_step']/1e9)"
-for args in "--codec snappy" "--op compress" "--op compress --codec snappy" "--chunks 1000000"; do
-  python bench.py --no-cpu-baseline $args 2>/dev/null | tail -1 >> $O/other_paths.jsonl
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_LDS --output-format csv -d $O/sq -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --traffic off > $O/sq.log 2>&1
+python - "$O/sq" <<'PY' | tee $O/sq_counters_per_chunk.txt
+import csv,glob,collections,sys
+agg=collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(sys.argv[1]+'/*/*counter_collection.csv'):
+    for r in csv.DictReader(open(f)):
+        k=r['Kernel_Name'].split('(')[0]
+        if 'cj::' in k: agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
+for k in sorted(agg):
+    print(k, ' '.join('%s=%.0f' % (c.replace('SQ_',''), sum(v)/len(v)/1e5) for c,v in sorted(agg[k].items())), '(per chunk of the 100 k)')
+PY
+for args in "--codec snappy" "--op compress" "--op compress --codec snappy" "--codec snappy --op roundtrip" "--chunks 1000000 --steps 20" "--workload mixed256k --steps 20" "--chunks 8192 --unique 2048" "--chunks 1024 --unique 1024"; do
+  python bench.py --no-cpu-baseline --traffic off $args 2>/dev/null | tail -1 >> $O/other_paths.jsonl
 done
-cut -c1-175 $O/other_paths.jsonl
-rm -rf $O/stats $O/fetch $O/write
+python - <<PY
+import json
+for l in open('$O/other_paths.jsonl'):
+    d=json.loads(l); print('%-95s %8.1f GB/s  %8.3f ms/step  frac %.4f' % (d['config']['workload'][:95], d['value'], d['ms_per_step'], d['roofline']['frac']))
+PY
+rm -rf $O/stats $O/sq

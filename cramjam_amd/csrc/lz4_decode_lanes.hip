@@ -88,6 +88,7 @@ __global__ __launch_bounds__(64 * kParseWaves) void lz4_parse_kernel(BatchArgs a
     uint2* csync = sync + (size_t)c * kSyncPitch;
 
     uint32_t ip = mis, op = 0, nseq = 0;
+    SyncBatch sb = {make_uint2(0, 0), make_uint2(0, 0), make_uint2(0, 0), make_uint2(0, 0)};
     // ---- wave-convergent walk: refill rounds, then one sequence per active lane ----
     while (ballot64(!done) != 0ull) {
         if (!done && ip >= st.hi) st.lo = st.hi = ip & ~127u;      // jumped past the window (long literal run): re-anchor
@@ -103,8 +104,7 @@ __global__ __launch_bounds__(64 * kParseWaves) void lz4_parse_kernel(BatchArgs a
         if (!done) {
             // one sequence; mirrors lz4_lane_walk<false> with reads through the line cache
             if ((nseq % kSyncEvery) == 0u) {
-                const uint32_t slot = nseq / kSyncEvery;
-                if (slot < kSyncStride) csync[slot] = make_uint2(ip - mis, op);
+                sb.put(csync, nseq / kSyncEvery, make_uint2(ip - mis, op));
             }
             nseq += 1;
         }
@@ -193,6 +193,7 @@ __global__ __launch_bounds__(64 * kParseWaves) void lz4_parse_kernel(BatchArgs a
         }
     }
     if (exists) {
+        sb.flush(csync, (nseq + kSyncEvery - 1u) / kSyncEvery);
         a.result[c] = r;
         meta[c] = pm;
     }

@@ -270,6 +270,7 @@ __global__ __launch_bounds__(64 * kParseWaves) void snappy_parse_kernel(BatchArg
     const auto rd = [&st](uint32_t p) { return st.ld32(p); };
 
     uint32_t ip = mis, op = 0, nrec = 0;
+    SyncBatch sb = {make_uint2(0, 0), make_uint2(0, 0), make_uint2(0, 0), make_uint2(0, 0)};
     while (ballot64(!done) != 0ull) {
         if (!done && ip >= st.hi) st.lo = st.hi = ip & ~127u;      // jumped past the window (long literal): re-anchor
         for (;;) {
@@ -280,8 +281,7 @@ __global__ __launch_bounds__(64 * kParseWaves) void snappy_parse_kernel(BatchArg
         }
         if (!done) {
             if ((nrec % kSyncEvery) == 0u) {
-                const uint32_t slot = nrec / kSyncEvery;
-                if (slot < kSyncStride) csync[slot] = make_uint2(ip - mis, op);
+                sb.put(csync, nrec / kSyncEvery, make_uint2(ip - mis, op));
             }
             nrec += 1;
         }
@@ -321,6 +321,7 @@ __global__ __launch_bounds__(64 * kParseWaves) void snappy_parse_kernel(BatchArg
         }
     }
     if (exists) {
+        sb.flush(csync, (nrec + kSyncEvery - 1u) / kSyncEvery);
         a.result[c] = r;
         meta[c] = pm;
     }

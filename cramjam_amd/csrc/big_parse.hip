@@ -123,7 +123,7 @@ __global__ __launch_bounds__(64) void big_mark_kernel(BigParse a0) {
             const uint32_t r = pos - B;
             asm volatile("ds_or_b32 %0, %1" :: "v"(a_bits + 4u * (r >> 5)), "v"(1u << (r & 31u)) : "memory");
             Seq s;
-            pos = G::at(rd, pos, a.iend, s, a.in) ? s.next : kPosErr;
+            pos = walk_step<G>(rd, pos, a.iend, s, a.in) ? s.next : kPosErr;
         }
     }
     __syncthreads();
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(64) void big_mark_kernel(BigParse a0) {
                 if ((w >> (r & 31u)) & 1u) going = false;
                 else {
                     Seq s;
-                    pos = G::at(rd, pos, a.iend, s, a.in) ? s.next : kPosErr;
+                    pos = walk_step<G>(rd, pos, a.iend, s, a.in) ? s.next : kPosErr;
                     if (pos >= E) going = false;
                 }
             }
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(64) void big_mark_kernel(BigParse a0) {
                 if ((w >> (r & 31u)) & 1u) going = false;
                 else {
                     Seq s;
-                    q = G::at(rd, q, a.iend, s, a.in) ? s.next : kPosErr;
+                    q = walk_step<G>(rd, q, a.iend, s, a.in) ? s.next : kPosErr;
                     if (q >= E) going = false;
                 }
             }
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(64) void big_thread_kernel(BigParse a0) {
                         const uint32_t r = q - B;
                         if ((gb[r >> 5] >> (r & 31u)) & 1u) break;
                         Seq s;
-                        q = G::at(rd, q, a.iend, s, a.in) ? s.next : kPosErr;
+                        q = walk_step<G>(rd, q, a.iend, s, a.in) ? s.next : kPosErr;
                     }
                     if (q < E) {
                         const uint32_t o = (q - B) / sub;
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(64) void big_count_kernel(BigParse a0) {
     while (ballot64(q < E && q != end) != 0ull) {
         if (q < E && q != end) {
             Seq s;
-            if (G::at(rd, q, a.iend, s, a.in)) { cnt += 1; outb += (uint64_t)s.lit + s.mlen; q = s.next; }
+            if (walk_step<G>(rd, q, a.iend, s, a.in)) { cnt += 1; outb += (uint64_t)s.lit + s.mlen; q = s.next; }
             else q = kPosErr;
         }
     }
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(64) void big_emit_kernel(BigParse a0) {
             if ((idx % kSyncEvery) == 0u) a.sync[idx / kSyncEvery] = make_uint2(q, (uint32_t)op);
             Seq s;
             bool fin = false;
-            if (!G::at(rd, q, a.iend, s, a.in) || !G::check(s, op, a.cap, fin)) bad = true;
+            if (!walk_step<G>(rd, q, a.iend, s, a.in) || !G::check(s, op, a.cap, fin)) bad = true;
             else if (fin) {
                 if (!G::result_ok(op, a.cap)) bad = true;
                 else { a.status[6] = (uint32_t)op; a.status[7] = (uint32_t)(op >> 32); a.status[8] = 1u; }

@@ -324,40 +324,6 @@ __device__ __forceinline__ uint32_t wave_excl_scan_add32(uint32_t v, uint32_t& t
     return x - v;
 }
 
-// One element at position ip, straight-line: the common LZ4 sequence (length extensions of at most one byte, not within 8 bytes of
-// the end) costs two LDS round trips and ~25 instructions; G::at — the general function with its loops — runs only where a lane
-// meets anything else (a wavefront walks at the pace of its slowest lane: the general function alone is ~1.4 k cycles per step).
-template <class G, class Rd>
-__device__ __forceinline__ bool walk_step(const Rd& rd, uint32_t ip, uint32_t iend, Seq& s) {
-    if constexpr (std::is_same<G, Lz4Grammar>::value) {
-        const uint32_t t4 = rd(ip);
-        const uint32_t token = t4 & 0xffu, e1 = (t4 >> 8) & 0xffu;
-        const bool x1 = (token >> 4) == 15u;
-        const uint32_t lit = (token >> 4) + (x1 ? e1 : 0u);
-        const uint32_t ip1 = ip + 1u + (x1 ? 1u : 0u), ip2 = ip1 + lit;
-        const uint32_t o4 = rd(ip2 < iend ? ip2 : ip);
-        const uint32_t mc = token & 15u, e2 = (o4 >> 16) & 0xffu;
-        const bool x2 = mc == 15u;
-        // rem_in >= lit + 8 keeps every bound G::at checks while it reads one-byte extensions
-        const bool fast = !(x1 && e1 == 255u) && !(x2 && e2 == 255u) && ip1 + 16u <= iend && iend - ip1 >= lit + 8u;
-        if (ballot64(!fast) == 0ull) {
-            s.lit = lit; s.lit_at = ip1; s.last = false; s.offset = o4 & 0xffffu;
-            s.mlen = mc + (x2 ? e2 : 0u) + 4u;
-            s.next = ip2 + 2u + (x2 ? 1u : 0u);
-            return true;
-        }
-        bool ok = true;
-        if (fast) {
-            s.lit = lit; s.lit_at = ip1; s.last = false; s.offset = o4 & 0xffffu;
-            s.mlen = mc + (x2 ? e2 : 0u) + 4u;
-            s.next = ip2 + 2u + (x2 ? 1u : 0u);
-        } else ok = G::at(rd, ip, iend, s);
-        return ok;
-    } else {
-        return G::at(rd, ip, iend, s);
-    }
-}
-
 // a_in: LDS address of stream position 0; aux: kFusedAux bytes of LDS; bits: 8 KiB, zeroed; table: the record table.
 // On success: nseq_out / U_out, *near_out += matches with an offset below kFwdNear.  Every thread of the workgroup calls it.
 template <class G, uint32_t kThreads>

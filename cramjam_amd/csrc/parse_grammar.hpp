@@ -3,6 +3,7 @@
 // stream offset p (little endian; bytes past the end may be anything — every length is bounds-checked against iend).
 #pragma once
 #include "cj_common.hpp"
+#include <type_traits>
 
 namespace cj {
 
@@ -174,5 +175,62 @@ struct SnappyGrammar {
     template <class T>
     static __device__ __forceinline__ bool result_ok(T op_end, T dn) { return op_end == dn; }
 };
+
+#if defined(__HIPCC__)
+// One element at position ip, straight-line: the common LZ4 sequence (length extensions of at most one byte, not within 8 bytes of
+// the end) costs two round trips and ~25 instructions; G::at — the general function with its loops — runs only where a lane
+// meets anything else (a wavefront walks at the pace of its slowest lane: the general function alone is ~1.4 k cycles per step).
+// Used by the walks of the fused parse (lz4_decode_lds.hip) and of the large-stream parse (big_parse.hip).
+template <class G, class Rd>
+__device__ __forceinline__ bool walk_step(const Rd& rd, uint32_t ip, uint32_t iend, Seq& s, const uint8_t* g = nullptr) {
+    if constexpr (std::is_same<G, Lz4Grammar>::value) {
+        const uint32_t t4 = rd(ip);
+        const uint32_t token = t4 & 0xffu, e1 = (t4 >> 8) & 0xffu;
+        const bool x1 = (token >> 4) == 15u;
+        const uint32_t lit = (token >> 4) + (x1 ? e1 : 0u);
+        const uint32_t ip1 = ip + 1u + (x1 ? 1u : 0u), ip2 = ip1 + lit;
+        const uint32_t o4 = rd(ip2 < iend ? ip2 : ip);
+        const uint32_t mc = token & 15u, e2 = (o4 >> 16) & 0xffu;
+        const bool x2 = mc == 15u;
+        // rem_in >= lit + 8 keeps every bound G::at checks while it reads one-byte extensions
+        const bool fast = !(x1 && e1 == 255u) && !(x2 && e2 == 255u) && ip1 + 16u <= iend && iend - ip1 >= lit + 8u;
+        if (ballot64(!fast) == 0ull) {
+            s.lit = lit; s.lit_at = ip1; s.last = false; s.offset = o4 & 0xffffu;
+            s.mlen = mc + (x2 ? e2 : 0u) + 4u;
+            s.next = ip2 + 2u + (x2 ? 1u : 0u);
+            return true;
+        }
+        bool ok = true;
+        if (fast) {
+            s.lit = lit; s.lit_at = ip1; s.last = false; s.offset = o4 & 0xffffu;
+            s.mlen = mc + (x2 ? e2 : 0u) + 4u;
+            s.next = ip2 + 2u + (x2 ? 1u : 0u);
+        } else ok = G::at(rd, ip, iend, s, g);
+        return ok;
+    } else {
+        // Snappy record = optional literal element (1- or 2-byte header) + optional copy-1 / copy-2 element, everything at least
+        // 4 bytes clear of the end: the same two round trips; longer headers, copy-4 and the stream's last record take G::at
+        const uint32_t t4 = rd(ip);
+        const uint32_t tag = t4 & 0xffu, l6 = tag >> 2;
+        const bool is_lit = (tag & 3u) == 0u;
+        const uint32_t lhdr = is_lit ? (l6 == 60u ? 2u : 1u) : 0u;
+        const uint32_t lit = is_lit ? (l6 == 60u ? ((t4 >> 8) & 0xffu) + 1u : l6 + 1u) : 0u;
+        const uint32_t ip2 = ip + lhdr + lit;
+        const bool in2 = ip2 + 4u <= iend && ip2 >= ip;
+        const uint32_t c4 = is_lit ? rd(in2 ? ip2 : ip) : t4;
+        const uint32_t ctag = c4 & 0xffu, kind = ctag & 3u;
+        const uint32_t clen = kind == 1u ? 4u + ((ctag >> 2) & 7u) : 1u + (ctag >> 2);
+        const uint32_t off = kind == 1u ? ((ctag >> 5) << 8) | ((c4 >> 8) & 0xffu) : (c4 >> 8) & 0xffffu;
+        const uint32_t ip3 = kind == 0u ? ip2 : ip2 + (kind == 1u ? 2u : 3u);
+        const bool fast = !(is_lit && l6 > 60u) && in2 && kind != 3u && ip3 < iend && (kind != 0u || is_lit);
+        bool ok = true;
+        if (fast) {
+            s.lit = lit; s.lit_at = ip + lhdr; s.last = false; s.next = ip3;
+            s.mlen = kind == 0u ? 0u : clen; s.offset = kind == 0u ? 0u : off;
+        } else ok = G::at(rd, ip, iend, s, g);
+        return ok;
+    }
+}
+#endif
 
 }  // namespace cj

@@ -1,7 +1,10 @@
-"""CPU model of the segmented parse (cramjam_amd/csrc/parse_spec.hip): 64 lanes walk 64 segments of a block from
-guessed start positions, join each other's paths, and the true path is stitched from the pieces.  The model mirrors the
-kernel phase by phase, for both grammars (LZ4 sequences, Snappy records), and is checked against the oracle decoders:
-same verdict, same decoded size, and sync points that are exactly the (ip, op) of every 8th sequence of a serial walk."""
+"""CPU model of the segmented parse inside the workgroup decoder (cramjam_amd/csrc/lz4_decode_lds.hip: fused_parse; round 1's
+parse_spec.hip was the same walk on one wavefront): LANES lanes walk LANES segments of a block from guessed start positions, join
+each other's paths, the true path is marked from lane 0 by pointer doubling and stitched from the pieces.  The model mirrors the
+kernel phase by phase, for both grammars (LZ4 sequences, Snappy records), and is checked against the oracle decoders: same
+verdict, same decoded size, and positions that are exactly the (ip, op) of every 8th sequence of a serial walk.  Every step
+also runs the kernels' STRAIGHT-LINE step (parse_grammar.hpp: walk_step) next to the general grammar function and requires
+the same answer wherever the straight-line step says it applies."""
 import random
 
 import pytest
@@ -92,14 +95,67 @@ def snappy_check(lit, mlen, off, last, op, dn):
     return True, op, last
 
 
-def spec_parse(b, cap, seq_at=seq_at, seq_check=lz4_check):
-    """returns (result, nseq, sync points) like the kernel's spec_walk; result < 0 = corrupt"""
+def lz4_fast_step(b, ip, iend):
+    """parse_grammar.hpp walk_step<Lz4Grammar>: None where the straight-line step does not apply"""
+    def rd32(p):
+        return [b[p + k] if p + k < len(b) else 0xA5 for k in range(4)]      # bytes past the end may be anything
+    t = rd32(ip)
+    token, e1 = t[0], t[1]
+    x1 = (token >> 4) == 15
+    lit = (token >> 4) + (e1 if x1 else 0)
+    ip1 = ip + 1 + (1 if x1 else 0); ip2 = ip1 + lit
+    o = rd32(ip2 if ip2 < iend else ip)
+    mc, e2 = token & 15, o[2]
+    x2 = mc == 15
+    fast = not (x1 and e1 == 255) and not (x2 and e2 == 255) and ip1 + 16 <= iend and iend - ip1 >= lit + 8
+    if not fast: return None
+    return (True, lit, mc + (e2 if x2 else 0) + 4, o[0] | (o[1] << 8), ip2 + 2 + (1 if x2 else 0), False)
+
+
+def snappy_fast_step(b, ip, iend):
+    """parse_grammar.hpp walk_step<SnappyGrammar>"""
+    def rd32(p):
+        return [b[p + k] if p + k < len(b) else 0xA5 for k in range(4)]
+    t = rd32(ip)
+    tag = t[0]; l6 = tag >> 2
+    is_lit = (tag & 3) == 0
+    lhdr = (2 if l6 == 60 else 1) if is_lit else 0
+    lit = ((t[1] + 1) if l6 == 60 else l6 + 1) if is_lit else 0
+    ip2 = ip + lhdr + lit
+    in2 = ip2 + 4 <= iend
+    c = rd32(ip2 if in2 else ip) if is_lit else t
+    ctag = c[0]; kind = ctag & 3
+    clen = 4 + ((ctag >> 2) & 7) if kind == 1 else 1 + (ctag >> 2)
+    off = (((ctag >> 5) << 8) | c[1]) if kind == 1 else (c[1] | (c[2] << 8))
+    ip3 = ip2 if kind == 0 else ip2 + (2 if kind == 1 else 3)
+    fast = not (is_lit and l6 > 60) and in2 and kind != 3 and ip3 < iend and (kind != 0 or is_lit)
+    if not fast: return None
+    return (True, lit, 0 if kind == 0 else clen, 0 if kind == 0 else off, ip3, False)
+
+
+def with_fast(general, fast):
+    def at(b, ip, iend):
+        g = general(b, ip, iend)
+        f = fast(b, ip, iend)
+        if f is not None:
+            assert g == f, ("straight-line step disagrees with the grammar function", ip, g, f)
+        return g
+    return at
+
+
+LANES = 256
+
+
+def spec_parse(b, cap, seq_at=seq_at, seq_check=lz4_check, lanes=LANES):
+    """returns (result, nseq, sync points) like the kernel's fused_parse; result < 0 = corrupt (the kernel hands those to the
+    wave kernel)"""
+    seq_at = with_fast(seq_at, lz4_fast_step if seq_at is globals()["seq_at"] else snappy_fast_step)
     iend = len(b)
-    nl = min(64, (iend + 255) // 256)
+    nl = min(lanes, (iend + 63) // 64)
     seg = ((((iend + nl - 1) // nl) + 3) & ~3) | 4
     marks = set()
     pos = []
-    for l in range(64):                                   # 1a
+    for l in range(lanes):                                   # 1a
         p = l * seg if (l < nl and l * seg < iend) else END
         while p >= 0 and p < (l + 1) * seg and p < iend:
             marks.add(p)
@@ -107,22 +163,39 @@ def spec_parse(b, cap, seq_at=seq_at, seq_check=lz4_check):
             p = nxt if ok else ERR
         pos.append(p)
     merge = []
-    for l in range(64):                                   # 1b
+    for l in range(lanes):                                # 1b
         p = pos[l]
         while p >= 0 and p < iend and p not in marks:
             ok, _, _, _, nxt, _ = seq_at(b, p, iend)
             p = nxt if ok else ERR
         if p >= iend: p = ERR
         merge.append(p)
-    entry = [0] * 64; chain = []; cur = 0                 # 2
-    for _ in range(64):
-        chain.append(cur)
-        m = merge[cur]
-        if m < 0: break
-        nxt = m // seg
-        assert nxt > cur
-        entry[nxt] = m; cur = nxt
-    cnt = [0] * 64; outb = [0] * 64                       # 3
+    # 2: the chain from lane 0, marked by pointer doubling (a piece that ends the stream points at itself)
+    active = [l < nl and l * seg < iend for l in range(lanes)]
+    nxt = [(merge[l] // seg if (active[l] and 0 <= merge[l] < iend) else l) for l in range(lanes)]
+    for l in range(lanes):
+        assert nxt[l] >= l
+    mark = [l == 0 for l in range(lanes)]
+    rounds = 0
+    while (1 << rounds) < lanes: rounds += 1
+    for _ in range(rounds):
+        new = list(mark)
+        for l in range(lanes):
+            if mark[l]: new[nxt[l]] = True
+        nxt = [nxt[nxt[l]] for l in range(lanes)]
+        mark = new
+    entry = [0] * lanes
+    chain = [l for l in range(lanes) if mark[l] and active[l]]
+    for l in chain:
+        if 0 <= merge[l] < iend: entry[merge[l] // seg] = merge[l]
+    # the serial chain of round 1's kernel visits the same lanes
+    ser = []; cur = 0
+    while True:
+        ser.append(cur)
+        if not (0 <= merge[cur] < iend): break
+        cur = merge[cur] // seg
+    assert ser == chain, (ser[:8], chain[:8])
+    cnt = [0] * lanes; outb = [0] * lanes                 # 3
     for l in chain:
         q = entry[l]
         while q >= 0 and q != merge[l]:

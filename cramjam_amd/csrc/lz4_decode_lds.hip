@@ -324,10 +324,10 @@ __device__ __forceinline__ uint32_t wave_excl_scan_add32(uint32_t v, uint32_t& t
     return x - v;
 }
 
-// a_in: LDS address of stream position 0; aux: kFusedAux bytes of LDS; bits: 8 KiB, zeroed; table: the record table.
+// a_in: LDS address of stream position 0; aux: kFusedAux bytes of LDS; bits: 8 KiB, zeroed; table2: the record table (8-byte records).
 // On success: nseq_out / U_out, *near_out += matches with an offset below kFwdNear.  Every thread of the workgroup calls it.
 template <class G, uint32_t kThreads>
-__device__ __forceinline__ bool fused_parse(uint32_t a_in, uint32_t iend, uint32_t cap, uint32_t* bits, uint32_t* aux, uint4* table,
+__device__ __forceinline__ bool fused_parse(uint32_t a_in, uint32_t iend, uint32_t cap, uint32_t* bits, uint32_t* aux, uint2* table2,
                                             uint32_t* s_near, uint32_t& nseq_out, uint32_t& U_out) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     uint32_t* s_merge = aux;
@@ -444,7 +444,7 @@ __device__ __forceinline__ bool fused_parse(uint32_t a_in, uint32_t iend, uint32
                 else {
                     const uint32_t dst = op + sq.lit;
                     const uint32_t w = sq.mlen == 0u ? 0u : ((sq.offset & 0xffffu) | (sq.mlen << 16));       // (a Snappy stream may END with a copy)
-                    table[idx] = make_uint4(sq.lit_at, sq.lit, dst, w);
+                    table2[idx] = make_uint2(sq.lit_at | (sq.lit << 16), (op & 0xffffu) | (w << 16));      // 8-byte record (lds2_body)
                     near += (w != 0u && sq.offset < 4096u) ? 1u : 0u;
                     op = op2;
                     if (fin) { final_op = op; saw_last = true; q = kPosEnd; }
@@ -522,6 +522,36 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                         (uint32_t)(uintptr_t)(smem + kOffVars + 128u) + 4u * (threadIdx.x & 63u)};
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     uint4* table = tabs + (size_t)blockIdx.x * (kSlab ? sl.tab_stride : kL2TabRecords);
+    // Batches of independent chunks keep 8-BYTE records: { lit_src | lit << 16, lit_start | offset << 16 } — the match
+    // destination is lit_start + lit and the match length is the NEXT record's lit_start minus that (mod 2^16: a chunk of exactly
+    // 64 KiB ends at position 0x10000), a sentinel { 0, U } follows the last record.  Half the table traffic of the 16-byte
+    // { lit_src, lit, dst, offset | length << 16 } records, which the slab and linked modes keep (their records are clipped, split
+    // and moved out of position order).  Records appended by the forwarding phase (literal copies, out of position order)
+    // keep the 16-byte form in their own region of the slot.
+    constexpr bool kCompact = !kSlab && !kLinked;
+    constexpr uint32_t kExtraBase = (kSyncStride * kSyncEvery + 1u) / 2u + 64u;      // first 16-byte slot behind the 8-byte records (+ sentinel)
+    uint2* table2 = reinterpret_cast<uint2*>(table);
+    const auto rec_store = [&](uint32_t i, uint32_t lit_src, uint32_t lit, uint32_t dst, uint32_t w) {      // a record in position order
+        if constexpr (kCompact) table2[i] = make_uint2(lit_src | (lit << 16), ((dst - lit) & 0xffffu) | ((w & 0xffffu) << 16));
+        else table[i] = make_uint4(lit_src, lit, dst, w);
+    };
+    const auto rec_load = [&](uint32_t i, uint32_t n_main) -> uint4 {                   // the 16-byte view of record i (i >= n_main: appended records)
+        if constexpr (kCompact) {
+            if (i >= n_main) return table[kExtraBase + (i - n_main)];
+            const uint4 t = ld16u(reinterpret_cast<const uint8_t*>(table2 + i));
+            const uint32_t lit = t.x >> 16, dst = (t.y & 0xffffu) + lit, off = t.y >> 16;
+            const uint32_t m = off ? ((t.w & 0xffffu) - dst) & 0xffffu : 0u;
+            return make_uint4(t.x & 0xffffu, lit, dst, off | (m << 16));
+        } else return table[i];
+    };
+    const auto rec_set_offset = [&](uint32_t i, const uint4& r, uint32_t off) {          // forwarding: another source (0 = the match is gone)
+        if constexpr (kCompact) reinterpret_cast<uint32_t*>(table2 + i)[1] = ((r.z - r.y) & 0xffffu) | (off << 16);
+        else table[i] = make_uint4(r.x, r.y, r.z, off ? (off | (r.w & 0xffff0000u)) : 0u);
+    };
+    const auto rec_append = [&](uint32_t k, uint32_t n_main, const uint4& r) {           // forwarding / slab clipping: records out of position order
+        if constexpr (kCompact) table[kExtraBase + k] = r;
+        else table[n_main + k] = r;
+    };
     uint32_t* s_ncross = reinterpret_cast<uint32_t*>(smem + kOffVars + 16u);     // kSlab: entries in the cross list / extra records
     uint32_t* s_nextra = reinterpret_cast<uint32_t*>(smem + kOffVars + 20u);
     uint32_t* s_fwd = reinterpret_cast<uint32_t*>(smem + kOffVars + 24u);          // D1f: rounds in which a record moved
@@ -718,10 +748,10 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         const uint32_t a_in = a_out + mis;
         if constexpr (kFused) {
             using G = typename std::conditional<kCodec == CJ_CODEC_SNAPPY_RAW, SnappyGrammar, Lz4Grammar>::type;
-            const bool ok = fused_parse<G, kL2Threads>(a_in, iend, f_cap, s_bits, reinterpret_cast<uint32_t*>(smem + kL2Bytes), table, s_small, nseq, U);
+            const bool ok = fused_parse<G, kL2Threads>(a_in, iend, f_cap, s_bits, reinterpret_cast<uint32_t*>(smem + kL2Bytes), table2, s_small, nseq, U);
             ParseMeta* meta_w = const_cast<ParseMeta*>(meta);
             if (!ok) { if (tid == 0) meta_w[c] = ParseMeta{0u, kRouteWave}; continue; }      // (uniform)
-            if (tid == 0) { meta_w[c] = ParseMeta{0u, 0u}; a.result[c] = (int64_t)U; }
+            if (tid == 0) { meta_w[c] = ParseMeta{0u, 0u}; a.result[c] = (int64_t)U; table2[nseq] = make_uint2(0u, U & 0xffffu); }
             for (uint32_t i = tid; i < 2048u; i += kL2Threads) s_bits[i] = 0u;                // the walk's marks: a bitmap again
             __syncthreads();
             CJ_PHASE_MARK(1);
@@ -800,7 +830,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 for (uint32_t j = 0; j < kSyncEvery && s < nseq; j++, s++) {
                     SnRecord rec;
                     (void)snappy_record_step(rd, ip, op, iend, U, rec);     // the parse kernel accepted this stream
-                    table[s] = make_uint4(rec.lit_src, rec.lit_len, rec.dst, rec.w);
+                    rec_store(s, rec.lit_src, rec.lit_len, rec.dst, rec.w);
                     near += (rec.w != 0u && (rec.w & 0xffffu) < kFwdNear) ? 1u : 0u;
                 }
                 if (near) atomicAdd(s_small, near);
@@ -837,11 +867,12 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                     w = offset | (mlen << 16);
                     near += offset < kFwdNear ? 1u : 0u;
                 }
-                table[s] = make_uint4(lit_src, lit, op, w);
+                rec_store(s, lit_src, lit, op, w);
                 op += mlen;
             }
             if (near) atomicAdd(s_small, near);
         }
+        if constexpr (kCompact && !kFused) { if (tid == 0) table2[nseq] = make_uint2(0u, U & 0xffffu); }      // sentinel: where the last record's match ends
         __syncthreads();
         CJ_PHASE_MARK(1);
 
@@ -869,7 +900,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 uint16_t* f_blk = reinterpret_cast<uint16_t*>(s_bits);
                 constexpr uint32_t kLit = 0x80000000u, kHole = 0x40000000u, kStop = 0x20000000u, kSplit = 0x10000000u, kVal = 0x0fffffffu;
                 for (uint32_t i = tid; i < nseq; i += kL2Threads) {
-                    const uint4 r = table[i];
+                    const uint4 r = rec_load(i, nseq);
                     const bool hole = r.y == 0u && (r.x & 0x80000000u) != 0u;      // kSlab remainder record: x = bytes before it that no record describes
                     const uint32_t start = r.z - r.y - (hole ? (r.x & 0x7fffffffu) : 0u);
                     const uint32_t off = r.w & 0xffffu, m = r.w >> 16;
@@ -953,7 +984,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                     uint32_t d = dst;
 #pragma unroll
                     for (int h = 0; h < 2; h++) {
-                        if (kind[h] == 1u) table[nseq + atomicAdd(s_nextra, 1u)] = make_uint4(val[h], len[h], d + len[h], 0u);
+                        if (kind[h] == 1u) rec_append(atomicAdd(s_nextra, 1u), nseq, make_uint4(val[h], len[h], d + len[h], 0u));
                         else if constexpr (kSlab) {
                             const uint64_t src_abs = a.out_off[c] + (h ? cut : sp) - val[h];
                             (sl.cross + (size_t)blockIdx.x * sl.cross_stride)[atomicAdd(s_ncross, 1u)] = make_uint4((uint32_t)src_abs, (uint32_t)(src_abs >> 32), d, len[h]);
@@ -965,23 +996,23 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 __syncthreads();
                 for (uint32_t i = tid; i + 1u < nseq; i += kL2Threads) {
                     const uint32_t st = f_st[i], v = st & kVal;
-                    const uint4 r = table[i];
+                    const uint4 r = rec_load(i, nseq);
                     const uint32_t m = r.w >> 16;
                     if (m == 0u) continue;
-                    if (st & kSplit) { table[i] = make_uint4(r.x, r.y, r.z, 0u); continue; }
+                    if (st & kSplit) { rec_set_offset(i, r, 0u); continue; }
                     if (st & kLit) {
-                        table[nseq + atomicAdd(s_nextra, 1u)] = make_uint4(v, m, r.z + m, 0u);      // a literal copy of m bytes ending at dst + m
-                        table[i] = make_uint4(r.x, r.y, r.z, 0u);
+                        rec_append(atomicAdd(s_nextra, 1u), nseq, make_uint4(v, m, r.z + m, 0u));      // a literal copy of m bytes ending at dst + m
+                        rec_set_offset(i, r, 0u);
                     } else if (v != (r.w & 0xffffu)) {
                         if constexpr (kSlab) {
                             if (v > r.z) {                                        // forwarded into an earlier slab: a cross copy of its own
                                 const uint64_t src_abs = a.out_off[c] + r.z - v;
                                 (sl.cross + (size_t)blockIdx.x * sl.cross_stride)[atomicAdd(s_ncross, 1u)] = make_uint4((uint32_t)src_abs, (uint32_t)(src_abs >> 32), r.z, m);
-                                table[i] = make_uint4(r.x, r.y, r.z, 0u);
+                                rec_set_offset(i, r, 0u);
                                 continue;
                             }
                         }
-                        table[i] = make_uint4(r.x, r.y, r.z, v | (m << 16));
+                        rec_set_offset(i, r, v);
                     }
                 }
                 __syncthreads();                                               // the index is dead: the bitmap is a bitmap again
@@ -996,13 +1027,13 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         // (the next batch's records are requested before the current batch is processed: a coalesced table read is a
         //  full global round trip and a wave owns only ~5 batches)
         uint4 rec_nx = make_uint4(0, 0, 0, 0);
-        if (wave * 64u + lane < nrec_all) rec_nx = table[wave * 64u + lane];
+        if (wave * 64u + lane < nrec_all) rec_nx = rec_load(wave * 64u + lane, nseq);
         for (uint32_t base = wave * 64u; base < nrec_all; base += kL2Threads) {
             const uint4 rec = rec_nx;
             rec_nx = make_uint4(0, 0, 0, 0);
             {   // the wave's last batch requests its FIRST batch again: D3 starts on it without another round trip
                 const uint32_t nb = base + kL2Threads < nrec_all ? base + kL2Threads : wave * 64u;
-                if (nb + lane < nrec_all) rec_nx = table[nb + lane];
+                if (nb + lane < nrec_all) rec_nx = rec_load(nb + lane, nseq);
             }
             uint32_t n = rec.y, src = rec.x, dst = rec.z - rec.y;
             uint64_t lm = ballot64(n >= kLongRun);
@@ -1120,7 +1151,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             for (uint32_t base = wave * 64u; base < nrec_all; base += kL2Threads) {
                 const uint4 rec = rec_nx;
                 rec_nx = make_uint4(0, 0, 0, 0);
-                if (base + kL2Threads + lane < nrec_all) rec_nx = table[base + kL2Threads + lane];
+                if (base + kL2Threads + lane < nrec_all) rec_nx = rec_load(base + kL2Threads + lane, nseq);
                 const uint32_t dst = rec.z, off = rec.w & 0xffffu, m = rec.w >> 16;
                 const uint32_t src = dst - off;
                 const uint32_t need = off < m ? off : m;
@@ -1266,13 +1297,13 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 } else {
                     rec = rec_nx;
                     rec_nx = make_uint4(0, 0, 0, 0);
-                    if (base + kL2Threads + lane < nrec_all) rec_nx = table[base + kL2Threads + lane];
+                    if (base + kL2Threads + lane < nrec_all) rec_nx = rec_load(base + kL2Threads + lane, nseq);
                 }
             } else {
                 if (base >= nrec_all) break;
                 rec = rec_nx;
                 rec_nx = make_uint4(0, 0, 0, 0);
-                if (base + kL2Threads + lane < nrec_all) rec_nx = table[base + kL2Threads + lane];
+                if (base + kL2Threads + lane < nrec_all) rec_nx = rec_load(base + kL2Threads + lane, nseq);
             }
             const uint32_t dst = rec.z, off = rec.w & 0xffffu, m = rec.w >> 16;
             const uint32_t src = dst - off;                   // kLinked: "negative" (wraps) when the source starts in the previous block

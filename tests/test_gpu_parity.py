@@ -196,10 +196,16 @@ def test_device_batch_synth_roundtrip(eng, chunk, mapping):
             assert d == (len(r), r), (codec, i, res[i])
 
 
-def test_default_pipeline_mixed_large_batch(eng):
-    """A batch through the DEFAULT path (up to CJ_FUSED_MAX_CHUNKS chunks: parse + decode in one kernel): every chunk goes to
-    the LDS workgroup decoder (many short sequences) or the wave decoder (few long runs, oversize, tiny); malformed chunks
-    must fail alone.  Every result and byte is compared with the oracle."""
+# both sides of CJ_FUSED_MAX_CHUNKS (24 576): parse + decode in one kernel below it, parse pass + workgroup decoder above
+PIPELINE_BATCHES = [8192 + 37, 24576 + 41]
+
+
+@pytest.mark.parametrize("n", PIPELINE_BATCHES)
+def test_default_pipeline_mixed_large_batch(eng, n):
+    """A batch through the DEFAULT path (up to CJ_FUSED_MAX_CHUNKS chunks: parse + decode in one kernel; more: the parse
+    pass, then the workgroup decoder): every chunk goes to the LDS workgroup decoder (many short sequences) or the wave
+    decoder (few long runs, oversize, tiny); malformed chunks must fail alone.  Every result and byte is compared with
+    the oracle."""
     import random
     rnd = random.Random(11)
     kinds = []
@@ -218,7 +224,6 @@ def test_default_pipeline_mixed_large_batch(eng):
         if i % 16 == 7:                                                   # corrupt a few
             b = bytearray(blk); b[len(b) // 2] ^= 0x5A; blk = bytes(b[:max(3, len(b) - 9)])
         uniq.append((raw, blk))
-    n = 8192 + 37
     blobs = [uniq[i % 48][1] for i in range(n)]
     caps = [len(uniq[i % 48][0]) for i in range(n)]
     res, out, off = _device_batch(eng, LZ4, DEC, 0, blobs, caps)
@@ -236,7 +241,8 @@ def test_default_pipeline_mixed_large_batch(eng):
     assert n_bad > 100
 
 
-def test_default_pipeline_mixed_large_batch_snappy(eng):
+@pytest.mark.parametrize("n", PIPELINE_BATCHES)
+def test_default_pipeline_mixed_large_batch_snappy(eng, n):
     """Snappy twin of the test above."""
     import random
     rnd = random.Random(12)
@@ -255,7 +261,6 @@ def test_default_pipeline_mixed_large_batch_snappy(eng):
         if i % 16 == 7:
             b = bytearray(blk); b[len(b) // 2] ^= 0x5A; blk = bytes(b[:max(3, len(b) - 9)])
         uniq.append((raw, blk))
-    n = 8192 + 21
     blobs = [uniq[i % 40][1] for i in range(n)]
     caps = [len(uniq[i % 40][0]) for i in range(n)]
     res, out, off = _device_batch(eng, SNAPPY, DEC, 0, blobs, caps)

@@ -131,7 +131,10 @@ __device__ __forceinline__ uint32_t last_same16(const uint4& x, const uint4& y) 
 // too evicts distant sources from the small table ~4x faster on match-heavy data (measured on synth-v1: ratio
 // 1.37 with dense insertion vs the CPU encoder's 1.63).
 constexpr uint32_t kNoSlot = 0xffffffffu;
-constexpr int kSub = 4;
+#ifndef CJ_ENC_SUB
+#define CJ_ENC_SUB 4
+#endif
+constexpr int kSub = CJ_ENC_SUB;
 constexpr uint32_t kRoundPositions = 64u * kSub;
 
 struct Round {

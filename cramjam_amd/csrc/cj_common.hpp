@@ -46,7 +46,18 @@ void launch_lz4_decode_fused(const BatchArgs& a, void* meta, void* tabs, uint32_
 size_t lz4_lds2_tab_bytes(uint32_t grid);
 size_t lz4_lds_scratch_sync_bytes(size_t n_chunks);
 size_t lz4_lds_scratch_meta_bytes(size_t n_chunks);
-void launch_lz4_encode(const BatchArgs& a, hipStream_t s);
+// Encoders, large batches: besides the ten LDS-table wavefronts that fit a CU, `table_blocks` more wavefronts with their hash
+// table in a slot of global memory take chunks from the same counter (cj_match.hpp: encode_persistent_kernel).  They are
+// launched on `aux` between the two events, so that they are resident together with the LDS blocks.
+struct EncFill {
+    hipStream_t aux;
+    hipEvent_t fork, join;
+    uint32_t* counter;          // one zeroed word per launch (this struct's owner serialises launches)
+    uint16_t* tables;           // table_blocks x kEncTableBytes
+    uint32_t lds_blocks, table_blocks;
+};
+constexpr size_t kEncTableBytes = 16384;
+void launch_lz4_encode(const BatchArgs& a, hipStream_t s, const EncFill* fill = nullptr);
 void launch_snappy_decode(const BatchArgs& a, hipStream_t s);                                   // one wavefront per chunk
 void launch_snappy_decode_lanes(const BatchArgs& a, hipStream_t s);                            // one lane per chunk
 void launch_snappy_parse(const BatchArgs& a, void* sync, void* meta, hipStream_t s);
@@ -65,7 +76,7 @@ void launch_lz4_decode_lds2_slabs(const BatchArgs& a, const void* sync, const vo
                                   const void* first, uint32_t stream_len, uint32_t* done, void* cross, uint32_t tab_stride,
                                   uint32_t cross_stride, uint32_t grid, hipStream_t s, int codec, bool rel = false);
 void launch_snappy_decode_routed(const BatchArgs& a, const void* meta, hipStream_t s);       // wave kernel on chunks the parse kernel routed to it
-void launch_snappy_encode(const BatchArgs& a, hipStream_t s);
+void launch_snappy_encode(const BatchArgs& a, hipStream_t s, const EncFill* fill = nullptr);
 
 #if defined(__HIPCC__)
 

@@ -84,6 +84,10 @@ struct cj_engine {
     cj::DevBuf d_frame;            // frame.hip: assembled / staged framed stream
     cj::DevBuf d_tab;              // LDS decoder variant 2: per-workgroup record tables
     cj::DevBuf d_big, d_bigtab;    // large.hip: parse scratch / record tables of one large stream (under `mu`)
+    // encoders, large batches (cj::EncFill): second stream for the global-table blocks, their tables + the chunk counter
+    hipStream_t enc_aux = nullptr;
+    hipEvent_t enc_fork = nullptr, enc_join = nullptr, enc_free = nullptr;
+    cj::DevBuf d_enc;
     int n_cu = 0;
 };
 

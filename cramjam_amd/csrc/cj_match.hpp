@@ -387,5 +387,53 @@ __device__ __forceinline__ void insert_uncovered(uint16_t* ht, uint32_t pos, uin
     if (hslot != kNoSlot && !covered) ht[hslot] = (uint16_t)(pos + lane_id());
 }
 
+// ---- persistent encoder blocks ------------------------------------------------------------------------------
+// One wavefront per block, chunks from a shared counter.  kGlobalTable = false: hash table in LDS — ten such blocks fill a
+// CU's 160 KiB and leave 6 of its 16 wave slots (at <= 128 VGPRs) empty; true: hash table in the block's slot of a global
+// scratch array (L2-resident), no LDS — these blocks take the empty slots.  Alone, a wavefront with its table in L2 is as
+// fast as one with an LDS table (7.9 vs 8.2 GB/s, 3 resp. 5 per CU); per-wavefront rates fall as the CU fills (LZ4: 10 LDS
+// wavefronts 66 GB/s, + 3 global 75 GB/s, + 6 global 75 GB/s), so three per CU are launched.  Enc::chunk(a, c, ht) = one chunk.
+static_assert(kHashSize * 2u <= kEncTableBytes, "table slot");
+#ifndef CJ_ENC_TABLE_WAVES_PER_EU
+#define CJ_ENC_TABLE_WAVES_PER_EU 3
+#endif
+template <class Enc, bool kGlobalTable>
+__device__ __forceinline__ void encode_persistent_body(const BatchArgs& a, uint32_t* counter, uint16_t* ht) {
+    for (;;) {
+        uint32_t c = 0;
+        if (threadIdx.x == 0) c = atomicAdd(counter, 1u);
+        const uint32_t chunk = uni(c);                               // lane 0's value (one wavefront per block)
+        if (chunk >= a.n_chunks) return;
+        Enc::chunk(a, chunk, ht);
+    }
+}
+// (four wavefronts per SIMD as the register target — the ten blocks of a CU must leave registers for the table blocks; the
+//  compiler notes that 16 KiB of LDS per block allows only 2.5 per SIMD: -Wpass-failed, expected.  amdgpu_num_vgpr(128)
+//  instead gives the same 126 registers but a schedule that is 4 % slower)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wpass-failed"
+template <class Enc>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void encode_lds_blocks_kernel(BatchArgs a, uint32_t* counter) {
+    __shared__ uint16_t ht_lds[kHashSize];                           // exactly 16 KiB: one more word and only nine blocks fit a CU
+    encode_persistent_body<Enc, false>(a, counter, ht_lds);
+}
+#pragma clang diagnostic pop
+template <class Enc>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CJ_ENC_TABLE_WAVES_PER_EU, CJ_ENC_TABLE_WAVES_PER_EU)))
+void encode_table_blocks_kernel(BatchArgs a, uint32_t* counter, uint16_t* tables) {
+    encode_persistent_body<Enc, true>(a, counter, tables + (size_t)blockIdx.x * (kEncTableBytes / 2u));
+}
+
+template <class Enc>
+inline void launch_encode_filled(const BatchArgs& a, hipStream_t s, const EncFill& f) {
+    (void)hipMemsetAsync(f.counter, 0, 4, s);
+    (void)hipEventRecord(f.fork, s);
+    hipLaunchKernelGGL((encode_lds_blocks_kernel<Enc>), dim3(f.lds_blocks), dim3(64), 0, s, a, f.counter);
+    (void)hipStreamWaitEvent(f.aux, f.fork, 0);
+    hipLaunchKernelGGL((encode_table_blocks_kernel<Enc>), dim3(f.table_blocks), dim3(64), 0, f.aux, a, f.counter, f.tables);
+    (void)hipEventRecord(f.join, f.aux);
+    (void)hipStreamWaitEvent(s, f.join, 0);
+}
+
 #endif
 }  // namespace cj

@@ -75,13 +75,47 @@ int launch_decode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a, hipStrea
     return 0;
 }
 
+// LZ4 block / Snappy raw encode of a batch of independent chunks, one wavefront per chunk.  A CU holds ten wavefronts with a
+// 16 KiB hash table in LDS.  A batch with at least that many chunks (fewer: every chunk gets an LDS wavefront at once, 2 048
+// chunks 2.24 ms against 2.58) runs as persistent blocks — ten LDS-table blocks per CU on `s` plus kEncTableBlocksPerCu blocks
+// per CU whose table lives in global memory, on the engine's second stream, all taking chunks from one counter
+// (cj_match.hpp).  100 k chunks: LZ4 66 -> 75 GB/s, Snappy 61 -> 73; 2 560 chunks 4.0 -> 3.0 ms (the counter also evens out
+// the CUs); 4 or 6 table blocks per CU give what 3 give.
+#ifndef CJ_ENC_TABLE_BLOCKS
+#define CJ_ENC_TABLE_BLOCKS 3
+#endif
+constexpr uint32_t kEncLdsBlocksPerCu = 10, kEncTableBlocksPerCu = CJ_ENC_TABLE_BLOCKS;
+
+int launch_encode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a, hipStream_t s) {
+    const bool lz4 = codec == CJ_CODEC_LZ4_BLOCK;
+    std::lock_guard<std::mutex> lock(e->scratch_mu);
+    if (e->n_cu == 0) HIP_TRY(hipDeviceGetAttribute(&e->n_cu, hipDeviceAttributeMultiprocessorCount, e->device), CJ_E_NO_DEVICE);
+    if (a.n_chunks < kEncLdsBlocksPerCu * (uint32_t)e->n_cu || (a.flags & cj::kFlagSplitPieces)) {
+        if (lz4) cj::launch_lz4_encode(a, s); else cj::launch_snappy_encode(a, s);
+        return 0;
+    }
+    const uint32_t table_blocks = kEncTableBlocksPerCu * (uint32_t)e->n_cu;
+    if (!e->enc_aux) {
+        HIP_TRY(hipStreamCreateWithFlags(&e->enc_aux, hipStreamNonBlocking), CJ_E_NO_DEVICE);
+        HIP_TRY(hipEventCreateWithFlags(&e->enc_fork, hipEventDisableTiming), CJ_E_NO_DEVICE);
+        HIP_TRY(hipEventCreateWithFlags(&e->enc_join, hipEventDisableTiming), CJ_E_NO_DEVICE);
+    }
+    if (!e->enc_free) HIP_TRY(hipEventCreateWithFlags(&e->enc_free, hipEventDisableTiming), CJ_E_NO_DEVICE);
+    else HIP_TRY(hipStreamWaitEvent(s, e->enc_free, 0), CJ_E_NO_DEVICE);      // the previous batch (maybe on another stream) is done with the counter and the tables
+    if (!e->d_enc.reserve(256 + (size_t)table_blocks * cj::kEncTableBytes)) return CJ_E_OOM;   // (sized once: n_cu is fixed)
+    cj::EncFill f;
+    f.aux = e->enc_aux; f.fork = e->enc_fork; f.join = e->enc_join;
+    f.counter = (uint32_t*)e->d_enc.p; f.tables = (uint16_t*)((uint8_t*)e->d_enc.p + 256);
+    f.lds_blocks = kEncLdsBlocksPerCu * (uint32_t)e->n_cu; f.table_blocks = table_blocks;
+    if (lz4) cj::launch_lz4_encode(a, s, &f); else cj::launch_snappy_encode(a, s, &f);
+    HIP_TRY(hipEventRecord(e->enc_free, s), CJ_E_NO_DEVICE);
+    return 0;
+}
+
 int launch_slice(cj_engine* e, cj_codec codec, cj_op op, const cj::BatchArgs& a, hipStream_t s) {
     if (codec != CJ_CODEC_LZ4_BLOCK && codec != CJ_CODEC_SNAPPY_RAW) return CJ_E_BAD_ARG;
-    if (op == CJ_OP_DECOMPRESS) {
-        const int rc = launch_decode(e, codec, a, s);
-        if (rc != 0) return rc;
-    } else if (codec == CJ_CODEC_LZ4_BLOCK) cj::launch_lz4_encode(a, s);
-    else cj::launch_snappy_encode(a, s);
+    const int rc = op == CJ_OP_DECOMPRESS ? launch_decode(e, codec, a, s) : launch_encode(e, codec, a, s);
+    if (rc != 0) return rc;
     HIP_TRY(hipGetLastError(), CJ_E_NO_DEVICE);
     return 0;
 }
@@ -246,6 +280,9 @@ void cj_engine_destroy(cj_engine* e) {
     e->d_in.release(); e->d_out.release(); e->d_meta.release(); e->d_sync.release(); e->d_pmeta.release(); e->d_lanelist.release(); e->d_frame.release(); e->d_tab.release(); e->d_big.release(); e->d_bigtab.release();
     e->h_in.release(); e->h_out.release();
     if (e->scratch_free) (void)hipEventDestroy(e->scratch_free);
+    e->d_enc.release();
+    for (hipEvent_t ev : {e->enc_fork, e->enc_join, e->enc_free}) if (ev) (void)hipEventDestroy(ev);
+    if (e->enc_aux) (void)hipStreamDestroy(e->enc_aux);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }

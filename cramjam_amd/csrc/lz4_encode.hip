@@ -53,13 +53,8 @@ __device__ __forceinline__ void lz4_emit_queue(const uint8_t* in, uint8_t* out, 
 // piece would (ratio 1.62 vs 1.63 on the benchmark data, 4.79 vs 4.88 on text); each writes its own stream, and the
 // streams are stitched / concatenated like any other pieces.  256 KiB .. 4 MiB: 1.8-1.9 ms -> 0.6-0.7 ms per call.
 template <bool kSplit>
-__global__ __launch_bounds__(kSplit ? 256 : kEncThreads) void lz4_encode_kernel(BatchArgs a) {
-    __shared__ uint16_t ht_all[kSplit ? 4 : kEncWaves][kHashSize];
-    const uint32_t wave = uni(threadIdx.x >> 6);
-    const uint32_t chunk = uni(kSplit ? blockIdx.x * 4u + wave : blockIdx.x * kEncWaves + wave);
-    uint16_t* ht = ht_all[wave];
-    if (chunk >= a.n_chunks) return;
-    const uint64_t base_off = kSplit ? a.in_off[blockIdx.x * 4u] : a.in_off[chunk];
+__device__ __forceinline__ void lz4_encode_chunk(const BatchArgs& a, uint32_t chunk, uint16_t* ht) {
+    const uint64_t base_off = kSplit ? a.in_off[chunk & ~3u] : a.in_off[chunk];
     const uint8_t* in = a.in_base + base_off;               // position 0 = start of the piece
     const uint32_t q0 = (uint32_t)(a.in_off[chunk] - base_off);      // this wave's range = [q0, n)
     const uint64_t n64 = q0 + a.in_len[chunk];
@@ -188,8 +183,22 @@ __global__ __launch_bounds__(kSplit ? 256 : kEncThreads) void lz4_encode_kernel(
     if (lane == 0) a.result[chunk] = (int64_t)(((uint64_t)op + (prefix ? 4u : 0u)) | tail_report);
 }
 
-void launch_lz4_encode(const BatchArgs& a, hipStream_t s) {
+template <bool kSplit>
+__global__ __launch_bounds__(kSplit ? 256 : kEncThreads) void lz4_encode_kernel(BatchArgs a) {
+    __shared__ uint16_t ht_all[kSplit ? 4 : kEncWaves][kHashSize];
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    const uint32_t chunk = uni(kSplit ? blockIdx.x * 4u + wave : blockIdx.x * kEncWaves + wave);
+    if (chunk >= a.n_chunks) return;
+    lz4_encode_chunk<kSplit>(a, chunk, ht_all[wave]);
+}
+
+struct Lz4Enc {
+    static __device__ __forceinline__ void chunk(const BatchArgs& a, uint32_t c, uint16_t* ht) { lz4_encode_chunk<false>(a, c, ht); }
+};
+
+void launch_lz4_encode(const BatchArgs& a, hipStream_t s, const EncFill* fill) {
     if (a.n_chunks == 0) return;
+    if (fill && !(a.flags & kFlagSplitPieces)) { launch_encode_filled<Lz4Enc>(a, s, *fill); return; }
     dim3 grid((a.n_chunks + kEncWaves - 1) / kEncWaves), block(kEncThreads);
     if (a.flags & kFlagSplitPieces) {
         hipLaunchKernelGGL(lz4_encode_kernel<true>, dim3((a.n_chunks + 3u) / 4u), dim3(256), 0, s, a);

@@ -356,6 +356,40 @@ def test_large_batch_compress_then_decompress_property(eng, codec):
         want = raw_h[(i % U) * S:(i % U + 1) * S].tobytes()
         got = oracle.lz4_decompress_raw(blob, S) if codec == LZ4 else oracle.snappy_decompress(blob)
         assert got == (S, want), i
+    # batches of this size run as persistent blocks, some with their hash table in LDS and some with it in global memory
+    # (engine.hip launch_encode): which kind compresses a chunk is a race, the bytes must not depend on it
+    assert (clen.reshape(-1, U) == clen[:U]).all()
+    rows = comp_h.reshape(n, stride)
+    for i in range(U):
+        assert (rows[i::U, :int(clen[i])] == rows[i, :int(clen[i])]).all(), i
+
+
+@pytest.mark.parametrize("codec", [LZ4, SNAPPY])
+def test_encoder_persistent_blocks_on_mixed_chunks(eng, codec):
+    """The large-batch encoder path (persistent LDS-table + global-table blocks) on chunks of every shape: empty, tiny, zeros,
+    random, short periods, ragged sizes, above 64 KiB.  Every copy of a chunk must compress to the same bytes, and those
+    bytes must decode with the oracle."""
+    import random
+    rnd = random.Random(21)
+    uniq = [b"", b"a", b"abcd" * 3, bytes(65536), hashlib.shake_256(b"e").digest(65536), (b"xyz" * 30000)[:65536],
+            oracle.synth_v1(70000, 3), oracle.synth_v1(4096, 4) + bytes(3000) + hashlib.shake_256(b"f").digest(5000)]
+    uniq += [oracle.synth_v1(rnd.randrange(1, 65537), 10 + i) for i in range(16)]
+    uniq += [(bytes([i]) * rnd.randrange(1, 300) + oracle.synth_v1(3000, i))[:rnd.randrange(13, 3300)] for i in range(8)]
+    U = len(uniq)
+    n = 8192 + 3 * U + 5
+    L = N.lib()
+    bound = [(L.cj_lz4_block_compress_bound(len(r), 0) if codec == LZ4 else L.cj_snappy_raw_max_compress_len(len(r))) for r in uniq]
+    res, out, off = _device_batch(eng, codec, ENC, 0, [uniq[i % U] for i in range(n)], [bound[i % U] for i in range(n)])
+    first = []
+    for i in range(U):
+        assert 0 < res[i] <= bound[i], (i, res[i])
+        blob = out[int(off[i]):int(off[i]) + int(res[i])].tobytes()
+        got = oracle.lz4_decompress_raw(blob, len(uniq[i])) if codec == LZ4 else oracle.snappy_decompress(blob)
+        assert got == (len(uniq[i]), uniq[i]), i
+        first.append(blob)
+    for i in range(U, n):
+        assert res[i] == res[i % U], i
+        assert out[int(off[i]):int(off[i]) + int(res[i])].tobytes() == first[i % U], i
 
 
 def _shaped_chunks(seed, count, size=65536):

@@ -9,6 +9,8 @@ timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -3 | tee $O/pytest_gpu
 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json; echo
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --no-cpu-baseline --traffic off > $O/stats.log 2>&1
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv; head -8 $O/kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_enc -- python bench.py --op compress --no-cpu-baseline --traffic off --steps 10 > $O/stats_enc.log 2>&1
+cp $(find $O/stats_enc -name "*kernel_stats.csv" | head -1) $O/kernel_stats_compress.csv; head -5 $O/kernel_stats_compress.csv
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_LDS --output-format csv -d $O/sq -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --traffic off > $O/sq.log 2>&1
 python - "$O/sq" <<'PY' | tee $O/sq_counters_per_chunk.txt
 import csv,glob,collections,sys
@@ -28,4 +30,4 @@ import json
 for l in open('$O/other_paths.jsonl'):
     d=json.loads(l); print('%-95s %8.1f GB/s  %8.3f ms/step  frac %.4f' % (d['config']['workload'][:95], d['value'], d['ms_per_step'], d['roofline']['frac']))
 PY
-rm -rf $O/stats $O/sq
+rm -rf $O/stats $O/sq $O/stats_enc

@@ -24,7 +24,11 @@ struct BatchArgs {
 // internal flag bits (never part of the C-ABI): 0x1000 = LDS decoder phase profile, 0x2000 = linked-frame parse
 // (bit 63 of in_len marks a STORED block; no minimum sequence count for the LDS decoder)
 constexpr uint32_t kFlagLinkedFrame = 0x2000u;
-constexpr uint32_t kFlagSplitPieces = 0x8000u;     // encoders (large.hip): chunks 4b .. 4b+3 are the quarters of one piece, compressed by one block
+constexpr uint32_t kFlagSplitPieces = 0x8000u;     // encoders (large.hip): the chunks are consecutive sub-pieces of 64 KiB pieces, `per` of them per piece
+                                                   // (flag bits 16..19 = log2(per): 4 = quarters of 16 KiB, 16 = sub-pieces of 4 KiB); position 0 of a
+                                                   // sub-piece's walk = the start of its piece, what lies before it is indexed first (ht_preindex)
+constexpr uint32_t kFlagSplitShift = 16;
+__host__ __device__ inline uint32_t split_per(uint32_t flags) { return 1u << ((flags >> kFlagSplitShift) & 15u); }
 constexpr uint32_t kFlagReportTail = 0x4000u;      // LZ4 encoder (large.hip): result = size | length of the final literal run << 32
 
 constexpr int kWavesPerBlock = 4;

@@ -39,8 +39,8 @@ __device__ __forceinline__ void ht_clear(uint16_t* ht) {
     for (uint32_t i = lane_id(); i < kHashSize / 2; i += 64u) p[i] = 0u;
 }
 
-// kSplit encoders: index the data BEFORE this wave's quarter (positions [0, q0), every kPreStep-th one, ascending so that
-// the most recent position wins a slot), so that the quarter finds the matches a serial walk over the piece would
+// kSplit encoders: index the data BEFORE this wave's sub-piece (positions [0, q0), every kPreStep-th one, ascending so that
+// the most recent position wins a slot), so that the sub-piece finds the matches a serial walk over the piece would
 #ifndef CJ_PRE_STEP
 #define CJ_PRE_STEP 1u
 #endif

@@ -166,8 +166,8 @@ using cj::launch;
 
 // single buffers above this size take large.hip's piece-parallel path (compress)
 constexpr size_t kLargeMin = 65536;
-// compress: already above one quarter piece (four wavefronts on a 64 KiB buffer instead of one: 1.7 -> 0.6 ms)
-constexpr size_t kLargeMinCompress = 16384;
+// compress: already above two 4 KiB sub-pieces (sixteen wavefronts on a 64 KiB buffer instead of one: 1.7 -> 0.3 ms)
+constexpr size_t kLargeMinCompress = 8192;
 
 int64_t single(cj_codec codec, cj_op op, uint32_t flags, const uint8_t* in, size_t n, uint8_t* out, size_t cap) {
     cj_engine* e = default_engine();

@@ -193,7 +193,7 @@ int64_t cj_snappy_frame_compress(const uint8_t* in, size_t n, uint8_t* out, size
     if (n == 0) return 0;                  // snap emits the stream identifier together with the first chunk only
     const size_t np = (n + kPiece - 1) / kPiece;
     if (np > 0xFFFFFFF0ull) return CJ_E_BAD_ARG;
-    if (n > 16384 && n <= cj::large_split_max()) return cj::large_snappy_frame(in, n, out, cap);     // four wavefronts per piece (large.hip)
+    if (n > 8192 && n <= cj::large_split_max()) return cj::large_snappy_frame(in, n, out, cap);     // sub-pieces, one wavefront each (large.hip)
 
     std::lock_guard<std::mutex> lock(e->mu);
     HIP_TRY(hipSetDevice(e->device), CJ_E_NO_DEVICE);
@@ -444,9 +444,9 @@ int64_t cj_lz4_frame_compress_blocks(const uint8_t* in, size_t n, uint8_t* out, 
     const size_t np = (n + kLz4fBlock - 1) / kLz4fBlock;
     if (np > 0xFFFFFFF0ull) return CJ_E_BAD_ARG;
     if (np == 0) return 0;
-    // up to 32 MiB: four wavefronts per 64 KiB block (quarter pieces joined into one LZ4 block, large.hip) — one wavefront
-    // per block would make every call at least the 1.7 ms it needs for 64 KiB
-    if (n > 16384 && n <= cj::large_split_max()) return cj::large_lz4_frame_blocks(in, n, out, cap);
+    // up to 32 MiB: sixteen (above 16 MiB: four) wavefronts per 64 KiB block (sub-pieces joined into one LZ4 block, large.hip) —
+    // one wavefront per block would make every call at least the 1.7 ms it needs for 64 KiB
+    if (n > 8192 && n <= cj::large_split_max()) return cj::large_lz4_frame_blocks(in, n, out, cap);
     uint64_t fpos = 0;
     std::lock_guard<std::mutex> lock(e->mu);
     HIP_TRY(hipSetDevice(e->device), CJ_E_NO_DEVICE);

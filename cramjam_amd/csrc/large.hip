@@ -28,11 +28,23 @@ namespace {
 constexpr size_t kPiece = 65536;
 constexpr size_t kLz4Stride = 65824;          // LZ4_compressBound(65536) = 65809, rounded up to 16
 constexpr size_t kSnStride = 76512;           // snap max_compress_len(65536) = 76490, rounded up to 16
-// buffers of up to kSplitMax bytes: quarter pieces, four wavefronts per 64 KiB (lz4_encode.hip, kSplit) — one wavefront needs
-// ~1.7 ms for 64 KiB, and below ~500 pieces most of the GPU's wavefront slots are idle anyway
-constexpr size_t kSplitMax = 32u << 20, kQuarter = 16384;
-constexpr size_t kLz4QStride = 16480;         // LZ4_compressBound(16384) = 16464
-constexpr size_t kSnQStride = 19152;          // snap max_compress_len(16384) = 19146
+// buffers of up to kSplitMax bytes: every 64 KiB piece is cut into sub-pieces, one wavefront each (lz4_encode.hip, kSplit) —
+// one wavefront needs ~1.7 ms for 64 KiB (~6 µs per 256-position round, whatever else runs), and below ~500 pieces most of the
+// GPU's wavefront slots are idle anyway.  Up to kFineMax bytes: 16 sub-pieces of 4 KiB (16 rounds each), above: quarters of
+// 16 KiB.  One call, quarters -> 4 KiB sub-pieces: 16 KiB 0.44 -> 0.20 ms, 64 KiB 0.59 -> 0.30, 1 MiB 0.68 -> 0.37 (text 1.08 ->
+// 0.37), 4 MiB 0.74 -> 0.44, 16 MiB 1.6 -> 1.56 (copies); ratio 1.62 -> 1.60 (benchmark data), 4.79 -> 4.78 (text).
+constexpr size_t kSplitMax = 32u << 20, kFineMax = 16u << 20;
+struct SubPieces {
+    size_t sub;              // bytes per sub-piece
+    size_t per;              // sub-pieces per 64 KiB piece
+    size_t lz4_stride;       // LZ4_compressBound(sub) rounded up to 16
+    size_t sn_stride;        // snap max_compress_len(sub) rounded up to 16
+    uint32_t flags;          // kFlagSplitPieces | log2(per) << kFlagSplitShift
+};
+inline SubPieces sub_pieces(size_t n) {
+    if (n <= kFineMax) return {4096, 16, 4128, 4816, kFlagSplitPieces | (4u << kFlagSplitShift)};      // 4096 + 16 + 16; 32 + 4096 + 682 = 4810
+    return {16384, 4, 16480, 19152, kFlagSplitPieces | (2u << kFlagSplitShift)};                       // 16464; 19146
+}
 
 __host__ __device__ inline uint32_t lz4_len_ext(uint32_t len) { return len < 15u ? 0u : (len - 15u) / 255u + 1u; }
 
@@ -145,13 +157,14 @@ int64_t large_snappy_compress(const uint8_t* in, size_t n, uint8_t* out, size_t 
     if (!e) return CJ_E_NO_DEVICE;
     if (n > 0xFFFFFFFFull) return CJ_E_SNAPPY_TOO_BIG;
     const bool split = n <= kSplitMax;
-    const size_t piece = split ? kQuarter : kPiece, stride = split ? kSnQStride : kSnStride;
+    const SubPieces sp = sub_pieces(n);
+    const size_t piece = split ? sp.sub : kPiece, stride = split ? sp.sn_stride : kSnStride;
     const size_t np = (n + piece - 1) / piece;
     std::lock_guard<std::mutex> lock(e->mu);
     HIP_TRY(hipSetDevice(e->device), CJ_E_NO_DEVICE);
     hipStream_t s = e->stream;
     std::vector<int64_t> res;
-    int rc = compress_pieces(e, CJ_CODEC_SNAPPY_RAW, split ? kFlagSplitPieces : 0u, in, n, piece, np, stride, res);
+    int rc = compress_pieces(e, CJ_CODEC_SNAPPY_RAW, split ? sp.flags : 0u, in, n, piece, np, stride, res);
     if (rc != 0) return rc;
     HIP_TRY(hipStreamSynchronize(s), CJ_E_NO_DEVICE);
 
@@ -187,7 +200,8 @@ int64_t large_lz4_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap
     cj_engine* e = default_engine();
     if (!e) return CJ_E_NO_DEVICE;
     const bool split = n <= kSplitMax;
-    const size_t piece = split ? kQuarter : kPiece, stride = split ? kLz4QStride : kLz4Stride;
+    const SubPieces sp = sub_pieces(n);
+    const size_t piece = split ? sp.sub : kPiece, stride = split ? sp.lz4_stride : kLz4Stride;
     const size_t np = (n + piece - 1) / piece;
     const size_t pre = prefix ? 4 : 0;
     if (cap < pre) return CJ_E_COMPRESS_FAILED;
@@ -195,7 +209,7 @@ int64_t large_lz4_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap
     HIP_TRY(hipSetDevice(e->device), CJ_E_NO_DEVICE);
     hipStream_t s = e->stream;
     std::vector<int64_t> res;
-    int rc = compress_pieces(e, CJ_CODEC_LZ4_BLOCK, kFlagReportTail | (split ? kFlagSplitPieces : 0u), in, n, piece, np, stride, res);
+    int rc = compress_pieces(e, CJ_CODEC_LZ4_BLOCK, kFlagReportTail | (split ? sp.flags : 0u), in, n, piece, np, stride, res);
     if (rc != 0) return rc;
     uint64_t* d_meta = (uint64_t*)e->d_meta.p;
     uint8_t* d_tmp = (uint8_t*)e->d_out.p;
@@ -225,17 +239,19 @@ int64_t large_lz4_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap
 
 
 // The block sequence of an LZ4 frame (u32 size word + data per 64 KiB of input; frame.hip: cj_lz4_frame_compress_blocks) for
-// inputs of up to kSplitMax bytes: every 64 KiB block is compressed by four wavefronts (quarter pieces) and joined into one
+// inputs of up to kSplitMax bytes: every 64 KiB block is compressed by 16 / 4 wavefronts (sub-pieces) and joined into one
 // LZ4 block; a block that does not shrink is stored.
 int64_t large_lz4_frame_blocks(const uint8_t* in, size_t n, uint8_t* out, size_t cap) {
     cj_engine* e = default_engine();
     if (!e) return CJ_E_NO_DEVICE;
+    const SubPieces sp = sub_pieces(n);
+    const size_t kQuarter = sp.sub, kLz4QStride = sp.lz4_stride;            // (q = sub-piece: 16 or 4 per block)
     const size_t nq = (n + kQuarter - 1) / kQuarter, nb = (n + kPiece - 1) / kPiece;
     std::lock_guard<std::mutex> lock(e->mu);
     HIP_TRY(hipSetDevice(e->device), CJ_E_NO_DEVICE);
     hipStream_t s = e->stream;
     std::vector<int64_t> res;
-    int rc = compress_pieces(e, CJ_CODEC_LZ4_BLOCK, kFlagReportTail | kFlagSplitPieces, in, n, kQuarter, nq, kLz4QStride, res);
+    int rc = compress_pieces(e, CJ_CODEC_LZ4_BLOCK, kFlagReportTail | sp.flags, in, n, kQuarter, nq, kLz4QStride, res);
     if (rc != 0) return rc;
     uint64_t* d_meta = (uint64_t*)e->d_meta.p;
     uint8_t* d_tmp = (uint8_t*)e->d_out.p;
@@ -252,7 +268,7 @@ int64_t large_lz4_frame_blocks(const uint8_t* in, size_t n, uint8_t* out, size_t
     std::vector<uint64_t> seg(4 * nb);                     // src | dst_off | len | hdr per block (copy_segments)
     uint64_t fpos = 0;
     for (size_t b = 0; b < nb; b++) {
-        const size_t q0 = 4 * b, q1 = std::min(nq, q0 + 4);
+        const size_t q0 = sp.per * b, q1 = std::min(nq, q0 + sp.per);
         const uint64_t len = std::min(kPiece, n - b * kPiece);
         const uint64_t cl = plan_stitch(plan, q0, q1, fpos + 4, n, kQuarter, kLz4QStride, d_tmp, res, first);
         const bool stored = cl >= len;                     // LZ4F_makeBlock: a block that does not shrink is stored
@@ -282,18 +298,20 @@ int64_t large_lz4_frame_blocks(const uint8_t* in, size_t n, uint8_t* out, size_t
 }
 
 // A Snappy framed stream (frame.hip: cj_snappy_frame_compress) for inputs of up to kSplitMax bytes: every 64 KiB piece is
-// compressed by four wavefronts; its chunk = header (type, length, masked CRC-32C of the uncompressed piece) + varint(piece
-// length) + the four quarters' element streams.  snap's rule: a piece is stored when it does not shrink by an eighth.
+// compressed by 16 / 4 wavefronts; its chunk = header (type, length, masked CRC-32C of the uncompressed piece) + varint(piece
+// length) + the sub-pieces' element streams.  snap's rule: a piece is stored when it does not shrink by an eighth.
 int64_t large_snappy_frame(const uint8_t* in, size_t n, uint8_t* out, size_t cap) {
     static const uint8_t kIdent[10] = {0xff, 0x06, 0x00, 0x00, 's', 'N', 'a', 'P', 'p', 'Y'};
     cj_engine* e = default_engine();
     if (!e) return CJ_E_NO_DEVICE;
+    const SubPieces sp = sub_pieces(n);
+    const size_t kQuarter = sp.sub, kSnQStride = sp.sn_stride;              // (q = sub-piece: 16 or 4 per piece)
     const size_t nq = (n + kQuarter - 1) / kQuarter, np = (n + kPiece - 1) / kPiece;
     std::lock_guard<std::mutex> lock(e->mu);
     HIP_TRY(hipSetDevice(e->device), CJ_E_NO_DEVICE);
     hipStream_t s = e->stream;
     std::vector<int64_t> res;
-    int rc = compress_pieces(e, CJ_CODEC_SNAPPY_RAW, kFlagSplitPieces, in, n, kQuarter, nq, kSnQStride, res);
+    int rc = compress_pieces(e, CJ_CODEC_SNAPPY_RAW, sp.flags, in, n, kQuarter, nq, kSnQStride, res);
     if (rc != 0) return rc;
     uint64_t* d_meta = (uint64_t*)e->d_meta.p;             // 12 nq rows reserved; 0 .. 5 nq in use
     uint8_t* d_tmp = (uint8_t*)e->d_out.p;
@@ -312,7 +330,7 @@ int64_t large_snappy_frame(const uint8_t* in, size_t n, uint8_t* out, size_t cap
     std::vector<uint32_t> vints(np, 0);
     uint64_t fpos = 10;
     for (size_t p = 0; p < np; p++) {
-        const size_t q0 = 4 * p, q1 = std::min(nq, q0 + 4);
+        const size_t q0 = sp.per * p, q1 = std::min(nq, q0 + sp.per);
         const uint64_t len = pm[np + p];
         uint32_t vl = 0, v = 0;
         for (uint64_t x = len;; ) { if (x < 0x80u) { v |= (uint32_t)x << (8 * vl); vl++; break; } v |= (uint32_t)((x & 0x7f) | 0x80u) << (8 * vl); vl++; x >>= 7; }

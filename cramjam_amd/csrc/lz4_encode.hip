@@ -47,14 +47,16 @@ __device__ __forceinline__ void lz4_emit_queue(const uint8_t* in, uint8_t* out, 
 }
 
 // kSplit (large.hip, buffers of up to 32 MiB, where one wavefront per 64 KiB piece would leave most of the GPU idle and
-// every call would take the 1.7 ms one wavefront needs for 64 KiB): a block of FOUR wavefronts compresses one 64 KiB piece —
-// chunks 4b .. 4b+3 are its consecutive quarters, position 0 = the start of the piece.  Each wavefront has its own hash
-// table and first indexes the data BEFORE its quarter (ht_preindex: a few µs), so it finds what a serial walk over the
-// piece would (ratio 1.62 vs 1.63 on the benchmark data, 4.79 vs 4.88 on text); each writes its own stream, and the
-// streams are stitched / concatenated like any other pieces.  256 KiB .. 4 MiB: 1.8-1.9 ms -> 0.6-0.7 ms per call.
+// every call would take the 1.7 ms one wavefront needs for 64 KiB): every 64 KiB piece is cut into split_per(flags) = 16 or 4
+// consecutive sub-pieces (4 KiB / 16 KiB), one wavefront each — the chunks of the batch ARE the sub-pieces, position 0 of a
+// walk = the start of its piece.  Each wavefront has its own hash table and first indexes the data BEFORE its sub-piece
+// (ht_preindex: a few µs), so it finds what a serial walk over the piece would (ratio 1.60 resp. 1.62 vs 1.63 on the benchmark
+// data, 4.78 resp. 4.79 vs 4.88 on text); each writes its own stream, and the streams are stitched / concatenated like any
+// other pieces.  64 KiB .. 4 MiB per call: 1.8-1.9 ms on one wavefront per piece, 0.6-0.7 ms with quarters, 0.30-0.44 ms with
+// 4 KiB sub-pieces.  (Blocks of four wavefronts: four tables fill the 64 KiB of static LDS.)
 template <bool kSplit>
 __device__ __forceinline__ void lz4_encode_chunk(const BatchArgs& a, uint32_t chunk, uint16_t* ht) {
-    const uint64_t base_off = kSplit ? a.in_off[chunk & ~3u] : a.in_off[chunk];
+    const uint64_t base_off = kSplit ? a.in_off[chunk & ~(split_per(a.flags) - 1u)] : a.in_off[chunk];      // the piece's first sub-piece
     const uint8_t* in = a.in_base + base_off;               // position 0 = start of the piece
     const uint32_t q0 = (uint32_t)(a.in_off[chunk] - base_off);      // this wave's range = [q0, n)
     const uint64_t n64 = q0 + a.in_len[chunk];

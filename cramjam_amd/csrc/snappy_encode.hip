@@ -97,7 +97,7 @@ __device__ __forceinline__ void snappy_emit_queue(const uint8_t* in, uint8_t* ou
 // kSplit: four wavefronts per 64 KiB piece, each with its own pre-indexed hash table — see lz4_encode.hip
 template <bool kSplit>
 __device__ __forceinline__ void snappy_encode_chunk(const BatchArgs& a, uint32_t chunk, uint16_t* ht) {
-    const uint64_t base_off = kSplit ? a.in_off[chunk & ~3u] : a.in_off[chunk];
+    const uint64_t base_off = kSplit ? a.in_off[chunk & ~(split_per(a.flags) - 1u)] : a.in_off[chunk];      // the piece's first sub-piece
     const uint8_t* in = a.in_base + base_off;               // position 0 = start of the piece
     const uint32_t q0 = (uint32_t)(a.in_off[chunk] - base_off);      // this wave's range = [q0, n)
     const uint64_t n64 = q0 + a.in_len[chunk];

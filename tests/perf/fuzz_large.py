@@ -105,13 +105,15 @@ def run_frames(cases, seed, verbose=False):
 
 
 def run_compress(cases, seed, verbose=False):
-    """the compressors on random sizes (clustered around the 16 KiB / 64 KiB piece boundaries and their multiples): the oracle's
-    decoders must give the input back from the block, raw and both framed outputs"""
+    """the compressors on random sizes (clustered around the 4 KiB / 16 KiB sub-piece and 64 KiB piece boundaries, their multiples
+    and the 8 KiB / 16 MiB switches of the sub-piece size): the oracle's decoders must give the input back from the block, raw
+    and both framed outputs"""
     rnd.seed(seed)
     t0 = time.time(); done = 0; bad = []
     pool = b"".join(d for _, d in shapes())
     while done < cases and not bad:
-        base = rnd.choice((0, 16384, 32768, 49152, 65536, 131072, 196608, 262144, 1 << 20, rnd.randrange(1 << 22)))
+        base = rnd.choice((0, 4096, 8192, 12288, 16384, 32768, 49152, 61440, 65536, 65536 + 4096, 131072, 196608, 262144, 1 << 20,
+                           4096 * rnd.randrange(1, 300), rnd.randrange(1 << 22), (16 << 20) if rnd.randrange(8) == 0 else 65536 * rnd.randrange(1, 40)))
         n = max(0, base + rnd.randrange(-40, 41)) if rnd.randrange(3) else rnd.randrange(1 << rnd.randrange(1, 23))
         o = rnd.randrange(max(1, len(pool) - n)) if n < len(pool) else 0
         data = (pool[o:o + n] if rnd.randrange(5) else rnd.randbytes(n))[:n]

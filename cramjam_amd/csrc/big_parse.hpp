@@ -4,9 +4,14 @@
 
 namespace cj {
 
-constexpr uint32_t kBigPieceSmall = 16384, kBigPieceLarge = 65536;   // input bytes per parse piece (one wavefront): streams
-                                                                      // below / from kBigPieceSwitch bytes (fewer serial steps in K2)
-constexpr uint32_t kBigPieceSwitch = 4u << 20;
+// input bytes per parse piece (one wavefront walks it as 64 sub-segments): small streams take small pieces — one call on a few hundred KB
+// is a chain of latency-bound kernels, and a lane's walk is as long as its sub-segment; large ones 64 KiB (fewer serial steps in K2)
+#ifndef CJ_BIG_PIECE_TINY
+#define CJ_BIG_PIECE_TINY 4096
+#endif
+constexpr uint32_t kBigPieceTiny = CJ_BIG_PIECE_TINY, kBigPieceSmall = 16384, kBigPieceLarge = 65536;
+constexpr uint32_t kBigPieceTinyMax = 1u << 20, kBigPieceSwitch = 4u << 20;       // stream length: below -> tiny, below -> small, else large
+inline uint32_t big_piece_for(uint32_t stream_len) { return stream_len < kBigPieceTinyMax ? kBigPieceTiny : stream_len < kBigPieceSwitch ? kBigPieceSmall : kBigPieceLarge; }
 
 struct BigParse {
     const uint8_t* in;       // stream position 0 (device; padded by >= 16 readable bytes)

@@ -76,6 +76,7 @@ int large_decompress_many(::cj_engine* e, int codec, size_t nj, const uint8_t* c
 int large_decompress_listed(::cj_engine* e, int codec, uint32_t flags, size_t n_listed, const size_t* idx, const uint8_t* const* in_ptrs, const size_t* in_lens,
                             uint8_t* const* out_ptrs, const size_t* out_caps, int64_t* result);
 int64_t large_decompress(int codec, uint32_t flags, const uint8_t* in, size_t n, uint8_t* out, size_t cap);
+bool large_few_elements(int codec, uint32_t flags, const uint8_t* in, size_t n, size_t cap);   // a small stream of a handful of long runs: the one-wavefront kernel is quicker
 void launch_lz4_decode_lds2_slabs(const BatchArgs& a, const void* sync, const void* meta, void* tabs, uint32_t* counter,
                                   const void* first, uint32_t stream_len, uint32_t* done, void* cross, uint32_t tab_stride,
                                   uint32_t cross_stride, uint32_t grid, hipStream_t s, int codec, bool rel = false);

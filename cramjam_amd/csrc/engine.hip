@@ -450,7 +450,7 @@ int64_t cj_lz4_block_decompress(const uint8_t* in, size_t n, uint8_t* out, size_
             if (announced > 255ull * (uint64_t)n + 64ull) return CJ_E_CORRUPT;
         }
     }
-    if ((n > kLargeMin || announced > kLargeMin) && in && out)
+    if ((n > kLargeMin || announced > kLargeMin) && in && out && !cj::large_few_elements(CJ_CODEC_LZ4_BLOCK, size_prepended ? CJ_FLAG_LZ4_SIZE_PREFIX : 0u, in, n, cap))
         return cj::large_decompress(CJ_CODEC_LZ4_BLOCK, size_prepended ? CJ_FLAG_LZ4_SIZE_PREFIX : 0u, in, n, out, cap);
     return single(CJ_CODEC_LZ4_BLOCK, CJ_OP_DECOMPRESS, size_prepended ? CJ_FLAG_LZ4_SIZE_PREFIX : 0u, in, n, out, cap);
 }
@@ -467,7 +467,7 @@ int64_t cj_snappy_raw_decompress(const uint8_t* in, size_t n, uint8_t* out, size
         const int64_t dn = cj_snappy_raw_decompress_len(in, n);
         if (dn > 0 && (uint64_t)dn <= cap && (uint64_t)dn > 22ull * (uint64_t)n + 64ull) return CJ_E_SNAPPY_CORRUPT;
     }
-    if (in && out && (n > kLargeMin || (n > 0 && cj_snappy_raw_decompress_len(in, n) > (int64_t)kLargeMin)))
+    if (in && out && (n > kLargeMin || (n > 0 && cj_snappy_raw_decompress_len(in, n) > (int64_t)kLargeMin)) && !cj::large_few_elements(CJ_CODEC_SNAPPY_RAW, 0u, in, n, cap))
         return cj::large_decompress(CJ_CODEC_SNAPPY_RAW, 0u, in, n, out, cap);
     return single(CJ_CODEC_SNAPPY_RAW, CJ_OP_DECOMPRESS, 0u, in, n, out, cap);
 }

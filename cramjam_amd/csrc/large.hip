@@ -423,6 +423,49 @@ static bool large_prologue(int codec, uint32_t flags, const uint8_t* in, size_t 
     return true;
 }
 
+// Is the stream made of a handful of elements (incompressible data: one literal run; a run-length pattern: a literal and one
+// long match)?  Host-side look at the first kFewElements element headers — it only decides WHICH device path decodes the
+// stream (the one-wavefront kernel copies long runs cooperatively and needs no parse: 123 KB of JPEG 0.18 ms against 0.37;
+// it is one wavefront, ~1 GB/s, so only streams of up to kFewMaxBytes take it); anything odd answers false and the large
+// path reports the error.
+constexpr uint32_t kFewElements = 64;          // (a 123 KB JPEG compressed by the sub-piece encoder is 31 literal elements)
+constexpr size_t kFewMaxBytes = 256u << 10;
+bool large_few_elements(int codec, uint32_t flags, const uint8_t* in, size_t n, size_t cap) {
+    uint64_t skip = 0, start = 0, cap64 = cap; int64_t early = 0;
+    if (!in || !large_prologue(codec, flags, in, n, cap, skip, start, cap64, early)) return false;
+    if (cap64 > kFewMaxBytes || n - skip > kFewMaxBytes + 4096) return false;
+    const uint8_t* p = in + skip;
+    const uint64_t end = n - skip;
+    uint64_t ip = start;
+    for (uint32_t k = 0; k < kFewElements; k++) {
+        if (ip >= end) return ip == end && codec == CJ_CODEC_SNAPPY_RAW;
+        if (codec == CJ_CODEC_SNAPPY_RAW) {
+            const uint32_t tag = p[ip];
+            if ((tag & 3u) == 0u) {
+                uint64_t len = (tag >> 2) + 1u, hdr = 1;
+                if (len > 60u) {
+                    const uint32_t nb = (uint32_t)len - 60u;
+                    if (ip + 1 + nb > end) return false;
+                    len = 0;
+                    for (uint32_t j = 0; j < nb; j++) len |= (uint64_t)p[ip + 1 + j] << (8u * j);
+                    len += 1; hdr = 1 + nb;
+                }
+                ip += hdr + len;
+            } else ip += (tag & 3u) == 1u ? 2u : (tag & 3u) == 2u ? 3u : 5u;
+        } else {
+            const uint32_t token = p[ip++];
+            uint64_t lit = token >> 4;
+            if (lit == 15u) { uint32_t b; do { if (ip >= end) return false; b = p[ip++]; lit += b; } while (b == 255u); }
+            ip += lit;
+            if (ip == end) return true;                     // the last, literal-only sequence
+            if (ip + 2 > end) return false;
+            ip += 2;
+            if ((token & 15u) == 15u) { uint32_t b; do { if (ip >= end) return false; b = p[ip++]; } while (b == 255u); }
+        }
+    }
+    return false;
+}
+
 static std::vector<uint32_t>* g_dbg_sync = nullptr;       // set by cj_debug_big_parse only (single-threaded test hook)
 static uint64_t g_dbg_nseq = 0;
 
@@ -437,7 +480,7 @@ int64_t large_decompress(int codec, uint32_t flags, const uint8_t* in, size_t n,
         if (!large_prologue(codec, flags, in, n, cap, skip, start, cap64, early)) return early;
     }
     const uint32_t iend = (uint32_t)(n - skip);
-    const uint32_t piece = iend < kBigPieceSwitch ? kBigPieceSmall : kBigPieceLarge;
+    const uint32_t piece = big_piece_for(iend);
     const uint32_t np = (uint32_t)((iend - start + piece - 1) / piece);
 
     std::lock_guard<std::mutex> lock(e->mu);
@@ -526,7 +569,7 @@ int large_decompress_many(cj_engine* e, int codec, size_t nj, const uint8_t* con
     std::vector<BigParse> bps(nj);
     std::vector<uint2> pmap;
     size_t in_total = 0, big_total = 0;
-    uint32_t max_piece = kBigPieceSmall;
+    uint32_t max_piece = kBigPieceTiny;
     std::vector<size_t> big_off(nj);
     // the blocks of one frame lie in ONE host buffer, a few header bytes apart: one copy to the device instead of one per block
     const uint8_t* span_lo = ins[0]; const uint8_t* span_hi = ins[0] + lens[0];
@@ -540,7 +583,7 @@ int large_decompress_many(cj_engine* e, int codec, size_t nj, const uint8_t* con
         BigParse& bp = bps[j];
         bp = BigParse{};
         bp.iend = (uint32_t)lens[j]; bp.start = starts ? (uint32_t)starts[j] : 0u; bp.cap = caps[j];
-        bp.piece = bp.iend < kBigPieceSwitch ? kBigPieceSmall : kBigPieceLarge;
+        bp.piece = big_piece_for(bp.iend);
         bp.np = (bp.iend - bp.start + bp.piece - 1) / bp.piece;
         max_piece = std::max(max_piece, bp.piece);
         for (uint32_t p = 0; p < bp.np; p++) pmap.push_back(make_uint2((uint32_t)j, p));

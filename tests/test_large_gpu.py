@@ -122,6 +122,48 @@ def test_snappy_decompress_raw_large(name, data):
         assert cramjam.snappy.decompress_raw_into(blob, out) == len(data) and out.tobytes() == data, src
 
 
+def test_small_streams_of_a_few_long_runs():
+    """64 KiB .. 256 KiB streams made of a handful of elements (incompressible data, run-length patterns) take the
+    one-wavefront kernel instead of the parse + slab path (large.hip: large_few_elements); streams just beyond either limit
+    take the large path.  Bytes and verdicts must be the oracle's on both sides of the switch, damaged streams included."""
+    rnd = random.Random(17)
+    datas = [rnd.randbytes(100000), bytes(200000), rnd.randbytes(70000) + bytes(70000) + rnd.randbytes(3), rnd.randbytes(262144), rnd.randbytes(262145),
+             b"".join(rnd.randbytes(9000) + bytes([i]) * 9000 for i in range(7)), b"".join(rnd.randbytes(6000) + bytes([i]) * 5000 for i in range(17))]
+    for data in datas:
+        n = len(data)
+        lz = oracle.lz4_compress_raw(data)[1]
+        sn = oracle.snappy_compress(data)[1]
+        assert bytes(cramjam.lz4.decompress_block(lz, output_len=n)) == data
+        assert bytes(cramjam.lz4.decompress_block(n.to_bytes(4, "little") + lz)) == data
+        assert bytes(cramjam.snappy.decompress_raw(sn)) == data
+        for t in range(24):
+            for codec, blob in (("lz4", lz), ("snappy", sn)):
+                b = bytearray(blob)
+                kind = t % 6
+                if kind == 0: b = b[:len(b) - 1 - t]
+                elif kind == 1: b[rnd.randrange(min(len(b), 12))] ^= 1 << rnd.randrange(8)      # the first headers
+                elif kind == 2: b[rnd.randrange(len(b))] ^= 0x10
+                elif kind == 3: b += b"\x00" * (1 + t % 3)
+                elif kind == 4: b[len(b) - 1 - rnd.randrange(min(len(b), 9))] ^= 0xff
+                else: i = rnd.randrange(len(b)); b[i:i] = rnd.randbytes(2)
+                b = bytes(b)
+                if codec == "lz4":
+                    er, eo = oracle.lz4_decompress_raw(b, n)
+                    try:
+                        got = bytes(cramjam.lz4.decompress_block(b, output_len=n))
+                        assert er >= 0 and got[:er] == eo[:er], (codec, n, t, er)
+                    except cramjam.DecompressionError:
+                        assert er < 0, (codec, n, t, er)
+                else:
+                    el = oracle.snappy_decompress_len(b)
+                    er, eo = oracle.snappy_decompress(b) if 0 <= el <= (1 << 24) else (-1, b"")
+                    try:
+                        got = bytes(cramjam.snappy.decompress_raw(b))
+                        assert er >= 0 and got == eo[:er], (codec, n, t, er)
+                    except cramjam.DecompressionError:
+                        assert er < 0, (codec, n, t, er)
+
+
 def test_large_decompress_verdicts_match_the_oracle():
     rnd = random.Random(77)
     data = b"".join(oracle.synth_v1(PIECE, i) for i in range(5)) + bytes(70000) + rnd.randbytes(90000)

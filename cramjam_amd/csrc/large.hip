@@ -245,19 +245,19 @@ int64_t large_lz4_frame_blocks(const uint8_t* in, size_t n, uint8_t* out, size_t
     cj_engine* e = default_engine();
     if (!e) return CJ_E_NO_DEVICE;
     const SubPieces sp = sub_pieces(n);
-    const size_t kQuarter = sp.sub, kLz4QStride = sp.lz4_stride;            // (q = sub-piece: 16 or 4 per block)
-    const size_t nq = (n + kQuarter - 1) / kQuarter, nb = (n + kPiece - 1) / kPiece;
+    const size_t sub = sp.sub, sub_stride = sp.lz4_stride;                  // (q = sub-piece: 16 or 4 per block)
+    const size_t nq = (n + sub - 1) / sub, nb = (n + kPiece - 1) / kPiece;
     std::lock_guard<std::mutex> lock(e->mu);
     HIP_TRY(hipSetDevice(e->device), CJ_E_NO_DEVICE);
     hipStream_t s = e->stream;
     std::vector<int64_t> res;
-    int rc = compress_pieces(e, CJ_CODEC_LZ4_BLOCK, kFlagReportTail | sp.flags, in, n, kQuarter, nq, kLz4QStride, res);
+    int rc = compress_pieces(e, CJ_CODEC_LZ4_BLOCK, kFlagReportTail | sp.flags, in, n, sub, nq, sub_stride, res);
     if (rc != 0) return rc;
     uint64_t* d_meta = (uint64_t*)e->d_meta.p;
     uint8_t* d_tmp = (uint8_t*)e->d_out.p;
     uint8_t* d_in = (uint8_t*)e->d_in.p;
     uint32_t* d_first = (uint32_t*)(d_meta + 5 * nq);
-    hipLaunchKernelGGL(lz4_stitch_plan_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, d_tmp, (uint32_t)kLz4QStride, d_first, (uint32_t)nq);
+    hipLaunchKernelGGL(lz4_stitch_plan_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, d_tmp, (uint32_t)sub_stride, d_first, (uint32_t)nq);
     HIP_TRY(hipGetLastError(), CJ_E_NO_DEVICE);
     std::vector<uint32_t> first(nq);
     HIP_TRY(hipMemcpyAsync(first.data(), d_first, nq * 4, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
@@ -270,7 +270,7 @@ int64_t large_lz4_frame_blocks(const uint8_t* in, size_t n, uint8_t* out, size_t
     for (size_t b = 0; b < nb; b++) {
         const size_t q0 = sp.per * b, q1 = std::min(nq, q0 + sp.per);
         const uint64_t len = std::min(kPiece, n - b * kPiece);
-        const uint64_t cl = plan_stitch(plan, q0, q1, fpos + 4, n, kQuarter, kLz4QStride, d_tmp, res, first);
+        const uint64_t cl = plan_stitch(plan, q0, q1, fpos + 4, n, sub, sub_stride, d_tmp, res, first);
         const bool stored = cl >= len;                     // LZ4F_makeBlock: a block that does not shrink is stored
         if (stored) for (size_t q = q0; q < q1; q++) plan[q] = Stitch{0, 0, 0, 0, 0, 0};
         const uint64_t body = stored ? len : cl;
@@ -305,13 +305,13 @@ int64_t large_snappy_frame(const uint8_t* in, size_t n, uint8_t* out, size_t cap
     cj_engine* e = default_engine();
     if (!e) return CJ_E_NO_DEVICE;
     const SubPieces sp = sub_pieces(n);
-    const size_t kQuarter = sp.sub, kSnQStride = sp.sn_stride;              // (q = sub-piece: 16 or 4 per piece)
-    const size_t nq = (n + kQuarter - 1) / kQuarter, np = (n + kPiece - 1) / kPiece;
+    const size_t sub = sp.sub, sub_stride = sp.sn_stride;                   // (q = sub-piece: 16 or 4 per piece)
+    const size_t nq = (n + sub - 1) / sub, np = (n + kPiece - 1) / kPiece;
     std::lock_guard<std::mutex> lock(e->mu);
     HIP_TRY(hipSetDevice(e->device), CJ_E_NO_DEVICE);
     hipStream_t s = e->stream;
     std::vector<int64_t> res;
-    int rc = compress_pieces(e, CJ_CODEC_SNAPPY_RAW, sp.flags, in, n, kQuarter, nq, kSnQStride, res);
+    int rc = compress_pieces(e, CJ_CODEC_SNAPPY_RAW, sp.flags, in, n, sub, nq, sub_stride, res);
     if (rc != 0) return rc;
     uint64_t* d_meta = (uint64_t*)e->d_meta.p;             // 12 nq rows reserved; 0 .. 5 nq in use
     uint8_t* d_tmp = (uint8_t*)e->d_out.p;
@@ -336,7 +336,7 @@ int64_t large_snappy_frame(const uint8_t* in, size_t n, uint8_t* out, size_t cap
         for (uint64_t x = len;; ) { if (x < 0x80u) { v |= (uint32_t)x << (8 * vl); vl++; break; } v |= (uint32_t)((x & 0x7f) | 0x80u) << (8 * vl); vl++; x >>= 7; }
         vints[p] = v;
         uint64_t comp = vl;
-        for (size_t q = q0; q < q1; q++) comp += (uint64_t)res[q] - varint_len(std::min(kQuarter, n - q * kQuarter));
+        for (size_t q = q0; q < q1; q++) comp += (uint64_t)res[q] - varint_len(std::min(sub, n - q * sub));
         const bool stored = comp >= len - len / 8;
         const uint64_t body = stored ? len : comp;
         sa[p] = stored ? (uint64_t)(uintptr_t)(d_in + p * kPiece) : 0ull;       // compressed: the varint (address patched below)
@@ -346,8 +346,8 @@ int64_t large_snappy_frame(const uint8_t* in, size_t n, uint8_t* out, size_t cap
         if (!stored) {
             uint64_t pos = fpos + 8 + vl;
             for (size_t q = q0; q < q1; q++) {
-                const uint32_t ph = varint_len(std::min(kQuarter, n - q * kQuarter));
-                sb[q] = (uint64_t)(uintptr_t)(d_tmp + q * kSnQStride + ph);
+                const uint32_t ph = varint_len(std::min(sub, n - q * sub));
+                sb[q] = (uint64_t)(uintptr_t)(d_tmp + q * sub_stride + ph);
                 sb[nq + q] = pos;
                 sb[2 * nq + q] = (uint64_t)res[q] - ph;
                 pos += sb[2 * nq + q];

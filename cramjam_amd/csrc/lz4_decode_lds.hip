@@ -442,7 +442,6 @@ __device__ __forceinline__ bool fused_parse(uint32_t a_in, uint32_t iend, uint32
                 uint32_t op2 = op;
                 if (!walk_step<G>(rd, q, iend, sq) || !G::check(sq, op2, cap, fin) || idx >= total_seq) bad = true;
                 else {
-                    const uint32_t dst = op + sq.lit;
                     const uint32_t w = sq.mlen == 0u ? 0u : ((sq.offset & 0xffffu) | (sq.mlen << 16));       // (a Snappy stream may END with a copy)
                     table2[idx] = make_uint2(sq.lit_at | (sq.lit << 16), (op & 0xffffu) | (w << 16));      // 8-byte record (lds2_body)
                     near += (w != 0u && sq.offset < 4096u) ? 1u : 0u;

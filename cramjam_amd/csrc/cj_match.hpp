@@ -293,47 +293,107 @@ struct Selection {
     bool coop;                   // a selected sequence needs whole-wave handling: the caller redoes the round serially
 };
 
+// wave scans over the 64 lanes (ds_bpermute through __shfl: the encoders leave the LDS pipe almost idle)
+__device__ __forceinline__ uint32_t wave_excl_add(uint32_t v, uint32_t& total) {
+    const uint32_t lane = lane_id();
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)x, d, 64);
+        if (lane >= (uint32_t)d) x += t;
+    }
+    total = rdlane(x, 63);
+    return x - v;
+}
+// max over the lanes BELOW this one (first = the value for lane 0); total = max over first and all 64 lanes
+__device__ __forceinline__ uint32_t wave_excl_max(uint32_t v, uint32_t first, uint32_t& total) {
+    const uint32_t lane = lane_id();
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)x, d, 64);
+        if (lane >= (uint32_t)d) x = x > t ? x : t;
+    }
+    const uint32_t top = rdlane(x, 63);
+    total = top > first ? top : first;
+    const uint32_t below = (uint32_t)__shfl_up((int)x, 1, 64);
+    return lane == 0u ? first : (below > first ? below : first);
+}
+// min over this lane and the lanes ABOVE it; total = min over all 64 lanes
+__device__ __forceinline__ uint32_t wave_suffix_min(uint32_t v, uint32_t& total) {
+    const uint32_t lane = lane_id();
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_down((int)x, d, 64);
+        if (lane + (uint32_t)d < 64u) x = x < t ? x : t;
+    }
+    total = rdlane(x, 0);
+    return x;
+}
+
 // size_fn(lit, mcode, off) = encoded bytes of one sequence; coop_fn(lit, mcode) = needs whole-wave emission
 template <class SizeFn, class CoopFn>
 __device__ __forceinline__ void select_walk(const Round& r, uint32_t pos, uint32_t anchor, uint32_t op, Selection& s,
                                             SizeFn size_fn, CoopFn coop_fn) {
     const uint32_t lane = lane_id();
-    uint32_t cur = anchor, cur_op = op, cnt = 0;
-    bool coop = false;
-#pragma unroll
-    for (int j = 0; j < kSub; j++) s.covered[j] = pos + 64u * j + lane < anchor;     // inside a match of an earlier round
+    // ---- the serial part: which candidates are selected and where the previous selected match ended ----
+    uint32_t cur = anchor, cnt = 0;
 #pragma unroll
     for (int j = 0; j < kSub; j++) {
         const uint32_t pj = pos + 64u * j;
+        const uint32_t e_lane = pj + lane + 4u + (r.ext[j] & 0xffu);       // end of this lane's match if it is selected
         uint64_t mask = r.mask[j], sel = 0ull;
-        uint32_t pe = 0, po = 0;
+        uint32_t pe = 0;
         if (cur > pj) mask = cur - pj >= 64u ? 0ull : mask & (~0ull << (cur - pj));
         while (mask) {
             const uint32_t first = ctz64(mask);
-            const uint32_t ext = rdlane(r.ext[j], first), p = pj + first;
-            const uint32_t room = p - cur;
-            uint32_t bk = (ext >> 8) & 0x3fu;
-            bk = bk < room ? bk : room;
-            const uint32_t lit = room - bk, mcode = (ext & 0xffu) + bk, e = p + 4u + (ext & 0xffu);
-            // capped extensions: forward -> the match end above is too short; backward -> only if the literal run leaves room
-            coop = coop || coop_fn(lit, mcode) || (ext & 0x4000u) != 0u || ((ext & 0x8000u) != 0u && room > 16u);
+            const uint32_t e = rdlane(e_lane, first);
             sel |= 1ull << first;
             pe = lane == first ? cur : pe;
-            po = lane == first ? cur_op : po;
-            cur_op += size_fn(lit, mcode, p - rdlane(r.cand[j], first));
-#pragma unroll
-            for (int jj = 0; jj < kSub; jj++) {
-                const uint32_t my = pos + 64u * jj + lane;
-                s.covered[jj] = s.covered[jj] || (my > p - bk && my < e);
-            }
             cur = e; cnt += 1;
             mask = e - pj >= 64u ? 0ull : mask & (~0ull << (e - pj));
         }
         s.sel[j] = sel;
         s.prev_end[j] = pe;
-        s.out_pos[j] = po;
     }
-    s.anchor = cur; s.op = cur_op; s.count = cnt; s.coop = coop;
+    s.anchor = cur; s.count = cnt;
+    // ---- everything else for all selected candidates at once: backward clamp, sizes -> output positions (prefix sum),
+    //      coverage = inside [start + 1, end) of a selected match (prefix max of the ends, suffix min of the starts) ----
+    uint32_t start[kSub];
+    uint32_t run_op = op, run_end = anchor;
+    bool coop = false;
+#pragma unroll
+    for (int j = 0; j < kSub; j++) {
+        const uint32_t p = pos + 64u * j + lane, ext = r.ext[j];
+        const bool sel = ((s.sel[j] >> lane) & 1ull) != 0ull;
+        const uint32_t room = p - s.prev_end[j];
+        uint32_t bk = (ext >> 8) & 0x3fu;
+        bk = bk < room ? bk : room;
+        const uint32_t lit = room - bk, mcode = (ext & 0xffu) + bk;
+        // capped extensions: forward -> the match end above is too short; backward -> only if the literal run leaves room
+        coop = coop || (sel && (coop_fn(lit, mcode) || (ext & 0x4000u) != 0u || ((ext & 0x8000u) != 0u && room > 16u)));
+        uint32_t total;
+        const uint32_t before = wave_excl_add(sel ? size_fn(lit, mcode, p - r.cand[j]) : 0u, total);
+        s.out_pos[j] = run_op + before;
+        run_op += total;
+        uint32_t top;
+        const uint32_t end_before = wave_excl_max(sel ? p + 4u + (ext & 0xffu) : 0u, run_end, top);     // ends of the selected matches at lower positions (and of earlier rounds)
+        run_end = top;
+        s.covered[j] = p < end_before;
+        start[j] = sel ? p - bk : 0xffffffffu;
+    }
+    uint32_t run_start = 0xffffffffu;
+#pragma unroll
+    for (int j = kSub - 1; j >= 0; j--) {
+        const uint32_t p = pos + 64u * j + lane;
+        uint32_t low;
+        const uint32_t st = wave_suffix_min(start[j], low);              // start of the next selected match at this or a higher position
+        s.covered[j] = s.covered[j] || p > (st < run_start ? st : run_start);
+        run_start = low < run_start ? low : run_start;
+    }
+    s.op = run_op;
+    s.coop = ballot64(coop) != 0ull;
 }
 
 // number of set bits of m below this lane
@@ -407,9 +467,9 @@ __device__ __forceinline__ void encode_persistent_body(const BatchArgs& a, uint3
         Enc::chunk(a, chunk, ht);
     }
 }
-// (four wavefronts per SIMD as the register target — the ten blocks of a CU must leave registers for the table blocks; the
-//  compiler notes that 16 KiB of LDS per block allows only 2.5 per SIMD: -Wpass-failed, expected.  amdgpu_num_vgpr(128)
-//  instead gives the same 126 registers but a schedule that is 4 % slower)
+// (four wavefronts per SIMD as the register target.  The compiler notes that 16 KiB of LDS per block allow only 2.5 per SIMD —
+//  -Wpass-failed, expected — and takes up to 168 registers; measured alternatives: the table as DYNAMIC shared memory keeps the
+//  target, 128 registers, and is 10 % slower (68 vs 77 GB/s); amdgpu_num_vgpr is not honoured here)
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wpass-failed"
 template <class Enc>

@@ -293,43 +293,54 @@ struct Selection {
     bool coop;                   // a selected sequence needs whole-wave handling: the caller redoes the round serially
 };
 
-// wave scans over the 64 lanes (ds_bpermute through __shfl: the encoders leave the LDS pipe almost idle)
+// Wave scans over the 64 lanes with DPP moves (one VALU instruction per step, no LDS): row_shr / row_shl 1, 2, 4, 8 scan the
+// rows of 16 lanes; across rows the prefix scans use row_bcast:15 / row_bcast:31 (gfx9 family), the suffix scan three
+// v_readlane.  A lane whose DPP source lies outside its row (or whose row is masked off) receives `identity`.
+template <uint32_t kCtrl, uint32_t kRowMask = 0xfu>
+__device__ __forceinline__ uint32_t dpp_from(uint32_t identity, uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)x, (int)kCtrl, (int)kRowMask, 0xf, false);
+}
+constexpr uint32_t kDppRowShr = 0x110u, kDppRowShl = 0x100u, kDppBcast15 = 0x142u, kDppBcast31 = 0x143u, kDppWaveShr1 = 0x138u;
+
 __device__ __forceinline__ uint32_t wave_excl_add(uint32_t v, uint32_t& total) {
-    const uint32_t lane = lane_id();
     uint32_t x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = (uint32_t)__shfl_up((int)x, d, 64);
-        if (lane >= (uint32_t)d) x += t;
-    }
+    x += dpp_from<kDppRowShr + 1u>(0u, x);
+    x += dpp_from<kDppRowShr + 2u>(0u, x);
+    x += dpp_from<kDppRowShr + 4u>(0u, x);
+    x += dpp_from<kDppRowShr + 8u>(0u, x);
+    x += dpp_from<kDppBcast15, 0xau>(0u, x);
+    x += dpp_from<kDppBcast31, 0xcu>(0u, x);
     total = rdlane(x, 63);
     return x - v;
 }
+__device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 // max over the lanes BELOW this one (first = the value for lane 0); total = max over first and all 64 lanes
 __device__ __forceinline__ uint32_t wave_excl_max(uint32_t v, uint32_t first, uint32_t& total) {
-    const uint32_t lane = lane_id();
     uint32_t x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = (uint32_t)__shfl_up((int)x, d, 64);
-        if (lane >= (uint32_t)d) x = x > t ? x : t;
-    }
-    const uint32_t top = rdlane(x, 63);
-    total = top > first ? top : first;
-    const uint32_t below = (uint32_t)__shfl_up((int)x, 1, 64);
-    return lane == 0u ? first : (below > first ? below : first);
+    x = umax(x, dpp_from<kDppRowShr + 1u>(0u, x));
+    x = umax(x, dpp_from<kDppRowShr + 2u>(0u, x));
+    x = umax(x, dpp_from<kDppRowShr + 4u>(0u, x));
+    x = umax(x, dpp_from<kDppRowShr + 8u>(0u, x));
+    x = umax(x, dpp_from<kDppBcast15, 0xau>(0u, x));
+    x = umax(x, dpp_from<kDppBcast31, 0xcu>(0u, x));
+    total = umax(rdlane(x, 63), first);
+    return umax(dpp_from<kDppWaveShr1>(first, x), first);              // lane 0 receives `first`
 }
 // min over this lane and the lanes ABOVE it; total = min over all 64 lanes
 __device__ __forceinline__ uint32_t wave_suffix_min(uint32_t v, uint32_t& total) {
-    const uint32_t lane = lane_id();
+    constexpr uint32_t kNone = 0xffffffffu;
     uint32_t x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = (uint32_t)__shfl_down((int)x, d, 64);
-        if (lane + (uint32_t)d < 64u) x = x < t ? x : t;
-    }
-    total = rdlane(x, 0);
-    return x;
+    x = umin(x, dpp_from<kDppRowShl + 1u>(kNone, x));
+    x = umin(x, dpp_from<kDppRowShl + 2u>(kNone, x));
+    x = umin(x, dpp_from<kDppRowShl + 4u>(kNone, x));
+    x = umin(x, dpp_from<kDppRowShl + 8u>(kNone, x));                  // lane 16 r = min of row r
+    const uint32_t r1 = rdlane(x, 16), r2 = rdlane(x, 32), r3 = rdlane(x, 48);
+    const uint32_t m3 = r3, m2 = umin(r2, r3), m1 = umin(r1, m2);      // min over the rows from 3 / 2 / 1 up
+    const uint32_t row = lane_id() >> 4;
+    const uint32_t above = row == 0u ? m1 : row == 1u ? m2 : row == 2u ? m3 : kNone;
+    total = umin(rdlane(x, 0), m1);
+    return umin(x, above);
 }
 
 // size_fn(lit, mcode, off) = encoded bytes of one sequence; coop_fn(lit, mcode) = needs whole-wave emission

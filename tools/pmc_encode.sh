@@ -23,9 +23,12 @@ agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1]+'/*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
         k=r['Kernel_Name'].split('(')[0]
-        if 'encode_kernel' in k and int(r.get('Grid_Size', r.get('Grid_Size_X', 0)) or 0) >= 20000*64: agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
+        if 'cj::' in k and 'encode' in k: agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
+tot=collections.defaultdict(float)
 for k in agg:
-    print(sys.argv[2], k, ' '.join('%s=%.0f' % (c.replace('SQ_',''), sum(v)/len(v)/2e4) for c,v in sorted(agg[k].items())), '(per chunk)')
+    for c,v in agg[k].items(): tot[c]+=sum(v)/len(v)          # per launch; a step = the LDS-table kernel + the global-table kernel
+    print(sys.argv[2], k, ' '.join('%s=%.0f' % (c.replace('SQ_',''), sum(v)/len(v)/2e4) for c,v in sorted(agg[k].items())), '(per launch / 20 000 chunks)')
+print(sys.argv[2], 'all encoder kernels', ' '.join('%s=%.0f' % (c.replace('SQ_',''), v/2e4) for c,v in sorted(tot.items())), '(per chunk)')
 PY
     done
   done

@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
 echo "new:"; python tests/perf/encoder_fingerprint.py
-bash tools/exp_encoders.sh seldpp product
+bash tools/exp_encoders.sh extskip product

@@ -8,7 +8,10 @@
 
 namespace cj {
 
-constexpr uint32_t kParseWaves = 2;                    // waves per block (ring storage 2 x 64 x 272 B = 34 KiB static LDS)
+#ifndef CJ_PARSE_WAVES
+#define CJ_PARSE_WAVES 2
+#endif
+constexpr uint32_t kParseWaves = CJ_PARSE_WAVES;                    // waves per block (ring storage 2 x 64 x 272 B = 34 KiB static LDS)
 constexpr uint32_t kRingBytes = 256;                   // two 128 B lines per lane
 constexpr uint32_t kRingStride = kRingBytes + 16;      // 16 B aligned rings (one ds_write_b128 per fetched piece); the lanes read at unrelated
                                                        // offsets anyway, so the exact skew between rings does not matter for bank conflicts

@@ -95,7 +95,10 @@ __device__ __forceinline__ uint32_t wave_extend_back(const uint8_t* in, uint32_t
 // Matches that hit a cap (long runs) are finished cooperatively by wave_extend / wave_extend_back.
 // (fwd: equal bytes after the 4 verified ones; back: equal bytes before the position / candidate, limited to the
 //  pending literal run and to the candidate's own position.)
-constexpr uint32_t kLaneFwdCap = 64;
+#ifndef CJ_LANE_FWD_CAP
+#define CJ_LANE_FWD_CAP 64
+#endif
+constexpr uint32_t kLaneFwdCap = CJ_LANE_FWD_CAP;
 
 __device__ __forceinline__ uint4 ld16m(const uint8_t* p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
 
@@ -122,9 +125,11 @@ __device__ __forceinline__ uint32_t last_same16(const uint4& x, const uint4& y) 
 // issued for all sub-rounds before the first result is used — the round costs the same ~4 dependent global round
 // trips as a 64-position round did (own dwords, candidate dwords, extension blocks, literal sources of the emitted
 // sequences), which is what bounds these kernels (10 waves per CU: the 16 KiB table per wave fills the LDS).
-// Probing 256 positions against a table that is up to 255 positions stale loses < 1 % of ratio on the benchmark
-// data (simulated: 1.650 -> 1.645) — near repeats are still found through older table entries and the backward
-// extension.  last_start: last position where a match may start (needs 4 readable bytes); limit: a match must end
+// Probing a round of positions against a table that is up to a round stale loses < 1 % of ratio on the benchmark
+// data (256 positions, simulated: 1.650 -> 1.645; measured 256 / 320 / 384 positions: 1.628 / 1.625 / 1.623) — near repeats are
+// still found through older table entries and the backward extension; the caller starts a chunk with short rounds while
+// the table is empty.  Round size: kSub = 5 (320 positions) since the selection left the serial chain — 4: 81 GB/s, 5: 87,
+// 6: 68 (past 168 registers only two wavefronts fit a SIMD).  last_start: last position where a match may start (needs 4 readable bytes); limit: a match must end
 // here at the latest; anchor: start of the pending literal run.  The table is NOT updated here: the caller inserts,
 // after it has consumed the ballots, only the positions that did not end up inside an emitted match
 // (insert_uncovered).  Positions inside a match repeat content whose source is already indexed; inserting them
@@ -132,7 +137,7 @@ __device__ __forceinline__ uint32_t last_same16(const uint4& x, const uint4& y) 
 // 1.37 with dense insertion vs the CPU encoder's 1.63).
 constexpr uint32_t kNoSlot = 0xffffffffu;
 #ifndef CJ_ENC_SUB
-#define CJ_ENC_SUB 4
+#define CJ_ENC_SUB 5
 #endif
 constexpr int kSub = CJ_ENC_SUB;
 constexpr uint32_t kRoundPositions = 64u * kSub;

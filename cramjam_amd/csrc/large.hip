@@ -29,8 +29,8 @@ constexpr size_t kPiece = 65536;
 constexpr size_t kLz4Stride = 65824;          // LZ4_compressBound(65536) = 65809, rounded up to 16
 constexpr size_t kSnStride = 76512;           // snap max_compress_len(65536) = 76490, rounded up to 16
 // buffers of up to kSplitMax bytes: every 64 KiB piece is cut into sub-pieces, one wavefront each (lz4_encode.hip, kSplit) —
-// one wavefront needs ~1.7 ms for 64 KiB (~6 µs per 256-position round, whatever else runs), and below ~500 pieces most of the
-// GPU's wavefront slots are idle anyway.  Up to kFineMax bytes: 16 sub-pieces of 4 KiB (16 rounds each), above: quarters of
+// one wavefront needs ~1.7 ms for 64 KiB (~6 µs per round of 320 positions, whatever else runs), and below ~500 pieces most of the
+// GPU's wavefront slots are idle anyway.  Up to kFineMax bytes: 16 sub-pieces of 4 KiB (13 rounds each), above: quarters of
 // 16 KiB.  One call, quarters -> 4 KiB sub-pieces: 16 KiB 0.44 -> 0.20 ms, 64 KiB 0.59 -> 0.30, 1 MiB 0.68 -> 0.37 (text 1.08 ->
 // 0.37), 4 MiB 0.74 -> 0.44, 16 MiB 1.6 -> 1.56 (copies); ratio 1.62 -> 1.60 (benchmark data), 4.79 -> 4.78 (text).
 constexpr size_t kSplitMax = 32u << 20, kFineMax = 16u << 20;

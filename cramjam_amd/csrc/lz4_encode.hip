@@ -84,11 +84,18 @@ __device__ __forceinline__ void lz4_encode_chunk(const BatchArgs& a, uint32_t ch
         uint32_t pos = q0;
         OwnDwords own;
         own.load(in, pos, last_start);
+        // A round probes its positions against the table as it was when the round began, so what repeats INSIDE a round is
+        // only found through older entries.  With an empty table (the start of a chunk; a sub-piece's table is pre-indexed)
+        // the first rounds are short — 64, 128, 256 positions — so that a small or very repetitive input does not lose a
+        // whole round's worth of matches (1 KiB of text: ratio 2.2 -> 3.7; 64 KiB chunks of the benchmark data 1.625 -> 1.629).
+        uint32_t span = q0 == 0u ? 64u : kRoundPositions;
         while (pos <= last_start) {
             Round r;
             if (own.pos != pos) own.load(in, pos, last_start);      // a match ran past the expected start of this round
-            probe_round(in, ht, pos, last_start, matchlimit, anchor, r, own);
-            const uint32_t round_end = pos + kRoundPositions;
+            const uint32_t round_last = last_start - pos < span ? last_start : pos + span - 1u;     // last position this round probes
+            probe_round(in, ht, pos, round_last, matchlimit, anchor, r, own);
+            const uint32_t round_end = pos + span;
+            span = span * 2u < kRoundPositions ? span * 2u : kRoundPositions;
             own.load(in, round_end, last_start);                  // next round's dwords: in flight during selection and emission
             bool covered[kSub] = {};
             uint32_t q_n = 0, q_lit0 = 0, q_lit = 0, q_off = 0, q_mcode = 0, q_op = 0;

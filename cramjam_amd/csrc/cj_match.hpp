@@ -488,8 +488,11 @@ __device__ __forceinline__ void encode_persistent_body(const BatchArgs& a, uint3
 //  target, 128 registers, and is 10 % slower (68 vs 77 GB/s); amdgpu_num_vgpr is not honoured here)
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wpass-failed"
+#ifndef CJ_ENC_LDS_WAVES_PER_EU
+#define CJ_ENC_LDS_WAVES_PER_EU 4
+#endif
 template <class Enc>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void encode_lds_blocks_kernel(BatchArgs a, uint32_t* counter) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CJ_ENC_LDS_WAVES_PER_EU, CJ_ENC_LDS_WAVES_PER_EU))) void encode_lds_blocks_kernel(BatchArgs a, uint32_t* counter) {
     __shared__ uint16_t ht_lds[kHashSize];                           // exactly 16 KiB: one more word and only nine blocks fit a CU
     encode_persistent_body<Enc, false>(a, counter, ht_lds);
 }

@@ -189,6 +189,32 @@ def verify_decoded(N, L, b, torch, dev):
     assert int(mism.item()) == 0, "%d chunks decoded wrong" % int(mism.item())
 
 
+def verify_compressed(N, L, b, torch, dev, np):
+    """every compressed chunk of a compress batch: decoded with the GPU decoder (parity-tested against the CPU oracle in tests/)
+    and compared with its input on the device, in slices of 3 x U chunks"""
+    NCH, S, U = b.NCH, b.S, b.U
+    clen = b.meta[4 * NCH:].cpu().numpy().view(np.int64)
+    assert (clen > 0).all(), "compress status: %s" % clen[clen <= 0][:8]
+    step = max(U, (24576 // U) * U)
+    scratch = torch.empty(min(step, NCH) * S, dtype=torch.uint8, device=dev)
+    for s0 in range(0, NCH, step):
+        n = min(step, NCH - s0)
+        ids = np.arange(s0, s0 + n, dtype=np.uint64)
+        meta = torch.from_numpy(np.concatenate([ids * np.uint64(b.stride_c), clen[s0:s0 + n].astype(np.uint64), (ids - np.uint64(s0)) * np.uint64(S),
+                                                np.full(n, S, np.uint64), np.zeros(n, np.uint64)]).view(np.int64)).to(dev)
+        mp = meta.data_ptr()
+        torch.cuda.synchronize()
+        b.eng.batch_device(b.codec, N.OP_DECOMPRESS, 0, n, b.out.data_ptr(), mp, mp + 8 * n, scratch.data_ptr(), mp + 16 * n, mp + 24 * n, mp + 32 * n)
+        b.eng.sync()
+        res = meta[4 * n:].cpu().numpy()
+        assert (res == S).all(), "round trip: decode status/length mismatch: %s" % res[res != S][:8]
+        mism = torch.zeros(1, dtype=torch.int64, device=dev)
+        N.check(L.cj_bench_compare(scratch.data_ptr(), mp + 16 * n, b.raw.data_ptr(), S, U, S, n, mism.data_ptr(), None))
+        torch.cuda.synchronize()
+        assert int(mism.item()) == 0, "%d compressed chunks do not decode to their input" % int(mism.item())
+    return clen
+
+
 def main():
     args = parse()
     in_torchrun = "RANK" in os.environ and "WORLD_SIZE" in os.environ
@@ -314,14 +340,12 @@ def main():
         ratio = bytes_out / bytes_in
         algo = bytes_in + bytes_out
     else:
-        res = b0.meta[4 * NCH:].cpu().numpy()
-        assert (res > 0).all()
+        res = verify_compressed(N, L, b0, torch, dev, np)
         bytes_out = int(res.sum())
         ratio = bytes_in / bytes_out
         algo = bytes_in + bytes_out
     if rt is not None:
-        res = rt.meta[4 * NCH:].cpu().numpy()
-        assert (res > 0).all(), "compress half of the round trip failed"
+        res = verify_compressed(N, L, rt, torch, dev, np)       # the compress half of the round trip
         algo += rt.bytes_in + int(res.sum())
     unc_bytes = sum(b.NCH for b in batches) * S
 
@@ -367,7 +391,9 @@ def main():
                        "compressed_by": " | ".join(sorted({b.comp_name for b in batches if b.comp_name})) or None,
                        "batches_in_flight": len(lanes),
                        "sharding": "chunk i -> gpu (i mod N), no collective; rank r generates synth-v1 indices r*%d .. r*%d+%d" % (U, U, U - 1),
-                       "verified": "all results + all output bytes compared on device"},
+                       "verified": ("all results + all output bytes compared on device" if dec and rt is None else
+                                    "every compressed chunk decoded again by the GPU decoder and compared with its input on device"
+                                    + ("; decode half: all results + all output bytes compared on device" if rt is not None else ""))},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic["total"] if traffic else None,
                          "traffic_detail": traffic, "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo},

@@ -12,6 +12,9 @@ started plainly; the driver's own torchrun command works as well).  Weak scaling
 global index i = k*N + r (round-robin, no data-path collective); with N > 1 every GPU holds 125 000 chunks
 (8 x 125 000 = BASELINE configs[3]), with N = 1 100 000 (configs[1]).
 
+Every run verifies its whole output outside the timed region: decoded chunks are compared with the generated data on the
+device; `--op compress` / `--op roundtrip` (configs[2]) decode every compressed chunk again and compare it with its input.
+
 `--workload mixed256k` is BASELINE configs[4]: 256 KiB chunks, even chunk indices LZ4-block / odd Snappy-raw,
 one engine (= one HIP stream) per codec per GPU running concurrently.
 

@@ -57,6 +57,11 @@ struct SyncBatch {
 
 __device__ __forceinline__ uint4 ld16u(const uint8_t* p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
 __device__ __forceinline__ void st16u(uint8_t* p, const uint4& v) { __builtin_memcpy(p, &v, 16); }
+#if defined(CJ_HOST_SIM)
+__device__ __forceinline__ uint4 ld16u_nt(const uint8_t* p) { return ld16u(p); }
+__device__ __forceinline__ void st16u_nt(uint8_t* p, const uint4& v) { st16u(p, v); }
+__device__ __forceinline__ void st16u_wt(uint8_t* p, const uint4& v) { st16u(p, v); }
+#else
 // Non-temporal 16 B load for the match sources: those reads land anywhere in the last 64 KiB of the chunk's output
 // and are never reused, but through the normal path they evict the partially written output lines of every lane
 // from L2 before they fill (PMC: 30.8 GB of HBM writes for 6.5 GB of output).
@@ -78,6 +83,7 @@ __device__ __forceinline__ void st16u_wt(uint8_t* p, const uint4& v) {
     cj_u32x4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(t) : "memory");
 }
+#endif
 
 // up to 4 bytes at in[ip..], zero-filled past iend
 __device__ __forceinline__ uint32_t ld_le_tail(const uint8_t* in, uint32_t ip, uint32_t iend) {

@@ -34,23 +34,45 @@ __device__ __forceinline__ uint32_t hash_slot(uint32_t v) {
 constexpr int kEncWaves = 1;   // one wave per block: 160 KiB / 16 KiB = 10 resident waves per CU (4-wave blocks would round down to 8)
 constexpr int kEncThreads = 64 * kEncWaves;
 
-__device__ __forceinline__ void ht_clear(uint16_t* ht) {
-    uint32_t* p = reinterpret_cast<uint32_t*>(ht);
-    for (uint32_t i = lane_id(); i < kHashSize / 2; i += 64u) p[i] = 0u;
-}
-
-// kSplit encoders: index the data BEFORE this wave's sub-piece (positions [0, q0), every kPreStep-th one, ascending so that
-// the most recent position wins a slot), so that the sub-piece finds the matches a serial walk over the piece would
 #ifndef CJ_PRE_STEP
 #define CJ_PRE_STEP 1u
 #endif
 constexpr uint32_t kPreStep = CJ_PRE_STEP;
-__device__ __forceinline__ void ht_preindex(const uint8_t* in, uint16_t* ht, uint32_t q0) {
-    for (uint32_t p = lane_id() * kPreStep; p < q0; p += 64u * kPreStep) {
-        const uint32_t h = hash_slot(ld32u(in + p));
-        ht[h] = (uint16_t)p;
+
+// The hash table of one wavefront: 16-bit positions in LDS, or (kGlobal, the table blocks of large batches) in the block's slot of
+// a global scratch array.  The slot is private to the wavefront, but its lanes are different work-items and DS-style in-order
+// execution does not hold for global memory: a load may be served before an earlier store of ANOTHER lane to that slot has
+// landed (seen on hardware: the first lookups of a chunk read the previous chunk's entries instead of the zeros just stored, and
+// copies of a chunk compressed to different bytes depending on which kind of block took them).  So the global table is accessed
+// with agent-scope atomics (loads and stores that go to L2, not the CU's vector L1) and `settle()` — wait until the stores are
+// acknowledged — separates every group of stores from the lookups that follow.
+template <bool kGlobal>
+struct HashTab {
+    uint16_t* p;
+    __device__ __forceinline__ uint32_t get(uint32_t h) const {
+        if constexpr (kGlobal) return __hip_atomic_load(p + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else return p[h];
     }
-}
+    __device__ __forceinline__ void set(uint32_t h, uint32_t v) const {
+        if constexpr (kGlobal) __hip_atomic_store(p + h, (uint16_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else p[h] = (uint16_t)v;
+    }
+    __device__ __forceinline__ void clear() const {
+        uint32_t* q = reinterpret_cast<uint32_t*>(p);
+        for (uint32_t i = lane_id(); i < kHashSize / 2; i += 64u) {
+            if constexpr (kGlobal) __hip_atomic_store(q + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else q[i] = 0u;
+        }
+    }
+    __device__ __forceinline__ void settle() const {
+        if constexpr (kGlobal) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // kSplit encoders: index the data BEFORE this wave's sub-piece (positions [0, q0), every kPreStep-th one, ascending so that
+    // the most recent position wins a slot), so that the sub-piece finds the matches a serial walk over the piece would
+    __device__ __forceinline__ void preindex(const uint8_t* in, uint32_t q0) const {
+        for (uint32_t pos = lane_id() * kPreStep; pos < q0; pos += 64u * kPreStep) set(hash_slot(ld32u(in + pos)), pos);
+    }
+};
 
 // count equal bytes of in[a..] vs in[b..] (b < a), stopping at position `limit` for a
 __device__ __forceinline__ uint32_t wave_extend(const uint8_t* in, uint32_t a, uint32_t b, uint32_t limit) {
@@ -164,7 +186,8 @@ struct OwnDwords {
     }
 };
 
-__device__ __forceinline__ void probe_round(const uint8_t* in, const uint16_t* ht, uint32_t pos, uint32_t last_start,
+template <bool kGlobal>
+__device__ __forceinline__ void probe_round(const uint8_t* in, const HashTab<kGlobal>& ht, uint32_t pos, uint32_t last_start,
                                             uint32_t limit, uint32_t anchor, Round& r, const OwnDwords& own) {
     const uint32_t lane = lane_id();
     uint32_t v[kSub];
@@ -184,7 +207,7 @@ __device__ __forceinline__ void probe_round(const uint8_t* in, const uint16_t* h
         if (my <= last_start) {
             const uint32_t h = hash_slot(v[j]);
             r.hslot[j] = h;
-            c = (my & 0xFFFF0000u) | ht[h];
+            c = (my & 0xFFFF0000u) | ht.get(h);
             if (c >= my) c -= 65536u;       // slot belongs to the previous 64 KiB lap (or is stale)
             ok[j] = c < my && my - c <= 65535u;
         }
@@ -459,8 +482,35 @@ __device__ __forceinline__ void lane_copy_exact(uint8_t* dst, const uint8_t* src
 // covered (per lane): the lane's position lies strictly inside an emitted match (not its first byte).  Tracked with
 // two VALU compares per sub-round and match — the scalar unit is the busiest pipe of these kernels (one per CU,
 // shared by all waves), 64-bit mask arithmetic there cost ~60 scalar instructions per match.
-__device__ __forceinline__ void insert_uncovered(uint16_t* ht, uint32_t pos, uint32_t hslot, bool covered) {
-    if (hslot != kNoSlot && !covered) ht[hslot] = (uint16_t)(pos + lane_id());
+template <bool kGlobal>
+__device__ __forceinline__ void insert_uncovered(const HashTab<kGlobal>& ht, uint32_t pos, uint32_t hslot, bool covered) {
+    if (hslot != kNoSlot && !covered) ht.set(hslot, pos + lane_id());
+}
+// All insertions of a round (sub-round j: positions pos + 64 j + lane).  Several lanes of a round may hash to the same slot; the
+// table must end up with the HIGHEST of their positions ("the most recent position wins").  In LDS that is what happens: a DS
+// write with equal addresses keeps the highest lane's data, and the sub-rounds are written in ascending order.  Global stores
+// make no such promise, so a table in global memory is read back and every lane whose position is higher than the one it finds
+// writes again, until nothing changes (a slot is contested by a handful of lanes at most: one or two passes).
+template <bool kGlobal>
+__device__ __forceinline__ void insert_round(const HashTab<kGlobal>& ht, uint32_t pos, const uint32_t (&hslot)[kSub], const bool (&covered)[kSub]) {
+#pragma unroll
+    for (int j = 0; j < kSub; j++) insert_uncovered(ht, pos + 64u * j, hslot[j], covered[j]);
+    ht.settle();
+    if constexpr (kGlobal) {
+        for (;;) {
+            bool again = false;
+#pragma unroll
+            for (int j = 0; j < kSub; j++) {
+                if (hslot[j] != kNoSlot && !covered[j]) {
+                    const uint32_t mine = 64u * j + lane_id();                          // relative to pos: < kRoundPositions
+                    const uint32_t there = (ht.get(hslot[j]) - pos) & 0xffffu;          // the slot holds a position of this round
+                    if (there < mine) { ht.set(hslot[j], pos + mine); again = true; }
+                }
+            }
+            if (ballot64(again) == 0ull) break;
+            ht.settle();
+        }
+    }
 }
 
 // ---- persistent encoder blocks ------------------------------------------------------------------------------
@@ -468,7 +518,8 @@ __device__ __forceinline__ void insert_uncovered(uint16_t* ht, uint32_t pos, uin
 // CU's 160 KiB and leave 6 of its 16 wave slots (at <= 128 VGPRs) empty; true: hash table in the block's slot of a global
 // scratch array (L2-resident), no LDS — these blocks take the empty slots.  Alone, a wavefront with its table in L2 is as
 // fast as one with an LDS table (7.9 vs 8.2 GB/s, 3 resp. 5 per CU); per-wavefront rates fall as the CU fills (LZ4: 10 LDS
-// wavefronts 66 GB/s, + 3 global 75 GB/s, + 6 global 75 GB/s), so three per CU are launched.  Enc::chunk(a, c, ht) = one chunk.
+// wavefronts 66 GB/s, + 3 global 75 GB/s, + 6 global 75 GB/s), so three per CU are launched.  Enc::chunk<kGlobal>(a, c, table) =
+// one chunk; HashTab<true> makes the global table behave exactly like the LDS one (same bytes out whichever block takes a chunk).
 static_assert(kHashSize * 2u <= kEncTableBytes, "table slot");
 #ifndef CJ_ENC_TABLE_WAVES_PER_EU
 #define CJ_ENC_TABLE_WAVES_PER_EU 3
@@ -480,7 +531,7 @@ __device__ __forceinline__ void encode_persistent_body(const BatchArgs& a, uint3
         if (threadIdx.x == 0) c = atomicAdd(counter, 1u);
         const uint32_t chunk = uni(c);                               // lane 0's value (one wavefront per block)
         if (chunk >= a.n_chunks) return;
-        Enc::chunk(a, chunk, ht);
+        Enc::template chunk<kGlobalTable>(a, chunk, HashTab<kGlobalTable>{ht});
     }
 }
 // (four wavefronts per SIMD as the register target.  The compiler notes that 16 KiB of LDS per block allow only 2.5 per SIMD —
@@ -508,6 +559,7 @@ inline void launch_encode_filled(const BatchArgs& a, hipStream_t s, const EncFil
     (void)hipMemsetAsync(f.counter, 0, 4, s);
     (void)hipEventRecord(f.fork, s);
     hipLaunchKernelGGL((encode_lds_blocks_kernel<Enc>), dim3(f.lds_blocks), dim3(64), 0, s, a, f.counter);
+    if (f.table_blocks == 0u) return;
     (void)hipStreamWaitEvent(f.aux, f.fork, 0);
     hipLaunchKernelGGL((encode_table_blocks_kernel<Enc>), dim3(f.table_blocks), dim3(64), 0, f.aux, a, f.counter, f.tables);
     (void)hipEventRecord(f.join, f.aux);

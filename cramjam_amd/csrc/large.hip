@@ -466,6 +466,9 @@ bool large_few_elements(int codec, uint32_t flags, const uint8_t* in, size_t n, 
     return false;
 }
 
+// debug aid: CJ_SLAB_PROFILE=1 switches the slab decoder's per-phase cycle counters on (read with cj_debug_lds_phase_cycles)
+static uint32_t slab_profile_flag() { static const uint32_t f = std::getenv("CJ_SLAB_PROFILE") ? 0x1000u : 0u; return f; }
+
 static std::vector<uint32_t>* g_dbg_sync = nullptr;       // set by cj_debug_big_parse only (single-threaded test hook)
 static uint64_t g_dbg_nseq = 0;
 
@@ -541,7 +544,7 @@ int64_t large_decompress(int codec, uint32_t flags, const uint8_t* in, size_t n,
     const size_t tab_bytes = (size_t)grid * tab_stride * 16, cross_bytes = (size_t)grid * cross_stride * 16;
     if (!e->d_bigtab.reserve(tab_bytes + cross_bytes + (size_t)grid * (tab_stride + 512u) * 4) || !e->d_out.reserve(total + 256)) return CJ_E_OOM;
     BatchArgs a;
-    fill_args(a, 0u, n_slabs, d_in, sd.in_off, sd.in_len, (uint8_t*)e->d_out.p, sd.out_off, sd.out_cap, sd.result);
+    fill_args(a, slab_profile_flag(), n_slabs, d_in, sd.in_off, sd.in_len, (uint8_t*)e->d_out.p, sd.out_off, sd.out_cap, sd.result);
     launch_lz4_decode_lds2_slabs(a, bp.sync, sd.meta, e->d_bigtab.p, (uint32_t*)(d_meta + r_misc) + 1, sd.first, iend,
                                  (uint32_t*)(d_meta + r_done), (uint8_t*)e->d_bigtab.p + tab_bytes, tab_stride, cross_stride, grid, s, codec);
     HIP_TRY(hipGetLastError(), CJ_E_NO_DEVICE);
@@ -688,7 +691,7 @@ int large_decompress_many(cj_engine* e, int codec, size_t nj, const uint8_t* con
     const size_t tab_bytes = (size_t)grid * tab_stride * 16, cross_bytes = (size_t)grid * cross_stride * 16;
     if (!e->d_bigtab.reserve(tab_bytes + cross_bytes + (size_t)grid * (tab_stride + 512u) * 4)) return CJ_E_OOM;
     BatchArgs a;
-    fill_args(a, 0u, n_slabs, d_in, m, m + n_slabs, (uint8_t*)e->d_out.p, m + 2 * n_slabs, m + 3 * n_slabs, (int64_t*)(m + 4 * n_slabs));
+    fill_args(a, slab_profile_flag(), n_slabs, d_in, m, m + n_slabs, (uint8_t*)e->d_out.p, m + 2 * n_slabs, m + 3 * n_slabs, (int64_t*)(m + 4 * n_slabs));
     launch_lz4_decode_lds2_slabs(a, sync_base, m + 5 * n_slabs, e->d_bigtab.p, (uint32_t*)(m + r_misc) + 1, m + 6 * n_slabs, 0u,
                                  (uint32_t*)(m + r_done), (uint8_t*)e->d_bigtab.p + tab_bytes, tab_stride, cross_stride, grid, s, codec);
     HIP_TRY(hipGetLastError(), CJ_E_NO_DEVICE);

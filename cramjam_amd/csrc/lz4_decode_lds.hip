@@ -72,6 +72,31 @@ __device__ __forceinline__ void lds_st8(uint32_t a, uint32_t v) {
     asm volatile("ds_write_b8 %0, %1" :: "v"(a), "v"(v) : "memory");
 }
 
+// The whole wavefront copies n bytes (wave-uniform) from global memory to the LDS byte address a_dst: a long literal run, or a long
+// copy from an earlier slab.  <= 3 head bytes until the destination is dword aligned, then lane l takes dwords l, l + 64, ... with
+// eight loads in flight (2 KiB per round trip, conflict-free stores), then the tail bytes.  Reads exactly [src, src + n).
+// (A byte per lane and round trip — the first version — took ~0.5 ms for a 64 KiB run: 360 k cycles per slab on data that is mostly
+//  literals, tests/perf/slab_phase_profile.py.)
+__device__ __forceinline__ void wave_copy_to_lds(uint32_t a_dst, const uint8_t* src, uint32_t n) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t h = (0u - a_dst) & 3u;
+    h = h < n ? h : n;
+    if (lane < h) lds_st8(a_dst + lane, src[lane]);
+    const uint8_t* s = src + h;
+    const uint32_t d = a_dst + h, m = n - h, nd = m >> 2;
+    uint32_t i = lane;
+    for (; i + 7u * 64u < nd; i += 8u * 64u) {
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; j++) v[j] = ld32u(s + 4u * (i + 64u * j));
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; j++) lds_st32(d + 4u * (i + 64u * j), v[j]);
+    }
+    for (; i < nd; i += 64u) lds_st32(d + 4u * i, ld32u(s + 4u * i));
+    const uint32_t t = m & 3u;
+    if (lane < t) lds_st8(d + 4u * nd + lane, s[4u * nd + lane]);
+}
+
 // ---- single-wait tiered copy --------------------------------------------------------------------
 // A misaligned DS access is replayed lane by lane (~64 LDS cycles per wave-instruction, measured), and
 // every scattered DS wave-instruction costs ~8 cycles of the CU's LDS pipe, so the copies are built to
@@ -1040,7 +1065,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 const uint32_t l = ctz64(lm);
                 lm &= lm - 1ull;
                 const uint32_t ln = rdlane(n, l), ls = rdlane(src, l), ld = rdlane(dst, l);
-                for (uint32_t k = lane; k < ln; k += 64u) lds_st8(a_out + ld + k, in[ls + k]);
+                wave_copy_to_lds(a_out + ld, in + ls, ln);
                 wave_bits_set(s_bits, ld, ld + ln);
                 if (lane == l) n = 0;
             }
@@ -1104,7 +1129,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                         lm &= lm - 1ull;
                         const uint32_t ln = rdlane(n, l), ld = rdlane(dst, l);
                         const uint8_t* lg = reinterpret_cast<const uint8_t*>(((uint64_t)rdlane((uint32_t)((uintptr_t)g >> 32), l) << 32) | rdlane((uint32_t)(uintptr_t)g, l));
-                        for (uint32_t k = lane; k < ln; k += 64u) lds_st8(a_out + ld + k, lg[k]);
+                        wave_copy_to_lds(a_out + ld, lg, ln);
                         wave_bits_set(s_bits, ld, ld + ln);
                         if (lane == l) n = 0;
                     }

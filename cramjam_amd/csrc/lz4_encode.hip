@@ -54,8 +54,8 @@ __device__ __forceinline__ void lz4_emit_queue(const uint8_t* in, uint8_t* out, 
 // data, 4.78 resp. 4.79 vs 4.88 on text); each writes its own stream, and the streams are stitched / concatenated like any
 // other pieces.  64 KiB .. 4 MiB per call: 1.8-1.9 ms on one wavefront per piece, 0.6-0.7 ms with quarters, 0.30-0.44 ms with
 // 4 KiB sub-pieces.  (Blocks of four wavefronts: four tables fill the 64 KiB of static LDS.)
-template <bool kSplit>
-__device__ __forceinline__ void lz4_encode_chunk(const BatchArgs& a, uint32_t chunk, uint16_t* ht) {
+template <bool kSplit, bool kGlobalTable>
+__device__ __forceinline__ void lz4_encode_chunk(const BatchArgs& a, uint32_t chunk, const HashTab<kGlobalTable>& ht) {
     const uint64_t base_off = kSplit ? a.in_off[chunk & ~(split_per(a.flags) - 1u)] : a.in_off[chunk];      // the piece's first sub-piece
     const uint8_t* in = a.in_base + base_off;               // position 0 = start of the piece
     const uint32_t q0 = (uint32_t)(a.in_off[chunk] - base_off);      // this wave's range = [q0, n)
@@ -77,8 +77,9 @@ __device__ __forceinline__ void lz4_encode_chunk(const BatchArgs& a, uint32_t ch
 
     uint32_t anchor = q0, op = 0;
     if (n - q0 >= 13u) {
-        ht_clear(ht);
-        if constexpr (kSplit) ht_preindex(in, ht, q0);
+        ht.clear();
+        if constexpr (kSplit) ht.preindex(in, q0);
+        ht.settle();
         const uint32_t last_start = n - 12u;    // a match may start here at the latest
         const uint32_t matchlimit = n - 5u;     // and must end here at the latest
         uint32_t pos = q0;
@@ -174,8 +175,7 @@ __device__ __forceinline__ void lz4_encode_chunk(const BatchArgs& a, uint32_t ch
                 }
             }
             lz4_emit_queue(in, out, q_n, q_lit0, q_lit, q_off, q_mcode, q_op);
-#pragma unroll
-            for (int j = 0; j < kSub; j++) insert_uncovered(ht, pos + 64u * j, r.hslot[j], covered[j]);
+            insert_round(ht, pos, r.hslot, covered);
             pos = anchor > round_end ? anchor : round_end;
         }
     }
@@ -198,11 +198,12 @@ __global__ __launch_bounds__(kSplit ? 256 : kEncThreads) void lz4_encode_kernel(
     const uint32_t wave = uni(threadIdx.x >> 6);
     const uint32_t chunk = uni(kSplit ? blockIdx.x * 4u + wave : blockIdx.x * kEncWaves + wave);
     if (chunk >= a.n_chunks) return;
-    lz4_encode_chunk<kSplit>(a, chunk, ht_all[wave]);
+    lz4_encode_chunk<kSplit, false>(a, chunk, HashTab<false>{ht_all[wave]});
 }
 
 struct Lz4Enc {
-    static __device__ __forceinline__ void chunk(const BatchArgs& a, uint32_t c, uint16_t* ht) { lz4_encode_chunk<false>(a, c, ht); }
+    template <bool kGlobalTable>
+    static __device__ __forceinline__ void chunk(const BatchArgs& a, uint32_t c, const HashTab<kGlobalTable>& ht) { lz4_encode_chunk<false, kGlobalTable>(a, c, ht); }
 };
 
 void launch_lz4_encode(const BatchArgs& a, hipStream_t s, const EncFill* fill) {

@@ -95,8 +95,8 @@ __device__ __forceinline__ void snappy_emit_queue(const uint8_t* in, uint8_t* ou
 }
 
 // kSplit: four wavefronts per 64 KiB piece, each with its own pre-indexed hash table — see lz4_encode.hip
-template <bool kSplit>
-__device__ __forceinline__ void snappy_encode_chunk(const BatchArgs& a, uint32_t chunk, uint16_t* ht) {
+template <bool kSplit, bool kGlobalTable>
+__device__ __forceinline__ void snappy_encode_chunk(const BatchArgs& a, uint32_t chunk, const HashTab<kGlobalTable>& ht) {
     const uint64_t base_off = kSplit ? a.in_off[chunk & ~(split_per(a.flags) - 1u)] : a.in_off[chunk];      // the piece's first sub-piece
     const uint8_t* in = a.in_base + base_off;               // position 0 = start of the piece
     const uint32_t q0 = (uint32_t)(a.in_off[chunk] - base_off);      // this wave's range = [q0, n)
@@ -121,8 +121,9 @@ __device__ __forceinline__ void snappy_encode_chunk(const BatchArgs& a, uint32_t
     }
     uint32_t anchor = q0;
     if (n - q0 >= 8u) {
-        ht_clear(ht);
-        if constexpr (kSplit) ht_preindex(in, ht, q0);
+        ht.clear();
+        if constexpr (kSplit) ht.preindex(in, q0);
+        ht.settle();
         const uint32_t last_start = n - 4u;
         uint32_t pos = q0;
         OwnDwords own;
@@ -209,8 +210,7 @@ __device__ __forceinline__ void snappy_encode_chunk(const BatchArgs& a, uint32_t
                 }
             }
             snappy_emit_queue(in, out, q_n, q_lit0, q_lit, q_off, q_mlen, q_op);
-#pragma unroll
-            for (int j = 0; j < kSub; j++) insert_uncovered(ht, pos + 64u * j, r.hslot[j], covered[j]);
+            insert_round(ht, pos, r.hslot, covered);
             pos = anchor > round_end ? anchor : round_end;
         }
     }
@@ -224,11 +224,12 @@ __global__ __launch_bounds__(kSplit ? 256 : kEncThreads) void snappy_encode_kern
     const uint32_t wave = uni(threadIdx.x >> 6);
     const uint32_t chunk = uni(kSplit ? blockIdx.x * 4u + wave : blockIdx.x * kEncWaves + wave);
     if (chunk >= a.n_chunks) return;
-    snappy_encode_chunk<kSplit>(a, chunk, ht_all[wave]);
+    snappy_encode_chunk<kSplit, false>(a, chunk, HashTab<false>{ht_all[wave]});
 }
 
 struct SnappyEnc {
-    static __device__ __forceinline__ void chunk(const BatchArgs& a, uint32_t c, uint16_t* ht) { snappy_encode_chunk<false>(a, c, ht); }
+    template <bool kGlobalTable>
+    static __device__ __forceinline__ void chunk(const BatchArgs& a, uint32_t c, const HashTab<kGlobalTable>& ht) { snappy_encode_chunk<false, kGlobalTable>(a, c, ht); }
 };
 
 void launch_snappy_encode(const BatchArgs& a, hipStream_t s, const EncFill* fill) {

@@ -365,6 +365,24 @@ def test_large_batch_compress_then_decompress_property(eng, codec):
 
 
 @pytest.mark.parametrize("codec", [LZ4, SNAPPY])
+def test_encoder_block_kinds_agree_with_the_plain_kernel(codec):
+    """A large batch runs as persistent blocks of two kinds (hash table in LDS / in global memory, engine.hip launch_encode);
+    a small one as one block per chunk.  Every copy of a chunk in the large batch must be byte-identical to what the plain
+    kernel emits for it — the global-memory table has to reproduce the LDS table's semantics exactly (stores acknowledged
+    before the lookups that follow, the highest position winning a contested slot: cj_match.hpp insert_round)."""
+    e = N.Engine(0)
+    U, n = 64, 8192
+    raws = [oracle.synth_v1(65536, 500 + i) for i in range(U)]
+    raws[5] = raws[5][:40000]; raws[9] = bytes(65536); raws[11] = (b"abcdefgh" * 9000)[:65536]; raws[13] = hashlib.shake_256(b"k").digest(30000) + raws[13][:30000]
+    res0, outs0 = e.batch_host(codec, ENC, 0, raws, [80000] * U)
+    ref = [bytes(o) for o in outs0]
+    res, outs = e.batch_host(codec, ENC, 0, [raws[i % U] for i in range(n)], [80000] * n)
+    bad = [i for i in range(n) if bytes(outs[i]) != ref[i % U]]
+    assert not bad, (len(bad), bad[:8])
+    e.close()
+
+
+@pytest.mark.parametrize("codec", [LZ4, SNAPPY])
 def test_encoder_persistent_blocks_on_mixed_chunks(eng, codec):
     """The large-batch encoder path (persistent LDS-table + global-table blocks) on chunks of every shape: empty, tiny, zeros,
     random, short periods, ragged sizes, above 64 KiB.  Every copy of a chunk must compress to the same bytes, and those

@@ -64,8 +64,12 @@ struct HashTab {
             else q[i] = 0u;
         }
     }
+    // after a group of stores, before the lookups that follow.  Global table: wait until the stores are acknowledged.  LDS table:
+    // DS operations of a wavefront execute in order, so only the COMPILER has to be told — clear() stores dwords through a
+    // punned pointer, and nothing else keeps the 16-bit lookups from being scheduled above them.
     __device__ __forceinline__ void settle() const {
         if constexpr (kGlobal) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("" ::: "memory");
     }
     // kSplit encoders: index the data BEFORE this wave's sub-piece (positions [0, q0), every kPreStep-th one, ascending so that
     // the most recent position wins a slot), so that the sub-piece finds the matches a serial walk over the piece would

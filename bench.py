@@ -325,7 +325,14 @@ def main():
         ph = (C.c_ulonglong * 8)()
         L.cj_debug_lds_phase_cycles(ph, 1)
         nb = max(int(ph[5]), 1)
-        print("LDS decoder cycles/chunk: S0 %d  D1 %d  D2 %d  D3 %d  D4 %d  (blocks %d)" % (ph[0] // nb, ph[1] // nb, ph[2] // nb, ph[3] // nb, ph[4] // nb, nb), file=sys.stderr)
+        if int(ph[5]):
+            print("LDS decoder cycles/chunk: S0 %d  D1 %d  D2 %d  D3 %d  D4 %d  (blocks %d)" % (ph[0] // nb, ph[1] // nb, ph[2] // nb, ph[3] // nb, ph[4] // nb, nb), file=sys.stderr)
+        pl = (C.c_ulonglong * 16)()
+        L.cj_debug_lvl_phase_cycles(pl, 1)
+        if int(pl[8]):
+            nb = int(pl[8])
+            print("level decoder cycles/chunk: " + "  ".join("%s %d" % (nm, pl[i] // nb) for i, nm in enumerate(("S0", "D1/P", "X", "L", "K", "D2", "D3", "D4")))
+                  + "  | levels %.1f  D3 barriers %.1f  (chunks %d)" % (pl[9] / nb, pl[10] / nb, nb), file=sys.stderr)
 
     # ---- verify at full size: every chunk's result and every output byte ----
     bytes_in = sum(b.bytes_in for b in batches)

@@ -48,6 +48,9 @@ void launch_lz4_decode_lds2_linked(const BatchArgs& a, const void* sync, const v
 // parse + decode in ONE kernel: the segmented parse runs inside the workgroup on the staged chunk; meta[c] = kRouteWave for chunks it leaves to the wave kernel
 void launch_lz4_decode_fused(const BatchArgs& a, void* meta, void* tabs, uint32_t* counter, uint32_t grid, hipStream_t s, int codec = 0);
 size_t lz4_lds2_tab_bytes(uint32_t grid);
+// the level-ordered workgroup decoder (lz4_decode_lvl.hip): same scratch, same counter; fused = the parse stage inside (sync unused)
+void launch_lz4_decode_lvl(const BatchArgs& a, const void* sync, void* meta, void* tabs, uint32_t* counter, uint32_t grid, hipStream_t s, int codec, bool fused);
+size_t lz4_lvl_tab_bytes(uint32_t grid);
 size_t lz4_lds_scratch_sync_bytes(size_t n_chunks);
 size_t lz4_lds_scratch_meta_bytes(size_t n_chunks);
 // Encoders, large batches: besides the ten LDS-table wavefronts that fit a CU, `table_blocks` more wavefronts with their hash

@@ -34,7 +34,7 @@ int lds_scratch(cj_engine* e, const cj::BatchArgs& a, hipStream_t s, bool with_s
     else HIP_TRY(hipStreamWaitEvent(s, e->scratch_free, 0), CJ_E_NO_DEVICE);   // previous user of the scratch
     HIP_TRY(hipMemsetAsync(e->d_lanelist.p, 0, 16, s), CJ_E_NO_DEVICE);        // [2] = the decoder's chunk counter
     if (e->n_cu == 0) HIP_TRY(hipDeviceGetAttribute(&e->n_cu, hipDeviceAttributeMultiprocessorCount, e->device), CJ_E_NO_DEVICE);
-    if (!e->d_tab.reserve(cj::lz4_lds2_tab_bytes(2u * (uint32_t)e->n_cu))) return CJ_E_OOM;
+    if (!e->d_tab.reserve(std::max(cj::lz4_lds2_tab_bytes(2u * (uint32_t)e->n_cu), cj::lz4_lvl_tab_bytes(2u * (uint32_t)e->n_cu)))) return CJ_E_OOM;
     return 0;
 }
 
@@ -54,20 +54,26 @@ int launch_decode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a, hipStrea
     if (a.flags & CJ_FLAG_FORCE_LDS_PER_CHUNK) mode = 2;
     if (mode == 0) { if (lz4) cj::launch_lz4_decode(a, s); else cj::launch_snappy_decode(a, s); return 0; }
     if (mode == 1) { if (lz4) cj::launch_lz4_decode_lanes(a, s); else cj::launch_snappy_decode_lanes(a, s); return 0; }
-    const bool fused = a.n_chunks <= (uint32_t)CJ_FUSED_MAX_CHUNKS;
+    // the workgroup decoder: level-ordered dense resolver (lz4_decode_lvl.hip); CJ_DECODER=lds2 selects the bitmap resolver
+    // (lz4_decode_lds.hip) for comparisons, CJ_FUSED=0 / 1 forces the separate / in-kernel parse at any batch size
+    static const bool use_lvl = [] { const char* v = std::getenv("CJ_DECODER"); return !(v && std::strcmp(v, "lds2") == 0); }();
+    static const int force_fused = [] { const char* v = std::getenv("CJ_FUSED"); return v ? std::atoi(v) : -1; }();
+    const bool fused = force_fused >= 0 ? force_fused != 0 : a.n_chunks <= (uint32_t)CJ_FUSED_MAX_CHUNKS;
     std::lock_guard<std::mutex> lock(e->scratch_mu);
     const int rc = lds_scratch(e, a, s, !fused);
     if (rc != 0) return rc;
     uint32_t* lists = (uint32_t*)e->d_lanelist.p;
     const uint32_t grid = 2u * (uint32_t)e->n_cu;
     if (fused) {
-        cj::launch_lz4_decode_fused(a, e->d_pmeta.p, e->d_tab.p, lists + 2, grid, s, codec);
+        if (use_lvl) cj::launch_lz4_decode_lvl(a, nullptr, e->d_pmeta.p, e->d_tab.p, lists + 2, grid, s, codec, true);
+        else cj::launch_lz4_decode_fused(a, e->d_pmeta.p, e->d_tab.p, lists + 2, grid, s, codec);
     } else {
         HIP_TRY(hipMemsetAsync(e->d_pmeta.p, 0, cj::lz4_lds_scratch_meta_bytes(a.n_chunks), s), CJ_E_NO_DEVICE);   // no chunk is pre-routed
         // validate, size, count sequences, sync points, route
         if (lz4) cj::launch_lz4_parse(a, e->d_sync.p, e->d_pmeta.p, s);
         else cj::launch_snappy_parse(a, e->d_sync.p, e->d_pmeta.p, s);
-        cj::launch_lz4_decode_lds2(a, e->d_sync.p, e->d_pmeta.p, e->d_tab.p, lists + 2, grid, s, codec);
+        if (use_lvl) cj::launch_lz4_decode_lvl(a, e->d_sync.p, e->d_pmeta.p, e->d_tab.p, lists + 2, grid, s, codec, false);
+        else cj::launch_lz4_decode_lds2(a, e->d_sync.p, e->d_pmeta.p, e->d_tab.p, lists + 2, grid, s, codec);
     }
     if (lz4) cj::launch_lz4_decode_routed(a, e->d_pmeta.p, s);                // few long runs / oversize chunks / errors
     else cj::launch_snappy_decode_routed(a, e->d_pmeta.p, s);

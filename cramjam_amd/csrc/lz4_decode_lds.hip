@@ -23,221 +23,9 @@
 // in flight changed nothing or lost; DESIGN.md §5.1 has the numbers.
 // The slab mode (one large stream: chunk c = slab c of its output) and the linked mode (LZ4 frames with linked blocks: the
 // previous block stays in a second window) share the body.
-#include "lz4_lane_walk.hpp"
-#include "snappy_records.hpp"
-#include "parse_grammar.hpp"
-#include <type_traits>
+#include "lds_shared.hpp"
 
 namespace cj {
-
-constexpr uint32_t kLongRun = 512;                   // runs at least this long are copied by the whole wavefront
-constexpr uint32_t kSpinLimit = 1u << 18;
-
-// record: x = literal source (position in the compressed stream), y = literal length, z = match destination
-//         (= op after literals), w = offset | match length << 16 (0 = no match: LZ4's final sequence, a Snappy literal)
-
-// ---- unaligned LDS accessors ------------------------------------------------------------------
-// gfx950 executes ds_read_b32/ds_write_b32 at any byte alignment (tools/lds_unaligned_probe.hip:
-// bit-exact, ~140 vs ~80 cycles dependent latency).  hipcc will not emit them for align-1 LDS accesses
-// (it splits into bytes), hence inline asm.  Every read carries its own s_waitcnt, so no result is
-// consumed early; writes need no wait (DS ops of one wave execute in order).  Addresses are LDS byte
-// offsets (low 32 bits of the flat address of a __shared__ object).
-__device__ __forceinline__ uint32_t lds_ld32(uint32_t a) {
-    uint32_t v;
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
-    return v;
-}
-// 4 bytes at ANY byte address through two ALIGNED dwords + v_alignbyte: an unaligned ds_read is replayed once per active lane
-// (~64 LDS cycles per wave-instruction with a full wave), this pair costs 4 when conflict-free.  D1 walks the token chain with it.
-__device__ __forceinline__ uint32_t lds_ld32a(uint32_t a) {
-    uint64_t v;
-    asm volatile("ds_read2_b32 %0, %1 offset1:1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a & ~3u) : "memory");
-    return __builtin_amdgcn_alignbyte((uint32_t)(v >> 32), (uint32_t)v, a & 3u);
-}
-__device__ __forceinline__ uint2 lds_ld64(uint32_t a) {
-    uint2 v;
-    asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:4\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(v.x), "=&v"(v.y) : "v"(a) : "memory");
-    return v;
-}
-__device__ __forceinline__ void lds_st32(uint32_t a, uint32_t v) {
-    asm volatile("ds_write_b32 %0, %1" :: "v"(a), "v"(v) : "memory");
-}
-__device__ __forceinline__ uint32_t lds_ld8(uint32_t a) {
-    uint32_t v;
-    asm volatile("ds_read_u8 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
-    return v;
-}
-__device__ __forceinline__ void lds_st8(uint32_t a, uint32_t v) {
-    asm volatile("ds_write_b8 %0, %1" :: "v"(a), "v"(v) : "memory");
-}
-
-// The whole wavefront copies n bytes (wave-uniform) from global memory to the LDS byte address a_dst: a long literal run, or a long
-// copy from an earlier slab.  <= 3 head bytes until the destination is dword aligned, then lane l takes dwords l, l + 64, ... with
-// eight loads in flight (2 KiB per round trip, conflict-free stores), then the tail bytes.  Reads exactly [src, src + n).
-// (A byte per lane and round trip — the first version — took ~0.5 ms for a 64 KiB run: 360 k cycles per slab on data that is mostly
-//  literals, tests/perf/slab_phase_profile.py.)
-__device__ __forceinline__ void wave_copy_to_lds(uint32_t a_dst, const uint8_t* src, uint32_t n) {
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t h = (0u - a_dst) & 3u;
-    h = h < n ? h : n;
-    if (lane < h) lds_st8(a_dst + lane, src[lane]);
-    const uint8_t* s = src + h;
-    const uint32_t d = a_dst + h, m = n - h, nd = m >> 2;
-    uint32_t i = lane;
-    for (; i + 7u * 64u < nd; i += 8u * 64u) {
-        uint32_t v[8];
-#pragma unroll
-        for (uint32_t j = 0; j < 8u; j++) v[j] = ld32u(s + 4u * (i + 64u * j));
-#pragma unroll
-        for (uint32_t j = 0; j < 8u; j++) lds_st32(d + 4u * (i + 64u * j), v[j]);
-    }
-    for (; i < nd; i += 64u) lds_st32(d + 4u * i, ld32u(s + 4u * i));
-    const uint32_t t = m & 3u;
-    if (lane < t) lds_st8(d + 4u * nd + lane, s[4u * nd + lane]);
-}
-
-// ---- single-wait tiered copy --------------------------------------------------------------------
-// A misaligned DS access is replayed lane by lane (~64 LDS cycles per wave-instruction, measured), and
-// every scattered DS wave-instruction costs ~8 cycles of the CU's LDS pipe, so the copies are built to
-// need FEW instructions: aligned dword reads only (over-reading is harmless) + v_alignbyte to undo the
-// source misalignment, ONE s_waitcnt per batch, and writes as <=3 head bytes + aligned dwords + <=3 tail
-// bytes.  Writes must be exact: a lane whose element is past its length writes to a private dummy
-// slot instead of being masked off (no exec-mask churn).  T = tier (max bytes per lane), wave-uniform.
-template <int ND> struct DW { uint32_t w[ND]; };
-
-__device__ __forceinline__ DW<6> lds_ld_aligned6(uint32_t a) {
-    DW<6> r;
-    asm volatile("ds_read_b32 %0, %6\n\tds_read_b32 %1, %6 offset:4\n\tds_read_b32 %2, %6 offset:8\n\tds_read_b32 %3, %6 offset:12\n\tds_read_b32 %4, %6 offset:16\n\tds_read_b32 %5, %6 offset:20\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(r.w[0]), "=&v"(r.w[1]), "=&v"(r.w[2]), "=&v"(r.w[3]), "=&v"(r.w[4]), "=&v"(r.w[5]) : "v"(a) : "memory");
-    return r;
-}
-__device__ __forceinline__ DW<10> lds_ld_aligned10(uint32_t a) {
-    DW<10> r;
-    asm volatile("ds_read_b32 %0, %10\n\tds_read_b32 %1, %10 offset:4\n\tds_read_b32 %2, %10 offset:8\n\tds_read_b32 %3, %10 offset:12\n\tds_read_b32 %4, %10 offset:16\n\tds_read_b32 %5, %10 offset:20\n\tds_read_b32 %6, %10 offset:24\n\tds_read_b32 %7, %10 offset:28\n\tds_read_b32 %8, %10 offset:32\n\tds_read_b32 %9, %10 offset:36\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(r.w[0]), "=&v"(r.w[1]), "=&v"(r.w[2]), "=&v"(r.w[3]), "=&v"(r.w[4]), "=&v"(r.w[5]), "=&v"(r.w[6]), "=&v"(r.w[7]), "=&v"(r.w[8]), "=&v"(r.w[9]) : "v"(a) : "memory");
-    return r;
-}
-__device__ __forceinline__ DW<18> lds_ld_aligned18(uint32_t a) {
-    DW<18> r;
-    asm volatile("ds_read_b32 %0, %18\n\tds_read_b32 %1, %18 offset:4\n\tds_read_b32 %2, %18 offset:8\n\tds_read_b32 %3, %18 offset:12\n\tds_read_b32 %4, %18 offset:16\n\tds_read_b32 %5, %18 offset:20\n\tds_read_b32 %6, %18 offset:24\n\tds_read_b32 %7, %18 offset:28\n\tds_read_b32 %8, %18 offset:32\n\tds_read_b32 %9, %18 offset:36\n\tds_read_b32 %10, %18 offset:40\n\tds_read_b32 %11, %18 offset:44\n\tds_read_b32 %12, %18 offset:48\n\tds_read_b32 %13, %18 offset:52\n\tds_read_b32 %14, %18 offset:56\n\tds_read_b32 %15, %18 offset:60\n\tds_read_b32 %16, %18 offset:64\n\tds_read_b32 %17, %18 offset:68\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(r.w[0]), "=&v"(r.w[1]), "=&v"(r.w[2]), "=&v"(r.w[3]), "=&v"(r.w[4]), "=&v"(r.w[5]), "=&v"(r.w[6]), "=&v"(r.w[7]), "=&v"(r.w[8]), "=&v"(r.w[9]), "=&v"(r.w[10]), "=&v"(r.w[11]), "=&v"(r.w[12]), "=&v"(r.w[13]), "=&v"(r.w[14]), "=&v"(r.w[15]), "=&v"(r.w[16]), "=&v"(r.w[17]) : "v"(a) : "memory");
-    return r;
-}
-
-struct Dummies { uint32_t b, w; };     // per-lane dummy byte address / aligned dummy dword address
-
-template <int T, class Loaded>
-__device__ __forceinline__ void lds_store_tier(const Loaded& r, uint32_t dst, uint32_t sh_bytes, uint32_t n, Dummies dm) {
-    constexpr int NV = T / 4 + 1;
-    uint32_t v[NV];                                    // v[i] = source bytes 4i .. 4i+3
-#pragma unroll
-    for (int i = 0; i < NV; i++) v[i] = __builtin_amdgcn_alignbyte(r.w[i + 1], r.w[i], sh_bytes);
-    const uint32_t h = (0u - dst) & 3u;               // bytes until dst is dword aligned
-    const uint32_t hh = h < n ? h : n;
-    const uint32_t nm = (n - hh) >> 2, t = (n - hh) & 3u;
-#pragma unroll
-    for (int q = 0; q < 3; q++) lds_st8((uint32_t)q < hh ? dst + q : dm.b, v[0] >> (8 * q));
-    uint32_t tv = 0;
-#pragma unroll
-    for (int i = 0; i < T / 4; i++) {
-        const uint32_t mi = __builtin_amdgcn_alignbyte(v[i + 1], v[i], h);     // bytes h+4i .. h+4i+3
-        lds_st32((uint32_t)i < nm ? dst + h + 4u * i : dm.w, mi);
-        tv = (uint32_t)i == nm ? mi : tv;
-    }
-    const uint32_t tpos = dst + hh + 4u * nm;
-#pragma unroll
-    for (int q = 0; q < 3; q++) lds_st8((uint32_t)q < t ? tpos + q : dm.b, tv >> (8 * q));
-}
-
-// copy n (<= tier, tier in {16,32,64} wave-uniform) bytes src -> dst, both LDS byte addresses; [src, src+n) is
-// final and does not overlap [dst, dst+n)
-__device__ __forceinline__ void lds_copy_tier(uint32_t tier, uint32_t dst, uint32_t src, uint32_t n, Dummies dm) {
-    const uint32_t sa = src & ~3u, sh = src & 3u;
-    if (tier <= 16u) lds_store_tier<16>(lds_ld_aligned6(sa), dst, sh, n, dm);
-    else if (tier <= 32u) lds_store_tier<32>(lds_ld_aligned10(sa), dst, sh, n, dm);
-    else lds_store_tier<64>(lds_ld_aligned18(sa), dst, sh, n, dm);
-}
-
-// ---- sparse exact copy (D3) --------------------------------------------------------------------------------
-// D3 copies with a handful of lanes active: the matches that became ready in this poll.  gfx950 executes LDS accesses at any
-// byte alignment for about one extra cycle per ACTIVE misaligned lane (tools/lds_unaligned_probe.hip: +64 cycles with 64
-// lanes, +16 with 16, +4 with 4), so there a copy of m <= 32 bytes is the first and the last 8 (16, 4) bytes of the match —
-// overlapping in the middle — read and stored at their exact addresses: 2-4 reads and 2-4 stores instead of the 6-10 aligned
-// dword reads, byte shifts and 10-14 head / dword / tail stores of lds_store_tier (which is built for 64 active lanes, D2).
-// [src, src + m) is final and does not overlap [dst, dst + m); up to 7 bytes past the source may be read (never stored).
-__device__ __forceinline__ void lds_copy_sparse(uint32_t dst, uint32_t src, uint32_t m) {
-    if (m > 16u) {
-        uint64_t r0, r1, r2, r3;
-        const uint32_t s2 = src + m - 16u, d2 = dst + m - 16u;
-        asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %5\n\tds_read_b64 %3, %5 offset:8\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(src), "v"(s2) : "memory");
-        asm volatile("ds_write_b64 %0, %2\n\tds_write_b64 %0, %3 offset:8\n\tds_write_b64 %1, %4\n\tds_write_b64 %1, %5 offset:8"
-                     :: "v"(dst), "v"(d2), "v"(r0), "v"(r1), "v"(r2), "v"(r3) : "memory");
-    } else if (m >= 8u) {
-        uint64_t r0, r1;
-        const uint32_t s2 = src + m - 8u, d2 = dst + m - 8u;
-        asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r0), "=&v"(r1) : "v"(src), "v"(s2) : "memory");
-        asm volatile("ds_write_b64 %0, %2\n\tds_write_b64 %1, %3" :: "v"(dst), "v"(d2), "v"(r0), "v"(r1) : "memory");
-    } else if (m >= 4u) {
-        uint64_t r0;
-        asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r0) : "v"(src) : "memory");
-        const uint32_t lo = (uint32_t)r0, hi = (uint32_t)(r0 >> (8u * (m - 4u)));
-        asm volatile("ds_write_b32 %0, %2\n\tds_write_b32 %1, %3" :: "v"(dst), "v"(dst + m - 4u), "v"(lo), "v"(hi) : "memory");
-    } else {                                               // 1..3 bytes (Snappy copies)
-        uint32_t r;
-        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(src) : "memory");
-        if (m & 2u) asm volatile("ds_write_b16 %0, %1" :: "v"(dst), "v"(r) : "memory");
-        if (m & 1u) asm volatile("ds_write_b8 %0, %1" :: "v"(dst + (m & 2u)), "v"(r >> (8u * (m & 2u))) : "memory");
-    }
-}
-
-__device__ __forceinline__ uint32_t wave_tier(uint32_t n, bool active) {       // wave-uniform tier for the active lanes
-    if (ballot64(active && n > 32u)) return 64u;
-    if (ballot64(active && n > 16u)) return 32u;
-    return 16u;
-}
-
-
-// ---- ready bitmap: one bit per output byte ---------------------------------------------------
-__device__ __forceinline__ void bits_set(uint32_t* bits, uint32_t lo, uint32_t hi) {     // [lo, hi), hi > lo
-    uint32_t w0 = lo >> 5, w1 = (hi - 1u) >> 5;
-    for (uint32_t w = w0; w <= w1; w++) {
-        uint32_t m = ~0u;
-        if (w == w0) m &= ~0u << (lo & 31u);
-        if (w == w1) m &= ~0u >> (31u - ((hi - 1u) & 31u));
-        __hip_atomic_fetch_or(&bits[w], m, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-}
-
-__device__ __forceinline__ bool bits_ready(uint32_t* bits, uint32_t lo, uint32_t hi) {   // [lo, hi), hi > lo
-    if (hi - lo <= 32u) {                 // the common case fits a 64-bit window: one double read
-        const uint2 v = lds_ld64((uint32_t)(uintptr_t)(bits + (lo >> 5)));     // may read one word past the bitmap: harmless
-        const uint64_t win = (((uint64_t)v.y << 32) | v.x) >> (lo & 31u);
-        const uint64_t m = ~0ull >> (64u - (hi - lo));
-        return (win & m) == m;
-    }
-    uint32_t w0 = lo >> 5, w1 = (hi - 1u) >> 5;
-    for (uint32_t w = w0; w <= w1; w++) {
-        uint32_t m = ~0u;
-        if (w == w0) m &= ~0u << (lo & 31u);
-        if (w == w1) m &= ~0u >> (31u - ((hi - 1u) & 31u));
-        uint32_t v = __hip_atomic_load(&bits[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if ((v & m) != m) return false;
-    }
-    return true;
-}
-
-// whole-wave version for long ranges (all lanes call with the same lo/hi)
-__device__ __forceinline__ void wave_bits_set(uint32_t* bits, uint32_t lo, uint32_t hi) {
-    const uint32_t w0 = lo >> 5, w1 = (hi - 1u) >> 5;
-    for (uint32_t w = w0 + lane_id(); w <= w1; w += 64u) {
-        uint32_t m = ~0u;
-        if (w == w0) m &= ~0u << (lo & 31u);
-        if (w == w1) m &= ~0u >> (31u - ((hi - 1u) & 31u));
-        __hip_atomic_fetch_or(&bits[w], m, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-}
 
 // phase cycle counters (debug aid, enabled by CJ_FLAG_DEBUG_PROFILE): S0, D1, D2, D3, D4, blocks
 __device__ unsigned long long g_lds_phase_cycles[8];
@@ -266,227 +54,6 @@ constexpr uint32_t kL2OffBits = 65536;
 constexpr uint32_t kL2OffVars = kL2OffBits + 8192;         // [0] fail flag, [8] current chunk, [64,128) dummy bytes, [128,384) dummy dwords
 constexpr uint32_t kL2Bytes = kL2OffVars + 384;            // 74112 B: two workgroups fit one CU's LDS
 constexpr uint32_t kL2TabRecords = 3u * kSyncStride * kSyncEvery;   // records of a chunk (the parse kernel routes chunks with more than 8 192 sequences elsewhere) + the extra literal copies of D1f (at most two per record, D1f takes at most 6 144 records)
-
-template <int ND>
-__device__ __forceinline__ DW<ND> gl_ld_aligned(const uint8_t* pa, const uint8_t* last) {   // ND aligned dwords, clamped to the last valid one
-    DW<ND> r;
-#pragma unroll
-    for (int i = 0; i < ND; i++) {
-        const uint8_t* q = pa + 4 * i;
-        r.w[i] = *reinterpret_cast<const uint32_t*>(q < last ? q : last);
-    }
-    return r;
-}
-
-// ND dwords (ND = 4k + 2) from the exact, arbitrarily aligned pointer g as k dwordx4 + one dwordx2 load: a scattered
-// wave load costs the texture-address unit about one cycle per lane whatever its width, so 6 dword loads per lane
-// (the aligned form above) take 3x as long as these 2.  May read up to 4*ND bytes from g: the caller checks that
-// this stays inside the chunk's last 16 B granule.
-template <int ND>
-__device__ __forceinline__ DW<ND> gl_ld_vec(const uint8_t* g) {
-    static_assert(ND % 4 == 2, "ND = 4k + 2");
-    DW<ND> r;
-#pragma unroll
-    for (int i = 0; i + 4 <= ND; i += 4) {
-        uint4 v;
-        __builtin_memcpy(&v, g + 4 * i, 16);
-        r.w[i] = v.x; r.w[i + 1] = v.y; r.w[i + 2] = v.z; r.w[i + 3] = v.w;
-    }
-    uint2 t;
-    __builtin_memcpy(&t, g + 4 * (ND - 2), 8);
-    r.w[ND - 2] = t.x; r.w[ND - 1] = t.y;
-    return r;
-}
-
-// The same for a source that needs no shift (exact pointer): lds_store_tier<T> stores source bytes < n <= T only, and with a
-// zero shift those come from the first T / 4 dwords — the two dwords after them only feed bytes that are never stored.  So T
-// bytes = T / 16 dwordx4 loads are enough: one scattered load instead of two for the 16-byte tier, two instead of three for 32
-// (D2 is bound by the address unit's ~1 cycle per lane per scattered load instruction, not by latency: requesting the next
-// batch's bytes a batch ahead made it slower, 22.7 k -> 28 k cycles per chunk, because it took a third instruction per record).
-template <int T>
-__device__ __forceinline__ DW<T / 4 + 2> gl_ld_exact(const uint8_t* g) {
-    DW<T / 4 + 2> r;
-#pragma unroll
-    for (int i = 0; i < T / 4; i += 4) {
-        uint4 v;
-        __builtin_memcpy(&v, g + 4 * i, 16);
-        r.w[i] = v.x; r.w[i + 1] = v.y; r.w[i + 2] = v.z; r.w[i + 3] = v.w;
-    }
-    r.w[T / 4] = 0u; r.w[T / 4 + 1] = 0u;
-    return r;
-}
-
-// =====================================================================================================
-// The PARSE STAGE INSIDE the decoder (kFused): no separate parse kernel, no sync points in memory, the compressed chunk is
-// read from HBM once.  S0 has staged the chunk in LDS; 256 lanes then walk 256 SEGMENTS of it at once — the segmented
-// speculative walk of parse_spec.hip (one wavefront per chunk there) on four wavefronts:
-//   P1a  lane l starts at the guessed position l * seg and walks its own segment, marking every position it visits
-//        (one bit per input byte, in the ready bitmap's space: it is not needed before D2);
-//   P1b  it walks on through the following segments until it steps on a marked position: from there its path IS that
-//        segment owner's path (the next-element function depends on the bytes only); merge[l] = that position;
-//   P2   the true path = lane 0's piece, then the piece of the lane it merged into, ...: a pointer chain over the lanes,
-//        marked from lane 0 by pointer doubling (8 rounds for 256 lanes) instead of 256 dependent hops;
-//   P3   the lanes on the chain count the sequences and output bytes of their piece, an exclusive scan over the lanes
-//        gives every piece its first sequence index and output position;
-//   P4   they walk their piece once more with the true (index, output position): the decoder's own validation rules
-//        (the same Lz4Grammar / SnappyGrammar functions as the parse kernels) and the 16-byte records of D1, written
-//        straight to the workgroup's record table.
-// Anything that is not a clean chunk of 256..8192 sequences (any violation, too few or too many sequences) is handed to
-// the wavefront-per-chunk kernel, which decodes every valid chunk and names every error exactly: returns false then.
-// =====================================================================================================
-constexpr uint32_t kFusedLanes = 256;
-constexpr uint32_t kFusedAux = 6u * kFusedLanes * 4u;              // merge, next, mark, entry, count, bytes: 6 KiB behind the decoder's LDS
-
-__device__ __forceinline__ uint32_t wave_excl_scan_add32(uint32_t v, uint32_t& total) {
-    const uint32_t lane = lane_id();
-    uint32_t x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = (uint32_t)__shfl_up((int)x, d, 64);
-        if (lane >= (uint32_t)d) x += t;
-    }
-    total = rdlane(x, 63);
-    return x - v;
-}
-
-// a_in: LDS address of stream position 0; aux: kFusedAux bytes of LDS; bits: 8 KiB, zeroed; table2: the record table (8-byte records).
-// On success: nseq_out / U_out, *near_out += matches with an offset below kFwdNear.  Every thread of the workgroup calls it.
-template <class G, uint32_t kThreads>
-__device__ __forceinline__ bool fused_parse(uint32_t a_in, uint32_t iend, uint32_t cap, uint32_t* bits, uint32_t* aux, uint2* table2,
-                                            uint32_t* s_near, uint32_t& nseq_out, uint32_t& U_out) {
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    uint32_t* s_merge = aux;
-    uint32_t* s_next = aux + kFusedLanes;
-    uint32_t* s_mark = aux + 2u * kFusedLanes;
-    uint32_t* s_entry = aux + 3u * kFusedLanes;
-    uint32_t* s_tot = aux + 4u * kFusedLanes;            // [0..8): per-wave totals (count, bytes); [16..24): verdict words
-    const uint32_t a_bits = (uint32_t)(uintptr_t)bits;
-    const auto rd = [a_in](uint32_t q) { return lds_ld32a(a_in + q); };
-    const bool plane = tid < kFusedLanes;                  // the parse lanes (wavefronts 0-3); everyone takes the barriers
-
-    uint32_t nl = (iend + 63u) / 64u;
-    nl = nl > kFusedLanes ? kFusedLanes : nl;
-    const uint32_t seg = (((iend + nl - 1u) / nl + 3u) & ~3u) | 4u;          // 4 x odd: the lanes' start positions spread over the banks
-    const bool active = plane && tid < nl && tid * seg < iend;
-    const uint32_t seg_end = (tid + 1u) * seg;
-    if (tid < 32u) s_tot[tid] = 0u;
-
-    // ---- P1a ----
-    uint32_t p = active ? tid * seg : kPosEnd;
-    if (plane) {
-        while (ballot64(p < seg_end && p < iend) != 0ull) {
-            if (p < seg_end && p < iend) {
-                asm volatile("ds_or_b32 %0, %1" :: "v"(a_bits + 4u * (p >> 5)), "v"(1u << (p & 31u)) : "memory");
-                Seq sq;
-                p = walk_step<G>(rd, p, iend, sq) ? sq.next : kPosErr;
-            }
-        }
-    }
-    __syncthreads();
-    // ---- P1b ----
-    uint32_t merge_pos = p;
-    if (plane) {
-        bool going = active && p < iend;
-        while (ballot64(going) != 0ull) {
-            if (going) {
-                uint32_t w;
-                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(a_bits + 4u * (p >> 5)) : "memory");
-                if ((w >> (p & 31u)) & 1u) { merge_pos = p; going = false; }
-                else {
-                    Seq sq;
-                    p = walk_step<G>(rd, p, iend, sq) ? sq.next : kPosErr;
-                    if (p >= iend) { merge_pos = p; going = false; }
-                }
-            }
-        }
-        if (active && merge_pos >= iend && merge_pos != kPosEnd) merge_pos = kPosErr;
-        const uint32_t nx0 = merge_pos < iend ? merge_pos / seg : tid;       // a piece that ends the stream points at itself
-        s_merge[tid] = merge_pos;
-        s_next[tid] = active ? nx0 : tid;
-        s_mark[tid] = tid == 0u ? 1u : 0u;
-        s_entry[tid] = 0u;
-    }
-    __syncthreads();
-    // ---- P2: mark the chain from lane 0 by pointer doubling ----
-    for (uint32_t round = 0; round < 8u; round++) {
-        uint32_t n1 = 0, n2 = 0;
-        if (plane) {
-            n1 = s_next[tid];
-            if (s_mark[tid]) s_mark[n1] = 1u;
-            n2 = s_next[n1];
-        }
-        __syncthreads();
-        if (plane) s_next[tid] = n2;
-        __syncthreads();
-    }
-    bool on_chain = false;
-    if (plane) {
-        on_chain = active && s_mark[tid] != 0u;
-        if (on_chain && merge_pos < iend) s_entry[merge_pos / seg] = merge_pos;
-    }
-    __syncthreads();
-    const uint32_t entry = plane ? s_entry[tid] : 0u;       // lane 0 enters at 0
-    const uint32_t piece_end = merge_pos;
-
-    // ---- P3: count ----
-    uint32_t cnt = 0, outb = 0;
-    if (plane) {
-        uint32_t q = on_chain ? entry : kPosEnd;
-        while (ballot64(q < iend && q != piece_end) != 0ull) {
-            if (q < iend && q != piece_end) {
-                Seq sq;
-                if (walk_step<G>(rd, q, iend, sq)) { cnt += 1; outb += sq.lit + sq.mlen; q = sq.next; }
-                else q = kPosErr;
-            }
-        }
-    }
-    uint32_t base_idx = 0, base_op = 0;
-    if (plane) {
-        uint32_t tc, tb;
-        base_idx = wave_excl_scan_add32(cnt, tc);
-        base_op = wave_excl_scan_add32(outb, tb);
-        if (lane == 0) { s_tot[wave] = tc; s_tot[4u + wave] = tb; }
-    }
-    __syncthreads();
-    if (plane) {
-        for (uint32_t w = 0; w < wave; w++) { base_idx += s_tot[w]; base_op += s_tot[4u + w]; }
-    }
-    const uint32_t total_seq = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
-    // (a valid chunk's pieces add up to at most `cap` output bytes; a wild count is caught by the checks of P4)
-    if (total_seq < kLdsMinSeq || total_seq > kSyncStride * kSyncEvery) return false;       // uniform: too few / too many sequences for this decoder
-
-    // ---- P4: validate + write the records ----
-    if (plane) {
-        bool bad = false, saw_last = false;
-        uint32_t final_op = 0, near = 0;
-        uint32_t q = on_chain ? entry : kPosEnd, idx = base_idx, op = base_op;
-        while (ballot64(q < iend && q != piece_end && !bad) != 0ull) {
-            if (q < iend && q != piece_end && !bad) {
-                Seq sq;
-                bool fin = false;
-                uint32_t op2 = op;
-                if (!walk_step<G>(rd, q, iend, sq) || !G::check(sq, op2, cap, fin) || idx >= total_seq) bad = true;
-                else {
-                    const uint32_t w = sq.mlen == 0u ? 0u : ((sq.offset & 0xffffu) | (sq.mlen << 16));       // (a Snappy stream may END with a copy)
-                    table2[idx] = make_uint2(sq.lit_at | (sq.lit << 16), (op & 0xffffu) | (w << 16));      // 8-byte record (lds2_body)
-                    near += (w != 0u && sq.offset < 4096u) ? 1u : 0u;
-                    op = op2;
-                    if (fin) { final_op = op; saw_last = true; q = kPosEnd; }
-                    else { q = sq.next; idx += 1; }
-                }
-            }
-        }
-        if (near) atomicAdd(s_near, near);
-        if (on_chain && (bad || piece_end == kPosErr)) atomicOr(&s_tot[16], 1u);
-        if (on_chain && saw_last) { atomicAdd(&s_tot[17], 1u); s_tot[18] = final_op; s_tot[19] = idx + 1u; }
-    }
-    __syncthreads();
-    const uint32_t op_end = s_tot[18];
-    if (s_tot[16] != 0u || s_tot[17] != 1u || s_tot[19] != total_seq || !G::result_ok(op_end, cap) || op_end == 0u) return false;
-    nseq_out = total_seq;
-    U_out = op_end;
-    return true;
-}
 
 
 // kLinked (LZ4 frames with linked blocks, frame.hip): the workgroup takes a whole FRAME (frames[f] = first block index,

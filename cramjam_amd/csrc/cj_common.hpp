@@ -51,6 +51,9 @@ size_t lz4_lds2_tab_bytes(uint32_t grid);
 // the level-ordered workgroup decoder (lz4_decode_lvl.hip): same scratch, same counter; fused = the parse stage inside (sync unused)
 void launch_lz4_decode_lvl(const BatchArgs& a, const void* sync, void* meta, void* tabs, uint32_t* counter, uint32_t grid, hipStream_t s, int codec, bool fused);
 size_t lz4_lvl_tab_bytes(uint32_t grid);
+// the all-LDS level-ordered decoder (lz4_decode_lvl1.hip): one workgroup of 1024 threads per CU; takes the chunks of up to 4032
+// sequences and marks them done in meta, the rest is left to launch_lz4_decode_lvl
+void launch_lz4_decode_lvl1(const BatchArgs& a, const void* sync, void* meta, uint32_t* counter, uint32_t grid, hipStream_t s, int codec);
 size_t lz4_lds_scratch_sync_bytes(size_t n_chunks);
 size_t lz4_lds_scratch_meta_bytes(size_t n_chunks);
 // Encoders, large batches: besides the ten LDS-table wavefronts that fit a CU, `table_blocks` more wavefronts with their hash

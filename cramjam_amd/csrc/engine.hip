@@ -57,6 +57,7 @@ int launch_decode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a, hipStrea
     // the workgroup decoder: level-ordered dense resolver (lz4_decode_lvl.hip); CJ_DECODER=lds2 selects the bitmap resolver
     // (lz4_decode_lds.hip) for comparisons, CJ_FUSED=0 / 1 forces the separate / in-kernel parse at any batch size
     static const bool use_lvl = [] { const char* v = std::getenv("CJ_DECODER"); return !(v && std::strcmp(v, "lds2") == 0); }();
+    static const bool use_lvl1 = [] { const char* v = std::getenv("CJ_DECODER"); return !(v && std::strcmp(v, "lvl") == 0); }();
     static const int force_fused = [] { const char* v = std::getenv("CJ_FUSED"); return v ? std::atoi(v) : -1; }();
     const bool fused = force_fused >= 0 ? force_fused != 0 : a.n_chunks <= (uint32_t)CJ_FUSED_MAX_CHUNKS;
     std::lock_guard<std::mutex> lock(e->scratch_mu);
@@ -72,8 +73,10 @@ int launch_decode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a, hipStrea
         // validate, size, count sequences, sync points, route
         if (lz4) cj::launch_lz4_parse(a, e->d_sync.p, e->d_pmeta.p, s);
         else cj::launch_snappy_parse(a, e->d_sync.p, e->d_pmeta.p, s);
-        if (use_lvl) cj::launch_lz4_decode_lvl(a, e->d_sync.p, e->d_pmeta.p, e->d_tab.p, lists + 2, grid, s, codec, false);
-        else cj::launch_lz4_decode_lds2(a, e->d_sync.p, e->d_pmeta.p, e->d_tab.p, lists + 2, grid, s, codec);
+        if (use_lvl) {
+            if (use_lvl1) cj::launch_lz4_decode_lvl1(a, e->d_sync.p, e->d_pmeta.p, lists + 3, (uint32_t)e->n_cu, s, codec);   // chunks of up to 4032 sequences, all in LDS
+            cj::launch_lz4_decode_lvl(a, e->d_sync.p, e->d_pmeta.p, e->d_tab.p, lists + 2, grid, s, codec, false);            // what it left
+        } else cj::launch_lz4_decode_lds2(a, e->d_sync.p, e->d_pmeta.p, e->d_tab.p, lists + 2, grid, s, codec);
     }
     if (lz4) cj::launch_lz4_decode_routed(a, e->d_pmeta.p, s);                // few long runs / oversize chunks / errors
     else cj::launch_snappy_decode_routed(a, e->d_pmeta.p, s);

@@ -224,6 +224,7 @@ CJ_API int cj_bench_compare(const void* d_got, const uint64_t* d_got_off, const 
 CJ_API int cj_debug_lds_phase_cycles(unsigned long long* out8, int reset);
 /* the level-ordered decoder's counters (same flag): S0, D1/P, X, L, K, D2, D3, D4 cycles, chunks, levels, D3 barriers */
 CJ_API int cj_debug_lvl_phase_cycles(unsigned long long* out16, int reset);
+CJ_API int cj_debug_lvl1_phase_cycles(unsigned long long* out16, int reset);   /* the all-LDS variant (one workgroup per CU) */
 CJ_API long long cj_debug_forwarded_chunks(int reset);            /* chunks / slabs that went through the forwarding phase */
 CJ_API unsigned long long cj_debug_linked_lds_frames(void);       /* linked-block LZ4 frames decoded by the two-window decoder */
 /* large-stream path with its parse stage's absolute sync points handed back (tests compare them with a serial walk) */

@@ -336,7 +336,7 @@ def main():
                 continue
             nb = int(pl[8])
             print(name + " cycles/chunk: " + "  ".join("%s %d" % (nm, pl[i] // nb) for i, nm in enumerate(("S0", "D1/P", "X", "L", "K", "D2", "D3", "D4")))
-                      + "  | levels %.1f  D3 barriers %.1f  (chunks %d)" % (pl[9] / nb, pl[10] / nb, nb), file=sys.stderr)
+                      + "  | levels %.1f  D3 barriers %.1f  (chunks %d)  extra marks 11.. %s" % (pl[9] / nb, pl[10] / nb, nb, [int(pl[i] // nb) for i in range(11, 16)]), file=sys.stderr)
 
     # ---- verify at full size: every chunk's result and every output byte ----
     bytes_in = sum(b.bytes_in for b in batches)

@@ -54,10 +54,12 @@ int launch_decode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a, hipStrea
     if (a.flags & CJ_FLAG_FORCE_LDS_PER_CHUNK) mode = 2;
     if (mode == 0) { if (lz4) cj::launch_lz4_decode(a, s); else cj::launch_snappy_decode(a, s); return 0; }
     if (mode == 1) { if (lz4) cj::launch_lz4_decode_lanes(a, s); else cj::launch_snappy_decode_lanes(a, s); return 0; }
-    // the workgroup decoder: level-ordered dense resolver (lz4_decode_lvl.hip); CJ_DECODER=lds2 selects the bitmap resolver
-    // (lz4_decode_lds.hip) for comparisons, CJ_FUSED=0 / 1 forces the separate / in-kernel parse at any batch size
-    static const bool use_lvl = [] { const char* v = std::getenv("CJ_DECODER"); return !(v && std::strcmp(v, "lds2") == 0); }();
-    static const bool use_lvl1 = [] { const char* v = std::getenv("CJ_DECODER"); return !(v && std::strcmp(v, "lvl") == 0); }();
+    // the workgroup decoder: the bitmap resolver (lz4_decode_lds.hip).  CJ_DECODER=lvl selects the level-ordered dense resolver
+    // (lz4_decode_lvl.hip), CJ_DECODER=lvl1 puts its all-LDS single-workgroup variant (lz4_decode_lvl1.hip) in front of it: both are
+    // bit-exact and both lost to the bitmap resolver on the benchmark data (profiles/r03/experiments); CJ_FUSED=0 / 1 forces the
+    // separate / in-kernel parse at any batch size
+    static const int which = [] { const char* v = std::getenv("CJ_DECODER"); return !v ? 0 : std::strcmp(v, "lvl") == 0 ? 1 : std::strcmp(v, "lvl1") == 0 ? 2 : 0; }();
+    static const bool use_lvl = which != 0, use_lvl1 = which == 2;
     static const int force_fused = [] { const char* v = std::getenv("CJ_FUSED"); return v ? std::atoi(v) : -1; }();
     const bool fused = force_fused >= 0 ? force_fused != 0 : a.n_chunks <= (uint32_t)CJ_FUSED_MAX_CHUNKS;
     std::lock_guard<std::mutex> lock(e->scratch_mu);

@@ -143,6 +143,24 @@ __device__ __forceinline__ void lvl_match_copy(bool act, uint32_t a_out, uint8_t
     }
 }
 
+// the same for a FULL wavefront of a large level: when every active lane holds a short match that does not overlap its source (the
+// rule on the benchmark data) it is one straight dword-grid copy, no loop and no long-run test
+__device__ __forceinline__ void lvl_match_copy_dense(bool act, uint32_t a_out, uint8_t* s_out, uint32_t dst, uint32_t off, uint32_t m, uint32_t dummy_w) {
+    if (ballot64(act && (off < m || m > 32u)) != 0ull) { lvl_match_copy(act, a_out, s_out, dst, off, m, dummy_w); return; }
+    const uint32_t at = a_out + dst;
+    if (ballot64(act && m > 16u) != 0ull) { if (act) lvl_copy32(at, at - off, m, dummy_w); }
+    else if (act) lvl_copy16(at, at - off, m, dummy_w);
+}
+
+// the same for a level of a few matches (the tail of the dependency DAG, copied by one wavefront): with a handful of active lanes an
+// LDS access at its exact byte address costs about one cycle per active lane, so a match of up to 32 bytes is 2-4 reads and 2-4
+// stores (lds_copy_sparse) instead of the ~40 instructions of the dword-grid copy.  Everything else takes lvl_match_copy.
+__device__ __forceinline__ void lvl_match_copy_sparse(bool act, uint32_t a_out, uint8_t* s_out, uint32_t dst, uint32_t off, uint32_t m, uint32_t dummy_w) {
+    const bool fast = act && off >= m && m <= 32u;
+    if (fast) lds_copy_sparse(a_out + dst, a_out + dst - off, m);
+    if (ballot64(act && !fast) != 0ull) lvl_match_copy(act && !fast, a_out, s_out, dst, off, m, dummy_w);
+}
+
 // position index lookup: record that holds output byte p, and whether p lies in its match part
 __device__ __forceinline__ void lvl_lookup(uint32_t a_A, uint32_t a_C, uint32_t p, uint32_t& q, bool& inm) {
     const uint32_t g = p >> 4, i = p & 15u;

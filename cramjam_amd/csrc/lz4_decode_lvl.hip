@@ -51,9 +51,9 @@ constexpr uint32_t kLvBytes = kLvOffFused;                      // 74 128 B
 constexpr uint32_t kLvBytesFused = kLvOffFused + kFusedAux;     // 80 272 B: two workgroups per CU (163 840 B)
 static_assert(2u * kLvBytesFused <= 163840u, "two workgroups per CU");
 static_assert(kLvOffStart + 2u * (kLvMaxLevel + 3u) <= kLvOffVars, "lstart fits in front of the variables");
-constexpr uint32_t kLvSlotBytes = 3u * kLvMaxRec * 16u / 2u;    // per workgroup in the table scratch: 8-byte records, then the sorted descriptors
+constexpr uint32_t kLvSlotBytes = 24u * kLvMaxRec + 1024u;      // per workgroup in the table scratch: 8-byte records, then the two sorted lists
 constexpr uint32_t kLvSortedOff = (kLvMaxRec + 64u) * 8u;
-static_assert(kLvSortedOff + kLvMaxRec * 8u <= kLvSlotBytes, "records + sorted descriptors fit the slot");
+static_assert(kLvSortedOff + 2u * kLvMaxRec * 8u <= kLvSlotBytes, "records + sorted descriptors fit the slot");
 
 __device__ unsigned long long g_lvl_phase_cycles[16];           // S0, D1/P, X, L, K, D2, D3, D4, chunks, levels, barriers of D3 (flag 0x1000)
 #define CJ_LV_MARK(idx)                                                                 \
@@ -83,6 +83,7 @@ __device__ __forceinline__ void lvl_body(const BatchArgs& a, const uint2* sync, 
     uint8_t* slot = tabs + (size_t)blockIdx.x * kLvSlotBytes;
     uint2* table2 = reinterpret_cast<uint2*>(slot);
     uint2* sorted = reinterpret_cast<uint2*>(slot + kLvSortedOff);
+    uint2* sorted_s = sorted + kLvMaxRec;
     const bool prof = (a.flags & 0x1000u) != 0;
     unsigned long long t_prev = prof ? __builtin_readcyclecounter() : 0ull;
     uint32_t next_c = 0;
@@ -234,71 +235,106 @@ __device__ __forceinline__ void lvl_body(const BatchArgs& a, const uint2* sync, 
         __syncthreads();                                     // the table is complete (and the staged bytes are dead)
         CJ_LV_MARK(1);
 
-        // ---- X: the position index ----
+        // ---- the chunk's records in REGISTERS: wavefront w owns the batches w, w + 8, ... of 64 records; up to 8 batches (chunks of up to
+        //      4 096 sequences) are loaded ONCE here and serve X, L, K and D2; longer chunks reload their groups of 8 batches per phase.
+        //      (A dependent global round trip costs 3-4 k cycles under load: l01 paid one per batch and phase.) ----
+        const uint32_t nbat = (nseq + 63u) >> 6, ng = (nbat + 63u) >> 6;
+        const bool one = ng == 1u;
+        uint32_t RX[8], RY[8], RN[8];                       // lit_src | lit << 16, start | offset << 16, start of the next record (16 bits)
+        const auto load_group = [&](uint32_t g) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t r = (wave + 8u * (8u * g + (uint32_t)j)) * 64u + lane;
+                uint4 t = make_uint4(0u, 0u, 0u, 0u);
+                if (r < nseq) t = ld16u(reinterpret_cast<const uint8_t*>(table2 + r));
+                RX[j] = t.x; RY[j] = t.y; RN[j] = t.w & 0xffffu;
+            }
+        };
+#define CJ_LV_FOR_BATCHES(...)                                                                    \
+        for (uint32_t g_ = 0; g_ < ng; g_++) {                                                    \
+            if (!one) load_group(g_);                                                             \
+            _Pragma("unroll") for (int j = 0; j < 8; j++) {                                       \
+                const uint32_t rbase = (wave + 8u * (8u * g_ + (uint32_t)j)) * 64u;               \
+                if (rbase < nseq) { const uint32_t r = rbase + lane; const bool valid = r < nseq; \
+                    const uint32_t lit = RX[j] >> 16, start = RY[j] & 0xffffu, off = RY[j] >> 16, dst = start + lit;       \
+                    const uint32_t m = off ? (RN[j] - dst) & 0xffffu : 0u;                        \
+                    __VA_ARGS__ } } }
+        if (one) load_group(0u);
+        if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CJ_LV_MARK(11); }      // 11: the records' round trip (global, L2)
+
+        // ---- X: the position index.  Record r owns the granules whose first byte lies in (start of r, start of r + 1] ----
         {
             uint4* z = reinterpret_cast<uint4*>(smem + kLvOffA);
             for (uint32_t i = tid; i < 1024u; i += kLvThreads) z[i] = make_uint4(0u, 0u, 0u, 0u);           // A: 16 KiB
             uint4* lv = reinterpret_cast<uint4*>(smem + kLvOffLvl);
-            for (uint32_t i = tid; i < (nseq + 7u) / 8u; i += kLvThreads) lv[i] = make_uint4(~0u, ~0u, ~0u, ~0u);   // every level unknown
+            for (uint32_t i = tid; i < (nseq + 7u) / 8u + 1u; i += kLvThreads) lv[i] = make_uint4(~0u, ~0u, ~0u, ~0u);   // every level unknown
             for (uint32_t i = tid; i < kLvMaxLevel + 3u; i += kLvThreads) s_hist[i] = 0u;
+            if (tid == 0) lds_st16(a_C, 0u);
         }
         __syncthreads();
-        const uint32_t g_last = (U - 1u) >> 4;
-        for (uint32_t r = tid; r < nseq; r += kLvThreads) {
-            const uint4 t = ld16u(reinterpret_cast<const uint8_t*>(table2 + r));                     // record r and the start of r + 1
-            const uint2 pr = r ? table2[r - 1u] : make_uint2(0u, 0u);
-            const uint32_t lit = t.x >> 16, start = t.y & 0xffffu, off = t.y >> 16, dst = start + lit;
-            const uint32_t m = off ? ((t.w & 0xffffu) - dst) & 0xffffu : 0u;
-            asm volatile("ds_or_b32 %0, %1" :: "v"(a_A + 4u * (start >> 4)), "v"(1u << (start & 15u)) : "memory");
-            if (m) asm volatile("ds_or_b32 %0, %1" :: "v"(a_A + 4u * (dst >> 4)), "v"(0x10000u << (dst & 15u)) : "memory");
-            // granules whose first byte lies in (start of r - 1, start of r]: the first record that starts at or after them is r
-            const uint32_t pstart = pr.y & 0xffffu, pdst = pstart + (pr.x >> 16), pm_ = pr.y >> 16;
-            const uint32_t gr = start >> 4;
-            for (uint32_t g = r ? (pstart >> 4) + 1u : 0u; g <= gr; g++)
-                lds_st16(a_C + 2u * g, r | ((r && pm_ && 16u * g >= pdst && 16u * g < start) ? 0x8000u : 0u));
-            if (r + 1u == nseq)                               // behind the last record's start
-                for (uint32_t g = gr + 1u; g <= g_last; g++) lds_st16(a_C + 2u * g, nseq | ((m && 16u * g >= dst) ? 0x8000u : 0u));
-        }
+        CJ_LV_MARK(12);                                      // 12: X's clears + barrier
+        CJ_LV_FOR_BATCHES({
+            if (valid) {
+                const uint32_t nstart = dst + m;                          // the start of r + 1 (not folded to 16 bits)
+                asm volatile("ds_or_b32 %0, %1" :: "v"(a_A + 4u * (start >> 4)), "v"(1u << (start & 15u)) : "memory");
+                if (m) asm volatile("ds_or_b32 %0, %1" :: "v"(a_A + 4u * (dst >> 4)), "v"(0x10000u << (dst & 15u)) : "memory");
+                for (uint32_t g = (start >> 4) + 1u; g <= (nstart >> 4); g++)
+                    lds_st16(a_C + 2u * g, (r + 1u) | ((m && 16u * g >= dst && 16u * g < nstart) ? 0x8000u : 0u));
+            }
+        })
         __syncthreads();
         CJ_LV_MARK(2);
 
         // ---- L: levels ----
         {
             uint32_t my_max = 0;
-            for (uint32_t base = wave * 64u; base < nseq; base += kLvThreads) {
-                const uint32_t r = base + lane;
-                const bool valid = r < nseq;
-                uint4 t = make_uint4(0u, 0u, 0u, 0u);
-                if (valid) t = ld16u(reinterpret_cast<const uint8_t*>(table2 + r));
-                const uint32_t lit = t.x >> 16, start = t.y & 0xffffu, off = t.y >> 16, dst = start + lit;
-                const uint32_t m = off ? ((t.w & 0xffffu) - dst) & 0xffffu : 0u;
+            CJ_LV_FOR_BATCHES({
                 bool pend = valid && m > 0u;
                 if (valid && m == 0u) lds_st16(a_lvl + 2u * r, 0u);
                 int32_t qa = 0, qb = -1;
-                if (pend) {
-                    const uint32_t s0 = dst - off, need = off < m ? off : m;
-                    uint32_t q0, q1; bool i0, i1;
-                    lvl_lookup(a_A, a_C, s0, q0, i0);
-                    lvl_lookup(a_A, a_C, s0 + need - 1u, q1, i1);
-                    qa = (int32_t)q0;
-                    qb = i1 ? (int32_t)q1 : (int32_t)q1 - 1;
+                if (pend) {                                               // both index lookups behind ONE wait
+                    const uint32_t s0 = dst - off, e1 = s0 + (off < m ? off : m) - 1u;
+                    uint32_t a0, c0, a1, c1;
+                    asm volatile("ds_read_b32 %0, %4\n\tds_read_u16 %1, %5\n\tds_read_b32 %2, %6\n\tds_read_u16 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(a0), "=&v"(c0), "=&v"(a1), "=&v"(c1)
+                                 : "v"(a_A + 4u * (s0 >> 4)), "v"(a_C + 2u * (s0 >> 4)), "v"(a_A + 4u * (e1 >> 4)), "v"(a_C + 2u * (e1 >> 4)) : "memory");
+                    const uint32_t k0 = (2u << (s0 & 15u)) - 1u, k1 = (2u << (e1 & 15u)) - 1u;
+                    const uint32_t s1 = a1 & k1, d1 = (a1 >> 16) & k1;
+                    qa = (int32_t)((c0 & 0x7fffu) + (uint32_t)__popc(a0 & k0) - 1u);
+                    const int32_t q1 = (int32_t)((c1 & 0x7fffu) + (uint32_t)__popc(s1) - 1u);
+                    const bool inm = (s1 | d1) == 0u ? (c1 >> 15) != 0u : (d1 != 0u && __clz((int)d1) <= __clz((int)s1));
+                    qb = inm ? q1 : q1 - 1;
                     qb = qb < (int32_t)r - 1 ? qb : (int32_t)r - 1;
                 }
+                const int32_t b4 = qa & ~1;
+                const bool shortr = qb - b4 <= 3;                         // the whole range in one aligned pair of dwords (the common case)
                 uint32_t spins = 0;
                 while (ballot64(pend) != 0ull) {
                     if (pend) {
                         uint32_t acc = 0;
                         bool fail = false;
-                        for (int32_t cur = qa; cur <= qb && !fail;) {
-                            const int32_t b4 = cur & ~1;
-                            uint64_t e;
-                            asm volatile("ds_read2_b32 %0, %1 offset1:1\n\ts_waitcnt lgkmcnt(0)" : "=v"(e) : "v"(a_lvl + 2u * (uint32_t)b4) : "memory");
-#pragma unroll
-                            for (int j = 0; j < 4; j++) {
-                                const uint32_t v = (uint32_t)(e >> (16 * j)) & 0xffffu;
-                                if (b4 + j >= cur && b4 + j <= qb) { fail = fail || v == kLvUnknown; acc = v > acc ? v : acc; }
+                        if (shortr) {
+                            if (qa <= qb) {
+                                uint64_t e;
+                                asm volatile("ds_read2_b32 %0, %1 offset1:1\n\ts_waitcnt lgkmcnt(0)" : "=v"(e) : "v"(a_lvl + 2u * (uint32_t)b4) : "memory");
+_Pragma("unroll")
+                                for (int q = 0; q < 4; q++) {
+                                    const uint32_t v = (uint32_t)(e >> (16 * q)) & 0xffffu;
+                                    if (b4 + q >= qa && b4 + q <= qb) { fail = fail || v == kLvUnknown; acc = v > acc ? v : acc; }
+                                }
                             }
-                            cur = b4 + 4;
+                        } else {
+                            for (int32_t cur = qa; cur <= qb && !fail;) {
+                                const int32_t c4 = cur & ~1;
+                                uint64_t e;
+                                asm volatile("ds_read2_b32 %0, %1 offset1:1\n\ts_waitcnt lgkmcnt(0)" : "=v"(e) : "v"(a_lvl + 2u * (uint32_t)c4) : "memory");
+_Pragma("unroll")
+                                for (int q = 0; q < 4; q++) {
+                                    const uint32_t v = (uint32_t)(e >> (16 * q)) & 0xffffu;
+                                    if (c4 + q >= cur && c4 + q <= qb) { fail = fail || v == kLvUnknown; acc = v > acc ? v : acc; }
+                                }
+                                cur = c4 + 4;
+                            }
                         }
                         if (!fail) {
                             uint32_t L = acc + 1u;
@@ -310,8 +346,12 @@ __device__ __forceinline__ void lvl_body(const BatchArgs& a, const uint2* sync, 
                         }
                     }
                     if (++spins > kSpinLimit) { s_var[2] = 1u; break; }
+#ifndef CJ_LV_SPIN_SLEEP
+#define CJ_LV_SPIN_SLEEP 1
+#endif
+                    if (spins > 1u) __builtin_amdgcn_s_sleep(CJ_LV_SPIN_SLEEP);           // producers first: a spinning wavefront takes issue slots and LDS cycles
                 }
-            }
+            })
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)my_max, d, 64); my_max = o > my_max ? o : my_max; }
             if (lane == 0 && my_max) atomicMax(&s_var[1], my_max);
@@ -324,39 +364,52 @@ __device__ __forceinline__ void lvl_body(const BatchArgs& a, const uint2* sync, 
             continue;                                        // (uniform; the barrier at the top of the loop orders the LDS reuse)
         }
 
-        // ---- K: slots per level, descriptors sorted by level ----
+        // ---- K: slots per level, descriptors sorted by level into TWO lists: the levels of more than 64 matches (copied by all
+        //      wavefronts, one lane per match) and the small ones (copied by wavefront 0 alone).  hist[L] becomes the level's next free
+        //      slot (bit 31: small list) and ends up as its END; lstart[L] keeps its start (bit 15: small list) ----
         if (wave == 0) {
-            uint32_t cnt[16], sum = 0;
+            uint32_t cnt[16], sumb = 0, sums = 0;
 #pragma unroll
-            for (int j = 0; j < 16; j++) { cnt[j] = s_hist[16u * lane + (uint32_t)j]; sum += cnt[j]; }
-            uint32_t total;
-            uint32_t run = wave_excl_scan_add32(sum, total);
+            for (int j = 0; j < 16; j++) {
+                cnt[j] = s_hist[16u * lane + (uint32_t)j];
+                if (cnt[j] > 64u) sumb += cnt[j]; else sums += cnt[j];
+            }
+            uint32_t totb, tots;
+            uint32_t runb = wave_excl_scan_add32(sumb, totb), runs = wave_excl_scan_add32(sums, tots);
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 const uint32_t L = 16u * lane + (uint32_t)j;
-                s_hist[L] = run;
-                s_start[L] = (uint16_t)run;
-                run += cnt[j];
+                const bool small = cnt[j] <= 64u;
+                s_hist[L] = small ? (runs | 0x80000000u) : runb;
+                s_start[L] = (uint16_t)(small ? (runs | 0x8000u) : runb);
+                if (small) runs += cnt[j]; else runb += cnt[j];
             }
-            if (lane == 0) { s_var[4] = total; s_start[kLvMaxLevel + 1u] = (uint16_t)total; s_start[kLvMaxLevel + 2u] = (uint16_t)total; }
+            if (lane == 0) { s_var[4] = totb; s_var[5] = tots; }
         }
         __syncthreads();
-        for (uint32_t r = tid; r < nseq; r += kLvThreads) {
-            const uint32_t L = lds_ld16(a_lvl + 2u * r);
-            if (L) {
-                const uint4 t = ld16u(reinterpret_cast<const uint8_t*>(table2 + r));
-                const uint32_t lit = t.x >> 16, start = t.y & 0xffffu, off = t.y >> 16, dst = start + lit;
-                const uint32_t m = ((t.w & 0xffffu) - dst) & 0xffffu;
+        CJ_LV_FOR_BATCHES({
+            if (valid && m) {
+                const uint32_t L = lds_ld16(a_lvl + 2u * r);
                 uint32_t sl;
                 asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(sl) : "v"(a_hist + 4u * L), "v"(1u) : "memory");
-                sorted[sl] = make_uint2(dst | (off << 16), m | (L << 16));
+                uint2* lst = (sl >> 31) ? sorted_s : sorted;
+                lst[sl & 0x7fffffffu] = make_uint2(dst | (off << 16), m | (L << 16));
             }
-        }
-        __syncthreads();                                     // the sorted list is complete; the window's scratch is dead
+        })
+        __syncthreads();                                     // the sorted lists are complete; the window's scratch is dead
         CJ_LV_MARK(4);
-        const uint32_t nm = s_var[4];
+        // D3's descriptors, requested NOW and used after D2 (a global round trip is ~6 k cycles here: none of them may sit between two
+        // levels).  Thread t holds the entries 512 k + t of the large list for eight k, lane l of wavefront 0 the entries 64 k + l of
+        // the small list for four k; longer lists are refilled block by block, eight / four blocks ahead.
+        const uint32_t nbig = s_var[4], nsmall = s_var[5];
+        uint2 EB[8], ES[4];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { EB[k] = make_uint2(0u, 0u); if (512u * (uint32_t)k + tid < nbig) EB[k] = sorted[512u * (uint32_t)k + tid]; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) { ES[k] = make_uint2(0u, 0u); if (wave == 0u && 64u * (uint32_t)k + lane < nsmall) ES[k] = sorted_s[64u * (uint32_t)k + lane]; }
 
-        // ---- D2: literals, one lane per record: global -> window ----
+        // ---- D2: literals, one lane per record: global -> window (the next batch's records are requested before the current batch
+        //      is processed) ----
         {
             uint4 rec_nx = make_uint4(0, 0, 0, 0);
             if (wave * 64u + lane < nseq) rec_nx = ld16u(reinterpret_cast<const uint8_t*>(table2 + wave * 64u + lane));
@@ -372,6 +425,13 @@ __device__ __forceinline__ void lvl_body(const BatchArgs& a, const uint2* sync, 
                     wave_copy_to_lds(a_out + rdlane(dst, l), in + rdlane(src, l), rdlane(n, l));
                     if (lane == l) n = 0;
                 }
+                // the chunk's last bytes (a vector load would leave the 16-byte granule of the last input byte): byte by byte
+                if (ballot64(n > 0u && src + n + 32u > safe_end) != 0ull) {
+                    if (n > 0u && src + n + 32u > safe_end) {
+                        for (uint32_t k = 0; k < n; k++) lds_st8(a_out + dst + k, in[src + k]);
+                        n = 0u;
+                    }
+                }
                 while (ballot64(n > 0u) != 0ull) {
                     const uint32_t hb = dst & 3u;
                     const bool wide = ballot64(n + hb > 16u) != 0ull;             // (wave-uniform) 32 bytes of the grid per pass instead of 16
@@ -379,38 +439,13 @@ __device__ __forceinline__ void lvl_body(const BatchArgs& a, const uint2* sync, 
                     const uint32_t step = n < room ? n : room;
                     if (step > 0u) {
                         const uint8_t* g = in + src - hb;                         // the source, shifted onto the destination's dword grid
-                        const bool inside = src >= hb && src - hb + (wide ? 32u : 16u) <= safe_end;
-                        if (wide) {
-                            uint32_t v[8];
-                            if (inside) {
-                                const uint4 x = ld16u(g), y = ld16u(g + 16);
-                                v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
-                            } else {                                              // the chunk's first / last bytes: aligned dwords, clamped
-                                const uint8_t* g0 = in + src;
-                                const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(g0) & 3u);
-                                const DW<10> w = gl_ld_aligned<10>(g0 - sh, last_dw);
-                                uint32_t u[9];
-#pragma unroll
-                                for (int k = 0; k < 9; k++) u[k] = __builtin_amdgcn_alignbyte(w.w[k + 1], w.w[k], sh);      // u[k] = source bytes 4k ..
-                                v[0] = u[0] << (8u * hb);
-#pragma unroll
-                                for (int k = 1; k < 8; k++) v[k] = hb ? __builtin_amdgcn_alignbyte(u[k], u[k - 1], 4u - hb) : u[k];
-                            }
+                        if (wide) {                                               // (the first record starts at destination 0: src >= hb)
+                            const uint4 x = ld16u(g), y = ld16u(g + 16);
+                            const uint32_t v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
                             lds_store_grid<8>(v, (a_out + dst) & ~3u, hb, step, dummy_w);
                         } else {
-                            uint32_t v[4];
-                            if (inside) { const uint4 x = ld16u(g); v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; }
-                            else {
-                                const uint8_t* g0 = in + src;
-                                const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(g0) & 3u);
-                                const DW<6> w = gl_ld_aligned<6>(g0 - sh, last_dw);
-                                uint32_t u[5];
-#pragma unroll
-                                for (int k = 0; k < 5; k++) u[k] = __builtin_amdgcn_alignbyte(w.w[k + 1], w.w[k], sh);
-                                v[0] = u[0] << (8u * hb);
-#pragma unroll
-                                for (int k = 1; k < 4; k++) v[k] = hb ? __builtin_amdgcn_alignbyte(u[k], u[k - 1], 4u - hb) : u[k];
-                            }
+                            const uint4 x = ld16u(g);
+                            const uint32_t v[4] = {x.x, x.y, x.z, x.w};
                             lds_store_grid<4>(v, (a_out + dst) & ~3u, hb, step, dummy_w);
                         }
                         n -= step; src += step; dst += step;
@@ -421,50 +456,82 @@ __device__ __forceinline__ void lvl_body(const BatchArgs& a, const uint2* sync, 
         __syncthreads();
         CJ_LV_MARK(5);
 
-        // ---- D3: matches, level by level ----
+#ifdef CJ_LV_D3_PRIO
+        __builtin_amdgcn_s_setprio(3);
+#endif
+        // ---- D3: matches, level by level.  A wavefront spends instructions only on the levels it takes part in: start / end / kind of
+        //      64 levels sit in the lanes of two registers, the large levels are one bit mask, and what is left per level for a wavefront
+        //      without work is a bit test and the barrier.  Small levels between two large ones are copied by wavefront 0 alone, one
+        //      after the other WITHOUT barriers (the DS operations of a wavefront execute in order). ----
         {
-            uint32_t pos = 0, L = 1, nbar = 0;
-            uint2 ent = make_uint2(0u, 0u);
-            if (tid < nm) ent = sorted[tid];
-            while (L <= nlev) {
-                // lane i: the end of level L + i
-                uint32_t li = L + 1u + lane;
-                li = li > nlev + 1u ? nlev + 1u : li;
-                const uint32_t le = li > nlev ? nm : lds_ld16(a_start + 2u * li);
-                const uint32_t e0 = rdlane(le, 0);
-                const bool multi = e0 - pos > 64u;
-                uint32_t seg_end = e0, Lnext = L + 1u;
-                if (!multi) {
-                    const uint64_t okm = ballot64(le - pos <= 64u && L + lane <= nlev);
-                    const uint32_t cnt = (uint32_t)__popcll(okm);                  // (the ends are monotonic: the low `cnt` lanes)
-                    seg_end = rdlane(le, uni(cnt - 1u));
-                    Lnext = L + cnt;
+            const uint32_t w64 = wave * 64u;
+            uint32_t nbar = 0, kb = 0, ks = 0;                  // EB[0] = block kb of the large list, ES[0] = block ks of the small list
+            bool dirty = false;                                  // wavefront 0 has copied small levels since the last barrier
+            for (uint32_t Lb = 1; Lb <= nlev; Lb += 64u) {
+                const uint32_t cnt64 = nlev - Lb + 1u < 64u ? nlev - Lb + 1u : 64u;
+                uint32_t st = 0, en = 0;                                                     // lane i: level Lb + i
+                if (lane < cnt64) {
+                    asm volatile("ds_read_u16 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(st), "=&v"(en)
+                                 : "v"(a_start + 2u * (Lb + lane)), "v"(a_hist + 4u * (Lb + lane)) : "memory");
                 }
-                bool next_multi = false;
-                if (Lnext <= nlev) {
-                    const uint32_t k = Lnext - L;                                  // lane k holds the end of level Lnext
-                    const uint32_t en = k < 64u ? rdlane(le, uni(k)) : (Lnext + 1u > nlev ? nm : (uint32_t)s_start[Lnext + 1u]);
-                    next_multi = en - seg_end > 64u;
-                }
-                uint2 ent_nx = make_uint2(0u, 0u);
-                if (seg_end + tid < nm) ent_nx = sorted[seg_end + tid];           // the next segment's descriptors, one segment ahead
-                if (multi) {
-                    lvl_match_copy(pos + tid < seg_end, a_out, s_out, ent.x & 0xffffu, ent.x >> 16, ent.y & 0xffffu, dummy_w);
-                    for (uint32_t b = pos + kLvThreads; b < seg_end; b += kLvThreads) {
-                        uint2 e2 = make_uint2(0u, 0u);
-                        if (b + tid < seg_end) e2 = sorted[b + tid];
-                        lvl_match_copy(b + tid < seg_end, a_out, s_out, e2.x & 0xffffu, e2.x >> 16, e2.y & 0xffffu, dummy_w);
+                const uint64_t mm = ballot64(lane < cnt64 && (st >> 15) == 0u);              // the large levels
+                st &= 0x7fffu; en &= 0x7fffffffu;
+                uint32_t i = 0;
+                while (i < cnt64) {
+                    if ((mm >> i) & 1ull) {
+                        uint32_t ls = rdlane(st, uni(i));
+                        const uint32_t le = rdlane(en, uni(i));
+                        if (dirty) { __syncthreads(); nbar += 1; dirty = false; }
+                        while (ls < le) {
+                            while (ls >= 512u * (kb + 1u)) {                                 // (uniform) next block of the large list
+#pragma unroll
+                                for (int k = 0; k < 7; k++) EB[k] = EB[k + 1];
+                                kb += 1u;
+                                EB[7] = make_uint2(0u, 0u);
+                                if (512u * (kb + 7u) + tid < nbig) EB[7] = sorted[512u * (kb + 7u) + tid];
+                            }
+                            const uint32_t part = le < 512u * (kb + 1u) ? le : 512u * (kb + 1u);
+                            const uint32_t e = 512u * kb + tid;
+                            if (512u * kb + w64 < part && 512u * kb + w64 + 64u > ls)        // this wavefront holds descriptors of [ls, part)
+                                lvl_match_copy_dense(e >= ls && e < part, a_out, s_out, EB[0].x & 0xffffu, EB[0].x >> 16, EB[0].y & 0xffffu, dummy_w);
+                            ls = part;
+                        }
+                        __syncthreads(); nbar += 1;
+                        i += 1u;
+                    } else {
+                        const uint64_t rest = mm >> i;
+                        const uint32_t j = rest ? i + ctz64(rest) : cnt64;             // the small levels i .. j - 1
+                        if (wave == 0u) {
+                            for (uint32_t k2 = i; k2 < j; k2++) {
+                                uint32_t ls = rdlane(st, uni(k2));
+                                const uint32_t le = rdlane(en, uni(k2));
+                                while (ls < le) {
+                                    while (ls >= 64u * (ks + 1u)) {
+#pragma unroll
+                                        for (int k = 0; k < 3; k++) ES[k] = ES[k + 1];
+                                        ks += 1u;
+                                        ES[3] = make_uint2(0u, 0u);
+                                        if (64u * (ks + 3u) + lane < nsmall) ES[3] = sorted_s[64u * (ks + 3u) + lane];
+                                    }
+                                    const uint32_t part = le < 64u * (ks + 1u) ? le : 64u * (ks + 1u);
+                                    const uint32_t e = 64u * ks + lane;
+                                    lvl_match_copy_sparse(e >= ls && e < part, a_out, s_out, ES[0].x & 0xffffu, ES[0].x >> 16, ES[0].y & 0xffffu, dummy_w);
+                                    ls = part;
+                                }
+                            }
+                        }
+                        dirty = true;
+                        i = j;
                     }
-                } else if (wave == 0u) {
-                    const uint32_t nseg = seg_end - pos, lev = ent.y >> 16;
-                    for (uint32_t Lc = L; Lc < Lnext; Lc++)
-                        lvl_match_copy(lane < nseg && lev == Lc, a_out, s_out, ent.x & 0xffffu, ent.x >> 16, ent.y & 0xffffu, dummy_w);
                 }
-                if (multi || next_multi || Lnext > nlev) { __syncthreads(); nbar += 1; }
-                pos = seg_end; L = Lnext; ent = ent_nx;
             }
+            if (dirty || nlev == 0u) { __syncthreads(); nbar += 1; }
             if (prof && tid == 0) { atomicAdd(&g_lvl_phase_cycles[9], (unsigned long long)nlev); atomicAdd(&g_lvl_phase_cycles[10], (unsigned long long)nbar); }
         }
+#undef CJ_LV_FOR_BATCHES
+#ifdef CJ_LV_D3_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         CJ_LV_MARK(6);
 
         // ---- D4: stream the window out (16 B per lane), exact tail ----

@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--chunk-bytes", type=int, default=None)
     ap.add_argument("--unique", type=int, default=8192, help="distinct chunks generated per GPU; replicated device-side to distinct addresses")
     ap.add_argument("--codec", default="lz4", choices=["lz4", "snappy"])
+    ap.add_argument("--data", default="synth-v1", choices=["synth-v1", "corpus64k"],
+                    help="corpus64k: the full 64 KiB chunks of the reference's benchmark files that travel with the tests (tests/golden/corpus), tiled to --chunks (SURVEY.md §8d)")
     ap.add_argument("--op", default="decompress", choices=["decompress", "compress", "roundtrip"],
                     help="roundtrip = one compress + one decompress of the batch per step (configs[2] with --codec snappy)")
     ap.add_argument("--workload", default="default", choices=["default", "mixed256k"])
@@ -100,13 +102,34 @@ class Batch:
     pass
 
 
-def build_batch(N, L, eng, dev, codec, op_dec, S, U, NCH, first_index, compressor, torch, np):
-    """U unique synth-v1 chunks (indices first_index ..) generated on the device, compressed (decompress workloads),
-    replicated device-side to NCH chunks at distinct addresses.  Returns a Batch."""
+def corpus_chunks(S):
+    """every full S-byte chunk of the benchmark-corpus files under tests/golden/corpus (data fixtures of the reference's
+    benchmarks/test_bench.py:38-64, sha256-pinned by manifest.json), in file order"""
+    import bz2
+    import hashlib
+    import json
+    d = os.path.join(ROOT, "tests", "golden", "corpus")
+    man = json.load(open(os.path.join(d, "manifest.json")))["files"]
+    out = []
+    for name in sorted(man):
+        raw = bz2.decompress(open(os.path.join(d, name + ".bz2"), "rb").read())
+        assert hashlib.sha256(raw).hexdigest() == man[name]["sha256"], name
+        out += [raw[i:i + S] for i in range(0, len(raw) - S + 1, S)]
+    return out, sorted(man)
+
+
+def build_batch(N, L, eng, dev, codec, op_dec, S, U, NCH, first_index, compressor, torch, np, data="synth-v1"):
+    """U unique chunks — synth-v1 (indices first_index ..) generated on the device, or the corpus chunks — compressed
+    (decompress workloads), replicated device-side to NCH chunks at distinct addresses.  Returns a Batch."""
     b = Batch()
     b.codec, b.dec, b.S, b.U, b.NCH, b.eng = codec, op_dec, S, U, NCH, eng
-    raw = torch.empty(U * S, dtype=torch.uint8, device=dev)
-    N.check(L.cj_bench_synth_v1(raw.data_ptr(), S, S, first_index, U, 0x5EED, None))
+    if data == "corpus64k":
+        chunks, _ = corpus_chunks(S)
+        assert len(chunks) >= U
+        raw = torch.from_numpy(np.frombuffer(b"".join(chunks[:U]), dtype=np.uint8).copy()).to(dev)
+    else:
+        raw = torch.empty(U * S, dtype=torch.uint8, device=dev)
+        N.check(L.cj_bench_synth_v1(raw.data_ptr(), S, S, first_index, U, 0x5EED, None))
     torch.cuda.synchronize()
     b.raw = raw
     bound = L.cj_lz4_block_compress_bound(S, 0) if codec == N.CODEC_LZ4_BLOCK else L.cj_snappy_raw_max_compress_len(S)
@@ -245,6 +268,8 @@ def main():
     use_dist = world > 1 or os.environ.get("CJ_FORCE_DIST") == "1"
     if use_dist:
         dist.init_process_group("nccl", device_id=dev)
+        dist.barrier()
+        C.CDLL(None).fflush(None)          # RCCL's version banner sits in C stdio's buffer: out now, so that the JSON line is the last line
     L = N.lib()
     eng = N.Engine(local)
 
@@ -254,6 +279,12 @@ def main():
     U = min(args.unique, NCH)
     if mixed:
         U = min(U, 2048)
+    corpus_files = None
+    if args.data == "corpus64k":
+        if mixed or S != 65536:
+            raise SystemExit("bench.py: --data corpus64k is the 64 KiB single-codec workload")
+        cc, corpus_files = corpus_chunks(S)
+        U = min(U, len(cc))
     codec = N.CODEC_LZ4_BLOCK if args.codec == "lz4" else N.CODEC_SNAPPY_RAW
     dec = args.op in ("decompress", "roundtrip")
     mode_flag = {"auto": 0, "wave": N.FLAG_FORCE_WAVE_PER_CHUNK, "lane": N.FLAG_FORCE_LANE_PER_CHUNK,
@@ -268,12 +299,12 @@ def main():
         batches.append(build_batch(N, L, eng, dev, N.CODEC_LZ4_BLOCK, True, S, U, NCH - NCH // 2, first_index, args.compressor, torch, np))
         batches.append(build_batch(N, L, eng2, dev, N.CODEC_SNAPPY_RAW, True, S, U, NCH // 2, first_index + (1 << 32), args.compressor, torch, np))
     else:
-        batches.append(build_batch(N, L, eng, dev, codec, dec, S, U, NCH, first_index, args.compressor, torch, np))
+        batches.append(build_batch(N, L, eng, dev, codec, dec, S, U, NCH, first_index, args.compressor, torch, np, args.data))
     b0 = batches[0]
     rt = None
     if args.op == "roundtrip":
         # configs[2]: compress the decoded batch again in the same step (the raw chunks are the compress input)
-        rt = build_batch(N, L, eng, dev, codec, False, S, U, NCH, first_index, args.compressor, torch, np)
+        rt = build_batch(N, L, eng, dev, codec, False, S, U, NCH, first_index, args.compressor, torch, np, args.data)
     torch.cuda.synchronize()
 
     calls = [(b.eng, batch_call(N, b, mode_flag)) for b in batches]
@@ -324,11 +355,12 @@ def main():
     wall = time.perf_counter() - t0
 
     if args.phase_profile and rank == 0:
-        ph = (C.c_ulonglong * 8)()
+        ph = (C.c_ulonglong * 16)()
         L.cj_debug_lds_phase_cycles(ph, 1)
         nb = max(int(ph[5]), 1)
         if int(ph[5]):
-            print("LDS decoder cycles/chunk: S0 %d  D1 %d  D2 %d  D3 %d  D4 %d  (blocks %d)" % (ph[0] // nb, ph[1] // nb, ph[2] // nb, ph[3] // nb, ph[4] // nb, nb), file=sys.stderr)
+            print("LDS decoder cycles/chunk: S0 %d  D1 %d  D2 %d  D3 %d  D4 %d  (blocks %d)  sub-marks 6.. %s" % (
+                ph[0] // nb, ph[1] // nb, ph[2] // nb, ph[3] // nb, ph[4] // nb, nb, [int(ph[i] // nb) for i in range(6, 16)]), file=sys.stderr)
         for name, fn in (("level decoder (table)", L.cj_debug_lvl_phase_cycles), ("level decoder (LDS)", L.cj_debug_lvl1_phase_cycles)):
             pl = (C.c_ulonglong * 16)()
             fn(pl, 1)
@@ -372,8 +404,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and dec and not mixed:
         cpu = cpu_baseline(args, codec, b0)
     traffic = None
+    kernels_ms = None
     if rank == 0 and world == 1 and (args.traffic == "on" or (args.traffic == "auto" and default_case)) and not os.environ.get("CJ_BENCH_CHILD"):
         traffic = measure_traffic()
+        kernels_ms = measure_kernels()
 
     if rank == 0:
         achieved = algo / (kernel_ms * 1e-3)
@@ -384,16 +418,17 @@ def main():
         else:
             metric = ("uncompressed GB/s (LZ4-block decomp, 64 KiB chunks)" if (dec and rt is None and args.codec == "lz4" and S == 65536)
                       else "uncompressed GB/s (%s %s, %d B chunks)" % (args.codec, args.op, S))
-            workload = "%s-block %s, %d x %d B synth-v1 chunks per GPU, device-resident" % (args.codec, args.op, NCH, S)
+            workload = "%s-block %s, %d x %d B %s chunks per GPU, device-resident" % (
+                args.codec, args.op, NCH, S, "synth-v1" if corpus_files is None else "benchmark-corpus (%d unique full chunks of %d files, tiled)" % (U, len(corpus_files)))
             if dec and args.codec == "lz4":
                 kernel = {"auto": "lz4_parse_kernel+lz4_decode_lds2_kernel", "lds": "lz4_parse_kernel+lz4_decode_lds2_kernel",
                           "wave": "lz4_decode_kernel", "lane": "lz4_decode_lanes_kernel"}[args.lz4_mode]
             elif dec:
                 kernel = "snappy_parse_kernel+lz4_decode_lds2_kernel<snappy>"
             else:
-                kernel = "%s_encode_kernel" % args.codec
+                kernel = encode_kernel_names(N, args.codec, NCH)
             if rt is not None:
-                kernel += "+%s_encode_kernel" % args.codec
+                kernel += "+" + encode_kernel_names(N, args.codec, NCH)
         line = {
             "metric": metric,
             "value": total_unc / (wall_max / args.steps) / 1e9,
@@ -401,18 +436,18 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall_max / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
+            "dtype": "u8", "data": "synthetic" if corpus_files is None else "reference benchmark corpus (tests/golden/corpus: %s), tiled" % ", ".join(corpus_files),
             "config": {"workload": workload, "chunks_per_gpu": NCH, "chunk_bytes": S, "unique_chunks": U, "ratio": round(ratio, 4),
                        "compressed_by": " | ".join(sorted({b.comp_name for b in batches if b.comp_name})) or None,
                        "batches_in_flight": len(lanes),
-                       "sharding": "chunk i -> gpu (i mod N), no collective; rank r generates synth-v1 indices r*%d .. r*%d+%d" % (U, U, U - 1),
+                       "sharding": "chunk i -> gpu (i mod N), no collective; " + ("rank r generates synth-v1 indices r*%d .. r*%d+%d" % (U, U, U - 1) if corpus_files is None else "every rank tiles the same corpus chunks"),
                        "verified": "NOT VERIFIED (--experiment-no-verify): this line is INVALID as a result" if args.experiment_no_verify else
                                    ("all results + all output bytes compared on device" if dec and rt is None else
                                     "every compressed chunk decoded again by the GPU decoder and compared with its input on device"
                                     + ("; decode half: all results + all output bytes compared on device" if rt is not None else ""))},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic["total"] if traffic else None,
-                         "traffic_detail": traffic, "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo},
+                         "traffic_detail": traffic, "kernel": kernel, "kernel_ms": kernel_ms, "kernels_ms": kernels_ms, "algorithmic_bytes_per_launch": algo},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
@@ -452,7 +487,7 @@ def usable_cores():
 def cpu_baseline(args, codec, b):
     """CPU decoders over the U unique chunks of this run, ONE persistent thread pool per leg (oracle/synth_batch_oracle.c):
     the oracle's C restatement (kind "port") and the host's liblz4 when present (kind "liblz4"; LZ4 only), each with all
-    cores and with one.  The top-level fields are the port on all cores; `legs` lists everything."""
+    cores and with one.  The top-level fields are liblz4 on all cores when present (else the port); `legs` lists everything."""
     import numpy as np
     import oracle
     OL = oracle.lib()
@@ -481,10 +516,60 @@ def cpu_baseline(args, codec, b):
         assert rc == 0 and (res[:n1] == S).all() and (out[:n1 * S] == b.raw_h[:n1 * S]).all(), "cpu decoder (%s) disagrees with the generator" % kind
         legs.append({"kind": kind, "cores": threads, "value": reps * n1 * S / el / 1e9, "unit": "GB/s",
                      "sample": "%d passes x %d unique %d B chunks (same inputs as the GPU run), one thread pool, %.1f s" % (reps, n1, S, el)})
-    top = dict(legs[0])
+    # top level: the fastest leg of the reference's own lineage — liblz4 on all cores when the host has it (the C code the
+    # reference links through lz4-sys), else the port; every leg stays in `legs`
+    best = next((g for g in legs if g["kind"] == "liblz4" and g["cores"] > 1), legs[0])
+    top = dict(best)
     top["host"] = cores_note
     top["legs"] = legs
     return top
+
+
+def encode_kernel_names(N, codec, nch):
+    """the kernels a compress batch of nch chunks runs as (engine.hip: launch_encode) — the names rocprofv3 prints"""
+    import torch
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    tag = "Lz4Enc" if codec == "lz4" else "SnappyEnc"
+    if nch >= 10 * cus:
+        return "encode_lds_blocks_kernel<%s>+encode_table_blocks_kernel<%s> (concurrent streams)" % (tag, tag)
+    return "%s_encode_kernel" % codec
+
+
+def measure_kernels():
+    """average duration of every library kernel of a step, measured now by a child run of THIS command under
+    rocprofv3 --kernel-trace --stats (3 timed steps + 1 warmup).  {kernel: ms per launch}; None when unavailable."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    base = [a for a in sys.argv[1:]]
+    for flag in ("--steps", "--warmup", "--cpu-seconds", "--traffic"):
+        while flag in base:
+            i = base.index(flag)
+            del base[i:i + 2]
+    child = [sys.executable, os.path.abspath(__file__)] + base + ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--traffic", "off"]
+    tmp = tempfile.mkdtemp(prefix="cj_kt_", dir="/tmp")
+    try:
+        env = dict(os.environ, CJ_BENCH_CHILD="1", TMPDIR="/tmp")
+        r = subprocess.run([prof, "--kernel-trace", "--stats", "--output-format", "csv", "-d", tmp, "--"] + child, cwd="/tmp", env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        files = glob.glob(os.path.join(tmp, "**", "*kernel_stats.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            return None
+        out = {}
+        for row in csv.DictReader(open(files[0])):
+            k = row["Name"]
+            if "cj::" not in k or "(anonymous" in k:
+                continue
+            out[k.split("(")[0].replace("void ", "")] = {"ms": float(row["AverageNs"]) / 1e6, "calls": int(row["Calls"])}
+        return out
+    except (OSError, subprocess.SubprocessError, KeyError, ValueError):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def measure_traffic():

@@ -28,12 +28,14 @@
 namespace cj {
 
 // phase cycle counters (debug aid, enabled by CJ_FLAG_DEBUG_PROFILE): S0, D1, D2, D3, D4, blocks
-__device__ unsigned long long g_lds_phase_cycles[8];
+// (accumulated in LDS by thread 0 and flushed once per chunk: an atomicAdd per mark sits in front of the next barrier's vmcnt(0)
+//  and costs a global round trip, 6-8 k cycles under this kernel's load — round 2's marks measured themselves)
+__device__ unsigned long long g_lds_phase_cycles[16];
 #define CJ_PHASE_MARK(idx)                                                              \
     do {                                                                                \
         if (prof && tid == 0) {                                                         \
             unsigned long long now_ = __builtin_readcyclecounter();                     \
-            atomicAdd(&g_lds_phase_cycles[idx], now_ - t_prev);                         \
+            s_prof[idx] += (uint32_t)(now_ - t_prev);                                   \
             t_prev = now_;                                                              \
         }                                                                               \
     } while (0)
@@ -50,17 +52,18 @@ __device__ unsigned long long g_lds_phase_cycles[8];
 #define CJ_L2_THREADS 512
 #endif
 constexpr uint32_t kL2Threads = CJ_L2_THREADS;
-constexpr uint32_t kL2OffBits = 65536;
+constexpr uint32_t kL2Pad = 640;                           // behind the window: the in-place margin of the staged chunk (LZ4 batches, D2)
+constexpr uint32_t kL2OffBits = 65536 + kL2Pad;
 constexpr uint32_t kL2OffVars = kL2OffBits + 8192;         // [0] fail flag, [8] current chunk, [64,128) dummy bytes, [128,384) dummy dwords
-constexpr uint32_t kL2Bytes = kL2OffVars + 384;            // 74112 B: two workgroups fit one CU's LDS
-constexpr uint32_t kL2TabRecords = 3u * kSyncStride * kSyncEvery;   // records of a chunk (the parse kernel routes chunks with more than 8 192 sequences elsewhere) + the extra literal copies of D1f (at most two per record, D1f takes at most 6 144 records)
+constexpr uint32_t kL2Bytes = kL2OffVars + 384 + 64;       // 74816 B (the last 64: phase counters): two workgroups fit one CU's LDS
+constexpr uint32_t kL2TabRecords = 3u * kSyncStride * kSyncEvery;   // records of a chunk (the parse kernel routes chunks with more than 16 384 sequences elsewhere) + the extra literal copies of D1f (at most two per record, D1f takes at most 6 144 records)
 
 
 // kLinked (LZ4 frames with linked blocks, frame.hip): the workgroup takes a whole FRAME (frames[f] = first block index,
 // block count) and walks its blocks in order; the LDS holds TWO 64 KiB windows, the block being decoded and the previous
 // block (every non-last block of such a frame decodes to exactly 64 KiB — the host checks that before it launches this
 // path), so a match that reaches back past the start of its block reads final bytes from the other window.
-constexpr uint32_t kL2LinkedBytes = 2u * 65536u + 8192u + 384u;        // 139 648 B: one workgroup per CU
+constexpr uint32_t kL2LinkedBytes = 2u * 65536u + 8192u + 384u + 64u;  // 139 712 B: one workgroup per CU
 
 // two workgroups of eight wavefronts per CU = four wavefronts per SIMD: the register allocator must stay within 128 VGPRs
 // (without the attribute it sees only the 512-thread bound and may take more, which silently halves the residency)
@@ -149,6 +152,8 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
     uint32_t* s_small = reinterpret_cast<uint32_t*>(smem + kOffVars + 28u);        // D1: matches with an offset below kFwdNear
     volatile uint32_t* s_prevok = reinterpret_cast<volatile uint32_t*>(smem + kOffVars + 32u);      // kSlab: a wave has seen the previous slab's flag and fenced
     const bool prof = (a.flags & 0x1000u) != 0;
+    uint32_t* s_prof = reinterpret_cast<uint32_t*>(smem + kOffVars + 384u);
+    if (prof && threadIdx.x < 16u) s_prof[threadIdx.x] = 0u;
     unsigned long long t_prev = prof ? __builtin_readcyclecounter() : 0ull;
     uint32_t fr_first = 0, fr_n = 0, fr_k = 0;               // kLinked: current frame and position in it
     // batches: thread 0 claims the NEXT chunk right after the current one is known, so the atomic's round trip runs under the
@@ -307,12 +312,23 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         //      reads are LDS reads; D2 re-reads the literal bytes from global memory (L2 hits) because it overwrites
         //      the window while other lanes still need their sources ----
         const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(in) & 15u);
+        // LZ4 batches stage the chunk RIGHT-ALIGNED, ending 64 + C/128 bytes behind the window's end: that is liblz4's in-place
+        // decoding margin ((C >> 8) + 32, LZ4_DECOMPRESS_INPLACE_MARGIN) and more, so the literals of every record lie at or to the right
+        // of their destination and D2 can take them from LDS instead of reading the chunk a second time from global memory
+        // (measured, profiles/r03/experiments d01: 607 vs 621 GB/s on the benchmark data, no difference on the corpus — a round of 512
+        //  records costs ~4.5 k cycles of stores, ready bits and barrier whatever the source of the bytes: kept as an experiment)
+#ifdef CJ_INPLACE_D2
+        constexpr bool kInPlace = kCompact && kCodec == CJ_CODEC_LZ4_BLOCK;
+#else
+        constexpr bool kInPlace = false;
+#endif
+        const uint32_t stage_off = kInPlace ? ((65536u + 64u + (iend >> 7)) - iend - mis) & ~15u : 0u;
         // this thread's first sync point (D1) is requested together with the chunk's bytes: one round trip instead of two
         uint2 p_first = make_uint2(0u, 0u);
         if constexpr (!kFused) p_first = csync[tid < nsp ? tid : 0u];
         {
             const uint4* src = reinterpret_cast<const uint4*>(in - mis);
-            uint4* dst = reinterpret_cast<uint4*>(s_out);
+            uint4* dst = reinterpret_cast<uint4*>(s_out + stage_off);
             const uint32_t nvec = staged ? (mis + iend + 15u) >> 4 : 0u;
             // five loads in flight per thread (a 40 KiB chunk is 5 x 512 vectors): written as one load and one store per
             // iteration the compiler waits for every load before the next one — five dependent round trips per chunk.  The
@@ -336,7 +352,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         CJ_PHASE_MARK(0);
 
         // ---- D1: expand sync points into sequence records (LDS -> global table) ----
-        const uint32_t a_in = a_out + mis;
+        const uint32_t a_in = a_out + stage_off + mis;
         if constexpr (kFused) {
             using G = typename std::conditional<kCodec == CJ_CODEC_SNAPPY_RAW, SnappyGrammar, Lz4Grammar>::type;
             const bool ok = fused_parse<G, kL2Threads>(a_in, iend, f_cap, s_bits, reinterpret_cast<uint32_t*>(smem + kL2Bytes), table2, s_small, nseq, U);
@@ -480,11 +496,13 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         //      start | dst << 16 and the state word (current offset / input position + flags); the records tile the window
         //      (start[i+1] = end of record i), so a match's length is start[i+1] - dst[i]; plus, per 16 bytes of output,
         //      the last record that starts at or before them.
+        bool fwd_taken = false;
         if constexpr (!kLinked) {
             // mostly near matches: the chains are deep, forwarding pays (it costs ~25 k cycles + 10 k per round).  kSlab: always
             // when the slab waits for bytes of earlier slabs — the forwarding runs before that wait, what it removes from
             // the dependency depth comes off the serial chain through the slabs
             if (nseq <= kFwdMaxRecords && staged && (*s_small * 2u > nseq || (kSlab && *s_ncross > 0u))) {
+                fwd_taken = true;
                 uint32_t* f_w0 = reinterpret_cast<uint32_t*>(s_out);
                 uint32_t* f_st = f_w0 + kFwdMaxRecords;
                 uint16_t* f_ls = reinterpret_cast<uint16_t*>(f_st + kFwdMaxRecords);      // literal source of every record (16 bits: the chunk is staged)
@@ -614,19 +632,9 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         }
 #endif
 
-        // ---- D2: literals, one lane per sequence: global -> LDS window ----
-        // (the next batch's records are requested before the current batch is processed: a coalesced table read is a
-        //  full global round trip and a wave owns only ~5 batches)
-        uint4 rec_nx = make_uint4(0, 0, 0, 0);
-        if (wave * 64u + lane < nrec_all) rec_nx = rec_load(wave * 64u + lane, nseq);
-        for (uint32_t base = wave * 64u; base < nrec_all; base += kL2Threads) {
-            const uint4 rec = rec_nx;
-            rec_nx = make_uint4(0, 0, 0, 0);
-            {   // the wave's last batch requests its FIRST batch again: D3 starts on it without another round trip
-                const uint32_t nb = base + kL2Threads < nrec_all ? base + kL2Threads : wave * 64u;
-                if (nb + lane < nrec_all) rec_nx = rec_load(nb + lane, nseq);
-            }
-            uint32_t n = rec.y, src = rec.x, dst = rec.z - rec.y;
+        // ---- D2: literals, one lane per sequence -> LDS window ----
+        // what is left of a run after its first bytes were taken from LDS / the whole run (old path): global -> window
+        const auto place_from_global = [&](uint32_t n, uint32_t src, uint32_t dst) {
             uint64_t lm = ballot64(n >= kLongRun);
             while (lm) {
                 const uint32_t l = ctz64(lm);
@@ -656,6 +664,71 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                     n -= step; src += step; dst += step;
                 }
             }
+        };
+        uint4 rec_nx = make_uint4(0, 0, 0, 0);
+        bool d2_done = false;
+        if constexpr (kInPlace) {
+            if (!fwd_taken) {
+                // IN PLACE: the staged chunk ends behind the window's end, every literal run moves to the LEFT (or stays), and the bytes
+                // a record writes can only cover staged bytes of records up to itself.  So the records are taken in ROUNDS of 512
+                // consecutive records — one per thread, every thread reads (up to 64 bytes of) its run into registers, barrier, every
+                // thread writes — and no run is read after something was written over it.  A dependent global round trip costs 6-8 k
+                // cycles under this kernel's load (profiles/r03/experiments) and the old path paid one per batch of 64 records
+                // (benchmark data: 24 k cycles for 6 batches per wave; text: 115 k for 20); here the records of eight rounds come in
+                // one round trip and the bytes come from LDS.  Matches start after the last round (their writes obey the same rule).
+                d2_done = true;
+                if (wave * 64u + lane < nrec_all) rec_nx = rec_load(wave * 64u + lane, nseq);      // D3's first batch: requested now
+                const uint32_t nrounds = (nseq + kL2Threads - 1u) / kL2Threads;
+                for (uint32_t g0 = 0; g0 < nrounds; g0 += 8u) {
+                    uint2 R[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const uint32_t r = (g0 + (uint32_t)k) * kL2Threads + tid;
+                        R[k] = make_uint2(0u, 0u);
+                        if (r < nseq) R[k] = table2[r];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        if (g0 + (uint32_t)k < nrounds) {                              // (uniform)
+                            uint32_t n = R[k].x >> 16, src = R[k].x & 0xffffu, dst = R[k].y & 0xffffu;
+                            const uint32_t nl = n >= kLongRun ? 0u : (n < 64u ? n : 64u);      // long runs: the whole wavefront, from global memory
+                            const uint32_t tier = wave_tier(nl, nl > 0u);
+                            const uint32_t as = nl ? a_in + src : a_out, sa = as & ~3u, sh = as & 3u;
+                            DW<6> w6 = {}; DW<10> w10 = {}; DW<18> w18 = {};
+                            if (tier <= 16u) w6 = lds_ld_aligned6(sa);
+                            else if (tier <= 32u) w10 = lds_ld_aligned10(sa);
+                            else w18 = lds_ld_aligned18(sa);
+                            CJ_PHASE_MARK(6);                                          // 6: the rounds' LDS reads (+ the records' round trip)
+                            __syncthreads();                                           // every run of the round is in registers
+                            CJ_PHASE_MARK(7);                                          // 7: the rounds' barriers
+                            if (nl > 0u) {
+                                if (tier <= 16u) lds_store_tier<16>(w6, a_out + dst, sh, nl, dm);
+                                else if (tier <= 32u) lds_store_tier<32>(w10, a_out + dst, sh, nl, dm);
+                                else lds_store_tier<64>(w18, a_out + dst, sh, nl, dm);
+                                CJ_PHASE_MARK(8);                                      // 8: the rounds' stores
+                                bits_set(s_bits, dst, dst + nl);
+                            }
+                            CJ_PHASE_MARK(9);                                          // 9: bits_set
+                            place_from_global(n - nl, src + nl, dst + nl);             // (rare) the rest of runs above 64 bytes
+                            CJ_PHASE_MARK(10);                                         // 10: the runs' remainders from global memory
+                        }
+                    }
+                }
+            }
+        }
+        if (!d2_done) {
+        // (the next batch's records are requested before the current batch is processed: a coalesced table read is a
+        //  full global round trip and a wave owns only ~5 batches)
+        if (wave * 64u + lane < nrec_all) rec_nx = rec_load(wave * 64u + lane, nseq);
+        for (uint32_t base = wave * 64u; base < nrec_all; base += kL2Threads) {
+            const uint4 rec = rec_nx;
+            rec_nx = make_uint4(0, 0, 0, 0);
+            {   // the wave's last batch requests its FIRST batch again: D3 starts on it without another round trip
+                const uint32_t nb = base + kL2Threads < nrec_all ? base + kL2Threads : wave * 64u;
+                if (nb + lane < nrec_all) rec_nx = rec_load(nb + lane, nseq);
+            }
+            place_from_global(rec.y, rec.x, rec.z - rec.y);
+        }
         }
         // kSlab — D2b: the parts of matches whose source lies before this slab come from the finished output of the earlier
         // slabs in global memory.  Each wave copies its share of the cross list as soon as it sees slab c-1's flag: from
@@ -1064,7 +1137,10 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         }
         if (tid == 0 && *s_fail) a.result[c] = CJ_E_CORRUPT;    // cannot happen for a stream the parse kernel accepted
         publish();
-        if (prof) { __syncthreads(); CJ_PHASE_MARK(4); if (tid == 0) atomicAdd(&g_lds_phase_cycles[5], 1ull); }
+        if (prof) {
+            __syncthreads(); CJ_PHASE_MARK(4);
+            if (tid < 16u) { const uint32_t v = tid == 5u ? 1u : s_prof[tid]; if (v) atomicAdd(&g_lds_phase_cycles[tid], (unsigned long long)v); s_prof[tid] = 0u; }
+        }
     }
 }
 
@@ -1164,9 +1240,9 @@ extern "C" long long cj_debug_forwarded_chunks(int reset) {
     if (reset) { unsigned long long z = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(cj::g_fwd_chunks), &z, 8) != hipSuccess) return -1; }
     return (long long)v;
 }
-extern "C" int cj_debug_lds_phase_cycles(unsigned long long* out8, int reset) {
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(cj::g_lds_phase_cycles), 64) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(cj::g_lds_phase_cycles), z, 64) != hipSuccess) return -1; }
+extern "C" int cj_debug_lds_phase_cycles(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(cj::g_lds_phase_cycles), 128) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(cj::g_lds_phase_cycles), z, 128) != hipSuccess) return -1; }
     return 0;
 }
 namespace cj {

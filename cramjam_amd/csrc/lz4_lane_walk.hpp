@@ -12,9 +12,10 @@ namespace cj {
 #if defined(__HIPCC__)
 
 constexpr uint32_t kSyncEvery = 8;        // sequences per sync point
-constexpr uint32_t kSyncPitch = 1024 + 16;      // distance (entries) between two chunks' sync points: 65 x 128 bytes, not a power of two
+constexpr uint32_t kSyncPitch = 2048 + 16;      // distance (entries) between two chunks' sync points: 129 x 128 bytes, not a power of two
                                               // (the 64 lanes of a parse wave would otherwise store into the same memory channel)
-constexpr uint32_t kSyncStride = 1024;    // sync points reserved per chunk (=> at most 8192 sequences on the LDS path)
+constexpr uint32_t kSyncStride = 2048;    // sync points reserved per chunk (=> at most 16 384 sequences on the LDS path: a 64 KiB chunk of LZ4 has at most
+                                          // 16 384; real text has ~10 000, which the 1 024 points of rounds 1-2 sent to the one-wavefront kernel)
 constexpr uint32_t kLdsOutMax = 65536;    // the LDS decoder holds at most this much output ...
 constexpr uint32_t kLdsInMax = 65504;     // ... and this much compressed input: variant 2 stages it in the 64 KiB output window (<= 15 B misalignment + 15 B round-up)
 

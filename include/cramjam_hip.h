@@ -220,8 +220,8 @@ CJ_API int cj_bench_synth_v1(void* d_out, uint64_t stride, uint64_t S, uint64_t 
 /* *d_mismatches += chunks i in [0, n) with got[got_off[i] .. +S) != want[(i % n_unique)*want_stride .. +S) */
 CJ_API int cj_bench_compare(const void* d_got, const uint64_t* d_got_off, const void* d_want, uint64_t want_stride,
                             uint32_t n_unique, uint64_t S, uint32_t n, void* d_mismatches, void* stream);
-/* per-phase cycle counters of the workgroup decoder (flag bit 0x1000 of a device batch): S0, D1, D2, D3, D4, chunks */
-CJ_API int cj_debug_lds_phase_cycles(unsigned long long* out8, int reset);
+/* per-phase cycle counters of the workgroup decoder (flag bit 0x1000 of a device batch): S0, D1, D2, D3, D4, chunks, 6.. sub-phases (16 slots) */
+CJ_API int cj_debug_lds_phase_cycles(unsigned long long* out16, int reset);
 /* the level-ordered decoder's counters (same flag): S0, D1/P, X, L, K, D2, D3, D4 cycles, chunks, levels, D3 barriers */
 CJ_API int cj_debug_lvl_phase_cycles(unsigned long long* out16, int reset);
 CJ_API int cj_debug_lvl1_phase_cycles(unsigned long long* out16, int reset);   /* the all-LDS variant (one workgroup per CU) */

@@ -9,7 +9,7 @@ import oracle, cramjam_amd as cj
 from cramjam_amd import _native as N
 L = N.lib(); eng = N.Engine(0)
 def phases(tag):
-    ph = (C.c_ulonglong * 8)()
+    ph = (C.c_ulonglong * 16)()
     L.cj_debug_lds_phase_cycles(ph, 1)
     nb = max(int(ph[5]), 1)
     print("%-44s S0 %6d  D1 %6d  D2 %6d  D3 %6d  D4 %6d  sum %7d  (%d slabs/chunks, %d through the forwarding phase)" % (tag, ph[0] // nb, ph[1] // nb, ph[2] // nb, ph[3] // nb, ph[4] // nb, sum(ph[:5]) // nb, nb, L.cj_debug_forwarded_chunks(1)), flush=True)
@@ -22,7 +22,7 @@ for codec, name in ((N.CODEC_LZ4_BLOCK, "lz4"), (N.CODEC_SNAPPY_RAW, "snappy")):
     in_ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in ins]); in_lens = (C.c_size_t * n)(*[a.size for a in ins])
     out_ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in outs]); caps = (C.c_size_t * n)(*[S] * n)
     res = (C.c_int64 * n)()
-    L.cj_debug_lds_phase_cycles((C.c_ulonglong * 8)(), 1)
+    L.cj_debug_lds_phase_cycles((C.c_ulonglong * 16)(), 1)
     for rep in range(3):
         N.check(L.cj_batch_host(eng.h, codec, N.OP_DECOMPRESS, 0, n, in_ptrs, in_lens, out_ptrs, caps, res))
     assert all(r == S for r in res) and outs[7].tobytes() == raws[7]
@@ -35,6 +35,6 @@ for codec, name in ((N.CODEC_LZ4_BLOCK, "lz4"), (N.CODEC_SNAPPY_RAW, "snappy")):
     phases("%s independent chunks, 2048 x 64 KiB" % name)
 big = b"".join(oracle.synth_v1(65536, i) for i in range(512))[:-777]
 blob = oracle.lz4_compress_raw(big)[1]
-L.cj_debug_lds_phase_cycles((C.c_ulonglong * 8)(), 1)
+L.cj_debug_lds_phase_cycles((C.c_ulonglong * 16)(), 1)
 for _ in range(3): assert bytes(cj.lz4.decompress_block(blob, output_len=len(big))) == big
 phases("lz4 slabs, one 32 MiB stream")

@@ -66,3 +66,44 @@ def test_fifty_four_mb_inputs(kind):
     s = bytes(cramjam.snappy.compress_raw(raw))
     assert bytes(cramjam.snappy.decompress_raw(s)) == raw
     assert oracle.snappy_decompress(s) == (len(raw), raw)
+
+
+_CHUNK_CHECK = r"""
+import bz2, json, os, sys
+import oracle
+from cramjam_amd import _native as N
+corpus = sys.argv[1]
+man = json.load(open(os.path.join(corpus, "manifest.json")))["files"]
+chunks = []
+for name in sorted(man):
+    raw = bz2.decompress(open(os.path.join(corpus, name + ".bz2"), "rb").read())
+    chunks += [raw[i:i + 65536] for i in range(0, len(raw), 65536)]          # every chunk, the files' short tails included
+assert len(chunks) >= 50
+eng = N.Engine(0)
+L = N.lib()
+for codec, comp, dec in ((N.CODEC_LZ4_BLOCK, lambda c: oracle.lz4_compress_raw(c)[1], lambda b, n: oracle.lz4_decompress_raw(b, n)),
+                         (N.CODEC_SNAPPY_RAW, lambda c: oracle.snappy_compress(c)[1], lambda b, n: oracle.snappy_decompress(b))):
+    blobs = [comp(c) for c in chunks]
+    for flags in (0, N.FLAG_FORCE_LDS_PER_CHUNK, N.FLAG_FORCE_WAVE_PER_CHUNK):
+        res, outs = eng.batch_host(codec, N.OP_DECOMPRESS, flags, blobs, [len(c) for c in chunks])
+        assert [int(r) for r in res] == [len(c) for c in chunks], (codec, flags)
+        assert all(bytes(o) == c for o, c in zip(outs, chunks)), (codec, flags)
+    caps = [(L.cj_lz4_block_compress_bound(len(c), 0) if codec == N.CODEC_LZ4_BLOCK else L.cj_snappy_raw_max_compress_len(len(c))) for c in chunks]
+    res, outs = eng.batch_host(codec, N.OP_COMPRESS, 0, chunks, caps)
+    for c, o in zip(chunks, outs):
+        assert dec(bytes(o), len(c)) == (len(c), c), codec
+print("corpus chunks ok", len(chunks))
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", ["1", "0"], ids=["parse-in-decoder", "parse-kernel+decoder"])
+def test_every_corpus_chunk_against_the_oracle(fused):
+    """SURVEY.md §8(d) `corpus-64k`: every 64 KiB chunk (and every file's short tail) of the corpus files that travel, compressed by the
+    oracle's encoders (bit-identical to liblz4 / libsnappy): the GPU decodes each to its input in the default pipeline, with the
+    workgroup decoder forced and with the one-wavefront kernel, on both sides of the parse-in-kernel threshold (real text has ~10 000
+    sequences per chunk and dependency chains a hundred levels deep); the GPU encoders' blocks decode with the oracle"""
+    import subprocess, sys
+    env = dict(os.environ, CJ_FUSED=fused, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", _CHUNK_CHECK, CORPUS], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "corpus chunks ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

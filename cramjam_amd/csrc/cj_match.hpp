@@ -8,6 +8,12 @@
 // it is NOT byte-identical to the CPU encoders (nor required to be: the reference pins compressed
 // bytes only for the 14-byte all-literal case, /root/reference/tests/test_variants.py:329-334).
 #pragma once
+// The matcher's byte-determinism rests on gfx9 semantics: stores are acknowledged under vmcnt (settle()), DPP row_bcast / wave_shr
+// exist, and among the lanes of ONE DS store instruction that hit the same address the highest lane wins (HashTab).  Another
+// architecture would compile and give other bytes per block kind — refuse it.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "cj_match.hpp: the encoders are written for gfx950 (gfx9 wave64: vmcnt-acknowledged stores, DPP row_bcast, DS same-address store order)"
+#endif
 #include "cj_common.hpp"
 
 namespace cj {

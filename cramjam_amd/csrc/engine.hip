@@ -300,11 +300,16 @@ void cj_engine_destroy(cj_engine* e) {
 
 int cj_engine_device(const cj_engine* e) { return e ? e->device : -1; }
 
+// the flag bits a C-ABI caller may set; everything else (piece splitting, tail reports, linked-frame parse: cj_common.hpp) belongs
+// to large.hip / frame.hip, which call cj::launch directly — a stray bit would make a kernel read descriptors that are not there
+static constexpr uint32_t kPublicFlags = CJ_FLAG_LZ4_SIZE_PREFIX | CJ_FLAG_FORCE_WAVE_PER_CHUNK | CJ_FLAG_FORCE_LANE_PER_CHUNK | CJ_FLAG_FORCE_LDS_PER_CHUNK
+                                         | 0x1000u /* decoder phase counters (cj_debug_*_phase_cycles) */;
+
 int cj_batch_device(cj_engine* e, cj_codec codec, cj_op op, uint32_t flags, size_t n_chunks,
                     const uint8_t* in_base, const uint64_t* in_off, const uint64_t* in_len,
                     uint8_t* out_base, const uint64_t* out_off, const uint64_t* out_cap,
                     int64_t* result, void* hip_stream) {
-    if (!e || n_chunks > 0xFFFFFFF0ull) return CJ_E_BAD_ARG;
+    if (!e || n_chunks > 0xFFFFFFF0ull || (flags & ~kPublicFlags)) return CJ_E_BAD_ARG;
     if (n_chunks == 0) return 0;
     HIP_TRY(hipSetDevice(e->device), CJ_E_NO_DEVICE);
     cj::BatchArgs a;
@@ -323,7 +328,7 @@ double cj_batch_device_timed(cj_engine* e, cj_codec codec, cj_op op, uint32_t fl
                              const uint8_t* in_base, const uint64_t* in_off, const uint64_t* in_len,
                              uint8_t* out_base, const uint64_t* out_off, const uint64_t* out_cap,
                              int64_t* result, int reps) {
-    if (!e || reps < 1 || n_chunks == 0 || n_chunks > 0xFFFFFFF0ull) return -1.0;
+    if (!e || reps < 1 || n_chunks == 0 || n_chunks > 0xFFFFFFF0ull || (flags & ~kPublicFlags)) return -1.0;
     HIP_TRY(hipSetDevice(e->device), -1.0);
     cj::BatchArgs a;
     fill_args(a, flags, n_chunks, in_base, in_off, in_len, out_base, out_off, out_cap, result);
@@ -344,7 +349,7 @@ double cj_batch_device_timed(cj_engine* e, cj_codec codec, cj_op op, uint32_t fl
 int cj_batch_host(cj_engine* e, cj_codec codec, cj_op op, uint32_t flags, size_t n,
                   const uint8_t* const* in_ptrs, const size_t* in_lens,
                   uint8_t* const* out_ptrs, const size_t* out_caps, int64_t* result) {
-    if (!e || (n && (!in_ptrs || !in_lens || !out_ptrs || !out_caps || !result))) return CJ_E_BAD_ARG;
+    if (!e || (n && (!in_ptrs || !in_lens || !out_ptrs || !out_caps || !result)) || (flags & ~kPublicFlags)) return CJ_E_BAD_ARG;
     if (n == 0) return 0;
     if (n > 0xFFFFFFF0ull) return CJ_E_BAD_ARG;
     // decompress: chunks above 64 KiB (by input or by capacity) would each be one serial stream on one wavefront; up to

@@ -55,7 +55,7 @@ constexpr uint32_t kL2Threads = CJ_L2_THREADS;
 constexpr uint32_t kL2Pad = 640;                           // behind the window: the in-place margin of the staged chunk (LZ4 batches, D2)
 constexpr uint32_t kL2OffBits = 65536 + kL2Pad;
 constexpr uint32_t kL2OffVars = kL2OffBits + 8192;         // [0] fail flag, [8] current chunk, [64,128) dummy bytes, [128,384) dummy dwords
-constexpr uint32_t kL2Bytes = kL2OffVars + 384 + 64;       // 74816 B (the last 64: phase counters): two workgroups fit one CU's LDS
+constexpr uint32_t kL2Bytes = kL2OffVars + 384 + 128;      // 74880 B (the last 128: phase counters, the next chunk's descriptors): two workgroups fit one CU's LDS
 constexpr uint32_t kL2TabRecords = 3u * kSyncStride * kSyncEvery;   // records of a chunk (the parse kernel routes chunks with more than 16 384 sequences elsewhere) + the extra literal copies of D1f (at most two per record, D1f takes at most 6 144 records)
 
 
@@ -63,7 +63,7 @@ constexpr uint32_t kL2TabRecords = 3u * kSyncStride * kSyncEvery;   // records o
 // block count) and walks its blocks in order; the LDS holds TWO 64 KiB windows, the block being decoded and the previous
 // block (every non-last block of such a frame decodes to exactly 64 KiB — the host checks that before it launches this
 // path), so a match that reaches back past the start of its block reads final bytes from the other window.
-constexpr uint32_t kL2LinkedBytes = 2u * 65536u + 8192u + 384u + 64u;  // 139 712 B: one workgroup per CU
+constexpr uint32_t kL2LinkedBytes = 2u * 65536u + 8192u + 384u + 128u; // 139 776 B: one workgroup per CU
 
 // two workgroups of eight wavefronts per CU = four wavefronts per SIMD: the register allocator must stay within 128 VGPRs
 // (without the attribute it sees only the 512-thread bound and may take more, which silently halves the residency)
@@ -160,6 +160,27 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
     // descriptor loads instead of in front of them (slabs are claimed when they are started: their order matters)
     uint32_t next_c = 0;
     if constexpr (!kLinked && !kSlab) { if (tid == 0) next_c = atomicAdd(counter, 1u); }
+    // Batches after a parse kernel: the NEXT chunk travels one iteration ahead.  Thread 0 requests its descriptors after D1 and parks
+    // them in LDS after D2 (no register lives across D3, where the allocator is at its 128), every thread requests its share of the
+    // compressed bytes + its first sync point right after D3 — in front of D4's 64 KiB of stores in the CU's memory pipe, instead of
+    // behind them at the top of the next iteration (a dependent global round trip costs 6-8 k cycles behind that drain; S0 was two
+    // of them).  The loop head then needs one barrier that waits for LDS only.
+    // (measured, profiles/r03/experiments d02: 581 vs 620 GB/s — the kernel sits at its 128 registers and the 22 that carry the next
+    //  chunk spill; S0 did not get shorter either, so the round trip is not waiting behind D4's stores: kept as an experiment)
+#ifdef CJ_CHUNK_PIPE
+    constexpr bool kPipe = !kLinked && !kSlab && !kFused;
+#else
+    constexpr bool kPipe = false;
+#endif
+    bool pf_valid = false;                                   // (uniform) the fields below describe the chunk of the coming iteration
+    uint32_t pf_c = 0;
+    ParseMeta pf_pm = {0u, 0u};
+    uint64_t pf_in_off = 0, pf_in_len = 0, pf_out_off = 0, pf_result = 0;
+    uint4 pf_v0 = make_uint4(0, 0, 0, 0), pf_v1 = pf_v0, pf_v2 = pf_v0, pf_v3 = pf_v0, pf_v4 = pf_v0;
+    uint2 pf_first = make_uint2(0u, 0u);
+    bool pf_bytes = false;                                   // ... and its first staging group is in pf_v0..4
+    uint32_t* s_nextc = reinterpret_cast<uint32_t*>(smem + kOffVars + 36u);
+    uint32_t* s_desc = reinterpret_cast<uint32_t*>(smem + kOffVars + 448u);      // next chunk: nseq, in_skip, in_off (2), in_len, out_off (2), result
 
     for (;;) {
         uint32_t c;
@@ -181,6 +202,12 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             if (tid == 0) *s_fail = 0u;
             for (uint32_t i = tid; i < 2048u; i += kL2Threads) s_bits[i] = 0u;
             __syncthreads();                                 // also: the previous block's D4 has finished reading its window
+        } else if (kPipe && pf_valid) {
+            c = pf_c;
+            if (c >= a.n_chunks) break;
+            if (tid == 0) { *s_fail = 0u; *s_ncross = 0u; *s_nextra = 0u; *s_small = 0u; *s_prevok = 0u; next_c = atomicAdd(counter, 1u); }
+            for (uint32_t i = tid; i < 2048u; i += kL2Threads) s_bits[i] = 0u;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // D4 has read the window (its stores may still drain)
         } else {
             if (tid == 0) { *s_chunk = kSlab ? atomicAdd(counter, 1u) : next_c; *s_fail = 0u; *s_ncross = 0u; *s_nextra = 0u; *s_small = 0u; *s_prevok = 0u; }
             for (uint32_t i = tid; i < 2048u; i += kL2Threads) s_bits[i] = 0u;
@@ -190,13 +217,19 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             if (c >= a.n_chunks) break;
             if constexpr (!kSlab) { if (tid == 0) next_c = atomicAdd(counter, 1u); }
         }
+        const bool piped = kPipe && pf_valid;                // this chunk's descriptors (and maybe bytes) arrived with the previous iteration
+        pf_valid = false;
         ParseMeta pm = {1u, 0u};                            // kFused: nothing has looked at the chunk yet
-        if constexpr (!kFused) pm = meta[c];
-        // the chunk's descriptors in ONE round trip: left to itself the compiler waits for pm.nseq (the early-out below) before it
-        // even requests the others, and the chunk's bytes are a third dependent round trip behind those
-        const uint64_t d_in_off = a.in_off[c], d_in_len = a.in_len[c], d_out_off = a.out_off[c];
-        const uint64_t d_result = kFused ? a.out_cap[c] : (uint64_t)a.result[c];      // kFused: the capacity (the parse computes the size)
-        asm volatile("" :: "v"(pm.nseq), "v"(pm.in_skip), "v"((uint32_t)d_in_off), "v"((uint32_t)d_in_len), "v"((uint32_t)d_out_off), "v"((uint32_t)d_result));
+        uint64_t d_in_off, d_in_len, d_out_off, d_result;
+        if (piped) { pm = pf_pm; d_in_off = pf_in_off; d_in_len = pf_in_len; d_out_off = pf_out_off; d_result = pf_result; }
+        else {
+            if constexpr (!kFused) pm = meta[c];
+            // the chunk's descriptors in ONE round trip: left to itself the compiler waits for pm.nseq (the early-out below) before it
+            // even requests the others, and the chunk's bytes are a third dependent round trip behind those
+            d_in_off = a.in_off[c]; d_in_len = a.in_len[c]; d_out_off = a.out_off[c];
+            d_result = kFused ? a.out_cap[c] : (uint64_t)a.result[c];      // kFused: the capacity (the parse computes the size)
+            asm volatile("" :: "v"(pm.nseq), "v"(pm.in_skip), "v"((uint32_t)d_in_off), "v"((uint32_t)d_in_len), "v"((uint32_t)d_out_off), "v"((uint32_t)d_result));
+        }
         uint32_t f_cap = 0;                                  // kFused: output capacity (LZ4) / announced length (Snappy) handed to the parse
         if constexpr (kFused) {
             // the prologue of the parse kernels: size prefix / length preamble, the special cases, what this decoder cannot hold.
@@ -212,7 +245,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 bool ok = false;
                 if (n64 == 0 || n64 > 0xFFFFFFF0ull) route = true;
                 else {
-                    const uint32_t h0 = ld32u(in0), h1 = ld32u(in0 + 4);         // (padded: reads past a tiny chunk stay in its granule... see cramjam_hip.h)
+                    const uint32_t h0 = ld32u(in0), h1 = n64 > 4 ? ld32u(in0 + 4) : 0u;     // (the second word only where the chunk has it: reads stay in the chunk's granules, cramjam_hip.h)
                     while (hdr < (uint32_t)n64 && i < 5u) {
                         const uint32_t bb = (hdr < 4u ? h0 >> (8u * hdr) : h1 >> (8u * (hdr - 4u))) & 0xffu;
                         hdr += 1;
@@ -325,7 +358,9 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         const uint32_t stage_off = kInPlace ? ((65536u + 64u + (iend >> 7)) - iend - mis) & ~15u : 0u;
         // this thread's first sync point (D1) is requested together with the chunk's bytes: one round trip instead of two
         uint2 p_first = make_uint2(0u, 0u);
-        if constexpr (!kFused) p_first = csync[tid < nsp ? tid : 0u];
+        const bool have_bytes = piped && pf_bytes;           // (uniform)
+        if (have_bytes) p_first = pf_first;
+        else if constexpr (!kFused) p_first = csync[tid < nsp ? tid : 0u];
         {
             const uint4* src = reinterpret_cast<const uint4*>(in - mis);
             uint4* dst = reinterpret_cast<uint4*>(s_out + stage_off);
@@ -345,7 +380,14 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 if (i3 < nvec) dst[i3] = v3;
                 if (i4 < nvec) dst[i4] = v4;
             };
-            if (nvec > 0u) group(tid);
+            if (have_bytes) {                                // the first group arrived while the previous chunk was streamed out
+                const uint32_t i0 = tid, i1 = i0 + kL2Threads, i2 = i0 + 2u * kL2Threads, i3 = i0 + 3u * kL2Threads, i4 = i0 + 4u * kL2Threads;
+                if (i0 < nvec) dst[i0] = pf_v0;
+                if (i1 < nvec) dst[i1] = pf_v1;
+                if (i2 < nvec) dst[i2] = pf_v2;
+                if (i3 < nvec) dst[i3] = pf_v3;
+                if (i4 < nvec) dst[i4] = pf_v4;
+            } else if (nvec > 0u) group(tid);
             for (uint32_t i0 = tid + 5u * kL2Threads; i0 < nvec; i0 += 5u * kL2Threads) group(i0);
         }
         __syncthreads();
@@ -482,6 +524,15 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         if constexpr (kCompact && !kFused) { if (tid == 0) table2[nseq] = make_uint2(0u, U & 0xffffu); }      // sentinel: where the last record's match ends
         __syncthreads();
         CJ_PHASE_MARK(1);
+        // (kPipe) thread 0: the next chunk's descriptors, requested now, parked in LDS after D2
+        ParseMeta nx_pm = {0u, 0u};
+        uint64_t nx_in_off = 0, nx_in_len = 0, nx_out_off = 0, nx_result = 0;
+        if constexpr (kPipe) {
+            if (tid == 0 && next_c < a.n_chunks) {
+                nx_pm = meta[next_c];
+                nx_in_off = a.in_off[next_c]; nx_in_len = a.in_len[next_c]; nx_out_off = a.out_off[next_c]; nx_result = (uint64_t)a.result[next_c];
+            }
+        }
 
 #ifndef CJ_NO_FORWARD
         // ---- D1f: MATCH FORWARDING.  D3 resolves matches as a dependency DAG and pays its latency per LEVEL; real data
@@ -729,6 +780,13 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             }
             place_from_global(rec.y, rec.x, rec.z - rec.y);
         }
+        }
+        if constexpr (kPipe) {
+            if (tid == 0) {
+                s_desc[0] = nx_pm.nseq; s_desc[1] = nx_pm.in_skip; s_desc[2] = (uint32_t)nx_in_off; s_desc[3] = (uint32_t)(nx_in_off >> 32);
+                s_desc[4] = (uint32_t)nx_in_len; s_desc[5] = (uint32_t)nx_out_off; s_desc[6] = (uint32_t)(nx_out_off >> 32); s_desc[7] = (uint32_t)nx_result;
+                *s_nextc = next_c;
+            }
         }
         // kSlab — D2b: the parts of matches whose source lies before this slab come from the finished output of the earlier
         // slabs in global memory.  Each wave copies its share of the cross list as soon as it sees slab c-1's flag: from
@@ -1123,7 +1181,27 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         __syncthreads();
         CJ_TRACE_T0(3);                                         // D3 done
         CJ_PHASE_MARK(3);
-
+        if constexpr (kPipe) {
+            pf_valid = true;
+            pf_bytes = false;
+            pf_c = *s_nextc;
+            pf_pm = ParseMeta{s_desc[0], s_desc[1]};
+            pf_in_off = ((uint64_t)s_desc[3] << 32) | s_desc[2]; pf_in_len = s_desc[4];
+            pf_out_off = ((uint64_t)s_desc[6] << 32) | s_desc[5]; pf_result = s_desc[7];
+            if (pf_c < a.n_chunks && pf_pm.nseq != 0u) {
+                const uint8_t* in1 = a.in_base + pf_in_off + pf_pm.in_skip;
+                const uint32_t iend1 = (uint32_t)pf_in_len - pf_pm.in_skip;
+                const uint32_t mis1 = (uint32_t)(reinterpret_cast<uintptr_t>(in1) & 15u);
+                const uint4* src1 = reinterpret_cast<const uint4*>(in1 - mis1);
+                const uint32_t last1 = ((mis1 + iend1 + 15u) >> 4) - 1u;
+                const uint32_t i0 = tid, i1 = i0 + kL2Threads, i2 = i0 + 2u * kL2Threads, i3 = i0 + 3u * kL2Threads, i4 = i0 + 4u * kL2Threads;
+                pf_v0 = src1[i0 < last1 ? i0 : last1]; pf_v1 = src1[i1 < last1 ? i1 : last1]; pf_v2 = src1[i2 < last1 ? i2 : last1];
+                pf_v3 = src1[i3 < last1 ? i3 : last1]; pf_v4 = src1[i4 < last1 ? i4 : last1];
+                const uint32_t nsp1 = (pf_pm.nseq + kSyncEvery - 1u) / kSyncEvery;
+                pf_first = (sync + (size_t)pf_c * kSyncPitch)[tid < nsp1 ? tid : 0u];
+                pf_bytes = true;
+            }
+        }
         // ---- D4: stream the window out (16 B per lane), exact tail ----
         {
             const uint32_t nvec = U >> 4;
@@ -1230,7 +1308,7 @@ void launch_lz4_decode_lds2_slabs(const BatchArgs& a, const void* sync, const vo
 
 }  // namespace cj
 #ifdef CJ_SLAB_TRACE
-extern "C" int cj_debug_slab_trace(unsigned long long* out, int n_slabs) {
+extern "C" CJ_API int cj_debug_slab_trace(unsigned long long* out, int n_slabs) {      // (variant builds only: tests/perf/slab_chain_trace.py)
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(cj::g_slab_trace), (size_t)n_slabs * 64) == hipSuccess ? 0 : -1;
 }
 #endif

@@ -134,6 +134,10 @@ __device__ __forceinline__ void lz4_encode_chunk(const BatchArgs& a, uint32_t ch
                     anchor = sl.anchor;
                 }
             }
+            if (!fast_round) {                                    // like select_walk: what an earlier round's match already covers is not indexed
+#pragma unroll
+                for (int j = 0; j < kSub; j++) covered[j] = pos + 64u * (uint32_t)j + lane < anchor;
+            }
 #pragma unroll
             for (int j = 0; j < kSub; j++) {
                 if (fast_round) break;
@@ -159,7 +163,7 @@ __device__ __forceinline__ void lz4_encode_chunk(const BatchArgs& a, uint32_t ch
                         op += 2;
                         if (mcode >= 15u) op = emit_len_ext(out, op, mcode - 15u);
                     } else {
-                        if (q_n == 64u) { lz4_emit_queue(in, out, q_n, q_lit0, q_lit, q_off, q_mcode, q_op); q_n = 0; }     // cannot happen with >= 4-byte matches; kept as a guard
+                        if (q_n == 64u) { lz4_emit_queue(in, out, q_n, q_lit0, q_lit, q_off, q_mcode, q_op); q_n = 0; }     // a round of 320 positions can select up to 80 matches of 4 bytes: the queue is flushed when its 64 lanes are full
                         if (lane == q_n) { q_lit0 = anchor; q_lit = lit; q_off = off; q_mcode = mcode; q_op = op; }
                         q_n += 1;
                         op += 1u + (lit >= 15u ? 1u + (lit - 15u) / 255u : 0u) + lit + 2u + (mcode >= 15u ? 1u + (mcode - 15u) / 255u : 0u);

@@ -176,6 +176,10 @@ __device__ __forceinline__ void snappy_encode_chunk(const BatchArgs& a, uint32_t
                     anchor = sl.anchor;
                 }
             }
+            if (!fast_round) {                                    // like select_walk: what an earlier round's match already covers is not indexed
+#pragma unroll
+                for (int j = 0; j < kSub; j++) covered[j] = pos + 64u * (uint32_t)j + lane < anchor;
+            }
 #pragma unroll
             for (int j = 0; j < kSub; j++) {
                 if (fast_round) break;
@@ -194,7 +198,7 @@ __device__ __forceinline__ void snappy_encode_chunk(const BatchArgs& a, uint32_t
                         if (lit) op = emit_snappy_literal(out, op, in + anchor, lit);
                         op = emit_snappy_copy(out, op, off, mlen);
                     } else {
-                        if (q_n == 64u) { snappy_emit_queue(in, out, q_n, q_lit0, q_lit, q_off, q_mlen, q_op); q_n = 0; }     // cannot happen with >= 4-byte matches; kept as a guard
+                        if (q_n == 64u) { snappy_emit_queue(in, out, q_n, q_lit0, q_lit, q_off, q_mlen, q_op); q_n = 0; }     // a round of 320 positions can select up to 80 matches of 4 bytes: the queue is flushed when its 64 lanes are full
                         if (lane == q_n) { q_lit0 = anchor; q_lit = lit; q_off = off; q_mlen = mlen; q_op = op; }
                         q_n += 1;
                         op += snappy_literal_size(lit) + snappy_copy_size(off, mlen);

@@ -12,6 +12,7 @@
 #include "cj_oracle.h"
 #include <dlfcn.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdatomic.h>
 #include <stdlib.h>
 #include <string.h>
@@ -69,10 +70,12 @@ int cjo_have_liblz4(void) { return liblz4_decoder() != 0; }
 typedef struct {
     int op, reps; size_t n; const uint8_t* in_base; const uint64_t* in_off; const uint64_t* in_len;
     uint8_t* out_base; size_t out_stride; int64_t* res; atomic_size_t* next; pthread_barrier_t* bar; int use_bar;
+    atomic_int go;          /* 0: the pool is still being started (workers wait), 1: run */
 } job_t;
 
 static void* worker(void* p) {
     job_t* j = (job_t*)p;
+    while (atomic_load_explicit(&j->go, memory_order_acquire) == 0) sched_yield();      /* the barrier is sized once every thread exists */
     lz4_safe_fn lz4 = j->op == 4 ? liblz4_decoder() : 0;
     for (int r = 0; r < j->reps; r++) {
         for (;;) {
@@ -106,16 +109,17 @@ int cjo_batch_run_reps(int op, int threads, int reps, size_t n_chunks, const uin
     pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
     if (!next || !th) { free(next); free(th); return -1; }
     pthread_barrier_t bar;
-    pthread_barrier_init(&bar, 0, (unsigned)threads);
-    job_t j = { op, reps, n_chunks, in_base, in_off, in_len, out_base, out_stride, res, next, &bar, threads > 1 };
+    job_t j = { op, reps, n_chunks, in_base, in_off, in_len, out_base, out_stride, res, next, &bar, 0, 0 };
     int started = 1;
     for (int t = 1; t < threads; t++) {
         if (pthread_create(&th[t], 0, worker, &j) != 0) break;
         started++;
     }
-    if (started != threads) {                 /* could not start the pool: the barrier would never open */
-        j.use_bar = 0; j.reps = 1;
-    }
+    /* the workers wait for `go`: the barrier is sized for the threads that actually exist (a pool that could only be started in
+     * part still finishes — with fewer threads — and the call reports -2), and nothing of the job changes after a worker has read it */
+    pthread_barrier_init(&bar, 0, (unsigned)started);
+    j.use_bar = started > 1;
+    atomic_store_explicit(&j.go, 1, memory_order_release);
     worker(&j);
     for (int t = 1; t < started; t++) pthread_join(th[t], 0);
     pthread_barrier_destroy(&bar);

@@ -557,3 +557,16 @@ def test_level_decoders_opt_in(which):
     env = dict(os.environ, CJ_DECODER=which, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, "-c", _LEVEL_DECODER_CHECK], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "level decoders ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_internal_flag_bits_are_refused_at_the_c_abi(eng):
+    """piece splitting / tail report / linked-frame bits (cj_common.hpp) belong to the library's own large-buffer and frame paths; a
+    C-ABI caller that sets one gets CJ_E_BAD_ARG instead of a kernel that reads descriptors which are not there"""
+    blob = oracle.lz4_compress_raw(oracle.synth_v1(4096, 1))[1]
+    for bad in (0x8000, 0x8000 | (4 << 16), 0x2000, 0x4000, 1 << 20):
+        with pytest.raises(N.EngineError):
+            eng.batch_host(LZ4, DEC, bad, [blob], [4096])
+        with pytest.raises(N.EngineError):
+            eng.batch_host(LZ4, N.OP_COMPRESS, bad, [b"x" * 100], [200])
+    res, outs = eng.batch_host(LZ4, DEC, N.FLAG_FORCE_LDS_PER_CHUNK, [blob], [4096])          # public bits still pass
+    assert int(res[0]) == 4096

@@ -66,7 +66,8 @@ int launch_decode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a, hipStrea
     const int rc = lds_scratch(e, a, s, !fused);
     if (rc != 0) return rc;
     uint32_t* lists = (uint32_t*)e->d_lanelist.p;
-    const uint32_t grid = 2u * (uint32_t)e->n_cu;
+    static const uint32_t per_cu = [] { const char* v = std::getenv("CJ_WG_PER_CU"); const int x = v ? std::atoi(v) : 2; return (uint32_t)(x == 1 ? 1 : 2); }();   // experiments: one workgroup per CU
+    const uint32_t grid = per_cu * (uint32_t)e->n_cu;
     if (fused) {
         if (use_lvl) cj::launch_lz4_decode_lvl(a, nullptr, e->d_pmeta.p, e->d_tab.p, lists + 2, grid, s, codec, true);
         else cj::launch_lz4_decode_fused(a, e->d_pmeta.p, e->d_tab.p, lists + 2, grid, s, codec);

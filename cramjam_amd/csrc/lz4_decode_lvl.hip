@@ -46,7 +46,7 @@ constexpr uint32_t kLvOffAux = kLvOffWin + 65536;
 constexpr uint32_t kLvOffHist = kLvOffAux;                      // u32 hist / slot[1026]  (fused: the parse's 8 KiB of marks overlay hist + lstart)
 constexpr uint32_t kLvOffStart = kLvOffHist + 4112;             // u16 lstart[1026]: first sorted entry of every level
 constexpr uint32_t kLvOffVars = kLvOffAux + 8192;               // 64 B of variables, 64 dummy bytes, 256 B of dummy dwords
-constexpr uint32_t kLvOffFused = kLvOffVars + 384;              // fused_parse's 6 KiB
+constexpr uint32_t kLvOffFused = kLvOffVars + 384 + 64;         // fused_parse's 6 KiB (behind the 64 bytes of phase counters)
 constexpr uint32_t kLvBytes = kLvOffFused;                      // 74 128 B
 constexpr uint32_t kLvBytesFused = kLvOffFused + kFusedAux;     // 80 272 B: two workgroups per CU (163 840 B)
 static_assert(2u * kLvBytesFused <= 163840u, "two workgroups per CU");
@@ -60,7 +60,7 @@ __device__ unsigned long long g_lvl_phase_cycles[16];           // S0, D1/P, X, 
     do {                                                                                \
         if (prof && tid == 0) {                                                         \
             unsigned long long now_ = __builtin_readcyclecounter();                     \
-            atomicAdd(&g_lvl_phase_cycles[idx], now_ - t_prev);                         \
+            s_prof[idx] += (uint32_t)(now_ - t_prev);                                   \
             t_prev = now_;                                                              \
         }                                                                               \
     } while (0)
@@ -85,6 +85,8 @@ __device__ __forceinline__ void lvl_body(const BatchArgs& a, const uint2* sync, 
     uint2* sorted = reinterpret_cast<uint2*>(slot + kLvSortedOff);
     uint2* sorted_s = sorted + kLvMaxRec;
     const bool prof = (a.flags & 0x1000u) != 0;
+    uint32_t* s_prof = reinterpret_cast<uint32_t*>(smem + kLvOffVars + 384u);      // phase counters, flushed once per chunk (a mark's atomicAdd would sit in front of the next barrier's vmcnt(0))
+    if (prof && threadIdx.x < 16u) s_prof[threadIdx.x] = 0u;
     unsigned long long t_prev = prof ? __builtin_readcyclecounter() : 0ull;
     uint32_t next_c = 0;
     if (tid == 0) next_c = atomicAdd(counter, 1u);
@@ -482,6 +484,7 @@ _Pragma("unroll")
                         uint32_t ls = rdlane(st, uni(i));
                         const uint32_t le = rdlane(en, uni(i));
                         if (dirty) { __syncthreads(); nbar += 1; dirty = false; }
+                        CJ_LV_MARK(6);                                           // 6: D3's walk over the levels
                         while (ls < le) {
                             while (ls >= 512u * (kb + 1u)) {                                 // (uniform) next block of the large list
 #pragma unroll
@@ -496,7 +499,9 @@ _Pragma("unroll")
                                 lvl_match_copy_dense(e >= ls && e < part, a_out, s_out, EB[0].x & 0xffffu, EB[0].x >> 16, EB[0].y & 0xffffu, dummy_w);
                             ls = part;
                         }
+                        CJ_LV_MARK(13);                                          // 13: wavefront 0's copies of the large levels
                         __syncthreads(); nbar += 1;
+                        CJ_LV_MARK(14);                                          // 14: ... its wait at their barriers
                         i += 1u;
                     } else {
                         const uint64_t rest = mm >> i;
@@ -521,12 +526,13 @@ _Pragma("unroll")
                             }
                         }
                         dirty = true;
+                        CJ_LV_MARK(15);                                          // 15: the runs of small levels (wavefront 0 copies)
                         i = j;
                     }
                 }
             }
             if (dirty || nlev == 0u) { __syncthreads(); nbar += 1; }
-            if (prof && tid == 0) { atomicAdd(&g_lvl_phase_cycles[9], (unsigned long long)nlev); atomicAdd(&g_lvl_phase_cycles[10], (unsigned long long)nbar); }
+            if (prof && tid == 0) { s_prof[9] += nlev; s_prof[10] += nbar; }
         }
 #undef CJ_LV_FOR_BATCHES
 #ifdef CJ_LV_D3_PRIO
@@ -541,7 +547,10 @@ _Pragma("unroll")
             for (uint32_t i = tid; i < nvec; i += kLvThreads) st16u_nt(out + 16u * i, src[i]);
             for (uint32_t i = (nvec << 4) + tid; i < U; i += kLvThreads) out[i] = s_out[i];
         }
-        if (prof) { __syncthreads(); CJ_LV_MARK(7); if (tid == 0) atomicAdd(&g_lvl_phase_cycles[8], 1ull); }
+        if (prof) {
+            __syncthreads(); CJ_LV_MARK(7);
+            if (tid < 16u) { const uint32_t v = tid == 8u ? 1u : s_prof[tid]; if (v) atomicAdd(&g_lvl_phase_cycles[tid], (unsigned long long)v); s_prof[tid] = 0u; }
+        }
     }
 }
 

@@ -111,11 +111,13 @@ def corpus_chunks(S):
     d = os.path.join(ROOT, "tests", "golden", "corpus")
     man = json.load(open(os.path.join(d, "manifest.json")))["files"]
     out = []
-    for name in sorted(man):
+    only = os.environ.get("CJ_CORPUS_FILES")                  # (experiments: a comma-separated subset)
+    names = [n for n in sorted(man) if not only or n in only.split(",")]
+    for name in names:
         raw = bz2.decompress(open(os.path.join(d, name + ".bz2"), "rb").read())
         assert hashlib.sha256(raw).hexdigest() == man[name]["sha256"], name
         out += [raw[i:i + S] for i in range(0, len(raw) - S + 1, S)]
-    return out, sorted(man)
+    return out, names
 
 
 def build_batch(N, L, eng, dev, codec, op_dec, S, U, NCH, first_index, compressor, torch, np, data="synth-v1"):

@@ -1,7 +1,7 @@
 # Round-end evidence run (on the GPU box): gpu tests, the default bench line (it measures its HBM traffic itself with two
 # rocprofv3 --pmc child runs), rocprofv3 kernel stats of the same command, SQ / LDS counters, and the secondary-path bench lines.
 # Outputs land in gpurun_out/<tag>/; copy the summaries into profiles/rNN/.
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
 O=gpurun_out/$TAG; rm -rf $O; mkdir -p $O
@@ -22,7 +22,7 @@ for f in glob.glob(sys.argv[1]+'/*/*counter_collection.csv'):
 for k in sorted(agg):
     print(k, ' '.join('%s=%.0f' % (c.replace('SQ_',''), sum(v)/len(v)/1e5) for c,v in sorted(agg[k].items())), '(per chunk of the 100 k)')
 PY
-for args in "--codec snappy" "--op compress" "--op compress --codec snappy" "--codec snappy --op roundtrip" "--chunks 1000000 --steps 20" "--workload mixed256k --steps 20" "--chunks 8192 --unique 2048" "--chunks 1024 --unique 1024"; do
+for args in "--data corpus64k --steps 20" "--data corpus64k --codec snappy --steps 20" "--codec snappy" "--op compress" "--op compress --codec snappy" "--codec snappy --op roundtrip" "--chunks 1000000 --steps 20" "--workload mixed256k --steps 20" "--chunks 8192 --unique 2048" "--chunks 1024 --unique 1024"; do
   python bench.py --no-cpu-baseline --traffic off $args 2>/dev/null | tail -1 >> $O/other_paths.jsonl
 done
 python - <<PY

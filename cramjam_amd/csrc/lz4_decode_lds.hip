@@ -767,6 +767,9 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 }
             }
         }
+#ifdef CJ_X_SKIP_D2
+        d2_done = true;
+#endif
         if (!d2_done) {
         // (the next batch's records are requested before the current batch is processed: a coalesced table read is a
         //  full global round trip and a wave owns only ~5 batches)
@@ -870,6 +873,9 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         //      publish (two ds_or) and the mask update: ~12 instructions when nothing is ready, ~35 with copies.
         //      Lanes outside the fast shape (longer than 32 bytes, self-overlapping, 1-3 bytes) keep the general path.
         if constexpr (!kSlab && !kLinked) {
+#ifdef CJ_X_SKIP_D3
+            if (false)
+#endif
             for (uint32_t base = wave * 64u; base < nrec_all; base += kL2Threads) {
                 const uint4 rec = rec_nx;
                 rec_nx = make_uint4(0, 0, 0, 0);

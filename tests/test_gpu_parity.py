@@ -570,3 +570,23 @@ def test_internal_flag_bits_are_refused_at_the_c_abi(eng):
             eng.batch_host(LZ4, N.OP_COMPRESS, bad, [b"x" * 100], [200])
     res, outs = eng.batch_host(LZ4, DEC, N.FLAG_FORCE_LDS_PER_CHUNK, [blob], [4096])          # public bits still pass
     assert int(res[0]) == 4096
+
+
+def test_chunks_of_up_to_16384_sequences_take_the_workgroup_decoder(eng):
+    """a 64 KiB LZ4 block holds at most 16 384 sequences; round 3 raised the parse kernels' sync-point capacity from 8 192 to that, so
+    chunks of 10-16 k four-byte matches (and real text, tests/test_corpus_gpu.py) decode on the workgroup path instead of one wavefront"""
+    import random
+    rnd = random.Random(7)
+    words = [rnd.randbytes(4) for _ in range(64)]
+    def mk(n, sep):
+        out = bytearray(b"".join(words))
+        while len(out) < n:
+            out += rnd.choice(words) + rnd.randbytes(sep)
+        return bytes(out[:n])
+    chunks = [mk(65536, 1), mk(65536, 2), mk(65536, 0), mk(65000, 0), mk(40000, 1)] * 13
+    for codec, comp in ((LZ4, lambda c: oracle.lz4_compress_raw(c)[1]), (SNAPPY, lambda c: oracle.snappy_compress(c)[1])):
+        blobs = [comp(c) for c in chunks[:5]] * 13
+        for flags in (0, N.FLAG_FORCE_LDS_PER_CHUNK):
+            res, outs = eng.batch_host(codec, DEC, flags, blobs, [len(c) for c in chunks])
+            assert [int(r) for r in res] == [len(c) for c in chunks], (codec, flags)
+            assert all(bytes(o) == c for o, c in zip(outs, chunks)), (codec, flags)

@@ -92,7 +92,10 @@ __device__ unsigned long long g_slab_trace[8192 * 8];
 #endif
 __device__ unsigned long long g_fwd_chunks = 0ull;            // test hook: chunks / slabs that went through D1f
 constexpr uint32_t kFwdMaxRecords = 6144;      // D1f (match forwarding): 10 bytes of index per record in the 64 KiB window
-constexpr uint32_t kFwdMaxRounds = CJ_FWD_ROUNDS, kFwdNear = 4096;
+#ifndef CJ_FWD_ROUNDS_BATCH
+#define CJ_FWD_ROUNDS_BATCH 2u
+#endif
+constexpr uint32_t kFwdMaxRounds = CJ_FWD_ROUNDS, kFwdBatchRounds = CJ_FWD_ROUNDS_BATCH, kFwdNear = 4096;
 struct SlabArgs { uint32_t* done; uint4* cross; uint32_t tab_stride, cross_stride, rel; uint32_t* defer; uint32_t defer_stride; };
 #ifndef CJ_SLAB_PATIENCE
 #define CJ_SLAB_PATIENCE 64u
@@ -534,6 +537,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             }
         }
 
+        bool fwd_taken = false;                              // (uniform) D1f ran: the records were rewritten, extra literal copies appended
 #ifndef CJ_NO_FORWARD
         // ---- D1f: MATCH FORWARDING.  D3 resolves matches as a dependency DAG and pays its latency per LEVEL; real data
         //      (text, logs, records) is deep: a phrase is copied from its previous occurrence, which was copied from the one
@@ -547,7 +551,6 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         //      start | dst << 16 and the state word (current offset / input position + flags); the records tile the window
         //      (start[i+1] = end of record i), so a match's length is start[i+1] - dst[i]; plus, per 16 bytes of output,
         //      the last record that starts at or before them.
-        bool fwd_taken = false;
         if constexpr (!kLinked) {
             // mostly near matches: the chains are deep, forwarding pays (it costs ~25 k cycles + 10 k per round).  kSlab: always
             // when the slab waits for bytes of earlier slabs — the forwarding runs before that wait, what it removes from
@@ -577,7 +580,10 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                     for (uint32_t b = i == 0u ? 0u : b0; b < b1; b++) f_blk[b] = (uint16_t)i;
                 }
                 __syncthreads();
-                for (uint32_t round = 0; round < kFwdMaxRounds; round++) {
+                // (batches: two rounds — corpus64k LZ4 / Snappy GB/s by cap: none 172 / 238, 2: 188 / 234, 4: 186 / 229, 8 and 16: 180 / 226;
+                //  slab mode keeps sixteen: there the depth it removes comes off the serial chain through the slabs)
+                const uint32_t max_rounds = kSlab ? kFwdMaxRounds : kFwdBatchRounds;
+                for (uint32_t round = 0; round < max_rounds; round++) {
                     uint32_t changed = 0;
                     for (uint32_t i = tid; i + 1u < nseq; i += kL2Threads) {
                         const uint32_t st = f_st[i];

@@ -95,7 +95,13 @@ constexpr uint32_t kFwdMaxRecords = 6144;      // D1f (match forwarding): 10 byt
 #ifndef CJ_FWD_ROUNDS_BATCH
 #define CJ_FWD_ROUNDS_BATCH 2u
 #endif
-constexpr uint32_t kFwdMaxRounds = CJ_FWD_ROUNDS, kFwdBatchRounds = CJ_FWD_ROUNDS_BATCH, kFwdNear = 4096;
+#ifndef CJ_FWD_NEAR
+#define CJ_FWD_NEAR 4096
+#endif
+#ifndef CJ_FWD_SHARE_NUM
+#define CJ_FWD_SHARE_NUM 2u                    // forwarding where more than 1 / 2 of the matches are near
+#endif
+constexpr uint32_t kFwdMaxRounds = CJ_FWD_ROUNDS, kFwdBatchRounds = CJ_FWD_ROUNDS_BATCH, kFwdNear = CJ_FWD_NEAR;
 struct SlabArgs { uint32_t* done; uint4* cross; uint32_t tab_stride, cross_stride, rel; uint32_t* defer; uint32_t defer_stride; };
 #ifndef CJ_SLAB_PATIENCE
 #define CJ_SLAB_PATIENCE 64u
@@ -555,7 +561,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             // mostly near matches: the chains are deep, forwarding pays (it costs ~25 k cycles + 10 k per round).  kSlab: always
             // when the slab waits for bytes of earlier slabs — the forwarding runs before that wait, what it removes from
             // the dependency depth comes off the serial chain through the slabs
-            if (nseq <= kFwdMaxRecords && staged && (*s_small * 2u > nseq || (kSlab && *s_ncross > 0u))) {
+            if (nseq <= kFwdMaxRecords && staged && (*s_small * CJ_FWD_SHARE_NUM > nseq || (kSlab && *s_ncross > 0u))) {
                 fwd_taken = true;
                 uint32_t* f_w0 = reinterpret_cast<uint32_t*>(s_out);
                 uint32_t* f_st = f_w0 + kFwdMaxRecords;

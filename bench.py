@@ -363,14 +363,6 @@ def main():
         if int(ph[5]):
             print("LDS decoder cycles/chunk: S0 %d  D1 %d  D2 %d  D3 %d  D4 %d  (blocks %d)  sub-marks 6.. %s" % (
                 ph[0] // nb, ph[1] // nb, ph[2] // nb, ph[3] // nb, ph[4] // nb, nb, [int(ph[i] // nb) for i in range(6, 16)]), file=sys.stderr)
-        for name, fn in (("level decoder (table)", L.cj_debug_lvl_phase_cycles), ("level decoder (LDS)", L.cj_debug_lvl1_phase_cycles)):
-            pl = (C.c_ulonglong * 16)()
-            fn(pl, 1)
-            if not int(pl[8]):
-                continue
-            nb = int(pl[8])
-            print(name + " cycles/chunk: " + "  ".join("%s %d" % (nm, pl[i] // nb) for i, nm in enumerate(("S0", "D1/P", "X", "L", "K", "D2", "D3", "D4")))
-                      + "  | levels %.1f  D3 barriers %.1f  (chunks %d)  extra marks 11.. %s" % (pl[9] / nb, pl[10] / nb, nb, [int(pl[i] // nb) for i in range(11, 16)]), file=sys.stderr)
 
     # ---- verify at full size: every chunk's result and every output byte ----
     bytes_in = sum(b.bytes_in for b in batches)

@@ -57,8 +57,6 @@ SYMBOLS = {
 BENCH_SYMBOLS = {
     "cj_bench_synth_v1": (_int, [_vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _vp]),
     "cj_debug_lds_phase_cycles": (_int, [_vp, _int]),
-    "cj_debug_lvl_phase_cycles": (_int, [_vp, _int]),
-    "cj_debug_lvl1_phase_cycles": (_int, [_vp, _int]),
     "cj_debug_linked_lds_frames": (C.c_ulonglong, []),
     "cj_debug_forwarded_chunks": (C.c_longlong, [_int]),
     "cj_debug_big_parse": (C.c_int64, [_int, _u32, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_size_t, _vp]),

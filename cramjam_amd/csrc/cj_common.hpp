@@ -21,7 +21,7 @@ struct BatchArgs {
     const uint32_t* hist;       // linked LZ4-frame blocks only (frame.hip): bytes of history before out_off[i]; nullptr = none
 };
 
-// internal flag bits (never part of the C-ABI): 0x1000 = LDS decoder phase profile, 0x2000 = linked-frame parse
+// internal flag bits (never part of the C-ABI; CJ_FLAG_DEBUG_PROFILE 0x1000 is public): 0x2000 = linked-frame parse
 // (bit 63 of in_len marks a STORED block; no minimum sequence count for the LDS decoder)
 constexpr uint32_t kFlagLinkedFrame = 0x2000u;
 constexpr uint32_t kFlagSplitPieces = 0x8000u;     // encoders (large.hip): the chunks are consecutive sub-pieces of 64 KiB pieces, `per` of them per piece
@@ -48,12 +48,6 @@ void launch_lz4_decode_lds2_linked(const BatchArgs& a, const void* sync, const v
 // parse + decode in ONE kernel: the segmented parse runs inside the workgroup on the staged chunk; meta[c] = kRouteWave for chunks it leaves to the wave kernel
 void launch_lz4_decode_fused(const BatchArgs& a, void* meta, void* tabs, uint32_t* counter, uint32_t grid, hipStream_t s, int codec = 0);
 size_t lz4_lds2_tab_bytes(uint32_t grid);
-// the level-ordered workgroup decoder (lz4_decode_lvl.hip): same scratch, same counter; fused = the parse stage inside (sync unused)
-void launch_lz4_decode_lvl(const BatchArgs& a, const void* sync, void* meta, void* tabs, uint32_t* counter, uint32_t grid, hipStream_t s, int codec, bool fused);
-size_t lz4_lvl_tab_bytes(uint32_t grid);
-// the all-LDS level-ordered decoder (lz4_decode_lvl1.hip): one workgroup of 1024 threads per CU; takes the chunks of up to 4032
-// sequences and marks them done in meta, the rest is left to launch_lz4_decode_lvl
-void launch_lz4_decode_lvl1(const BatchArgs& a, const void* sync, void* meta, uint32_t* counter, uint32_t grid, hipStream_t s, int codec);
 size_t lz4_lds_scratch_sync_bytes(size_t n_chunks);
 size_t lz4_lds_scratch_meta_bytes(size_t n_chunks);
 // Encoders, large batches: besides the ten LDS-table wavefronts that fit a CU, `table_blocks` more wavefronts with their hash

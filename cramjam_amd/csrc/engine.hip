@@ -34,7 +34,7 @@ int lds_scratch(cj_engine* e, const cj::BatchArgs& a, hipStream_t s, bool with_s
     else HIP_TRY(hipStreamWaitEvent(s, e->scratch_free, 0), CJ_E_NO_DEVICE);   // previous user of the scratch
     HIP_TRY(hipMemsetAsync(e->d_lanelist.p, 0, 16, s), CJ_E_NO_DEVICE);        // [2] = the decoder's chunk counter
     if (e->n_cu == 0) HIP_TRY(hipDeviceGetAttribute(&e->n_cu, hipDeviceAttributeMultiprocessorCount, e->device), CJ_E_NO_DEVICE);
-    if (!e->d_tab.reserve(std::max(cj::lz4_lds2_tab_bytes(2u * (uint32_t)e->n_cu), cj::lz4_lvl_tab_bytes(2u * (uint32_t)e->n_cu)))) return CJ_E_OOM;
+    if (!e->d_tab.reserve(cj::lz4_lds2_tab_bytes(2u * (uint32_t)e->n_cu))) return CJ_E_OOM;
     return 0;
 }
 
@@ -54,32 +54,23 @@ int launch_decode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a, hipStrea
     if (a.flags & CJ_FLAG_FORCE_LDS_PER_CHUNK) mode = 2;
     if (mode == 0) { if (lz4) cj::launch_lz4_decode(a, s); else cj::launch_snappy_decode(a, s); return 0; }
     if (mode == 1) { if (lz4) cj::launch_lz4_decode_lanes(a, s); else cj::launch_snappy_decode_lanes(a, s); return 0; }
-    // the workgroup decoder: the bitmap resolver (lz4_decode_lds.hip).  CJ_DECODER=lvl selects the level-ordered dense resolver
-    // (lz4_decode_lvl.hip), CJ_DECODER=lvl1 puts its all-LDS single-workgroup variant (lz4_decode_lvl1.hip) in front of it: both are
-    // bit-exact and both lost to the bitmap resolver on the benchmark data (profiles/r03/experiments); CJ_FUSED=0 / 1 forces the
-    // separate / in-kernel parse at any batch size
-    static const int which = [] { const char* v = std::getenv("CJ_DECODER"); return !v ? 0 : std::strcmp(v, "lvl") == 0 ? 1 : std::strcmp(v, "lvl1") == 0 ? 2 : 0; }();
-    static const bool use_lvl = which != 0, use_lvl1 = which == 2;
+    // the workgroup decoder (lz4_decode_lds.hip).  CJ_FUSED=0 / 1 forces the separate / in-kernel parse at any batch size (tests
+    // exercise both sides of the threshold with it)
     static const int force_fused = [] { const char* v = std::getenv("CJ_FUSED"); return v ? std::atoi(v) : -1; }();
     const bool fused = force_fused >= 0 ? force_fused != 0 : a.n_chunks <= (uint32_t)CJ_FUSED_MAX_CHUNKS;
     std::lock_guard<std::mutex> lock(e->scratch_mu);
     const int rc = lds_scratch(e, a, s, !fused);
     if (rc != 0) return rc;
     uint32_t* lists = (uint32_t*)e->d_lanelist.p;
-    static const uint32_t per_cu = [] { const char* v = std::getenv("CJ_WG_PER_CU"); const int x = v ? std::atoi(v) : 2; return (uint32_t)(x == 1 ? 1 : 2); }();   // experiments: one workgroup per CU
-    const uint32_t grid = per_cu * (uint32_t)e->n_cu;
+    const uint32_t grid = 2u * (uint32_t)e->n_cu;          // two persistent workgroups per CU
     if (fused) {
-        if (use_lvl) cj::launch_lz4_decode_lvl(a, nullptr, e->d_pmeta.p, e->d_tab.p, lists + 2, grid, s, codec, true);
-        else cj::launch_lz4_decode_fused(a, e->d_pmeta.p, e->d_tab.p, lists + 2, grid, s, codec);
+        cj::launch_lz4_decode_fused(a, e->d_pmeta.p, e->d_tab.p, lists + 2, grid, s, codec);
     } else {
         HIP_TRY(hipMemsetAsync(e->d_pmeta.p, 0, cj::lz4_lds_scratch_meta_bytes(a.n_chunks), s), CJ_E_NO_DEVICE);   // no chunk is pre-routed
         // validate, size, count sequences, sync points, route
         if (lz4) cj::launch_lz4_parse(a, e->d_sync.p, e->d_pmeta.p, s);
         else cj::launch_snappy_parse(a, e->d_sync.p, e->d_pmeta.p, s);
-        if (use_lvl) {
-            if (use_lvl1) cj::launch_lz4_decode_lvl1(a, e->d_sync.p, e->d_pmeta.p, lists + 3, (uint32_t)e->n_cu, s, codec);   // chunks of up to 4032 sequences, all in LDS
-            cj::launch_lz4_decode_lvl(a, e->d_sync.p, e->d_pmeta.p, e->d_tab.p, lists + 2, grid, s, codec, false);            // what it left
-        } else cj::launch_lz4_decode_lds2(a, e->d_sync.p, e->d_pmeta.p, e->d_tab.p, lists + 2, grid, s, codec);
+        cj::launch_lz4_decode_lds2(a, e->d_sync.p, e->d_pmeta.p, e->d_tab.p, lists + 2, grid, s, codec);
     }
     if (lz4) cj::launch_lz4_decode_routed(a, e->d_pmeta.p, s);                // few long runs / oversize chunks / errors
     else cj::launch_snappy_decode_routed(a, e->d_pmeta.p, s);
@@ -304,7 +295,7 @@ int cj_engine_device(const cj_engine* e) { return e ? e->device : -1; }
 // the flag bits a C-ABI caller may set; everything else (piece splitting, tail reports, linked-frame parse: cj_common.hpp) belongs
 // to large.hip / frame.hip, which call cj::launch directly — a stray bit would make a kernel read descriptors that are not there
 static constexpr uint32_t kPublicFlags = CJ_FLAG_LZ4_SIZE_PREFIX | CJ_FLAG_FORCE_WAVE_PER_CHUNK | CJ_FLAG_FORCE_LANE_PER_CHUNK | CJ_FLAG_FORCE_LDS_PER_CHUNK
-                                         | 0x1000u /* decoder phase counters (cj_debug_*_phase_cycles) */;
+                                         | CJ_FLAG_DEBUG_PROFILE;
 
 int cj_batch_device(cj_engine* e, cj_codec codec, cj_op op, uint32_t flags, size_t n_chunks,
                     const uint8_t* in_base, const uint64_t* in_off, const uint64_t* in_len,

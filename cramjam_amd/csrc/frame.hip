@@ -331,7 +331,7 @@ std::atomic<unsigned long long> g_linked_lds_frames{0};
 
 // Linked 64 KiB blocks through parse + lz4_decode_lds2_kernel<LZ4, linked>: ~100x the chain kernel on short-sequence data.
 // Needs every non-last block to decode to exactly 64 KiB (block k then starts at k * 64 KiB and its history is the whole
-// previous block) and every block to fit the LDS decoder (<= 8192 sequences, <= 65 504 input bytes); the parse kernel
+// previous block) and every block to fit the LDS decoder (<= 16 384 sequences, <= 65 504 input bytes); the parse kernel
 // establishes both.  Returns 0 when the frame was decoded this way, 1 when the caller must fall back to the chain
 // kernel, < 0 on a device error.
 int lz4_frame_linked_lds(cj_engine* e, const Lz4Frame& f, const uint8_t* d_in, std::vector<int64_t>& res, uint8_t** d_final) {

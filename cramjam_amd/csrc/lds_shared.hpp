@@ -282,7 +282,7 @@ __device__ __forceinline__ DW<T / 4 + 2> gl_ld_exact(const uint8_t* g) {
 //   P4   they walk their piece once more with the true (index, output position): the decoder's own validation rules
 //        (the same Lz4Grammar / SnappyGrammar functions as the parse kernels) and the 16-byte records of D1, written
 //        straight to the workgroup's record table.
-// Anything that is not a clean chunk of 256..8192 sequences (any violation, too few or too many sequences) is handed to
+// Anything that is not a clean chunk of kLdsMinSeq .. kSyncStride * kSyncEvery (256 .. 16 384) sequences (any violation, too few or too many sequences) is handed to
 // the wavefront-per-chunk kernel, which decodes every valid chunk and names every error exactly: returns false then.
 // =====================================================================================================
 constexpr uint32_t kFusedLanes = 256;

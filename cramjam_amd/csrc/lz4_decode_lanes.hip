@@ -9,7 +9,7 @@
 //   lz4_decode_lanes_kernel : full decode, 16 B "wild" copies with exact tails
 //   lz4_parse_kernel        : walk + validate only (reads nothing but the compressed stream), emits
 //                             (ip, op) sync points every 8 sequences + the decoded size; chunks the LDS
-//                             decoder cannot take (capacity > 64 KiB, > 8192 sequences) are decoded here.
+//                             decoder cannot take (capacity > 64 KiB, > 16 384 sequences) are routed to the wavefront kernel.
 #include "lz4_lane_walk.hpp"
 #include "lane_stream.hpp"
 

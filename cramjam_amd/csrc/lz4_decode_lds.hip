@@ -52,8 +52,7 @@ __device__ unsigned long long g_lds_phase_cycles[16];
 #define CJ_L2_THREADS 512
 #endif
 constexpr uint32_t kL2Threads = CJ_L2_THREADS;
-constexpr uint32_t kL2Pad = 640;                           // behind the window: the in-place margin of the staged chunk (LZ4 batches, D2)
-constexpr uint32_t kL2OffBits = 65536 + kL2Pad;
+constexpr uint32_t kL2OffBits = 65536;
 constexpr uint32_t kL2OffVars = kL2OffBits + 8192;         // [0] fail flag, [8] current chunk, [64,128) dummy bytes, [128,384) dummy dwords
 constexpr uint32_t kL2Bytes = kL2OffVars + 384 + 128;      // 74880 B (the last 128: phase counters, the next chunk's descriptors): two workgroups fit one CU's LDS
 constexpr uint32_t kL2TabRecords = 3u * kSyncStride * kSyncEvery;   // records of a chunk (the parse kernel routes chunks with more than 16 384 sequences elsewhere) + the extra literal copies of D1f (at most two per record, D1f takes at most 6 144 records)
@@ -160,7 +159,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
     uint32_t* s_fwd = reinterpret_cast<uint32_t*>(smem + kOffVars + 24u);          // D1f: rounds in which a record moved
     uint32_t* s_small = reinterpret_cast<uint32_t*>(smem + kOffVars + 28u);        // D1: matches with an offset below kFwdNear
     volatile uint32_t* s_prevok = reinterpret_cast<volatile uint32_t*>(smem + kOffVars + 32u);      // kSlab: a wave has seen the previous slab's flag and fenced
-    const bool prof = (a.flags & 0x1000u) != 0;
+    const bool prof = (a.flags & CJ_FLAG_DEBUG_PROFILE) != 0;
     uint32_t* s_prof = reinterpret_cast<uint32_t*>(smem + kOffVars + 384u);
     if (prof && threadIdx.x < 16u) s_prof[threadIdx.x] = 0u;
     unsigned long long t_prev = prof ? __builtin_readcyclecounter() : 0ull;
@@ -169,27 +168,6 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
     // descriptor loads instead of in front of them (slabs are claimed when they are started: their order matters)
     uint32_t next_c = 0;
     if constexpr (!kLinked && !kSlab) { if (tid == 0) next_c = atomicAdd(counter, 1u); }
-    // Batches after a parse kernel: the NEXT chunk travels one iteration ahead.  Thread 0 requests its descriptors after D1 and parks
-    // them in LDS after D2 (no register lives across D3, where the allocator is at its 128), every thread requests its share of the
-    // compressed bytes + its first sync point right after D3 — in front of D4's 64 KiB of stores in the CU's memory pipe, instead of
-    // behind them at the top of the next iteration (a dependent global round trip costs 6-8 k cycles behind that drain; S0 was two
-    // of them).  The loop head then needs one barrier that waits for LDS only.
-    // (measured, profiles/r03/experiments d02: 581 vs 620 GB/s — the kernel sits at its 128 registers and the 22 that carry the next
-    //  chunk spill; S0 did not get shorter either, so the round trip is not waiting behind D4's stores: kept as an experiment)
-#ifdef CJ_CHUNK_PIPE
-    constexpr bool kPipe = !kLinked && !kSlab && !kFused;
-#else
-    constexpr bool kPipe = false;
-#endif
-    bool pf_valid = false;                                   // (uniform) the fields below describe the chunk of the coming iteration
-    uint32_t pf_c = 0;
-    ParseMeta pf_pm = {0u, 0u};
-    uint64_t pf_in_off = 0, pf_in_len = 0, pf_out_off = 0, pf_result = 0;
-    uint4 pf_v0 = make_uint4(0, 0, 0, 0), pf_v1 = pf_v0, pf_v2 = pf_v0, pf_v3 = pf_v0, pf_v4 = pf_v0;
-    uint2 pf_first = make_uint2(0u, 0u);
-    bool pf_bytes = false;                                   // ... and its first staging group is in pf_v0..4
-    uint32_t* s_nextc = reinterpret_cast<uint32_t*>(smem + kOffVars + 36u);
-    uint32_t* s_desc = reinterpret_cast<uint32_t*>(smem + kOffVars + 448u);      // next chunk: nseq, in_skip, in_off (2), in_len, out_off (2), result
 
     for (;;) {
         uint32_t c;
@@ -211,12 +189,6 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             if (tid == 0) *s_fail = 0u;
             for (uint32_t i = tid; i < 2048u; i += kL2Threads) s_bits[i] = 0u;
             __syncthreads();                                 // also: the previous block's D4 has finished reading its window
-        } else if (kPipe && pf_valid) {
-            c = pf_c;
-            if (c >= a.n_chunks) break;
-            if (tid == 0) { *s_fail = 0u; *s_ncross = 0u; *s_nextra = 0u; *s_small = 0u; *s_prevok = 0u; next_c = atomicAdd(counter, 1u); }
-            for (uint32_t i = tid; i < 2048u; i += kL2Threads) s_bits[i] = 0u;
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // D4 has read the window (its stores may still drain)
         } else {
             if (tid == 0) { *s_chunk = kSlab ? atomicAdd(counter, 1u) : next_c; *s_fail = 0u; *s_ncross = 0u; *s_nextra = 0u; *s_small = 0u; *s_prevok = 0u; }
             for (uint32_t i = tid; i < 2048u; i += kL2Threads) s_bits[i] = 0u;
@@ -226,19 +198,14 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             if (c >= a.n_chunks) break;
             if constexpr (!kSlab) { if (tid == 0) next_c = atomicAdd(counter, 1u); }
         }
-        const bool piped = kPipe && pf_valid;                // this chunk's descriptors (and maybe bytes) arrived with the previous iteration
-        pf_valid = false;
         ParseMeta pm = {1u, 0u};                            // kFused: nothing has looked at the chunk yet
         uint64_t d_in_off, d_in_len, d_out_off, d_result;
-        if (piped) { pm = pf_pm; d_in_off = pf_in_off; d_in_len = pf_in_len; d_out_off = pf_out_off; d_result = pf_result; }
-        else {
-            if constexpr (!kFused) pm = meta[c];
-            // the chunk's descriptors in ONE round trip: left to itself the compiler waits for pm.nseq (the early-out below) before it
-            // even requests the others, and the chunk's bytes are a third dependent round trip behind those
-            d_in_off = a.in_off[c]; d_in_len = a.in_len[c]; d_out_off = a.out_off[c];
-            d_result = kFused ? a.out_cap[c] : (uint64_t)a.result[c];      // kFused: the capacity (the parse computes the size)
-            asm volatile("" :: "v"(pm.nseq), "v"(pm.in_skip), "v"((uint32_t)d_in_off), "v"((uint32_t)d_in_len), "v"((uint32_t)d_out_off), "v"((uint32_t)d_result));
-        }
+        if constexpr (!kFused) pm = meta[c];
+        // the chunk's descriptors in ONE round trip: left to itself the compiler waits for pm.nseq (the early-out below) before it
+        // even requests the others, and the chunk's bytes are a third dependent round trip behind those
+        d_in_off = a.in_off[c]; d_in_len = a.in_len[c]; d_out_off = a.out_off[c];
+        d_result = kFused ? a.out_cap[c] : (uint64_t)a.result[c];      // kFused: the capacity (the parse computes the size)
+        asm volatile("" :: "v"(pm.nseq), "v"(pm.in_skip), "v"((uint32_t)d_in_off), "v"((uint32_t)d_in_len), "v"((uint32_t)d_out_off), "v"((uint32_t)d_result));
         uint32_t f_cap = 0;                                  // kFused: output capacity (LZ4) / announced length (Snappy) handed to the parse
         if constexpr (kFused) {
             // the prologue of the parse kernels: size prefix / length preamble, the special cases, what this decoder cannot hold.
@@ -354,25 +321,12 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         //      reads are LDS reads; D2 re-reads the literal bytes from global memory (L2 hits) because it overwrites
         //      the window while other lanes still need their sources ----
         const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(in) & 15u);
-        // LZ4 batches stage the chunk RIGHT-ALIGNED, ending 64 + C/128 bytes behind the window's end: that is liblz4's in-place
-        // decoding margin ((C >> 8) + 32, LZ4_DECOMPRESS_INPLACE_MARGIN) and more, so the literals of every record lie at or to the right
-        // of their destination and D2 can take them from LDS instead of reading the chunk a second time from global memory
-        // (measured, profiles/r03/experiments d01: 607 vs 621 GB/s on the benchmark data, no difference on the corpus — a round of 512
-        //  records costs ~4.5 k cycles of stores, ready bits and barrier whatever the source of the bytes: kept as an experiment)
-#ifdef CJ_INPLACE_D2
-        constexpr bool kInPlace = kCompact && kCodec == CJ_CODEC_LZ4_BLOCK;
-#else
-        constexpr bool kInPlace = false;
-#endif
-        const uint32_t stage_off = kInPlace ? ((65536u + 64u + (iend >> 7)) - iend - mis) & ~15u : 0u;
         // this thread's first sync point (D1) is requested together with the chunk's bytes: one round trip instead of two
         uint2 p_first = make_uint2(0u, 0u);
-        const bool have_bytes = piped && pf_bytes;           // (uniform)
-        if (have_bytes) p_first = pf_first;
-        else if constexpr (!kFused) p_first = csync[tid < nsp ? tid : 0u];
+        if constexpr (!kFused) p_first = csync[tid < nsp ? tid : 0u];
         {
             const uint4* src = reinterpret_cast<const uint4*>(in - mis);
-            uint4* dst = reinterpret_cast<uint4*>(s_out + stage_off);
+            uint4* dst = reinterpret_cast<uint4*>(s_out);
             const uint32_t nvec = staged ? (mis + iend + 15u) >> 4 : 0u;
             // five loads in flight per thread (a 40 KiB chunk is 5 x 512 vectors): written as one load and one store per
             // iteration the compiler waits for every load before the next one — five dependent round trips per chunk.  The
@@ -389,21 +343,14 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 if (i3 < nvec) dst[i3] = v3;
                 if (i4 < nvec) dst[i4] = v4;
             };
-            if (have_bytes) {                                // the first group arrived while the previous chunk was streamed out
-                const uint32_t i0 = tid, i1 = i0 + kL2Threads, i2 = i0 + 2u * kL2Threads, i3 = i0 + 3u * kL2Threads, i4 = i0 + 4u * kL2Threads;
-                if (i0 < nvec) dst[i0] = pf_v0;
-                if (i1 < nvec) dst[i1] = pf_v1;
-                if (i2 < nvec) dst[i2] = pf_v2;
-                if (i3 < nvec) dst[i3] = pf_v3;
-                if (i4 < nvec) dst[i4] = pf_v4;
-            } else if (nvec > 0u) group(tid);
+            if (nvec > 0u) group(tid);
             for (uint32_t i0 = tid + 5u * kL2Threads; i0 < nvec; i0 += 5u * kL2Threads) group(i0);
         }
         __syncthreads();
         CJ_PHASE_MARK(0);
 
         // ---- D1: expand sync points into sequence records (LDS -> global table) ----
-        const uint32_t a_in = a_out + stage_off + mis;
+        const uint32_t a_in = a_out + mis;
         if constexpr (kFused) {
             using G = typename std::conditional<kCodec == CJ_CODEC_SNAPPY_RAW, SnappyGrammar, Lz4Grammar>::type;
             const bool ok = fused_parse<G, kL2Threads>(a_in, iend, f_cap, s_bits, reinterpret_cast<uint32_t*>(smem + kL2Bytes), table2, s_small, nseq, U);
@@ -533,16 +480,6 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         if constexpr (kCompact && !kFused) { if (tid == 0) table2[nseq] = make_uint2(0u, U & 0xffffu); }      // sentinel: where the last record's match ends
         __syncthreads();
         CJ_PHASE_MARK(1);
-        // (kPipe) thread 0: the next chunk's descriptors, requested now, parked in LDS after D2
-        ParseMeta nx_pm = {0u, 0u};
-        uint64_t nx_in_off = 0, nx_in_len = 0, nx_out_off = 0, nx_result = 0;
-        if constexpr (kPipe) {
-            if (tid == 0 && next_c < a.n_chunks) {
-                nx_pm = meta[next_c];
-                nx_in_off = a.in_off[next_c]; nx_in_len = a.in_len[next_c]; nx_out_off = a.out_off[next_c]; nx_result = (uint64_t)a.result[next_c];
-            }
-        }
-
         bool fwd_taken = false;                              // (uniform) D1f ran: the records were rewritten, extra literal copies appended
 #ifndef CJ_NO_FORWARD
         // ---- D1f: MATCH FORWARDING.  D3 resolves matches as a dependency DAG and pays its latency per LEVEL; real data
@@ -729,60 +666,6 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             }
         };
         uint4 rec_nx = make_uint4(0, 0, 0, 0);
-        bool d2_done = false;
-        if constexpr (kInPlace) {
-            if (!fwd_taken) {
-                // IN PLACE: the staged chunk ends behind the window's end, every literal run moves to the LEFT (or stays), and the bytes
-                // a record writes can only cover staged bytes of records up to itself.  So the records are taken in ROUNDS of 512
-                // consecutive records — one per thread, every thread reads (up to 64 bytes of) its run into registers, barrier, every
-                // thread writes — and no run is read after something was written over it.  A dependent global round trip costs 6-8 k
-                // cycles under this kernel's load (profiles/r03/experiments) and the old path paid one per batch of 64 records
-                // (benchmark data: 24 k cycles for 6 batches per wave; text: 115 k for 20); here the records of eight rounds come in
-                // one round trip and the bytes come from LDS.  Matches start after the last round (their writes obey the same rule).
-                d2_done = true;
-                if (wave * 64u + lane < nrec_all) rec_nx = rec_load(wave * 64u + lane, nseq);      // D3's first batch: requested now
-                const uint32_t nrounds = (nseq + kL2Threads - 1u) / kL2Threads;
-                for (uint32_t g0 = 0; g0 < nrounds; g0 += 8u) {
-                    uint2 R[8];
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const uint32_t r = (g0 + (uint32_t)k) * kL2Threads + tid;
-                        R[k] = make_uint2(0u, 0u);
-                        if (r < nseq) R[k] = table2[r];
-                    }
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        if (g0 + (uint32_t)k < nrounds) {                              // (uniform)
-                            uint32_t n = R[k].x >> 16, src = R[k].x & 0xffffu, dst = R[k].y & 0xffffu;
-                            const uint32_t nl = n >= kLongRun ? 0u : (n < 64u ? n : 64u);      // long runs: the whole wavefront, from global memory
-                            const uint32_t tier = wave_tier(nl, nl > 0u);
-                            const uint32_t as = nl ? a_in + src : a_out, sa = as & ~3u, sh = as & 3u;
-                            DW<6> w6 = {}; DW<10> w10 = {}; DW<18> w18 = {};
-                            if (tier <= 16u) w6 = lds_ld_aligned6(sa);
-                            else if (tier <= 32u) w10 = lds_ld_aligned10(sa);
-                            else w18 = lds_ld_aligned18(sa);
-                            CJ_PHASE_MARK(6);                                          // 6: the rounds' LDS reads (+ the records' round trip)
-                            __syncthreads();                                           // every run of the round is in registers
-                            CJ_PHASE_MARK(7);                                          // 7: the rounds' barriers
-                            if (nl > 0u) {
-                                if (tier <= 16u) lds_store_tier<16>(w6, a_out + dst, sh, nl, dm);
-                                else if (tier <= 32u) lds_store_tier<32>(w10, a_out + dst, sh, nl, dm);
-                                else lds_store_tier<64>(w18, a_out + dst, sh, nl, dm);
-                                CJ_PHASE_MARK(8);                                      // 8: the rounds' stores
-                                bits_set(s_bits, dst, dst + nl);
-                            }
-                            CJ_PHASE_MARK(9);                                          // 9: bits_set
-                            place_from_global(n - nl, src + nl, dst + nl);             // (rare) the rest of runs above 64 bytes
-                            CJ_PHASE_MARK(10);                                         // 10: the runs' remainders from global memory
-                        }
-                    }
-                }
-            }
-        }
-#ifdef CJ_X_SKIP_D2
-        d2_done = true;
-#endif
-        if (!d2_done) {
         // (the next batch's records are requested before the current batch is processed: a coalesced table read is a
         //  full global round trip and a wave owns only ~5 batches)
         if (wave * 64u + lane < nrec_all) rec_nx = rec_load(wave * 64u + lane, nseq);
@@ -794,14 +677,6 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 if (nb + lane < nrec_all) rec_nx = rec_load(nb + lane, nseq);
             }
             place_from_global(rec.y, rec.x, rec.z - rec.y);
-        }
-        }
-        if constexpr (kPipe) {
-            if (tid == 0) {
-                s_desc[0] = nx_pm.nseq; s_desc[1] = nx_pm.in_skip; s_desc[2] = (uint32_t)nx_in_off; s_desc[3] = (uint32_t)(nx_in_off >> 32);
-                s_desc[4] = (uint32_t)nx_in_len; s_desc[5] = (uint32_t)nx_out_off; s_desc[6] = (uint32_t)(nx_out_off >> 32); s_desc[7] = (uint32_t)nx_result;
-                *s_nextc = next_c;
-            }
         }
         // kSlab — D2b: the parts of matches whose source lies before this slab come from the finished output of the earlier
         // slabs in global memory.  Each wave copies its share of the cross list as soon as it sees slab c-1's flag: from
@@ -859,9 +734,6 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 if (wave == 0u) CJ_TRACE(2);                                   // wave 0's cross share copied
             }
         };
-#ifdef CJ_D23_BARRIER
-        __syncthreads();
-#endif
         CJ_PHASE_MARK(2);
 
         // ---- D3: matches (same resolver as variant 1).  No barrier after D2: readiness is exact per byte through the
@@ -885,9 +757,6 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         //      publish (two ds_or) and the mask update: ~12 instructions when nothing is ready, ~35 with copies.
         //      Lanes outside the fast shape (longer than 32 bytes, self-overlapping, 1-3 bytes) keep the general path.
         if constexpr (!kSlab && !kLinked) {
-#ifdef CJ_X_SKIP_D3
-            if (false)
-#endif
             for (uint32_t base = wave * 64u; base < nrec_all; base += kL2Threads) {
                 const uint4 rec = rec_nx;
                 rec_nx = make_uint4(0, 0, 0, 0);
@@ -1199,27 +1068,6 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         __syncthreads();
         CJ_TRACE_T0(3);                                         // D3 done
         CJ_PHASE_MARK(3);
-        if constexpr (kPipe) {
-            pf_valid = true;
-            pf_bytes = false;
-            pf_c = *s_nextc;
-            pf_pm = ParseMeta{s_desc[0], s_desc[1]};
-            pf_in_off = ((uint64_t)s_desc[3] << 32) | s_desc[2]; pf_in_len = s_desc[4];
-            pf_out_off = ((uint64_t)s_desc[6] << 32) | s_desc[5]; pf_result = s_desc[7];
-            if (pf_c < a.n_chunks && pf_pm.nseq != 0u) {
-                const uint8_t* in1 = a.in_base + pf_in_off + pf_pm.in_skip;
-                const uint32_t iend1 = (uint32_t)pf_in_len - pf_pm.in_skip;
-                const uint32_t mis1 = (uint32_t)(reinterpret_cast<uintptr_t>(in1) & 15u);
-                const uint4* src1 = reinterpret_cast<const uint4*>(in1 - mis1);
-                const uint32_t last1 = ((mis1 + iend1 + 15u) >> 4) - 1u;
-                const uint32_t i0 = tid, i1 = i0 + kL2Threads, i2 = i0 + 2u * kL2Threads, i3 = i0 + 3u * kL2Threads, i4 = i0 + 4u * kL2Threads;
-                pf_v0 = src1[i0 < last1 ? i0 : last1]; pf_v1 = src1[i1 < last1 ? i1 : last1]; pf_v2 = src1[i2 < last1 ? i2 : last1];
-                pf_v3 = src1[i3 < last1 ? i3 : last1]; pf_v4 = src1[i4 < last1 ? i4 : last1];
-                const uint32_t nsp1 = (pf_pm.nseq + kSyncEvery - 1u) / kSyncEvery;
-                pf_first = (sync + (size_t)pf_c * kSyncPitch)[tid < nsp1 ? tid : 0u];
-                pf_bytes = true;
-            }
-        }
         // ---- D4: stream the window out (16 B per lane), exact tail ----
         {
             const uint32_t nvec = U >> 4;

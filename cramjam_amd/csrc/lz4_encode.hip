@@ -134,9 +134,9 @@ __device__ __forceinline__ void lz4_encode_chunk(const BatchArgs& a, uint32_t ch
                     anchor = sl.anchor;
                 }
             }
-            if (!fast_round) {                                    // like select_walk: what an earlier round's match already covers is not indexed
+            if (!fast_round) {
 #pragma unroll
-                for (int j = 0; j < kSub; j++) covered[j] = pos + 64u * (uint32_t)j + lane < anchor;
+                for (int j = 0; j < kSub; j++) covered[j] = false;      // a round starts at pos >= anchor: nothing of it is covered yet
             }
 #pragma unroll
             for (int j = 0; j < kSub; j++) {

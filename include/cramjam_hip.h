@@ -162,6 +162,8 @@ typedef enum { CJ_OP_DECOMPRESS = 0, CJ_OP_COMPRESS = 1 } cj_op;
 #define CJ_FLAG_FORCE_WAVE_PER_CHUNK 0x100u
 #define CJ_FLAG_FORCE_LANE_PER_CHUNK 0x200u
 #define CJ_FLAG_FORCE_LDS_PER_CHUNK  0x400u
+/* debug aid: the workgroup decoder accumulates per-phase cycle counters (read with cj_debug_lds_phase_cycles; results unchanged) */
+#define CJ_FLAG_DEBUG_PROFILE        0x1000u
 /* decode batches up to this many chunks run parse + decode as ONE kernel (the segmented parse inside the workgroup decoder:
  * 1 chunk 0.16 ms instead of 0.25, 8 192 chunks 348 instead of 178 GB/s); above, a lane-per-chunk parse kernel in front of the
  * decoder is cheaper per chunk (measured crossover between 16 384 and 32 768 chunks, profiles/r02) */
@@ -220,11 +222,9 @@ CJ_API int cj_bench_synth_v1(void* d_out, uint64_t stride, uint64_t S, uint64_t 
 /* *d_mismatches += chunks i in [0, n) with got[got_off[i] .. +S) != want[(i % n_unique)*want_stride .. +S) */
 CJ_API int cj_bench_compare(const void* d_got, const uint64_t* d_got_off, const void* d_want, uint64_t want_stride,
                             uint32_t n_unique, uint64_t S, uint32_t n, void* d_mismatches, void* stream);
-/* per-phase cycle counters of the workgroup decoder (flag bit 0x1000 of a device batch): S0, D1, D2, D3, D4, chunks, 6.. sub-phases (16 slots) */
+/* per-phase cycle counters of the workgroup decoder (CJ_FLAG_DEBUG_PROFILE on a device batch): S0, D1, D2, D3, D4, chunks, 6.. sub-phases.
+ * out16 must hold SIXTEEN 64-bit slots (128 bytes; it was eight until round 3) */
 CJ_API int cj_debug_lds_phase_cycles(unsigned long long* out16, int reset);
-/* the level-ordered decoder's counters (same flag): S0, D1/P, X, L, K, D2, D3, D4 cycles, chunks, levels, D3 barriers */
-CJ_API int cj_debug_lvl_phase_cycles(unsigned long long* out16, int reset);
-CJ_API int cj_debug_lvl1_phase_cycles(unsigned long long* out16, int reset);   /* the all-LDS variant (one workgroup per CU) */
 CJ_API long long cj_debug_forwarded_chunks(int reset);            /* chunks / slabs that went through the forwarding phase */
 CJ_API unsigned long long cj_debug_linked_lds_frames(void);       /* linked-block LZ4 frames decoded by the two-window decoder */
 /* large-stream path with its parse stage's absolute sync points handed back (tests compare them with a serial walk) */

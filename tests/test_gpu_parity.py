@@ -523,42 +523,6 @@ def test_deep_chain_chunks_take_match_forwarding(eng):
         assert L.cj_debug_forwarded_chunks(0) >= len(chunks) // 2, codec
 
 
-_LEVEL_DECODER_CHECK = r"""
-import random, sys
-import oracle
-from cramjam_amd import _native as N
-eng = N.Engine(0)
-rnd = random.Random(31)
-def text(n):
-    out = bytearray()
-    while len(out) < n: out += b"%d bottles of beer on the wall, %d bottles of beer\n" % (rnd.randrange(977), rnd.randrange(1013))
-    return bytes(out[:n])
-chunks = [oracle.synth_v1(65536, i) for i in range(40)] + [text(65536), text(30000), bytes(50000), rnd.randbytes(65536),
-          b"".join(bytes([rnd.randrange(256)]) * rnd.randrange(1, 300) for _ in range(600))[:65536], (rnd.randbytes(3000) * 22)[:65536],
-          b"".join((b"ab" * rnd.randrange(2, 40) + b"xyz" * rnd.randrange(2, 30) + rnd.randbytes(rnd.randrange(1, 9))) for _ in range(900))[:61000]]
-chunks = chunks * 700                       # > CJ_FUSED_MAX_CHUNKS: parse kernel + level decoder, every workgroup takes many chunks
-for codec, comp in ((N.CODEC_LZ4_BLOCK, lambda c: oracle.lz4_compress_raw(c)[1]), (N.CODEC_SNAPPY_RAW, lambda c: oracle.snappy_compress(c)[1])):
-    uniq = {}
-    blobs = [uniq.setdefault(id(c), comp(c)) for c in chunks]
-    res, outs = eng.batch_host(codec, N.OP_DECOMPRESS, N.FLAG_FORCE_LDS_PER_CHUNK, blobs, [len(c) for c in chunks])
-    assert [int(r) for r in res] == [len(c) for c in chunks], codec
-    assert all(bytes(o) == c for o, c in zip(outs, chunks)), codec
-    res, outs = eng.batch_host(codec, N.OP_DECOMPRESS, N.FLAG_FORCE_LDS_PER_CHUNK, blobs[:47], [len(c) for c in chunks[:47]])      # small batch: parse inside
-    assert [int(r) for r in res] == [len(c) for c in chunks[:47]] and all(bytes(o) == c for o, c in zip(outs, chunks[:47])), codec
-print("level decoders ok")
-"""
-
-
-@pytest.mark.parametrize("which", ["lvl", "lvl1"])
-def test_level_decoders_opt_in(which):
-    """the level-ordered workgroup decoders (lz4_decode_lvl.hip, lz4_decode_lvl1.hip; opt-in with CJ_DECODER, profiles/r03/experiments)
-    decode a mixed batch — benchmark chunks, text, zeros, incompressible, runs, long matches, short periods — to the oracle's inputs"""
-    import os, subprocess, sys
-    env = dict(os.environ, CJ_DECODER=which, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    r = subprocess.run([sys.executable, "-c", _LEVEL_DECODER_CHECK], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "level decoders ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
-
-
 def test_internal_flag_bits_are_refused_at_the_c_abi(eng):
     """piece splitting / tail report / linked-frame bits (cj_common.hpp) belong to the library's own large-buffer and frame paths; a
     C-ABI caller that sets one gets CJ_E_BAD_ARG instead of a kernel that reads descriptors which are not there"""

@@ -169,6 +169,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
     uint32_t next_c = 0;
     if constexpr (!kLinked && !kSlab) { if (tid == 0) next_c = atomicAdd(counter, 1u); }
 
+    if constexpr (!kSlab && !kLinked) __builtin_amdgcn_s_setprio(2);
     for (;;) {
         uint32_t c;
         if constexpr (kLinked) {
@@ -735,6 +736,11 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             }
         };
         CJ_PHASE_MARK(2);
+        // Batches: the wavefronts that stage, expand and place literals (one serial instruction stream each, ~15 cycles per instruction
+        // with four wavefronts on a SIMD) issue ahead of the wavefronts that poll in D3 — the polls fill the gaps that remain.
+        // profiles/r04/experiments p01: D1 11.6 k -> 10.6 k, D2 23.9 k -> 21.6 k, D3 52.9 k -> 54.5 k cycles per chunk, 617.6 -> 627.4 GB/s
+        // (the opposite assignment: 611 GB/s).
+        if constexpr (!kSlab && !kLinked) __builtin_amdgcn_s_setprio(0);
 
         // ---- D3: matches (same resolver as variant 1).  No barrier after D2: readiness is exact per byte through the
         //      bitmap, so a wave starts on its matches while other waves are still placing literals ----
@@ -1068,6 +1074,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         __syncthreads();
         CJ_TRACE_T0(3);                                         // D3 done
         CJ_PHASE_MARK(3);
+        if constexpr (!kSlab && !kLinked) __builtin_amdgcn_s_setprio(2);
         // ---- D4: stream the window out (16 B per lane), exact tail ----
         {
             const uint32_t nvec = U >> 4;

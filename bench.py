@@ -103,21 +103,43 @@ class Batch:
 
 
 def corpus_chunks(S):
-    """every full S-byte chunk of the benchmark-corpus files under tests/golden/corpus (data fixtures of the reference's
-    benchmarks/test_bench.py:38-64, sha256-pinned by manifest.json), in file order"""
+    """the benchmark corpus of the reference (benchmarks/data, benchmarks/test_bench.py:38-64) as S-byte chunks, in file order: every full
+    chunk of the twelve files that travel whole under tests/golden/corpus, and the 12 sampled full chunks of each of the eight large
+    files (<name>.sample64k.bz2, tests/golden/make_corpus_samples.py) — all 20 files, sha256-pinned by manifest.json"""
     import bz2
     import hashlib
     import json
     d = os.path.join(ROOT, "tests", "golden", "corpus")
-    man = json.load(open(os.path.join(d, "manifest.json")))["files"]
+    mf = json.load(open(os.path.join(d, "manifest.json")))
+    man, samples = mf["files"], mf.get("samples", {})
     out = []
     only = os.environ.get("CJ_CORPUS_FILES")                  # (experiments: a comma-separated subset)
-    names = [n for n in sorted(man) if not only or n in only.split(",")]
+    names = [n for n in sorted(list(man) + list(samples)) if not only or n in only.split(",")]
     for name in names:
-        raw = bz2.decompress(open(os.path.join(d, name + ".bz2"), "rb").read())
-        assert hashlib.sha256(raw).hexdigest() == man[name]["sha256"], name
+        if name in man:
+            raw = bz2.decompress(open(os.path.join(d, name + ".bz2"), "rb").read())
+            assert hashlib.sha256(raw).hexdigest() == man[name]["sha256"], name
+        else:
+            assert S == samples[name]["chunk_bytes"], "the large files are carried as %d-byte chunk samples" % samples[name]["chunk_bytes"]
+            raw = bz2.decompress(open(os.path.join(d, name + ".sample64k.bz2"), "rb").read())
+            assert hashlib.sha256(raw).hexdigest() == samples[name]["sha256"], name
         out += [raw[i:i + S] for i in range(0, len(raw) - S + 1, S)]
     return out, names
+
+
+def load_libsnappy():
+    """the C++ snappy library through its C API (snappy-c.h): the lineage the reference's `snap` crate ports and is tested against"""
+    for name in ("libsnappy.so.1", "/opt/conda/lib/libsnappy.so.1", "/usr/lib/x86_64-linux-gnu/libsnappy.so.1", "libsnappy.so"):
+        try:
+            L = C.CDLL(name)
+            L.snappy_compress.restype = C.c_int
+            L.snappy_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]
+            L.snappy_max_compressed_length.restype = C.c_size_t
+            L.snappy_max_compressed_length.argtypes = [C.c_size_t]
+            return L, "libsnappy (system snappy_compress, %s)" % os.path.basename(name)
+        except (OSError, AttributeError):
+            continue
+    return None, None
 
 
 def build_batch(N, L, eng, dev, codec, op_dec, S, U, NCH, first_index, compressor, torch, np, data="synth-v1"):
@@ -143,17 +165,25 @@ def build_batch(N, L, eng, dev, codec, op_dec, S, U, NCH, first_index, compresso
     ids = np.arange(NCH, dtype=np.uint64)
     if op_dec:
         b.raw_h = raw.cpu().numpy()
-        lz4lib = None
+        lz4lib = snlib = None
         if codec == N.CODEC_LZ4_BLOCK and compressor in ("auto", "liblz4"):
             lz4lib, b.comp_name = load_liblz4()
-        if lz4lib is not None:
+        if codec == N.CODEC_SNAPPY_RAW and compressor in ("auto", "liblz4"):       # (the host library of the codec's lineage)
+            snlib, b.comp_name = load_libsnappy()
+        if lz4lib is not None or snlib is not None:
             from concurrent.futures import ThreadPoolExecutor
             comp_h = np.zeros(U * stride_c, dtype=np.uint8)
             clen = np.zeros(U, dtype=np.uint64)
 
             def work(i):
-                r = lz4lib.LZ4_compress_default(b.raw_h.ctypes.data + i * S, comp_h.ctypes.data + i * stride_c, S, stride_c)
-                assert r > 0
+                if lz4lib is not None:
+                    r = lz4lib.LZ4_compress_default(b.raw_h.ctypes.data + i * S, comp_h.ctypes.data + i * stride_c, S, stride_c)
+                    assert r > 0
+                else:
+                    n = C.c_size_t(stride_c)
+                    assert snlib.snappy_max_compressed_length(S) <= stride_c
+                    assert snlib.snappy_compress(b.raw_h.ctypes.data + i * S, S, comp_h.ctypes.data + i * stride_c, C.byref(n)) == 0
+                    r = n.value
                 clen[i] = r
             with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as ex:
                 list(ex.map(work, range(U)))
@@ -480,8 +510,8 @@ def usable_cores():
 
 def cpu_baseline(args, codec, b):
     """CPU decoders over the U unique chunks of this run, ONE persistent thread pool per leg (oracle/synth_batch_oracle.c):
-    the oracle's C restatement (kind "port") and the host's liblz4 when present (kind "liblz4"; LZ4 only), each with all
-    cores and with one.  The top-level fields are liblz4 on all cores when present (else the port); `legs` lists everything."""
+    the oracle's C restatement (kind "port") and the host's liblz4 / libsnappy when present (kinds "liblz4", "libsnappy"), each with
+    all cores and with one.  The top-level fields are the host library on all cores when present (else the port); `legs` lists everything."""
     import numpy as np
     import oracle
     OL = oracle.lib()
@@ -495,6 +525,8 @@ def cpu_baseline(args, codec, b):
     plan = [("port", 0 if lz4 else 2, cores, 0.35), ("port", 0 if lz4 else 2, 1, 0.15)]
     if lz4 and OL.cjo_have_liblz4():
         plan += [("liblz4", 4, cores, 0.35), ("liblz4", 4, 1, 0.15)]
+    if not lz4 and OL.cjo_have_libsnappy():
+        plan += [("libsnappy", 5, cores, 0.35), ("libsnappy", 5, 1, 0.15)]
     scale = args.cpu_seconds / sum(p[3] for p in plan)
     legs = []
     for kind, op, threads, share in plan:
@@ -512,7 +544,7 @@ def cpu_baseline(args, codec, b):
                      "sample": "%d passes x %d unique %d B chunks (same inputs as the GPU run), one thread pool, %.1f s" % (reps, n1, S, el)})
     # top level: the fastest leg of the reference's own lineage — liblz4 on all cores when the host has it (the C code the
     # reference links through lz4-sys), else the port; every leg stays in `legs`
-    best = next((g for g in legs if g["kind"] == "liblz4" and g["cores"] > 1), legs[0])
+    best = next((g for g in legs if g["kind"] in ("liblz4", "libsnappy") and g["cores"] > 1), legs[0])
     top = dict(best)
     top["host"] = cores_note
     top["legs"] = legs

@@ -57,6 +57,7 @@ def lib():
             ("cjo_batch_run", C.c_int, [C.c_int, C.c_int, sz, u8p, u8p, u8p, u8p, sz, u8p]),
             ("cjo_batch_run_reps", C.c_int, [C.c_int, C.c_int, C.c_int, sz, u8p, u8p, u8p, u8p, sz, u8p]),
             ("cjo_have_liblz4", C.c_int, []),
+            ("cjo_have_libsnappy", C.c_int, []),
         ]:
             f = getattr(L, name)
             f.restype, f.argtypes = res, args

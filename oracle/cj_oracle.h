@@ -125,6 +125,7 @@ int cjo_batch_run(int op, int threads, size_t n_chunks, const uint8_t* in_base, 
 int cjo_batch_run_reps(int op, int threads, int reps, size_t n_chunks, const uint8_t* in_base, const uint64_t* in_off,
                        const uint64_t* in_len, uint8_t* out_base, size_t out_stride, int64_t* res);
 int cjo_have_liblz4(void);
+int cjo_have_libsnappy(void);      /* op 5 = the host's libsnappy snappy_uncompress (dlopen; res = -1 when absent) */
 
 #ifdef __cplusplus
 }

@@ -65,6 +65,24 @@ static lz4_safe_fn liblz4_decoder(void) {
 }
 int cjo_have_liblz4(void) { return liblz4_decoder() != 0; }
 
+/* libsnappy's decoder through its C API (snappy-c.h: snappy_uncompress), when the host has the library: the C++ code the
+ * reference's `snap` crate is a port of.  op 5 below; -1 for every chunk when it is absent. */
+typedef int (*snappy_unc_fn)(const char*, size_t, char*, size_t*);
+static snappy_unc_fn g_sn_unc;
+static int g_sn_tried;
+static snappy_unc_fn libsnappy_decoder(void) {
+    if (!g_sn_tried) {
+        static const char* names[] = { "libsnappy.so.1", "/opt/conda/lib/libsnappy.so.1", "/usr/lib/x86_64-linux-gnu/libsnappy.so.1", "libsnappy.so" };
+        for (unsigned k = 0; k < sizeof names / sizeof names[0] && !g_sn_unc; k++) {
+            void* h = dlopen(names[k], RTLD_NOW | RTLD_LOCAL);
+            if (h) g_sn_unc = (snappy_unc_fn)dlsym(h, "snappy_uncompress");
+        }
+        g_sn_tried = 1;
+    }
+    return g_sn_unc;
+}
+int cjo_have_libsnappy(void) { return libsnappy_decoder() != 0; }
+
 /* A pool that lives for the whole call: `reps` passes over the batch, the threads are created ONCE and meet at a barrier
  * between passes (round 1 created and joined 255 threads per 33 ms pass and reported a tenth of what the cores can do). */
 typedef struct {
@@ -77,6 +95,7 @@ static void* worker(void* p) {
     job_t* j = (job_t*)p;
     while (atomic_load_explicit(&j->go, memory_order_acquire) == 0) sched_yield();      /* the barrier is sized once every thread exists */
     lz4_safe_fn lz4 = j->op == 4 ? liblz4_decoder() : 0;
+    snappy_unc_fn snu = j->op == 5 ? libsnappy_decoder() : 0;
     for (int r = 0; r < j->reps; r++) {
         for (;;) {
             size_t i = atomic_fetch_add(&j->next[r], 8);
@@ -91,6 +110,7 @@ static void* worker(void* p) {
                 case 1: j->res[i] = cjo_lz4_compress_raw(in, n, out, j->out_stride); break;
                 case 2: j->res[i] = cjo_snappy_decompress(in, n, out, j->out_stride); break;
                 case 3: j->res[i] = cjo_snappy_compress(in, n, out, j->out_stride); break;
+                case 5: { size_t on = j->out_stride; j->res[i] = snu && snu((const char*)in, n, (char*)out, &on) == 0 ? (int64_t)on : -1; } break;
                 default: j->res[i] = lz4 ? lz4((const char*)in, (char*)out, (int)n, (int)j->out_stride) : -1; break;
                 }
             }

@@ -16,7 +16,9 @@ import oracle
 from conftest import GOLDEN_DIR
 
 CORPUS = os.path.join(GOLDEN_DIR, "corpus")
-MANIFEST = json.load(open(os.path.join(CORPUS, "manifest.json")))["files"]
+_MAN = json.load(open(os.path.join(CORPUS, "manifest.json")))
+MANIFEST = _MAN["files"]
+SAMPLES = _MAN["samples"]            # 12 full 64 KiB chunks of each of the eight large files (tests/golden/make_corpus_samples.py)
 
 
 def _load(name):
@@ -26,9 +28,12 @@ def _load(name):
 
 
 def test_corpus_fixtures_are_intact():                      # CPU: the fixtures decode to what the manifest pins
-    assert len(MANIFEST) >= 6
+    assert len(MANIFEST) == 12 and len(SAMPLES) == 8       # all 20 files of /root/reference/benchmarks/data are represented
     for name in MANIFEST:
         _load(name)
+    for name, m in SAMPLES.items():
+        blob = bz2.decompress(open(os.path.join(CORPUS, name + ".sample64k.bz2"), "rb").read())
+        assert len(blob) == m["bytes"] == 65536 * len(m["picked_chunks"]) and hashlib.sha256(blob).hexdigest() == m["sha256"], name
 
 
 @pytest.mark.gpu
@@ -73,12 +78,16 @@ import bz2, json, os, sys
 import oracle
 from cramjam_amd import _native as N
 corpus = sys.argv[1]
-man = json.load(open(os.path.join(corpus, "manifest.json")))["files"]
+mf = json.load(open(os.path.join(corpus, "manifest.json")))
+man = mf["files"]
 chunks = []
 for name in sorted(man):
     raw = bz2.decompress(open(os.path.join(corpus, name + ".bz2"), "rb").read())
     chunks += [raw[i:i + 65536] for i in range(0, len(raw), 65536)]          # every chunk, the files' short tails included
-assert len(chunks) >= 50
+for name in sorted(mf["samples"]):                                              # + the sampled chunks of the eight large files
+    raw = bz2.decompress(open(os.path.join(corpus, name + ".sample64k.bz2"), "rb").read())
+    chunks += [raw[i:i + 65536] for i in range(0, len(raw), 65536)]
+assert len(chunks) >= 140
 eng = N.Engine(0)
 L = N.lib()
 for codec, comp, dec in ((N.CODEC_LZ4_BLOCK, lambda c: oracle.lz4_compress_raw(c)[1], lambda b, n: oracle.lz4_decompress_raw(b, n)),
@@ -99,7 +108,8 @@ print("corpus chunks ok", len(chunks))
 @pytest.mark.gpu
 @pytest.mark.parametrize("fused", ["1", "0"], ids=["parse-in-decoder", "parse-kernel+decoder"])
 def test_every_corpus_chunk_against_the_oracle(fused):
-    """SURVEY.md §8(d) `corpus-64k`: every 64 KiB chunk (and every file's short tail) of the corpus files that travel, compressed by the
+    """SURVEY.md §8(d) `corpus-64k`: every 64 KiB chunk (and every file's short tail) of the twelve corpus files that travel whole + 12 sampled
+    chunks of each of the eight large ones (all 20 files of the reference's benchmarks/data), compressed by the
     oracle's encoders (bit-identical to liblz4 / libsnappy): the GPU decodes each to its input in the default pipeline, with the
     workgroup decoder forced and with the one-wavefront kernel, on both sides of the parse-in-kernel threshold (real text has ~10 000
     sequences per chunk and dependency chains a hundred levels deep); the GPU encoders' blocks decode with the oracle"""

@@ -320,7 +320,7 @@ def main():
     codec = N.CODEC_LZ4_BLOCK if args.codec == "lz4" else N.CODEC_SNAPPY_RAW
     dec = args.op in ("decompress", "roundtrip")
     mode_flag = {"auto": 0, "wave": N.FLAG_FORCE_WAVE_PER_CHUNK, "lane": N.FLAG_FORCE_LANE_PER_CHUNK,
-                 "lds": N.FLAG_FORCE_LDS_PER_CHUNK}[args.lz4_mode] | (0x1000 if args.phase_profile else 0)
+                 "lds": N.FLAG_FORCE_LDS_PER_CHUNK}[args.lz4_mode] | (0x1000 if args.phase_profile else 0) | (N.FLAG_BIG_CHUNKS if S > 65536 and args.lz4_mode == "auto" else 0)
 
     # ---- workload: distinct synth-v1 chunk indices per rank (rank r generates indices r*U .. r*U+U-1) ----
     first_index = rank * U

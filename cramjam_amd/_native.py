@@ -12,6 +12,7 @@ FLAG_LZ4_SIZE_PREFIX = 1
 FLAG_FORCE_WAVE_PER_CHUNK = 0x100
 FLAG_FORCE_LANE_PER_CHUNK = 0x200
 FLAG_FORCE_LDS_PER_CHUNK = 0x400
+FLAG_BIG_CHUNKS = 0x800            # decompress: reserve record areas for chunks of 64 KiB .. 256 KiB (cramjam_hip.h)
 E_NO_DEVICE = -100
 
 _vp, _sz, _i64, _u32, _int = C.c_void_p, C.c_size_t, C.c_int64, C.c_uint32, C.c_int

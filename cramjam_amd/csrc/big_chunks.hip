@@ -1,0 +1,436 @@
+// big_chunks.hip — the parse stage for chunks of 64 KiB .. 256 KiB in a device batch (big_chunks.hpp; BASELINE configs[4]).
+// Accept / reject rules: those of the other mappings (liblz4 1.10.0 LZ4_decompress_safe, snap 1.1.1 raw::Decoder; reference call
+// sites /root/reference/src/lz4.rs:88,164,168, src/snappy.rs:57,106); wherever this kernel is not sure — any violation, a Snappy
+// copy that reaches further back than 65 535 bytes, more records than a region holds — the chunk stays with the wavefront-per-
+// chunk kernel, which decodes every valid chunk and names every error exactly.
+//
+//   big_list_kernel    one thread per chunk of the batch: a chunk whose capacity (LZ4) / announced length (Snappy) lies in
+//                      (64 KiB, 256 KiB] is appended to the list (the small-chunk pipeline has flagged it kRouteWave);
+//   big_parse_kernel   32 lanes per listed chunk.  Lane j starts 1 KiB in front of its boundary j * seg of the compressed
+//                      bytes and walks until it has crossed it (a malformed element there = "not a token": one byte further):
+//                      that position is its CANDIDATE.  From it the lane walks for real — the checks that do not need the
+//                      absolute output position, one 16-byte record per sequence into its region, positions counted from its
+//                      own start — until it stands EXACTLY on the candidate of the segment it has reached: from there that
+//                      lane's records are the chain's (the next-token function depends on the bytes only; a wrong candidate
+//                      costs time, never correctness).  Lane 0 starts on the first token, so the lanes reached from it — the
+//                      LIVE lanes — hold exactly the chunk's sequences, each once.  Epilogue: what lies in front of each live
+//                      lane (records, output bytes), the deferred checks (every offset reaches back at most to output byte 0,
+//                      LZ4's end-of-block margins, Snappy's announced length), and for every 64 KiB boundary of the output the
+//                      record that holds it (a binary search by the lane that owns it).
+#include "big_chunks.hpp"
+#include "parse_grammar.hpp"
+
+namespace cj {
+
+constexpr uint32_t kBigLead = 1024;                 // bytes in front of its boundary where a lane starts looking for the chain
+constexpr uint32_t kBigSegMin = 2048;               // shortest segment
+#ifndef CJ_BIG_AHEAD
+#define CJ_BIG_AHEAD 32
+#endif
+constexpr uint32_t kBigAhead = CJ_BIG_AHEAD;                  // cached bytes a lane must have ahead before a step (lz4_parse_kernel)
+constexpr uint32_t kBigPending = 0xFFFFFFFFu, kBigNone = 0xFFFFFFFEu, kBigNoLink = 0xFFu;
+constexpr uint32_t kBigListHdr = 4;
+constexpr uint32_t kBigWaves = 4;                   // wavefronts per block of the parse kernel
+
+// prologue shared by the listing and the parse kernel: the element stream of chunk c and its output bound, or false
+template <int kCodec>
+__device__ __forceinline__ bool big_prologue(const BatchArgs& a, uint32_t c, const uint8_t*& in, uint32_t& n, uint32_t& cap, uint32_t& skip) {
+    const uint8_t* in0 = a.in_base + a.in_off[c];
+    uint64_t n64 = a.in_len[c], cap64 = a.out_cap[c];
+    if constexpr (kCodec == CJ_CODEC_LZ4_BLOCK) {
+        const uint8_t* inp = in0;
+        if (lz4_block_prologue(a.flags, inp, n64, cap64) != 0) return false;
+        if (cap64 <= kLdsOutMax && n64 <= kLdsInMax) return false;             // the small-chunk pipeline's
+        if (cap64 > kBigOutMax || n64 > kBigInMax || n64 == 0) return false;
+        in = inp; n = (uint32_t)n64; cap = (uint32_t)cap64; skip = (uint32_t)(inp - in0);
+        return true;
+    } else {
+        if (n64 == 0 || n64 > 0xFFFFFFF0ull) return false;
+        uint64_t ulen = 0;
+        uint32_t shift = 0, i = 0, hdr = 0;
+        bool ok = false;
+        while (hdr < (uint32_t)n64 && i < 10u) {
+            const uint32_t b = in0[hdr];
+            hdr += 1;
+            if (b < 0x80u) { if (!(i == 9u && b > 1u)) { ulen |= (uint64_t)b << shift; ok = true; } break; }
+            ulen |= (uint64_t)(b & 0x7fu) << shift;
+            shift += 7; i += 1;
+        }
+        if (!ok || ulen > cap64 || ulen == 0 || hdr == (uint32_t)n64) return false;
+        if (ulen <= kLdsOutMax && n64 - hdr <= kLdsInMax) return false;
+        if (ulen > kBigOutMax || n64 - hdr > kBigInMax) return false;
+        in = in0 + hdr; n = (uint32_t)n64 - hdr; cap = (uint32_t)ulen; skip = hdr;
+        return true;
+    }
+}
+
+template <int kCodec>
+__global__ __launch_bounds__(256) void big_list_kernel(BatchArgs a, uint32_t* list) {
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    if (c >= a.n_chunks) return;
+    const uint8_t* in; uint32_t n, cap, skip;
+    if (!big_prologue<kCodec>(a, c, in, n, cap, skip)) return;
+    const uint32_t idx = atomicAdd(&list[0], 1u);
+    if (idx < list[1]) list[kBigListHdr + idx] = c;
+}
+
+// The lanes' view of their streams: a 128-byte ring per lane in LDS (two 64-byte units), refilled cooperatively like the 256-byte
+// rings of the small-chunk parse kernels (lane_stream.hpp) — 4 lanes fetch one lane's next unit with aligned 16-byte loads, 16
+// units per load instruction — at half the size: 9 KiB per wavefront, sixteen wavefronts per CU.  This walk is bound by memory
+// latency (a chunk of 256 KiB has long literal runs: most steps need a line of the stream that nobody has touched), and what
+// covers a round trip is other wavefronts.
+constexpr uint32_t kSsRing = 128, kSsUnit = 64;
+constexpr uint32_t kSsStride = kSsRing + 16u;           // 16-byte aligned rings (one ds_write_b128 per fetched piece)
+constexpr uint32_t kSsWaveBytes = 64u * kSsStride;
+constexpr uint32_t kSsLanesPerUnit = kSsUnit / 16u, kSsTargets = 64u / kSsLanesPerUnit, kSsLoads = 64u / kSsTargets;
+
+struct SegStream {
+    const uint8_t* base;    // 128-byte aligned address at or below the first stream byte
+    uint32_t lo, hi;        // cached window [lo, hi): multiples of 64, hi - lo <= 128
+    uint32_t end;           // offset of the end of the stream
+    uint32_t ring;          // LDS byte offset of this lane's ring
+    __device__ __forceinline__ uint32_t ring32(uint32_t p) const {        // the 4 bytes at p, read from the ring whether or not they are cached
+        const uint32_t a0 = ring + (p & (kSsRing - 4u)), a1 = ring + ((p + 4u) & (kSsRing - 4u));
+        uint32_t w0, w1;
+        asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(w0), "=&v"(w1) : "v"(a0), "v"(a1) : "memory");
+        return __builtin_amdgcn_alignbyte(w1, w0, p & 3u);
+    }
+    __device__ __forceinline__ bool in_window(uint32_t p) const { return p >= lo && p + 4u <= hi && p + 4u <= end; }
+    __device__ __forceinline__ uint32_t ld32(uint32_t p) const {           // anywhere in the stream (zero-filled past its end)
+        if (in_window(p)) return ring32(p);
+        const uint32_t v = ld_le_tail(base, p, end);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                               // vmcnt(0): here, not on the common path behind the branch
+        return v;
+    }
+};
+
+// what a lane needs to know about the lanes it fetches for (lane t = 16 r + lane / 4 in load r): their stream base and end never change
+struct SegPlan { uint32_t blo[kSsLoads], bhi[kSsLoads], end[kSsLoads]; };
+__device__ __forceinline__ SegPlan seg_plan(const SegStream& st) {
+    SegPlan p;
+    const uint32_t lane = lane_id();
+    const uint32_t blo = (uint32_t)(uintptr_t)st.base, bhi = (uint32_t)((uintptr_t)st.base >> 32);
+#pragma unroll
+    for (uint32_t r = 0; r < kSsLoads; r++) {
+        const int t = (int)(kSsTargets * r + lane / kSsLanesPerUnit);
+        p.blo[r] = (uint32_t)__shfl((int)blo, t); p.bhi[r] = (uint32_t)__shfl((int)bhi, t); p.end[r] = (uint32_t)__shfl((int)st.end, t);
+    }
+    return p;
+}
+// one wave-convergent refill round: every lane that has room gets its next 64-byte unit
+__device__ __forceinline__ void seg_refill(SegStream& st, bool want, uint32_t wave_ring, const SegPlan& plan) {
+    const uint32_t lane = lane_id(), piece = lane % kSsLanesPerUnit;
+    const uint32_t mine = st.hi | (want ? 1u : 0u);                    // hi is a multiple of 64
+    uint4 v[kSsLoads];
+    uint32_t dsta[kSsLoads];
+#pragma unroll
+    for (uint32_t r = 0; r < kSsLoads; r++) {
+        const uint32_t t = kSsTargets * r + lane / kSsLanesPerUnit;
+        const uint32_t th = (uint32_t)__shfl((int)mine, (int)t);
+        const uint32_t off = (th & ~1u) + 16u * piece;
+        v[r] = make_uint4(0, 0, 0, 0);
+        dsta[r] = 0xffffffffu;
+        if ((th & 1u) && off < plan.end[r]) {
+            const uint8_t* src = reinterpret_cast<const uint8_t*>(((uint64_t)plan.bhi[r] << 32) | plan.blo[r]) + off;
+            v[r] = *reinterpret_cast<const uint4*>(src);               // 16-byte aligned, never crosses into a page past the stream
+            dsta[r] = wave_ring + t * kSsStride + (off & (kSsRing - 1u));
+        }
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < kSsLoads; r++) {
+        if (dsta[r] != 0xffffffffu) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 q = {v[r].x, v[r].y, v[r].z, v[r].w};
+            asm volatile("ds_write_b128 %0, %1" :: "v"(dsta[r]), "v"(q) : "memory");
+        }
+    }
+    if (want) {
+        if (st.hi - st.lo >= kSsRing) st.lo += kSsUnit;
+        st.hi += kSsUnit;
+    }
+}
+
+struct BigElem { uint32_t lit, lit_at, mlen, offset, next; bool ok, last; };
+
+// one element at st-position ip (straight-line for the common shape, the grammar's general function for the lanes that meet
+// anything else): the step of lz4_parse_kernel / snappy_parse_kernel without the checks that need the output position
+template <int kCodec>
+__device__ __forceinline__ BigElem big_elem(const SegStream& st, uint32_t ip, uint32_t iend, bool going) {
+    BigElem e;
+    bool fast = false;
+    if constexpr (kCodec == CJ_CODEC_LZ4_BLOCK) {
+        const uint32_t t4 = st.ring32(ip);
+        const uint32_t token = t4 & 0xffu, e1 = (t4 >> 8) & 0xffu;
+        const bool x1 = (token >> 4) == 15u;
+        const uint32_t lit = (token >> 4) + (x1 ? e1 : 0u);
+        const uint32_t ip1 = ip + 1u + (x1 ? 1u : 0u), ip2 = ip1 + lit;
+        const bool w1 = st.in_window(ip), w2 = ip2 + 4u <= st.hi && ip2 + 4u <= iend;
+        const uint32_t o4 = st.ring32(ip2);
+        const uint32_t mc = token & 15u, e2 = (o4 >> 16) & 0xffu;
+        const bool x2 = mc == 15u;
+        fast = w1 && w2 && !(x1 && e1 == 255u) && !(x2 && e2 == 255u) && iend - ip1 >= lit + 8u;
+        e.lit = lit; e.lit_at = ip1; e.offset = o4 & 0xffffu; e.mlen = mc + (x2 ? e2 : 0u) + 4u;
+        e.next = ip2 + 2u + (x2 ? 1u : 0u); e.ok = true; e.last = false;
+    } else {
+        const uint32_t t4 = st.ring32(ip);
+        const uint32_t tag = t4 & 0xffu, l6 = tag >> 2;
+        const bool is_lit = (tag & 3u) == 0u;
+        const uint32_t lhdr = is_lit ? (l6 == 60u ? 2u : 1u) : 0u;
+        const uint32_t lit = is_lit ? (l6 == 60u ? ((t4 >> 8) & 0xffu) + 1u : l6 + 1u) : 0u;
+        const uint32_t ip2 = ip + lhdr + lit;
+        const bool w1 = st.in_window(ip), w2 = ip2 + 4u <= st.hi && ip2 + 4u <= iend;
+        const uint32_t c4 = st.ring32(ip2);
+        const uint32_t ctag = c4 & 0xffu, kind = ctag & 3u;
+        const uint32_t ip3 = ip2 + (kind == 1u ? 2u : 3u);
+        fast = w1 && w2 && !(is_lit && l6 > 60u) && (kind == 1u || kind == 2u) && ip3 < iend;
+        e.lit = lit; e.lit_at = ip + lhdr;
+        e.mlen = kind == 1u ? 4u + ((ctag >> 2) & 7u) : 1u + (ctag >> 2);
+        e.offset = kind == 1u ? ((ctag >> 5) << 8) | ((c4 >> 8) & 0xffu) : (c4 >> 8) & 0xffffu;
+        e.next = ip3; e.ok = true; e.last = false;
+    }
+    if (ballot64(going && !fast) != 0ull) {
+        if (going && !fast) {
+            using G = typename std::conditional<kCodec == CJ_CODEC_SNAPPY_RAW, SnappyGrammar, Lz4Grammar>::type;
+            const auto rd = [&st](uint32_t p) { return st.ld32(p); };
+            Seq s;
+            e.ok = G::at(rd, ip, iend, s, st.base);
+            e.lit = s.lit; e.lit_at = s.lit_at; e.mlen = s.mlen; e.offset = s.offset; e.next = s.next; e.last = s.last;
+        }
+    }
+    return e;
+}
+
+template <int kCodec>
+__global__ __launch_bounds__(64 * kBigWaves) void big_parse_kernel(BatchArgs a, const uint32_t* list, uint4* recs, BigMeta* bigmeta, ParseMeta* meta) {
+    __shared__ __attribute__((aligned(16))) uint8_t rings[kBigWaves * kSsWaveBytes];
+    __shared__ volatile uint32_t s_cand[kBigWaves * 64];
+    __shared__ volatile uint32_t s_live[kBigWaves * 64];
+    constexpr uint32_t k = kBigLanes;
+    const uint32_t gl = blockIdx.x * (64u * kBigWaves) + threadIdx.x;
+    const uint32_t bi = gl >> kBigLanesLog, j = gl & (k - 1u);
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t g0 = wave * 64u + (lane & ~(k - 1u));           // index (in the block) of lane 0 of my chunk
+    const uint32_t wave_ring = (uint32_t)(uintptr_t)rings + wave * kSsWaveBytes;
+    const uint32_t listed = list[0] < list[1] ? list[0] : list[1];
+    const bool exists = bi < listed;
+    const uint32_t c = exists ? list[kBigListHdr + bi] : 0u;
+
+    const uint8_t* in = nullptr;
+    uint32_t n = 0, cap = 0, skip = 0;
+    const bool walk = exists && big_prologue<kCodec>(a, c, in, n, cap, skip);          // (true for every listed chunk)
+    uint32_t seg = (((n + k - 1u) >> kBigLanesLog) + 15u) & ~15u;
+    seg = seg < kBigSegMin ? kBigSegMin : seg;
+    const uint32_t bj = j * seg;
+    bool done = !(walk && bj < n);
+    const uint32_t mis = done ? 0u : (uint32_t)(reinterpret_cast<uintptr_t>(in) & 127u);
+    SegStream st;
+    st.base = done ? nullptr : in - mis;
+    st.end = done ? 0u : mis + n;
+    st.ring = wave_ring + lane * kSsStride;
+    const uint32_t iend = st.end;
+    // positions below are st-positions (offsets from st.base): stream position + mis
+    const uint32_t my_b = mis + bj;
+    uint32_t ip = mis + (j == 0u || bj <= kBigLead ? 0u : bj - kBigLead);
+    st.lo = st.hi = ip & ~(kSsUnit - 1u);
+    const SegPlan plan = seg_plan(st);
+    bool lead = !done && j != 0u;
+    uint32_t tb = j + 1u;
+    uint32_t next_b = tb < k ? mis + tb * seg : 0xFFFFFFFFu;
+    s_cand[wave * 64u + lane] = done ? kBigNone : (j == 0u ? mis : kBigPending);
+    uint32_t link = kBigNoLink;
+    uint32_t cnt = 0, r = 0, lim = 0;                            // records written, output bytes so far (from 0), LZ4's end-of-block margin
+    int32_t need = 0;                                            // how far in front of this lane's first output byte its matches reach
+    bool bad = false, saw_last = false, fin = false;
+    uint4* region = recs + (size_t)bi * kBigRecPitch + (size_t)j * kBigRegion;
+    // records leave in groups of two slots = one aligned 32-byte store, in the WAVE's phase (iteration `it` fills slot it & 1): a lane
+    // that turns to its real walk in an odd iteration begins its region at slot 1 (`pad`)
+    uint4 p0 = make_uint4(0, 0, 0, 0), p1 = p0;
+    uint32_t it = 0, it_base = 0, pad = 0;
+    bool grp = false;
+
+    for (;;) {
+        if (!done && ip >= st.hi) st.lo = st.hi = ip & ~(kSsUnit - 1u);      // jumped past the window (long literal run): re-anchor
+        for (;;) {
+            const bool want = !done && st.hi < iend && (st.hi - st.lo < kSsRing || ip >= st.lo + kSsUnit);
+            const bool urgent = want && ip + kBigAhead > st.hi;
+            if (ballot64(urgent) == 0ull) break;
+            seg_refill(st, want, wave_ring, plan);
+        }
+        if (ballot64(!done) == 0ull) break;
+        bool go = !done && !fin;
+        bool emit = false;
+        uint4 slot = make_uint4(0u, 0u, r, 0u);                  // an empty record / the region's sentinel
+        if (ballot64(!done && (fin || (!lead && ip >= next_b))) != 0ull) {
+            if (!done && fin) { emit = true; done = true; }      // the sentinel behind the last record
+            else if (go && !lead && ip >= next_b) {              // across a boundary, on a token: the candidate of the segment it is in now?
+                while (tb + 1u < k && ip >= next_b + seg) { tb += 1u; next_b += seg; }
+                const uint32_t cm = s_cand[g0 + tb];
+                if (cm == kBigPending) { go = false; emit = true; cnt += 1u; }          // that lane is still in its lead-in: an empty record, wait a step
+                else if (cm == ip) { link = tb; done = true; go = false; emit = true; }  // the region's sentinel
+                else { tb += 1u; next_b = tb < k ? next_b + seg : 0xFFFFFFFFu; }
+            }
+        }
+        const BigElem e = big_elem<kCodec>(st, ip, iend, go);
+        if (ballot64(go && lead) != 0ull) {
+            if (go && lead) {
+                uint32_t nx = e.ok && !e.last ? e.next : ip + 1u;          // malformed here = this was no token: try the next byte
+                nx = nx <= ip ? ip + 1u : nx;
+                ip = nx;
+                if (ip >= my_b) {
+                    lead = false;
+                    const uint32_t cand = ip < iend ? ip : kBigNone;
+                    s_cand[wave * 64u + lane] = cand;
+                    if (cand == kBigNone) done = true;
+                    it_base = (it + 1u) & ~1u; pad = (it + 1u) & 1u;      // the first slot is put in the next iteration
+                }
+                go = false;
+            }
+        }
+        if (go) {
+            const uint32_t op2 = r + e.lit;
+            const bool has_match = kCodec == CJ_CODEC_LZ4_BLOCK ? !e.last : e.mlen != 0u;
+            const uint32_t off16 = e.offset & 0xffffu;
+            // (a Snappy copy that reaches further back than 65 535 bytes needs more than the previous slab: wavefront kernel)
+            const bool bad_now = !e.ok || (has_match && (e.offset == 0u || e.offset > 0xffffu)) || it - it_base + 4u > kBigRegion
+                                 || (!e.last && e.next >= iend) || e.lit > kBigInMax || e.mlen > 0x00ffffffu;
+            const int32_t reach = has_match ? (int32_t)off16 - (int32_t)op2 : need;
+            need = reach > need ? reach : need;
+            if (kCodec == CJ_CODEC_LZ4_BLOCK && has_match) lim = op2 + (e.mlen + 5u > 12u ? e.mlen + 5u : 12u);
+            const uint32_t mlen = has_match ? e.mlen : 0u;
+            emit = true;
+            slot = make_uint4((e.lit_at - mis) | ((mlen >> 16) << 24), e.lit, r, (has_match ? off16 : 0u) | ((mlen & 0xffffu) << 16));
+            cnt += 1u;
+            r = op2 + mlen;
+            ip = e.next;
+            saw_last = e.last;
+            fin = e.last;
+            if (bad_now || r > kBigOutMax) { bad = true; done = true; }
+        }
+        const uint32_t q = it & 1u;                               // (uniform)
+        if (q == 0u) p0 = emit ? slot : p0;
+        else p1 = emit ? slot : p1;
+        grp = grp || emit;
+        if (q == 1u) {
+#ifndef CJ_BIG_NOSTORE
+            if (grp) { region[it - 1u - it_base] = p0; region[it - it_base] = p1; }
+#endif
+            grp = false;
+        }
+        it += 1u;
+    }
+    if (grp) { region[(it & ~1u) - it_base] = p0; region[(it & ~1u) - it_base + 1u] = p1; }
+
+    // ---- epilogue: which lanes does the chain run through, what lies in front of each ----
+    volatile uint32_t* my_live = s_live + wave * 64u + lane;
+    bool live = walk && j == 0u;
+    *my_live = live ? 1u : 0u;
+    for (uint32_t round = 1; round < k; round++) {
+        if (live && link != kBigNoLink) s_live[g0 + link] = 1u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        live = *my_live != 0u;
+    }
+#ifdef CJ_BIG_DEBUG
+    if (bi < 2u) printf("big chunk %u lane %u: it %u cnt %u r %u link %u live %d bad %d last %d seg %u n %u\n", bi, j, it, cnt, r, link, (int)live, (int)bad, (int)saw_last, seg, n);
+#endif
+    const uint32_t v_cnt = live ? cnt : 0u, v_out = live ? r : 0u;
+    uint32_t s_cnt = v_cnt, s_out = v_out;
+    for (uint32_t d = 1; d < k; d <<= 1) {
+        const uint32_t t0 = (uint32_t)__shfl_up((int)s_cnt, d, 64), t1 = (uint32_t)__shfl_up((int)s_out, d, 64);
+        if (j >= d) { s_cnt += t0; s_out += t1; }
+    }
+    const uint32_t first = s_cnt - v_cnt, opb = s_out - v_out;
+    const uint32_t last_lane = (lane & ~(k - 1u)) + k - 1u;
+    const uint32_t nseq = (uint32_t)__shfl((int)s_cnt, (int)last_lane, 64), total = (uint32_t)__shfl((int)s_out, (int)last_lane, 64);
+    bool lane_ok = true;
+    if (live) {
+        lane_ok = !bad && (link != kBigNoLink || saw_last) && need <= (int32_t)opb;
+        if constexpr (kCodec == CJ_CODEC_LZ4_BLOCK) {
+            if (lim != 0u) lane_ok = lane_ok && (uint64_t)opb + lim <= cap;          // its last sequence with a match
+            if (saw_last) lane_ok = lane_ok && (uint64_t)opb + r <= cap;
+        }
+    }
+    const uint64_t okm = ballot64(lane_ok), lastm = ballot64(live && saw_last);
+    const uint64_t gmask = (k >= 64u ? ~0ull : ((1ull << k) - 1ull)) << (lane & ~(k - 1u));
+    bool chunk_ok = walk && (okm & gmask) == gmask && __popcll(lastm & gmask) == 1;
+    if constexpr (kCodec == CJ_CODEC_SNAPPY_RAW) chunk_ok = chunk_ok && total == cap;
+    else chunk_ok = chunk_ok && total <= cap;
+    chunk_ok = chunk_ok && total > kLdsOutMax && nseq >= 1u;      // (a chunk that decodes to at most 64 KiB: the wavefront kernel — rare, and the slab walk below assumes two slabs)
+
+    // ---- the record that holds output byte 65536 * s: the live lane whose output range contains it searches its region ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this lane's records are in memory (L2)
+    BigMeta* bm = bigmeta + bi;
+    if (exists && chunk_ok && live) {
+        for (uint32_t sb = 1; sb < kBigSlabs; sb++) {
+            const uint32_t b = sb * 65536u;
+            if (b >= total || b < opb || b >= opb + r) continue;      // not in this chunk / not in this lane's part (r > 0 here)
+            const uint32_t rel = b - opb;
+            uint32_t lo = 0, hi = cnt;                             // largest idx in [0, cnt) with lit_start[idx] <= rel (idx 0 has lit_start 0)
+            while (hi - lo > 1u) {
+                const uint32_t mid = (lo + hi) >> 1;
+                const uint32_t z = __hip_atomic_load(&reinterpret_cast<const uint32_t*>(region + pad + mid)[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (z <= rel) lo = mid; else hi = mid;
+            }
+            bm->slab_first[sb] = first + lo;
+        }
+    }
+    if (exists) {
+        if (chunk_ok) {
+            bm->first[j] = first;
+            bm->opb[j] = opb | (pad << 28);
+            if (j == 0u) {
+                bm->chunk = c; bm->nseq = nseq; bm->in_skip = skip; bm->U = total; bm->slab_first[0] = 0u;
+                a.result[c] = (int64_t)total;
+                meta[c] = ParseMeta{0u, 0u};                       // handled here: the wavefront kernel skips it
+            }
+        } else if (j == 0u) { bm->chunk = c; bm->nseq = 0u; }      // stays with the wavefront kernel (the small-chunk pipeline flagged it)
+    }
+}
+
+__global__ __launch_bounds__(256) void big_items_kernel(BatchArgs a, const uint32_t* list, const BigMeta* bigmeta, uint32_t cap,
+                                                        uint64_t* rows, ParseMeta* item_meta, uint32_t* done) {
+    const uint32_t w = blockIdx.x * 256u + threadIdx.x, items = kBigSlabs * cap;
+    if (w >= items) return;
+    const uint32_t bi = w % cap, sl = w / cap;
+    const uint32_t listed = list[0] < list[1] ? list[0] : list[1];
+    uint64_t in_off = 0, in_len = 0, out_off = 0, out_cap = 0, res = 0;
+    uint32_t nrec = 0;
+    if (bi < listed) {
+        const BigMeta* bm = bigmeta + bi;
+        const uint32_t U = bm->U, nseq = bm->nseq;
+        if (nseq != 0u && sl * 65536u < U) {
+            const uint32_t c = bm->chunk;
+            const uint32_t R0 = bm->slab_first[sl], R1 = (sl + 1u) * 65536u < U ? bm->slab_first[sl + 1u] : nseq - 1u;
+            nrec = R1 - R0 + 1u;
+            in_off = a.in_off[c] + bm->in_skip; in_len = a.in_len[c] - bm->in_skip;
+            out_off = a.out_off[c] + (uint64_t)sl * 65536u; out_cap = (uint64_t)sl * 65536u;      // (out_cap = the slab's first output position in its chunk: what the slab mode calls the stream position)
+            res = U - sl * 65536u < 65536u ? U - sl * 65536u : 65536u;
+        }
+    }
+    rows[w] = in_off; rows[items + w] = in_len; rows[2 * (size_t)items + w] = out_off; rows[3 * (size_t)items + w] = out_cap; rows[4 * (size_t)items + w] = res;
+    item_meta[w] = ParseMeta{nrec, 0u};
+    done[w] = 0u;
+}
+
+void launch_big_items(const BatchArgs& a, const uint32_t* list, const void* bigmeta, uint32_t cap, uint64_t* rows, void* item_meta, uint32_t* done, hipStream_t s) {
+    if (cap == 0) return;
+    hipLaunchKernelGGL(big_items_kernel, dim3((kBigSlabs * cap + 255u) / 256u), dim3(256), 0, s, a, list, (const BigMeta*)bigmeta, cap, rows, (ParseMeta*)item_meta, done);
+}
+
+size_t big_recs_bytes(size_t cap) { return cap * (size_t)kBigRecPitch * sizeof(uint4); }
+size_t big_meta_bytes(size_t cap) { return cap * sizeof(BigMeta); }
+
+void launch_big_parse(const BatchArgs& a, int codec, uint32_t* list, uint32_t cap, void* recs, void* bigmeta, void* meta, hipStream_t s) {
+    if (a.n_chunks == 0 || cap == 0) return;
+    const dim3 lgrid((a.n_chunks + 255u) / 256u);
+    const uint32_t per_block = (64u * kBigWaves) >> kBigLanesLog;
+    const dim3 pgrid((cap + per_block - 1u) / per_block), block(64u * kBigWaves);
+    if (codec == CJ_CODEC_SNAPPY_RAW) {
+        hipLaunchKernelGGL((big_list_kernel<CJ_CODEC_SNAPPY_RAW>), lgrid, dim3(256), 0, s, a, list);
+        hipLaunchKernelGGL((big_parse_kernel<CJ_CODEC_SNAPPY_RAW>), pgrid, block, 0, s, a, (const uint32_t*)list, (uint4*)recs, (BigMeta*)bigmeta, (ParseMeta*)meta);
+    } else {
+        hipLaunchKernelGGL((big_list_kernel<CJ_CODEC_LZ4_BLOCK>), lgrid, dim3(256), 0, s, a, list);
+        hipLaunchKernelGGL((big_parse_kernel<CJ_CODEC_LZ4_BLOCK>), pgrid, block, 0, s, a, (const uint32_t*)list, (uint4*)recs, (BigMeta*)bigmeta, (ParseMeta*)meta);
+    }
+}
+
+}  // namespace cj

@@ -36,6 +36,15 @@ struct DevBuf {
         cap = want;
         return true;
     }
+    // for buffers of gigabytes (the record areas of big chunks): no growth slack
+    bool reserve_exact(size_t n) {
+        if (n <= cap) return true;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        if (!hip_ok(hipMalloc(&p, n), "hipMalloc")) { p = nullptr; return false; }
+        cap = n;
+        return true;
+    }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
@@ -83,6 +92,7 @@ struct cj_engine {
     std::vector<uint64_t> h_meta;
     cj::DevBuf d_frame;            // frame.hip: assembled / staged framed stream
     cj::DevBuf d_tab;              // LDS decoder variant 2: per-workgroup record tables
+    cj::DevBuf d_bigrecs, d_bigmisc, d_bigslabtab;   // chunks of 64 KiB .. 256 KiB in a device batch (big_chunks.hpp, CJ_FLAG_BIG_CHUNKS): record areas; list + summaries + slab items; the slab decoder's tables
     cj::DevBuf d_big, d_bigtab;    // large.hip: parse scratch / record tables of one large stream (under `mu`)
     // encoders, large batches (cj::EncFill): second stream for the global-table blocks, their tables + the chunk counter
     hipStream_t enc_aux = nullptr;

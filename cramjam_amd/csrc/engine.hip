@@ -3,6 +3,7 @@
 // runtime; all codec arithmetic is in the four *_decode/_encode.hip kernels.  There is no CPU codec
 // in this library: if no device is usable the entry points return CJ_E_NO_DEVICE.
 #include "cj_engine.hpp"
+#include "big_chunks.hpp"
 
 using cj::hip_ok;
 using cj::parallel_chunks;
@@ -46,6 +47,8 @@ int lds_scratch(cj_engine* e, const cj::BatchArgs& a, hipStream_t s, bool with_s
 //                      pass over the input (100 k chunks: 18 ms fused, 10.6 ms with the parse kernel)
 //   then               the wavefront-per-chunk kernel on what the parse left over (errors, chunks above 64 KiB, few long runs)
 //   flags              CJ_FLAG_FORCE_WAVE_PER_CHUNK / _LANE_PER_CHUNK: one mapping for every chunk (tests, comparisons)
+constexpr size_t kBigCap = 8192;          // big chunks (CJ_FLAG_BIG_CHUNKS) that get a record area per slice (1 MiB each); the rest take the wavefront kernel
+
 int launch_decode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a, hipStream_t s) {
     const bool lz4 = codec == CJ_CODEC_LZ4_BLOCK;
     int mode = 2;
@@ -71,6 +74,32 @@ int launch_decode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a, hipStrea
         if (lz4) cj::launch_lz4_parse(a, e->d_sync.p, e->d_pmeta.p, s);
         else cj::launch_snappy_parse(a, e->d_sync.p, e->d_pmeta.p, s);
         cj::launch_lz4_decode_lds2(a, e->d_sync.p, e->d_pmeta.p, e->d_tab.p, lists + 2, grid, s, codec);
+    }
+    if (a.flags & CJ_FLAG_BIG_CHUNKS) {
+        // chunks of 64 KiB .. 256 KiB (flagged kRouteWave above): listed, parsed by eight lanes each into records, decoded slab by slab
+        // with two workgroups per CU (big_chunks.hpp); what that stage does not take stays flagged for the wavefront kernel
+        const uint32_t cap = (uint32_t)std::min<size_t>(a.n_chunks, kBigCap);
+        const uint32_t items = cj::kBigSlabs * cap;
+        const uint32_t tab_stride = 4u * (16384u + 64u), cross_stride = 3u * (16384u + 64u);
+        // d_bigmisc: list (4 + cap words) | BigMeta x cap | item rows (5 x 8 bytes x items) | item meta | done flags | counter
+        const size_t o_meta = ((4 + (size_t)cap) * 4 + 255) & ~(size_t)255, o_rows = (o_meta + cj::big_meta_bytes(cap) + 255) & ~(size_t)255,
+                     o_imeta = o_rows + cj::kBigItemRows * 8 * (size_t)items, o_done = o_imeta + 8 * (size_t)items, o_ctr = o_done + 4 * (size_t)items, total = o_ctr + 256;
+        if (!e->d_bigrecs.reserve_exact(cj::big_recs_bytes(cap)) || !e->d_bigmisc.reserve(total)
+            || !e->d_bigslabtab.reserve((size_t)grid * tab_stride * 16 + (size_t)grid * cross_stride * 16 + (size_t)grid * (tab_stride + 512u) * 4)) return CJ_E_OOM;
+        uint8_t* m = (uint8_t*)e->d_bigmisc.p;
+        uint32_t* list = (uint32_t*)m;
+        const uint32_t hdr[4] = {0u, cap, 0u, 0u};
+        HIP_TRY(hipMemcpyAsync(list, hdr, sizeof hdr, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
+        HIP_TRY(hipMemsetAsync(m + o_ctr, 0, 256, s), CJ_E_NO_DEVICE);
+        cj::launch_big_parse(a, codec, list, cap, e->d_bigrecs.p, m + o_meta, e->d_pmeta.p, s);
+        uint64_t* rows = (uint64_t*)(m + o_rows);
+        cj::launch_big_items(a, list, m + o_meta, cap, rows, m + o_imeta, (uint32_t*)(m + o_done), s);
+        cj::BatchArgs it = a;
+        it.in_off = rows; it.in_len = rows + items; it.out_off = rows + 2 * (size_t)items; it.out_cap = rows + 3 * (size_t)items;
+        it.result = (int64_t*)(rows + 4 * (size_t)items); it.n_chunks = items; it.flags = a.flags & CJ_FLAG_DEBUG_PROFILE;
+        uint8_t* t = (uint8_t*)e->d_bigslabtab.p;
+        cj::launch_lz4_decode_big_slabs(it, m + o_imeta, e->d_bigrecs.p, m + o_meta, cap, t, (uint32_t*)(m + o_ctr), (uint32_t*)(m + o_done),
+                                        t + (size_t)grid * tab_stride * 16, tab_stride, cross_stride, std::min(grid, items), s, codec);
     }
     if (lz4) cj::launch_lz4_decode_routed(a, e->d_pmeta.p, s);                // few long runs / oversize chunks / errors
     else cj::launch_snappy_decode_routed(a, e->d_pmeta.p, s);
@@ -280,7 +309,7 @@ int cj_engine_create(int device, cj_engine** out) {
 void cj_engine_destroy(cj_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
-    e->d_in.release(); e->d_out.release(); e->d_meta.release(); e->d_sync.release(); e->d_pmeta.release(); e->d_lanelist.release(); e->d_frame.release(); e->d_tab.release(); e->d_big.release(); e->d_bigtab.release();
+    e->d_in.release(); e->d_out.release(); e->d_meta.release(); e->d_sync.release(); e->d_bigrecs.release(); e->d_bigmisc.release(); e->d_bigslabtab.release(); e->d_pmeta.release(); e->d_lanelist.release(); e->d_frame.release(); e->d_tab.release(); e->d_big.release(); e->d_bigtab.release();
     e->h_in.release(); e->h_out.release();
     if (e->scratch_free) (void)hipEventDestroy(e->scratch_free);
     e->d_enc.release();
@@ -294,7 +323,7 @@ int cj_engine_device(const cj_engine* e) { return e ? e->device : -1; }
 
 // the flag bits a C-ABI caller may set; everything else (piece splitting, tail reports, linked-frame parse: cj_common.hpp) belongs
 // to large.hip / frame.hip, which call cj::launch directly — a stray bit would make a kernel read descriptors that are not there
-static constexpr uint32_t kPublicFlags = CJ_FLAG_LZ4_SIZE_PREFIX | CJ_FLAG_FORCE_WAVE_PER_CHUNK | CJ_FLAG_FORCE_LANE_PER_CHUNK | CJ_FLAG_FORCE_LDS_PER_CHUNK
+static constexpr uint32_t kPublicFlags = CJ_FLAG_LZ4_SIZE_PREFIX | CJ_FLAG_FORCE_WAVE_PER_CHUNK | CJ_FLAG_FORCE_LANE_PER_CHUNK | CJ_FLAG_FORCE_LDS_PER_CHUNK | CJ_FLAG_BIG_CHUNKS
                                          | CJ_FLAG_DEBUG_PROFILE;
 
 int cj_batch_device(cj_engine* e, cj_codec codec, cj_op op, uint32_t flags, size_t n_chunks,
@@ -367,6 +396,7 @@ int cj_batch_host(cj_engine* e, cj_codec codec, cj_op op, uint32_t flags, size_t
             for (size_t k = 0; k < rest.size(); k++) result[rest[k]] = rr[k];
             return 0;
         }
+        if (!big.empty()) flags |= CJ_FLAG_BIG_CHUNKS;        // many big chunks: the batch's own big-chunk path (up to 256 KiB each; big_chunks.hpp)
     }
     std::lock_guard<std::mutex> lock(e->mu);
     HIP_TRY(hipSetDevice(e->device), CJ_E_NO_DEVICE);

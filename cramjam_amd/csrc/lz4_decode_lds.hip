@@ -24,6 +24,7 @@
 // The slab mode (one large stream: chunk c = slab c of its output) and the linked mode (LZ4 frames with linked blocks: the
 // previous block stays in a second window) share the body.
 #include "lds_shared.hpp"
+#include "big_chunks.hpp"
 
 namespace cj {
 
@@ -101,7 +102,7 @@ constexpr uint32_t kFwdMaxRecords = 6144;      // D1f (match forwarding): 10 byt
 #define CJ_FWD_SHARE_NUM 2u                    // forwarding where more than 1 / 2 of the matches are near
 #endif
 constexpr uint32_t kFwdMaxRounds = CJ_FWD_ROUNDS, kFwdBatchRounds = CJ_FWD_ROUNDS_BATCH, kFwdNear = CJ_FWD_NEAR;
-struct SlabArgs { uint32_t* done; uint4* cross; uint32_t tab_stride, cross_stride, rel; uint32_t* defer; uint32_t defer_stride; };
+struct SlabArgs { uint32_t* done; uint4* cross; uint32_t tab_stride, cross_stride, rel; uint32_t* defer; uint32_t defer_stride; uint32_t prev = 1u; };      // prev: slab c waits for slab c - prev
 #ifndef CJ_SLAB_PATIENCE
 #define CJ_SLAB_PATIENCE 64u
 #endif
@@ -109,9 +110,17 @@ constexpr uint32_t kSlabPatience = CJ_SLAB_PATIENCE;
 // rel = 1 (LZ4 frames with linked blocks, frame.hip): chunk c is block c of the frame — its sync points are its own (ip, op
 // relative to the block), the stream length is the block's, a STORED block is copied; history = the blocks before it.
 
-template <int kCodec, bool kLinked, bool kSlab, bool kFused = false>
+// kRecFeed (with kSlab; chunks of 64 KiB .. 256 KiB in a device batch, big_chunks.hpp): the work items are the 64 KiB slabs of the
+// listed chunks' output in SLAB-MAJOR order (item w = slab w / cap of listed chunk w % cap: when slab s of a chunk is claimed,
+// its slab s - 1 finished thousands of claims ago, so the completion flags never make anybody wait), and the chunk's sequences are
+// records in memory (big_parse_kernel): D1 is one thread per record — find its region, add the region's position base, clip
+// to the slab exactly like the walking D1 of the large-stream slabs — instead of one thread per eight sequences walking tokens.
+struct FeedArgs { const uint4* recs; const BigMeta* bigmeta; uint32_t cap; };
+
+template <int kCodec, bool kLinked, bool kSlab, bool kFused = false, bool kRecFeed = false>
 __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync, const ParseMeta* meta, uint4* tabs, uint32_t* counter,
-                                          const uint2* frames, uint32_t n_frames, const SlabArgs& sl) {
+                                          const uint2* frames, uint32_t n_frames, const SlabArgs& sl, const FeedArgs& fd = FeedArgs{nullptr, nullptr, 0u}) {
+    static_assert(!kRecFeed || (kSlab && !kLinked && !kFused), "records are fed to the slab mode");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr uint32_t kOffBits = kLinked ? 131072u : kL2OffBits, kOffVars = kOffBits + 8192u;
     uint8_t* s_out = smem;
@@ -279,7 +288,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 __syncthreads();
                 CJ_TRACE_T0(4);                                            // stores acknowledged
                 if (tid == 0) {
-                    if (has_prev) while (__hip_atomic_load(&sl.done[c - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
+                    if (has_prev) while (__hip_atomic_load(&sl.done[c - sl.prev], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
                     if (wt_tail) {                           // a chunk whose size is not a multiple of 16 ended with plain byte stores
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -315,16 +324,16 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         // offset (relative to in) up to which reads are safe: the end of the 16 B granule holding the last input byte
         const uint32_t safe_end = ((((uint32_t)(reinterpret_cast<uintptr_t>(in) & 15u)) + iend + 15u) & ~15u) - (uint32_t)(reinterpret_cast<uintptr_t>(in) & 15u);
         uint8_t* out = a.out_base + d_out_off;
-        const uint2* csync = kSlab ? sync + frames[c].x : sync + (size_t)c * kSyncPitch;
+        const uint2* csync = kRecFeed ? nullptr : kSlab ? sync + frames[c].x : sync + (size_t)c * kSyncPitch;
         const uint32_t nsp = (nseq + kSyncEvery - 1u) / kSyncEvery;
-        const bool staged = !kSlab || iend <= kLdsInMax;   // kSlab: a slab inside a long literal run may span more input than the window holds
+        const bool staged = !kRecFeed && (!kSlab || iend <= kLdsInMax);   // kSlab: a slab inside a long literal run may span more input than the window holds; kRecFeed: nothing walks the bytes
         // ---- S0: stage the compressed chunk in the (still unused) output window so that D1's dependent token
         //      reads are LDS reads; D2 re-reads the literal bytes from global memory (L2 hits) because it overwrites
         //      the window while other lanes still need their sources ----
         const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(in) & 15u);
         // this thread's first sync point (D1) is requested together with the chunk's bytes: one round trip instead of two
         uint2 p_first = make_uint2(0u, 0u);
-        if constexpr (!kFused) p_first = csync[tid < nsp ? tid : 0u];
+        if constexpr (!kFused && !kRecFeed) p_first = csync[tid < nsp ? tid : 0u];
         {
             const uint4* src = reinterpret_cast<const uint4*>(in - mis);
             uint4* dst = reinterpret_cast<uint4*>(s_out);
@@ -368,22 +377,13 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         } else
         if constexpr (kSlab) {
             using G = typename std::conditional<kCodec == CJ_CODEC_SNAPPY_RAW, SnappyGrammar, Lz4Grammar>::type;
-            const uint32_t in_lo = frames[c].y;
-            const uint32_t s_iend = sl.rel ? iend : pm.in_skip;           // the stream's end, relative to this slab's input
             const uint64_t S = a.out_off[c];
             const int64_t op_bias = sl.rel ? 0 : (int64_t)a.out_cap[c];   // the stream's sync points count output from the stream's start; S is the slab's place in the output BUFFER
-            const auto rd = [&](uint32_t p) { return staged ? lds_ld32a(a_in + p) : ld32u(in + p); };
             uint4* cross = sl.cross + (size_t)blockIdx.x * sl.cross_stride;
-            for (uint32_t sp = tid; sp < nsp; sp += kL2Threads) {
-                const uint2 p = sp == tid ? p_first : csync[sp];
-                uint32_t ip = p.x - in_lo;
-                int64_t op = (int64_t)(uint64_t)p.y - op_bias;          // may be negative: the group starts before the slab
-                uint32_t sq = sp * kSyncEvery, near = 0;
-                for (uint32_t j = 0; j < kSyncEvery && sq < nseq; j++, sq++) {
-                    if (op >= (int64_t)U) { table[sq] = make_uint4(0u, 0u, U, 0u); continue; }     // the rest of the group lies past the slab
-                    Seq q;
-                    (void)G::at(rd, ip, s_iend, q, in);                      // the parse stage accepted this stream
-                    uint32_t lit = q.lit, src = q.lit_at, mlen = q.mlen;
+            // one sequence (literal source, lengths, offset, output position relative to the slab — maybe negative) -> its record,
+            // clipped to the slab; the part of its match whose source lies before the slab -> the cross list.  Returns "near match".
+            const auto slab_emit = [&](uint32_t sq, uint32_t src, uint32_t lit, uint32_t mlen, uint32_t off, int64_t op) -> uint32_t {
+                    uint32_t near = 0;
                     int64_t o0 = op;
                     if (o0 < 0) { const uint32_t cut = (uint64_t)(-o0) < lit ? (uint32_t)(-o0) : lit; src += cut; lit -= cut; o0 += cut; }
                     int64_t d0 = o0 + lit;
@@ -396,7 +396,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                         d0 = o0 + lit;
                         if (d0 + mlen > (int64_t)U) mlen = U - (uint32_t)d0;
                     }
-                    const uint32_t dst = (uint32_t)d0, off = q.offset;
+                    const uint32_t dst = (uint32_t)d0;
                     uint4 rec = make_uint4(src, lit, dst, 0u);
                     if (mlen > 0u) {
                         if (off > dst) {                                  // source starts before the slab
@@ -417,10 +417,52 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                         near += off < kFwdNear ? 1u : 0u;
                     }
                     table[sq] = rec;
+                    return near;
+            };
+            if constexpr (kRecFeed) {
+                // the slab's records: from the one that holds its first output byte to the one that holds the next slab's
+                const uint32_t bi = c % fd.cap, slab = c / fd.cap;
+                const BigMeta* bm = fd.bigmeta + bi;
+                const uint32_t R0 = bm->slab_first[slab];
+                // per region: first record, slot adjustment, position base — in LDS behind the decoder's own (the regions are found by
+                // a binary search: a lane without records shares its first index with the next lane that has some)
+                uint32_t* s_feed = reinterpret_cast<uint32_t*>(smem + kL2Bytes);
+                if (tid < kBigLanes) {
+                    const uint32_t f = tid ? bm->first[tid] : 0u, o = bm->opb[tid];
+                    s_feed[tid] = f; s_feed[kBigLanes + tid] = tid * kBigRegion + (o >> 28) - f; s_feed[2u * kBigLanes + tid] = o & 0x0fffffffu;
+                }
+                __syncthreads();
+                const uint4* crecs = fd.recs + (size_t)bi * kBigRecPitch;
+                uint32_t near = 0;
+                for (uint32_t i = tid; i < nseq; i += kL2Threads) {
+                    const uint32_t gi = R0 + i;
+                    uint32_t t = 0;
+#pragma unroll
+                    for (uint32_t step = kBigLanes / 2u; step != 0u; step >>= 1) t += gi >= s_feed[t + step] ? step : 0u;
+                    const uint4 r = crecs[gi + s_feed[kBigLanes + t]];
+                    const uint32_t mlen = (r.w >> 16) | ((r.x >> 24) << 16);
+                    near += slab_emit(i, r.x & 0x00ffffffu, r.y, mlen, r.w & 0xffffu, (int64_t)(uint64_t)(r.z + s_feed[2u * kBigLanes + t]) - op_bias);
+                }
+                if (near) atomicAdd(s_small, near);
+            } else {
+            const uint32_t in_lo = frames[c].y;
+            const uint32_t s_iend = sl.rel ? iend : pm.in_skip;           // the stream's end, relative to this slab's input
+            const auto rd = [&](uint32_t p) { return staged ? lds_ld32a(a_in + p) : ld32u(in + p); };
+            for (uint32_t sp = tid; sp < nsp; sp += kL2Threads) {
+                const uint2 p = sp == tid ? p_first : csync[sp];
+                uint32_t ip = p.x - in_lo;
+                int64_t op = (int64_t)(uint64_t)p.y - op_bias;          // may be negative: the group starts before the slab
+                uint32_t sq = sp * kSyncEvery, near = 0;
+                for (uint32_t j = 0; j < kSyncEvery && sq < nseq; j++, sq++) {
+                    if (op >= (int64_t)U) { table[sq] = make_uint4(0u, 0u, U, 0u); continue; }     // the rest of the group lies past the slab
+                    Seq q;
+                    (void)G::at(rd, ip, s_iend, q, in);                      // the parse stage accepted this stream
+                    near += slab_emit(sq, q.lit_at, q.lit, q.mlen, q.offset, op);
                     ip = q.next;
                     op += (int64_t)q.lit + q.mlen;
                 }
                 if (near) atomicAdd(s_small, near);
+            }
             }
             __syncthreads();
             nrec_all = nseq + *s_nextra;
@@ -693,7 +735,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 if (*s_prevok == 0u) {
                     uint32_t f = 0;
                     for (;;) {
-                        if (lane == 0) f = __hip_atomic_load(&sl.done[c - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (lane == 0) f = __hip_atomic_load(&sl.done[c - sl.prev], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         f = rdlane(f, 0);
                         if (f != 0u || !block || *s_prevok != 0u) break;
                         __builtin_amdgcn_s_sleep(8);
@@ -1061,7 +1103,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                     if constexpr (kSlab) {                         // a long wait is legitimate while the previous slab is still running
                         if (has_prev && !prev_seen) {
                             uint32_t f = 0;
-                            if (lane == 0) f = __hip_atomic_load(&sl.done[c - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (lane == 0) f = __hip_atomic_load(&sl.done[c - sl.prev], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             prev_seen = rdlane(f, 0) != 0u;
                             spins = 0;
                             continue;
@@ -1109,6 +1151,13 @@ __global__ __launch_bounds__(kL2Threads) __attribute__((amdgpu_waves_per_eu(4, 4
     lds2_body<kCodec, false, true>(a, sync, meta, tabs, counter, first, stream_len, sl);
 }
 
+// the slabs of the big chunks of a device batch, records fed by big_parse_kernel (kRecFeed)
+template <int kCodec>
+__global__ __launch_bounds__(kL2Threads) __attribute__((amdgpu_waves_per_eu(4, 4))) void lz4_decode_bigslabs_kernel(
+        BatchArgs a, const ParseMeta* meta, uint4* tabs, uint32_t* counter, SlabArgs sl, FeedArgs fd) {
+    lds2_body<kCodec, false, true, false, true>(a, nullptr, meta, tabs, counter, nullptr, 0u, sl, fd);
+}
+
 // parse + decode in one kernel (batches of independent chunks).  meta: written here (kRouteWave for the chunks left to the wave kernel)
 template <int kCodec>
 __global__ __launch_bounds__(kL2Threads) CJ_L2_ATTR void lz4_decode_fused_kernel(BatchArgs a, ParseMeta* meta, uint4* tabs, uint32_t* counter) {
@@ -1126,6 +1175,25 @@ void launch_lz4_decode_fused(const BatchArgs& a, void* meta, void* tabs, uint32_
     }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_fused_kernel<CJ_CODEC_LZ4_BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     hipLaunchKernelGGL((lz4_decode_fused_kernel<CJ_CODEC_LZ4_BLOCK>), dim3(grid), dim3(kL2Threads), bytes, s, a, (ParseMeta*)meta, (uint4*)tabs, counter);
+}
+
+// items: the slab work items' descriptors (a.n_chunks = kBigSlabs * cap of them), meta: their ParseMeta (nseq = records of the slab, 0 = nothing to do)
+void launch_lz4_decode_big_slabs(const BatchArgs& items, const void* meta, const void* recs, const void* bigmeta, uint32_t cap, void* tabs, uint32_t* counter,
+                                 uint32_t* done, void* cross, uint32_t tab_stride, uint32_t cross_stride, uint32_t grid, hipStream_t s, int codec) {
+    if (items.n_chunks == 0) return;
+    const uint32_t defer_stride = tab_stride + 8u * 64u;
+    const SlabArgs sl = {done, (uint4*)cross, tab_stride, cross_stride, 0u,
+                         reinterpret_cast<uint32_t*>((uint4*)cross + (size_t)grid * cross_stride), defer_stride, cap};
+    const FeedArgs fd = {(const uint4*)recs, (const BigMeta*)bigmeta, cap};
+    constexpr uint32_t bytes = kL2Bytes + 3u * kBigLanes * 4u;          // + the regions' table (kRecFeed)
+    static_assert(2u * bytes <= 163840u, "two workgroups per CU");
+    if (codec == CJ_CODEC_SNAPPY_RAW) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_bigslabs_kernel<CJ_CODEC_SNAPPY_RAW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        hipLaunchKernelGGL((lz4_decode_bigslabs_kernel<CJ_CODEC_SNAPPY_RAW>), dim3(grid), dim3(kL2Threads), bytes, s, items, (const ParseMeta*)meta, (uint4*)tabs, counter, sl, fd);
+        return;
+    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_bigslabs_kernel<CJ_CODEC_LZ4_BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    hipLaunchKernelGGL((lz4_decode_bigslabs_kernel<CJ_CODEC_LZ4_BLOCK>), dim3(grid), dim3(kL2Threads), bytes, s, items, (const ParseMeta*)meta, (uint4*)tabs, counter, sl, fd);
 }
 
 size_t lz4_lds2_tab_bytes(uint32_t grid) { return (size_t)grid * kL2TabRecords * sizeof(uint4); }

@@ -162,6 +162,10 @@ typedef enum { CJ_OP_DECOMPRESS = 0, CJ_OP_COMPRESS = 1 } cj_op;
 #define CJ_FLAG_FORCE_WAVE_PER_CHUNK 0x100u
 #define CJ_FLAG_FORCE_LANE_PER_CHUNK 0x200u
 #define CJ_FLAG_FORCE_LDS_PER_CHUNK  0x400u
+/* decompress: the batch may hold chunks of 64 KiB .. 256 KiB (capacity / announced length) and they matter — the engine reserves
+ * record areas for up to 8 192 of them per slice (1 MiB each) and decodes them slab by slab with workgroups;
+ * without the flag (and for what exceeds the reservation) such chunks take one wavefront each: correct, ~2.5x slower in bulk */
+#define CJ_FLAG_BIG_CHUNKS          0x800u
 /* debug aid: the workgroup decoder accumulates per-phase cycle counters (read with cj_debug_lds_phase_cycles; results unchanged) */
 #define CJ_FLAG_DEBUG_PROFILE        0x1000u
 /* decode batches up to this many chunks run parse + decode as ONE kernel (the segmented parse inside the workgroup decoder:

@@ -1,0 +1,148 @@
+"""Chunks of 64 KiB .. 256 KiB in a device batch (BASELINE configs[4]: 256 KiB chunks, both codecs) through the big-chunk path —
+CJ_FLAG_BIG_CHUNKS: 32-lane segmented parse into records (csrc/big_chunks.hip) + the slab mode of the workgroup decoder fed
+with them — against the oracle: valid chunks of every shape bit-exactly, damaged chunks with the oracle's verdict and bytes,
+small and big chunks mixed in one batch.  Reference behaviour: one call of /root/reference/src/lz4.rs:78-95 (decompress_block) /
+src/snappy.rs:52-60 (decompress_raw) per chunk; a batch is many of them at once."""
+import random
+
+import numpy as np
+import pytest
+
+import oracle
+from cramjam_amd import _native as N
+
+pytestmark = pytest.mark.gpu
+LZ4, SN, DEC = N.CODEC_LZ4_BLOCK, N.CODEC_SNAPPY_RAW, N.OP_DECOMPRESS
+S = 262144
+
+
+def _text(n, seed):
+    r = random.Random(seed); out = bytearray()
+    while len(out) < n: out += b"%d bottles of beer on the wall, %d bottles of beer\n" % (r.randrange(977), r.randrange(1013))
+    return bytes(out[:n])
+
+
+def _mixed(n, seed):        # short sequences with long literal runs in between (runs longer than a parse segment included)
+    r = random.Random(seed); out = bytearray()
+    while len(out) < n:
+        out += oracle.synth_v1(r.randrange(2000, 30000), r.randrange(1 << 20)); out += r.randbytes(r.choice((40, 700, 1500, 3000, 9000, 70000)))
+    return bytes(out[:n])
+
+
+def _run(eng, codec, blobs, caps, flags):
+    n = len(blobs)
+    in_len = np.array([len(b) for b in blobs], np.uint64)
+    in_off = np.concatenate([[0], np.cumsum(in_len + 7)[:-1]]).astype(np.uint64)           # chunks at odd alignments
+    packed = np.zeros(int(in_off[-1] + in_len[-1]) + 64, np.uint8)
+    for k, b in enumerate(blobs): packed[int(in_off[k]):int(in_off[k]) + len(b)] = np.frombuffer(b, np.uint8)
+    out_cap = np.array(caps, np.uint64); out_off = np.concatenate([[0], np.cumsum(out_cap + 5)[:-1]]).astype(np.uint64)
+    total = int(out_off[-1] + out_cap[-1]) + 64
+    d_in = eng.alloc(packed.nbytes); d_out = eng.alloc(total); d_meta = eng.alloc(5 * n * 8)
+    eng.h2d(d_in, packed); eng.h2d(d_meta, np.concatenate([in_off, in_len, out_off, out_cap])); eng.h2d(d_out, np.full(total, 0xAB, np.uint8))
+    eng.batch_device(codec, DEC, flags, n, d_in, d_meta, d_meta + 8 * n, d_out, d_meta + 16 * n, d_meta + 24 * n, d_meta + 32 * n)
+    eng.sync()
+    res = eng.d2h(d_meta + 32 * n, 8 * n, "int64"); out = eng.d2h(d_out, total)
+    for p in (d_in, d_out, d_meta): eng.free(p)
+    return res, out, out_off
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = N.Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def raws():
+    rnd = random.Random(5)
+    r = [oracle.synth_v1(S, 100 + i) for i in range(10)] + [oracle.synth_v1(n, 7 + n) for n in (262143, 200000, 131072, 131073, 70000, 65537, 65536, 30000, 900)]
+    r += [bytes(S), rnd.randbytes(S), _text(S, 1), _text(150000, 2), _mixed(S, 3), _mixed(S, 4), _mixed(180000, 5), (rnd.randbytes(3000) * 90)[:S],
+          b"ab" * 100000, bytes(100000) + rnd.randbytes(100000), b"", b"x"]
+    return r
+
+
+@pytest.mark.parametrize("codec", [LZ4, SN])
+def test_big_and_small_chunks_in_one_batch_against_the_oracle(eng, raws, codec):
+    comp = (lambda r: oracle.lz4_compress_raw(r)[1]) if codec == LZ4 else (lambda r: oracle.snappy_compress(r)[1])
+    blobs = [comp(r) for r in raws] * 5                       # every workgroup takes several slabs
+    want = raws * 5
+    for flags in (N.FLAG_BIG_CHUNKS, 0):                      # with the big-chunk path, and without it (one wavefront per big chunk)
+        res, out, off = _run(eng, codec, blobs, [len(r) for r in want], flags)
+        for i, r in enumerate(want):
+            if codec == LZ4 and len(r) == 0:
+                assert res[i] == 0
+                continue
+            assert res[i] == len(r), (codec, flags, i, int(res[i]), len(r))
+            assert out[int(off[i]):int(off[i]) + len(r)].tobytes() == r, (codec, flags, i)
+            assert (out[int(off[i]) + len(r):int(off[i]) + len(r) + 5] == 0xAB).all(), (codec, flags, i)      # nothing past the capacity
+
+
+def test_lz4_capacity_above_the_decoded_size_and_size_prefix(eng, raws):
+    """output_len is a CAPACITY for LZ4 raw blocks (the reference passes it to LZ4_decompress_safe, src/lz4.rs:88): a big capacity over a
+    smaller block, and the u32 size prefix of store_size=True in front of big blocks"""
+    pick = [r for r in raws if len(r) > 0][:14]
+    blobs = [oracle.lz4_compress_raw(r)[1] for r in pick]
+    res, out, off = _run(eng, LZ4, blobs, [S] * len(pick), N.FLAG_BIG_CHUNKS)
+    for i, r in enumerate(pick):
+        assert res[i] == len(r) and out[int(off[i]):int(off[i]) + len(r)].tobytes() == r, (i, int(res[i]), len(r))
+    pref = [len(r).to_bytes(4, "little") + b for r, b in zip(pick, blobs)]
+    res, out, off = _run(eng, LZ4, pref, [S + 9] * len(pick), N.FLAG_BIG_CHUNKS | N.FLAG_LZ4_SIZE_PREFIX)
+    for i, r in enumerate(pick):
+        assert res[i] == len(r) and out[int(off[i]):int(off[i]) + len(r)].tobytes() == r, (i, int(res[i]), len(r))
+
+
+@pytest.mark.parametrize("codec", [LZ4, SN])
+def test_damaged_big_chunks_get_the_oracles_verdict(eng, raws, codec):
+    rnd = random.Random(17 + codec)
+    big = [r for r in raws if len(r) > 65536]
+    comp = (lambda r: oracle.lz4_compress_raw(r)[1]) if codec == LZ4 else (lambda r: oracle.snappy_compress(r)[1])
+    blobs = [comp(r) for r in big]
+    dam, caps = [], []
+    for t in range(160):
+        i = rnd.randrange(len(big))
+        b = bytearray(blobs[i])
+        kind = rnd.randrange(4)
+        if kind == 0: b[rnd.randrange(len(b))] ^= 1 << rnd.randrange(8)
+        elif kind == 1: b = b[:rnd.randrange(1, len(b))]
+        elif kind == 2:
+            p = rnd.randrange(len(b)); b[p:p + 2] = rnd.randbytes(2)
+        else: b += rnd.randbytes(rnd.randrange(1, 5))
+        dam.append(bytes(b)); caps.append(len(big[i]) if rnd.randrange(3) else len(big[i]) - rnd.randrange(1, 50))
+    if codec == SN:
+        caps = [min(max(oracle.snappy_decompress_len(d), 0), 1 << 19) for d in dam]
+    res, out, off = _run(eng, codec, dam, caps, N.FLAG_BIG_CHUNKS)
+    for k, (d, cap) in enumerate(zip(dam, caps)):
+        er, eo = oracle.lz4_decompress_raw(d, cap) if codec == LZ4 else oracle.snappy_decompress(d, cap)
+        if codec == LZ4 and er < 0:
+            assert res[k] < 0, (k, len(d), cap, int(res[k]), er)
+        else:
+            assert res[k] == er, (codec, k, len(d), cap, int(res[k]), er)
+            if er >= 0:
+                assert out[int(off[k]):int(off[k]) + er].tobytes() == eo, (codec, k)
+
+
+def test_snappy_copy_that_reaches_beyond_the_previous_slab(eng):
+    """a Snappy copy-4 element may reach further back than 65 535 bytes (the encoders never emit one, decoders must accept it): such
+    a chunk is left to the one-wavefront kernel and decodes like any other"""
+    rnd = random.Random(3)
+    head = rnd.randbytes(200000)
+    raw = head + head[1000:1064] + rnd.randbytes(500)                    # 64 bytes copied from 199 000 bytes back
+
+    def lit(b):
+        out = bytearray()
+        for i in range(0, len(b), 60):
+            p = b[i:i + 60]; out += bytes([(len(p) - 1) << 2]) + p
+        return bytes(out)
+
+    def varint(n):
+        out = bytearray()
+        while n >= 0x80: out.append((n & 0x7f) | 0x80); n >>= 7
+        out.append(n)
+        return bytes(out)
+
+    stream = varint(len(raw)) + lit(head) + bytes([((64 - 1) << 2) | 3]) + (199000).to_bytes(4, "little") + lit(raw[200064:])
+    assert oracle.snappy_decompress(stream) == (len(raw), raw)
+    res, out, off = _run(eng, SN, [stream] * 3, [len(raw)] * 3, N.FLAG_BIG_CHUNKS)
+    for i in range(3):
+        assert res[i] == len(raw) and out[int(off[i]):int(off[i]) + len(raw)].tobytes() == raw

@@ -178,7 +178,8 @@ def test_device_batch_synth_roundtrip(eng, chunk, mapping):
     raws[3] = bytes(chunk); raws[5] = hashlib.shake_256(b"x").digest(chunk); raws[7] = raws[7][:chunk - 1]; raws[9] = b""
     for codec in (LZ4, SNAPPY):
         comp = [(oracle.lz4_compress_raw(r) if codec == LZ4 else oracle.snappy_compress(r))[1] for r in raws]
-        res, out, off = _device_batch(eng, codec, DEC, mapping, comp, [len(r) for r in raws])
+        big = N.FLAG_BIG_CHUNKS if chunk > 65536 else 0          # (ignored by the forced one-wavefront / one-lane mappings)
+        res, out, off = _device_batch(eng, codec, DEC, mapping | big, comp, [len(r) for r in raws])
         for i, r in enumerate(raws):
             if codec == LZ4 and len(r) == 0:
                 assert res[i] == 0
@@ -279,7 +280,8 @@ def test_default_pipeline_mixed_large_batch_snappy(eng, n):
 
 def test_mixed_codecs_256k_concurrent_streams():
     """BASELINE configs[4] at reduced N: interleaved LZ4-block / Snappy-raw 256 KiB chunks, one engine (= one HIP
-    stream) per codec, both batches in flight at once; every chunk checked against the oracle."""
+    stream) per codec, both batches in flight at once through the big-chunk path (CJ_FLAG_BIG_CHUNKS: segmented parse + slab
+    decoder); every chunk checked against the oracle."""
     e_lz4, e_sn = N.Engine(0), N.Engine(0)
     S = 262144
     raws = [oracle.synth_v1(S, 100 + i) for i in range(24)]
@@ -298,7 +300,7 @@ def test_mixed_codecs_256k_concurrent_streams():
         out_off = (np.arange(n) * S).astype(np.uint64); out_cap = np.full(n, S, np.uint64)
         d_in = eng.alloc(packed.nbytes); d_out = eng.alloc(n * S); d_meta = eng.alloc(5 * n * 8)
         eng.h2d(d_in, packed); eng.h2d(d_meta, np.concatenate([in_off, in_len, out_off, out_cap]))
-        eng.batch_device(codec, DEC, 0, n, d_in, d_meta, d_meta + 8 * n, d_out, d_meta + 16 * n, d_meta + 24 * n, d_meta + 32 * n)
+        eng.batch_device(codec, DEC, N.FLAG_BIG_CHUNKS, n, d_in, d_meta, d_meta + 8 * n, d_out, d_meta + 16 * n, d_meta + 24 * n, d_meta + 32 * n)
         return d_in, d_out, d_meta, n
 
     h1 = submit(e_lz4, LZ4, lz)            # asynchronous: returns after enqueue

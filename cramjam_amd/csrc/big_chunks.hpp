@@ -42,7 +42,8 @@ size_t big_recs_bytes(size_t cap);
 size_t big_meta_bytes(size_t cap);
 // list[0] = number of listed chunks (counted on the device), list[1] = capacity, list[4 + i] = chunk index.  The small-chunk
 // pipeline has flagged every chunk above 64 KiB kRouteWave in `meta`; a chunk this stage takes gets meta = {0, 0} and its result.
-void launch_big_parse(const BatchArgs& a, int codec, uint32_t* list, uint32_t cap, void* recs, void* bigmeta, void* meta, hipStream_t s);
+size_t big_walk_scratch_bytes(size_t cap);
+void launch_big_parse(const BatchArgs& a, int codec, uint32_t* list, uint32_t cap, void* recs, void* bigmeta, void* meta, void* scratch, hipStream_t s);
 // the slab work items of the listed chunks in slab-major order (item w = slab w / cap of listed chunk w % cap): descriptor rows
 // in_off | in_len | out_off | out_cap | result (8 bytes x items each, in that order from `rows`), their ParseMeta, zeroed flags
 constexpr size_t kBigItemRows = 5;

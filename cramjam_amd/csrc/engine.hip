@@ -83,7 +83,8 @@ int launch_decode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a, hipStrea
         const uint32_t tab_stride = 4u * (16384u + 64u), cross_stride = 3u * (16384u + 64u);
         // d_bigmisc: list (4 + cap words) | BigMeta x cap | item rows (5 x 8 bytes x items) | item meta | done flags | counter
         const size_t o_meta = ((4 + (size_t)cap) * 4 + 255) & ~(size_t)255, o_rows = (o_meta + cj::big_meta_bytes(cap) + 255) & ~(size_t)255,
-                     o_imeta = o_rows + cj::kBigItemRows * 8 * (size_t)items, o_done = o_imeta + 8 * (size_t)items, o_ctr = o_done + 4 * (size_t)items, total = o_ctr + 256;
+                     o_imeta = o_rows + cj::kBigItemRows * 8 * (size_t)items, o_done = o_imeta + 8 * (size_t)items, o_ctr = o_done + 4 * (size_t)items,
+                     o_walk = o_ctr + 256, total = o_walk + cj::big_walk_scratch_bytes(cap);
         if (!e->d_bigrecs.reserve_exact(cj::big_recs_bytes(cap)) || !e->d_bigmisc.reserve(total)
             || !e->d_bigslabtab.reserve((size_t)grid * tab_stride * 16 + (size_t)grid * cross_stride * 16 + (size_t)grid * (tab_stride + 512u) * 4)) return CJ_E_OOM;
         uint8_t* m = (uint8_t*)e->d_bigmisc.p;
@@ -91,7 +92,7 @@ int launch_decode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a, hipStrea
         const uint32_t hdr[4] = {0u, cap, 0u, 0u};
         HIP_TRY(hipMemcpyAsync(list, hdr, sizeof hdr, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
         HIP_TRY(hipMemsetAsync(m + o_ctr, 0, 256, s), CJ_E_NO_DEVICE);
-        cj::launch_big_parse(a, codec, list, cap, e->d_bigrecs.p, m + o_meta, e->d_pmeta.p, s);
+        cj::launch_big_parse(a, codec, list, cap, e->d_bigrecs.p, m + o_meta, e->d_pmeta.p, m + o_walk, s);
         uint64_t* rows = (uint64_t*)(m + o_rows);
         cj::launch_big_items(a, list, m + o_meta, cap, rows, m + o_imeta, (uint32_t*)(m + o_done), s);
         cj::BatchArgs it = a;

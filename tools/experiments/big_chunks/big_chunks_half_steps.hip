@@ -24,7 +24,10 @@ namespace cj {
 
 constexpr uint32_t kBigLead = 1024;                 // bytes in front of its boundary where a lane starts looking for the chain
 constexpr uint32_t kBigSegMin = 2048;               // shortest segment
-constexpr uint32_t kBigAhead = 32;                  // cached bytes a lane must have ahead before a step (lz4_parse_kernel)
+#ifndef CJ_BIG_AHEAD
+#define CJ_BIG_AHEAD 32
+#endif
+constexpr uint32_t kBigAhead = CJ_BIG_AHEAD;                  // cached bytes a lane must have ahead before a step (lz4_parse_kernel)
 constexpr uint32_t kBigNone = 0xFFFFFFFEu, kBigNoLink = 0xFFu;      // (0xFFFFFFFF, the scratch's memset value: no candidate yet)
 constexpr uint32_t kBigListHdr = 4;
 constexpr uint32_t kBigWaves = 4;                   // wavefronts per block of the parse kernel
@@ -76,7 +79,11 @@ __global__ __launch_bounds__(256) void big_list_kernel(BatchArgs a, uint32_t* li
 // units per load instruction — at half the size: 9 KiB per wavefront, sixteen wavefronts per CU.  This walk is bound by memory
 // latency (a chunk of 256 KiB has long literal runs: most steps need a line of the stream that nobody has touched), and what
 // covers a round trip is other wavefronts.
-constexpr uint32_t kSsRing = 128, kSsUnit = 64;
+#ifndef CJ_SS_RING
+#define CJ_SS_RING 128
+#define CJ_SS_UNIT 64
+#endif
+constexpr uint32_t kSsRing = CJ_SS_RING, kSsUnit = CJ_SS_UNIT;
 constexpr uint32_t kSsStride = kSsRing + 16u;           // 16-byte aligned rings (one ds_write_b128 per fetched piece)
 constexpr uint32_t kSsWaveBytes = 64u * kSsStride;
 constexpr uint32_t kSsLanesPerUnit = kSsUnit / 16u, kSsTargets = 64u / kSsLanesPerUnit, kSsLoads = 64u / kSsTargets;
@@ -147,53 +154,69 @@ __device__ __forceinline__ void seg_refill(SegStream& st, bool want, uint32_t wa
     }
 }
 
-struct BigElem { uint32_t lit, lit_at, mlen, offset, next; bool ok, last; };
+struct BigElem { uint32_t lit, lit_at, mlen, offset, next; bool ok, last, half_a; };
+// A sequence whose literal run reaches past the lane's ring (the benchmark's 256 KiB chunks: 80-byte sequences) is taken in TWO
+// iterations: the first reads its token and jumps to the offset field — the ring re-anchors there and ONE refill round brings that
+// line — the second reads the field from the ring.  Taken in one iteration it needs the field from global memory in the middle of
+// the step (a dependent round trip for the whole wavefront) and the refill round behind it: 14 k cycles per iteration measured.
+struct BigHalf { bool on; uint32_t lit, lit_at, tag, tok; };      // on: ip stands on the second part; tag: the token / literal tag; tok: its position
 
-// one element at st-position ip (straight-line for the common shape, the grammar's general function for the lanes that meet
+// one element at st-position ip (straight-line for the common shapes, the grammar's general function for the lanes that meet
 // anything else): the step of lz4_parse_kernel / snappy_parse_kernel without the checks that need the output position
 template <int kCodec>
-__device__ __forceinline__ BigElem big_elem(const SegStream& st, uint32_t ip, uint32_t iend, bool going) {
+__device__ __forceinline__ BigElem big_elem(const SegStream& st, uint32_t ip, uint32_t iend, bool going, BigHalf& hs) {
     BigElem e;
+    e.half_a = false; e.ok = true; e.last = false;
     bool fast = false;
+    const uint32_t w4 = st.ring32(ip);                           // token / tag — or, in the second half, the offset field / copy element
+    const bool win = st.in_window(ip);
     if constexpr (kCodec == CJ_CODEC_LZ4_BLOCK) {
-        const uint32_t t4 = st.ring32(ip);
-        const uint32_t token = t4 & 0xffu, e1 = (t4 >> 8) & 0xffu;
+        const uint32_t token = hs.on ? hs.tag : w4 & 0xffu, e1 = (w4 >> 8) & 0xffu;
         const bool x1 = (token >> 4) == 15u;
-        const uint32_t lit = (token >> 4) + (x1 ? e1 : 0u);
-        const uint32_t ip1 = ip + 1u + (x1 ? 1u : 0u), ip2 = ip1 + lit;
-        const bool w1 = st.in_window(ip), w2 = ip2 + 4u <= st.hi && ip2 + 4u <= iend;
-        const uint32_t o4 = st.ring32(ip2);
+        const uint32_t lit = hs.on ? hs.lit : (token >> 4) + (x1 ? e1 : 0u);
+        const uint32_t ip1 = hs.on ? hs.lit_at : ip + 1u + (x1 ? 1u : 0u), ip2 = hs.on ? ip : ip1 + lit;
+        const bool w2 = ip2 + 4u <= st.hi && ip2 + 4u <= iend && ip2 >= st.lo;
+        const uint32_t o4 = hs.on ? w4 : st.ring32(ip2);
         const uint32_t mc = token & 15u, e2 = (o4 >> 16) & 0xffu;
         const bool x2 = mc == 15u;
-        fast = w1 && w2 && !(x1 && e1 == 255u) && !(x2 && e2 == 255u) && iend - ip1 >= lit + 8u;
+        // rem_in >= lit + 8 implies every bound the general walk checks while it reads one-byte extensions
+        const bool first_ok = hs.on || (win && !(x1 && e1 == 255u) && iend - ip1 >= lit + 8u);
+        fast = first_ok && w2 && !(x2 && e2 == 255u);
+        e.half_a = going && !hs.on && first_ok && !w2;          // the token is read, the offset field lies behind the ring: jump to it
         e.lit = lit; e.lit_at = ip1; e.offset = o4 & 0xffffu; e.mlen = mc + (x2 ? e2 : 0u) + 4u;
-        e.next = ip2 + 2u + (x2 ? 1u : 0u); e.ok = true; e.last = false;
+        e.next = e.half_a ? ip2 : ip2 + 2u + (x2 ? 1u : 0u);
+        if (e.half_a) { hs.lit = lit; hs.lit_at = ip1; hs.tag = token; hs.tok = ip; }
     } else {
-        const uint32_t t4 = st.ring32(ip);
-        const uint32_t tag = t4 & 0xffu, l6 = tag >> 2;
-        const bool is_lit = (tag & 3u) == 0u;
+        const uint32_t tag = hs.on ? hs.tag : w4 & 0xffu, l6 = tag >> 2;
+        const bool is_lit = hs.on || (tag & 3u) == 0u;
         const uint32_t lhdr = is_lit ? (l6 == 60u ? 2u : 1u) : 0u;
-        const uint32_t lit = is_lit ? (l6 == 60u ? ((t4 >> 8) & 0xffu) + 1u : l6 + 1u) : 0u;
-        const uint32_t ip2 = ip + lhdr + lit;
-        const bool w1 = st.in_window(ip), w2 = ip2 + 4u <= st.hi && ip2 + 4u <= iend;
-        const uint32_t c4 = st.ring32(ip2);
+        const uint32_t lit = hs.on ? hs.lit : is_lit ? (l6 == 60u ? ((w4 >> 8) & 0xffu) + 1u : l6 + 1u) : 0u;
+        const uint32_t lit_at = hs.on ? hs.lit_at : ip + lhdr;
+        const uint32_t ip2 = hs.on ? ip : lit_at + lit;                             // the copy element
+        const bool w2 = ip2 + 4u <= st.hi && ip2 + 4u <= iend && ip2 >= st.lo;
+        const uint32_t c4 = hs.on ? w4 : st.ring32(ip2);
         const uint32_t ctag = c4 & 0xffu, kind = ctag & 3u;
-        const uint32_t ip3 = ip2 + (kind == 1u ? 2u : 3u);
-        fast = w1 && w2 && !(is_lit && l6 > 60u) && (kind == 1u || kind == 2u) && ip3 < iend;
-        e.lit = lit; e.lit_at = ip + lhdr;
-        e.mlen = kind == 1u ? 4u + ((ctag >> 2) & 7u) : 1u + (ctag >> 2);
-        e.offset = kind == 1u ? ((ctag >> 5) << 8) | ((c4 >> 8) & 0xffu) : (c4 >> 8) & 0xffffu;
-        e.next = ip3; e.ok = true; e.last = false;
+        const uint32_t ip3 = kind == 0u ? ip2 : ip2 + (kind == 1u ? 2u : 3u);
+        const bool first_ok = hs.on || (win && !(is_lit && l6 > 60u));
+        // second part: a copy element with a 1- or 2-byte offset — or (only where a literal came first) another literal: the record ends in front of it
+        fast = first_ok && w2 && (kind == 1u || kind == 2u || (kind == 0u && is_lit)) && ip3 < iend;
+        e.half_a = going && !hs.on && first_ok && is_lit && !w2 && lit_at + lit + 4u <= iend;
+        e.lit = lit; e.lit_at = lit_at;
+        e.mlen = kind == 0u ? 0u : kind == 1u ? 4u + ((ctag >> 2) & 7u) : 1u + (ctag >> 2);
+        e.offset = kind == 0u ? 0u : kind == 1u ? ((ctag >> 5) << 8) | ((c4 >> 8) & 0xffu) : (c4 >> 8) & 0xffffu;
+        e.next = e.half_a ? ip2 : ip3;
+        if (e.half_a) { hs.lit = lit; hs.lit_at = lit_at; hs.tag = tag; hs.tok = ip; }
     }
-    if (ballot64(going && !fast) != 0ull) {
-        if (going && !fast) {
+    if (ballot64(going && !fast && !e.half_a) != 0ull) {
+        if (going && !fast && !e.half_a) {                       // anything else: the grammar's general function from the element's first byte
             using G = typename std::conditional<kCodec == CJ_CODEC_SNAPPY_RAW, SnappyGrammar, Lz4Grammar>::type;
             const auto rd = [&st](uint32_t p) { return st.ld32(p); };
             Seq s;
-            e.ok = G::at(rd, ip, iend, s, st.base);
+            e.ok = G::at(rd, hs.on ? hs.tok : ip, iend, s, st.base);
             e.lit = s.lit; e.lit_at = s.lit_at; e.mlen = s.mlen; e.offset = s.offset; e.next = s.next; e.last = s.last;
         }
     }
+    if (going) hs.on = e.half_a;
     return e;
 }
 
@@ -240,6 +263,7 @@ __global__ __launch_bounds__(64 * kBigWaves) void big_walk_kernel(BatchArgs a, c
     uint32_t ip = mis + (j == 0u || bj <= kBigLead ? 0u : bj - kBigLead);
     st.lo = st.hi = ip & ~(kSsUnit - 1u);
     const SegPlan plan = seg_plan(st);
+    BigHalf hs = {false, 0u, 0u, 0u, 0u};
     bool lead = !done && j != 0u, retried = false;
     uint32_t lsteps = 0;                                         // elements walked in the lead-in
     uint32_t tb = j + 1u;
@@ -268,25 +292,31 @@ __global__ __launch_bounds__(64 * kBigWaves) void big_walk_kernel(BatchArgs a, c
         bool go = !done && !fin;
         bool emit = false;
         uint4 slot = make_uint4(0u, 0u, r, 0u);                  // the region's sentinel
-        if (ballot64(!done && (fin || (!lead && ip >= next_b))) != 0ull) {
+        if (ballot64(!done && (fin || (!lead && !hs.on && ip >= next_b))) != 0ull) {
             if (!done && fin) { emit = true; done = true; }      // the sentinel behind the last record
-            else if (go && !lead && ip >= next_b) {              // across a boundary, on a token: the candidate of the segment it is in now?
+            else if (go && !lead && !hs.on && ip >= next_b) {    // across a boundary, on a token: the candidate of the segment it is in now?
                 while (tb + 1u < k && ip >= next_b + seg) { tb += 1u; next_b += seg; }
                 const uint32_t cm = __hip_atomic_load(ccand + tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (cm == ip) { link = tb; done = true; go = false; emit = true; }      // the region's sentinel
                 else { tb += 1u; next_b = tb < k ? next_b + seg : 0xFFFFFFFFu; }        // another position, or not known yet: walk on
             }
         }
-        const BigElem e = big_elem<kCodec>(st, ip, iend, go);
+        const BigElem e = big_elem<kCodec>(st, ip, iend, go, hs);
         if (ballot64(go && lead) != 0ull) {
             if (go && lead) {
                 uint32_t nx = e.ok && !e.last ? e.next : ip + 1u;          // malformed here = this was no token: try the next byte
                 nx = nx <= ip ? ip + 1u : nx;
+                if (!e.ok || e.last) hs.on = false;
                 ip = nx;
-                lsteps += 1u;
+                lsteps += e.half_a ? 0u : 1u;
                 // A walk from a wrong position falls into step with the chain with some probability per ELEMENT of the chain it passes, so
-                // the lead-in has to cover enough elements, not bytes: where 1 KiB held fewer than 24 (long literal runs), the lane
-                // starts over further back, at 32 elements' worth by the density it has just seen.
+                // the lead-in has to cover enough elements, not bytes: where 1 KiB held fewer than 24 (long literal runs — the
+                // benchmark's 256 KiB chunks have 80-byte sequences behind their first 64 KiB), the lane starts over further back, at
+                // 32 elements' worth by the density it has just seen.  (Without: 18 % of the boundaries of such data were missed, and
+                // every miss makes the lane in front walk on through one more segment — profiles/r04/experiments b03.)
+                if (hs.on) {
+                    // (the first half of an element: its second half is the next iteration's)
+                } else
                 if (ip >= my_b && lsteps < 24u && !retried) {
                     retried = true;
                     uint32_t back = 32u * kBigLead / lsteps;
@@ -305,6 +335,12 @@ __global__ __launch_bounds__(64 * kBigWaves) void big_walk_kernel(BatchArgs a, c
                 go = false;
             }
         }
+        if (go && e.half_a) {                                    // the first half of a sequence: an empty record keeps the wave's slot phase
+            emit = true;
+            cnt += 1u;
+            ip = e.next;
+            if (it - it_base + 4u > kBigRegion) { bad = true; done = true; }
+        } else
         if (go) {
             const uint32_t op2 = r + e.lit;
             const bool has_match = kCodec == CJ_CODEC_LZ4_BLOCK ? !e.last : e.mlen != 0u;
@@ -467,7 +503,7 @@ void launch_big_parse(const BatchArgs& a, int codec, uint32_t* list, uint32_t ca
     const uint32_t capr = (cap + 63u) & ~63u;
     uint32_t* cands = (uint32_t*)scratch;
     BigLane* lanes = (BigLane*)((uint8_t*)scratch + (size_t)capr * kBigLanes * 4);
-    (void)hipMemsetAsync(cands, 0xFF, (size_t)capr * kBigLanes * 4, s);          // 0xFFFFFFFF = no candidate yet
+    (void)hipMemsetAsync(cands, 0xFF, (size_t)capr * kBigLanes * 4, s);          // kBigPending everywhere
     const dim3 lgrid((a.n_chunks + 255u) / 256u);
     const dim3 wgrid((capr * kBigLanes + 64u * kBigWaves - 1u) / (64u * kBigWaves)), wblock(64u * kBigWaves);
     const dim3 sgrid((cap * kBigLanes + 255u) / 256u);

@@ -1,7 +1,7 @@
 # Round-end evidence run (on the GPU box): gpu tests, the default bench line (it measures its HBM traffic itself with two
 # rocprofv3 --pmc child runs), rocprofv3 kernel stats of the same command, SQ / LDS counters, and the secondary-path bench lines.
 # Outputs land in gpurun_out/<tag>/; copy the summaries into profiles/rNN/.
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
 O=gpurun_out/$TAG; rm -rf $O; mkdir -p $O
@@ -22,12 +22,17 @@ for f in glob.glob(sys.argv[1]+'/*/*counter_collection.csv'):
 for k in sorted(agg):
     print(k, ' '.join('%s=%.0f' % (c.replace('SQ_',''), sum(v)/len(v)/1e5) for c,v in sorted(agg[k].items())), '(per chunk of the 100 k)')
 PY
-for args in "--data corpus64k --steps 20" "--data corpus64k --codec snappy --steps 20" "--codec snappy" "--op compress" "--op compress --codec snappy" "--codec snappy --op roundtrip" "--chunks 1000000 --steps 20" "--workload mixed256k --steps 20" "--chunks 8192 --unique 2048" "--chunks 1024 --unique 1024"; do
+# the corpus lines carry their own traffic and cpu_baseline (all 20 files, liblz4 / libsnappy streams)
+python bench.py --data corpus64k --steps 20 --traffic on --cpu-seconds 10 2>/dev/null | tail -1 >> $O/other_paths.jsonl
+python bench.py --data corpus64k --codec snappy --steps 20 --traffic on --cpu-seconds 10 2>/dev/null | tail -1 >> $O/other_paths.jsonl
+for args in "--codec snappy" "--op compress" "--op compress --codec snappy" "--codec snappy --op roundtrip" "--chunks 1000000 --steps 20" "--workload mixed256k --steps 20" "--codec lz4 --chunk-bytes 262144 --chunks 8192 --unique 2048 --steps 20" "--codec snappy --chunk-bytes 262144 --chunks 8192 --unique 2048 --steps 20" "--chunks 8192 --unique 2048" "--chunks 1024 --unique 1024"; do
   python bench.py --no-cpu-baseline --traffic off $args 2>/dev/null | tail -1 >> $O/other_paths.jsonl
 done
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_mixed -- python bench.py --workload mixed256k --no-cpu-baseline --traffic off --steps 10 > $O/stats_mixed.log 2>&1
+cp $(find $O/stats_mixed -name "*kernel_stats.csv" | head -1) $O/kernel_stats_mixed256k.csv; head -8 $O/kernel_stats_mixed256k.csv | cut -c1-70,200-300
 python - <<PY
 import json
 for l in open('$O/other_paths.jsonl'):
     d=json.loads(l); print('%-95s %8.1f GB/s  %8.3f ms/step  frac %.4f' % (d['config']['workload'][:95], d['value'], d['ms_per_step'], d['roofline']['frac']))
 PY
-rm -rf $O/stats $O/sq $O/stats_enc
+rm -rf $O/stats $O/sq $O/stats_enc $O/stats_mixed

@@ -129,6 +129,42 @@ __device__ __forceinline__ void lds_store_tier(const Loaded& r, uint32_t dst, ui
     for (int q = 0; q < 3; q++) lds_st8((uint32_t)q < t ? tpos + q : dm.b, tv >> (8 * q));
 }
 
+// ---- D2 for a sequence that OWNS the bytes behind its literals --------------------------------------------------------
+// A sequence whose match this lane writes later (D3, same wavefront, program order) may spill up to 3 bytes past the end of its
+// literals: they land in its own match region, which no other lane reads before the bitmap says so.  That removes everything
+// lds_store_tier spends on exactness: bytes 0..3 go out as ONE store at the exact address (misaligned: replayed lane by lane, ~64
+// cycles of the LDS pipe, but one instruction), the rest as aligned dwords from the first aligned address on, each predicated on
+// holding at least one literal byte — no head / tail byte stores, no tail dword selection.  n <= T; n = 0: nothing is stored.
+template <int OFF>
+__device__ __forceinline__ void lds_st32_off(uint32_t a, uint32_t v) {
+    asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(a), "v"(v), "n"(OFF) : "memory");
+}
+template <int I, int N>
+__device__ __forceinline__ void own_dwords(const uint32_t* v, uint32_t h, int32_t r, uint32_t ah, uint32_t dummy) {
+    if constexpr (I < N) {
+        lds_st32_off<4 * I>(r > 4 * I ? ah : dummy, __builtin_amdgcn_alignbyte(v[I + 1], v[I], h));
+        own_dwords<I + 1, N>(v, h, r, ah, dummy);
+    }
+}
+template <int T>
+__device__ __forceinline__ void lds_store_own(const uint32_t* w, uint32_t a, uint32_t n, Dummies dm) {      // w: source bytes 0 .. T-1 (T / 4 dwords)
+    uint32_t v[T / 4 + 1];
+#pragma unroll
+    for (int i = 0; i < T / 4; i++) v[i] = w[i];
+    v[T / 4] = 0u;
+    const uint32_t h = (0u - a) & 3u;
+    const int32_t r = (int32_t)n - (int32_t)h;              // literal bytes from the first aligned address on
+    const uint32_t ah = a + h, dummy = dm.w - 28u;          // (dm.w - 28 + 4i stays inside the dummy slots)
+    lds_st32(n ? a : dm.w, v[0]);
+    own_dwords<0, T / 4>(v, h, r, ah, dummy);
+}
+// the ready bits of [lo, lo + n), n <= 32: two words, no loop (n = 0: two ORs of nothing)
+__device__ __forceinline__ void bits_set32(uint32_t* bits, uint32_t lo, uint32_t n) {
+    const uint64_t m = ((1ull << n) - 1ull) << (lo & 31u);
+    const uint32_t wa = (uint32_t)(uintptr_t)bits + ((lo >> 5) << 2);
+    asm volatile("ds_or_b32 %0, %1\n\tds_or_b32 %0, %2 offset:4" :: "v"(wa), "v"((uint32_t)m), "v"((uint32_t)(m >> 32)) : "memory");
+}
+
 // copy n (<= tier, tier in {16,32,64} wave-uniform) bytes src -> dst, both LDS byte addresses; [src, src+n) is
 // final and does not overlap [dst, dst+n)
 __device__ __forceinline__ void lds_copy_tier(uint32_t tier, uint32_t dst, uint32_t src, uint32_t n, Dummies dm) {

@@ -155,6 +155,23 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             return make_uint4(t.x & 0xffffu, lit, dst, off | (m << 16));
         } else return table[i];
     };
+    // The same in two steps for the batch loops of D2 and D3: the stored form is REQUESTED a batch ahead (no branch around the load:
+    // an index past the end reads the last record) and only looked at when its batch starts — written as one rec_load the decoding
+    // sits behind the load and the wave waits for the round trip on the spot (that was 2 x ~5 round trips per chunk on the chain).
+    const auto rec_fetch = [&](uint32_t i, uint32_t n_main, uint32_t n_all) -> uint4 {
+        const uint32_t ic = i < n_all ? i : (n_all ? n_all - 1u : 0u);
+        if constexpr (kCompact) return ld16u(reinterpret_cast<const uint8_t*>(table) + (ic < n_main ? ic * 8u : (kExtraBase + (ic - n_main)) * 16u));
+        else return table[ic];
+    };
+    const auto rec_view = [&](const uint4& t, uint32_t i, uint32_t n_main, uint32_t n_all) -> uint4 {
+        if (i >= n_all) return make_uint4(0, 0, 0, 0);
+        if constexpr (kCompact) {
+            if (i >= n_main) return t;
+            const uint32_t lit = t.x >> 16, dst = (t.y & 0xffffu) + lit, off = t.y >> 16;
+            const uint32_t m = off ? ((t.w & 0xffffu) - dst) & 0xffffu : 0u;
+            return make_uint4(t.x & 0xffffu, lit, dst, off | (m << 16));
+        } else return t;
+    };
     const auto rec_set_offset = [&](uint32_t i, const uint4& r, uint32_t off) {          // forwarding: another source (0 = the match is gone)
         if constexpr (kCompact) reinterpret_cast<uint32_t*>(table2 + i)[1] = ((r.z - r.y) & 0xffffu) | (off << 16);
         else table[i] = make_uint4(r.x, r.y, r.z, off ? (off | (r.w & 0xffff0000u)) : 0u);
@@ -708,17 +725,51 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 }
             }
         };
-        uint4 rec_nx = make_uint4(0, 0, 0, 0);
         // (the next batch's records are requested before the current batch is processed: a coalesced table read is a
         //  full global round trip and a wave owns only ~5 batches)
-        if (wave * 64u + lane < nrec_all) rec_nx = rec_load(wave * 64u + lane, nseq);
-        for (uint32_t base = wave * 64u; base < nrec_all; base += kL2Threads) {
-            const uint4 rec = rec_nx;
-            rec_nx = make_uint4(0, 0, 0, 0);
-            {   // the wave's last batch requests its FIRST batch again: D3 starts on it without another round trip
-                const uint32_t nb = base + kL2Threads < nrec_all ? base + kL2Threads : wave * 64u;
-                if (nb + lane < nrec_all) rec_nx = rec_load(nb + lane, nseq);
+        const uint32_t i0 = wave * 64u + lane;
+        const auto fetch_batch = [&](uint32_t b) { return rec_fetch(b < nrec_all ? b + lane : i0, nseq, nrec_all); };   // past the wave's last batch: its FIRST again — D3 starts on it
+        uint4 raw_nx = rec_fetch(i0, nseq, nrec_all);
+#ifndef CJ_NO_OWN_D2
+        if constexpr (kCompact) {
+            // A sequence whose match this lane copies in D3 OWNS the bytes behind its literals (lds_store_own): up to 32 literal
+            // bytes per sequence go the lean way, and their 32 source bytes are requested one batch ahead (two loads per record,
+            // no branch around them: the wait for the batch that is placed must not cover the requests of the next one).
+            struct OwnLit { uint32_t n, src, dst, nl; uint32_t v[8]; };
+            const uint8_t* lit_base = iend >= 32u ? in : reinterpret_cast<const uint8_t*>(table);      // 32 readable bytes for the lanes that load nothing
+            const auto own_issue = [&](const uint4& rec, OwnLit& L) {
+                L.n = rec.y; L.src = rec.x; L.dst = rec.z - rec.y;
+                const bool own = (rec.w & 0xffffu) != 0u && (rec.w >> 16) >= 4u && L.src + 32u <= safe_end && L.n < kLongRun;
+                L.nl = own ? (L.n < 32u ? L.n : 32u) : 0u;
+                const uint8_t* g = lit_base + (L.nl ? L.src : 0u);
+                uint4 q0, q1;
+                __builtin_memcpy(&q0, g, 16);
+                __builtin_memcpy(&q1, g + 16, 16);
+                L.v[0] = q0.x; L.v[1] = q0.y; L.v[2] = q0.z; L.v[3] = q0.w; L.v[4] = q1.x; L.v[5] = q1.y; L.v[6] = q1.z; L.v[7] = q1.w;
+            };
+            const auto own_place = [&](OwnLit& L) {
+                if (ballot64(L.nl > 16u)) lds_store_own<32>(L.v, a_out + L.dst, L.nl, dm);
+                else lds_store_own<16>(L.v, a_out + L.dst, L.nl, dm);
+                bits_set32(s_bits, L.dst, L.nl);
+                if (ballot64(L.n > L.nl)) place_from_global(L.n - L.nl, L.src + L.nl, L.dst + L.nl);
+            };
+            OwnLit A, B;                                     // (two named buffers, the loop unrolled by two: a copy would wait for the loads)
+            own_issue(rec_view(raw_nx, i0, nseq, nrec_all), A);
+            raw_nx = fetch_batch(wave * 64u + kL2Threads);
+            for (uint32_t base = wave * 64u; base < nrec_all; base += 2u * kL2Threads) {
+                own_issue(rec_view(raw_nx, base + kL2Threads + lane, nseq, nrec_all), B);
+                raw_nx = fetch_batch(base + 2u * kL2Threads);
+                own_place(A);
+                if (base + kL2Threads >= nrec_all) break;
+                own_issue(rec_view(raw_nx, base + 2u * kL2Threads + lane, nseq, nrec_all), A);
+                raw_nx = fetch_batch(base + 3u * kL2Threads);
+                own_place(B);
             }
+        } else
+#endif
+        for (uint32_t base = wave * 64u; base < nrec_all; base += kL2Threads) {
+            const uint4 rec = rec_view(raw_nx, base + lane, nseq, nrec_all);
+            raw_nx = fetch_batch(base + kL2Threads);
             place_from_global(rec.y, rec.x, rec.z - rec.y);
         }
         // kSlab — D2b: the parts of matches whose source lies before this slab come from the finished output of the earlier
@@ -806,9 +857,8 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         //      Lanes outside the fast shape (longer than 32 bytes, self-overlapping, 1-3 bytes) keep the general path.
         if constexpr (!kSlab && !kLinked) {
             for (uint32_t base = wave * 64u; base < nrec_all; base += kL2Threads) {
-                const uint4 rec = rec_nx;
-                rec_nx = make_uint4(0, 0, 0, 0);
-                if (base + kL2Threads + lane < nrec_all) rec_nx = rec_load(base + kL2Threads + lane, nseq);
+                const uint4 rec = rec_view(raw_nx, base + lane, nseq, nrec_all);
+                if (base + kL2Threads < nrec_all) raw_nx = rec_fetch(base + kL2Threads + lane, nseq, nrec_all);
                 const uint32_t dst = rec.z, off = rec.w & 0xffffu, m = rec.w >> 16;
                 const uint32_t src = dst - off;
                 const uint32_t need = off < m ? off : m;
@@ -940,7 +990,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 }
             }
         } else
-        // rec_nx = the wave's first batch (requested by D2's last iteration, or by D2's prologue if the wave has no batch)
+        // raw_nx = the wave's first batch (requested by D2's last iteration, or by D2's prologue if the wave has no batch)
         for (uint32_t base = wave * 64u;; base += kL2Threads) {
             uint4 rec;
             uint32_t ridx = base + lane;
@@ -952,15 +1002,13 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                     if (dpos + lane < ndef) { ridx = dlist[dpos + lane]; rec = table[ridx]; }
                     dpos += 64u;
                 } else {
-                    rec = rec_nx;
-                    rec_nx = make_uint4(0, 0, 0, 0);
-                    if (base + kL2Threads + lane < nrec_all) rec_nx = rec_load(base + kL2Threads + lane, nseq);
+                    rec = rec_view(raw_nx, base + lane, nseq, nrec_all);
+                    if (base + kL2Threads < nrec_all) raw_nx = rec_fetch(base + kL2Threads + lane, nseq, nrec_all);
                 }
             } else {
                 if (base >= nrec_all) break;
-                rec = rec_nx;
-                rec_nx = make_uint4(0, 0, 0, 0);
-                if (base + kL2Threads + lane < nrec_all) rec_nx = rec_load(base + kL2Threads + lane, nseq);
+                rec = rec_view(raw_nx, base + lane, nseq, nrec_all);
+                if (base + kL2Threads < nrec_all) raw_nx = rec_fetch(base + kL2Threads + lane, nseq, nrec_all);
             }
             const uint32_t dst = rec.z, off = rec.w & 0xffffu, m = rec.w >> 16;
             const uint32_t src = dst - off;                   // kLinked: "negative" (wraps) when the source starts in the previous block

@@ -833,7 +833,10 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         // with four wavefronts on a SIMD) issue ahead of the wavefronts that poll in D3 — the polls fill the gaps that remain.
         // profiles/r04/experiments p01: D1 11.6 k -> 10.6 k, D2 23.9 k -> 21.6 k, D3 52.9 k -> 54.5 k cycles per chunk, 617.6 -> 627.4 GB/s
         // (the opposite assignment: 611 GB/s).
-        if constexpr (!kSlab && !kLinked) __builtin_amdgcn_s_setprio(0);
+#ifndef CJ_D3_PRIO
+#define CJ_D3_PRIO 0
+#endif
+        if constexpr (!kSlab && !kLinked) __builtin_amdgcn_s_setprio(CJ_D3_PRIO);
 
         // ---- D3: matches (same resolver as variant 1).  No barrier after D2: readiness is exact per byte through the
         //      bitmap, so a wave starts on its matches while other waves are still placing literals ----
@@ -856,139 +859,198 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         //      publish (two ds_or) and the mask update: ~12 instructions when nothing is ready, ~35 with copies.
         //      Lanes outside the fast shape (longer than 32 bytes, self-overlapping, 1-3 bytes) keep the general path.
         if constexpr (!kSlab && !kLinked) {
-            for (uint32_t base = wave * 64u; base < nrec_all; base += kL2Threads) {
-                const uint4 rec = rec_view(raw_nx, base + lane, nseq, nrec_all);
-                if (base + kL2Threads < nrec_all) raw_nx = rec_fetch(base + kL2Threads + lane, nseq, nrec_all);
+            // (one batch per wave at a time.  Two — the stuck batch stays in its slot while the other slot runs through the wave's following
+            //  batches — was measured: D3 56 k -> 65 k cycles per chunk on the benchmark data, 266 k -> 299 k on the corpus; a trip that polls
+            //  two slots takes twice as long, and the trip time is what a level of the dependency chain costs.  profiles/r04/experiments d01)
+            struct D3Slot {
+                uint32_t pa, pm0, pm1, qa, qm0, qm1, as0, as1, as3, ad0, ad1, ad3;     // fast lanes: poll word + mask, publish word + mask, copy plan
+                uint32_t dst, off, m;                                                  // the other lanes
+                bool spend;
+                uint64_t mp, mA, mB, mC;                                               // fast lanes still waiting; by copy shape
+                bool any_slow, live;
+            };
+            const auto d3_fill = [&](D3Slot& S, const uint4& rec) __attribute__((always_inline)) {
                 const uint32_t dst = rec.z, off = rec.w & 0xffffu, m = rec.w >> 16;
                 const uint32_t src = dst - off;
                 const uint32_t need = off < m ? off : m;
-                bool pending = m > 0u;
+                const bool pending = m > 0u;
                 const bool fast = pending && m >= 4u && m <= 32u && off >= m;
-                uint32_t pa = 0, pm0 = 0, pm1 = 0, qa = 0, qm0 = 0, qm1 = 0;
+                S.pa = 0; S.pm0 = 0; S.pm1 = 0; S.qa = 0; S.qm0 = 0; S.qm1 = 0;
                 if (fast) {
                     const uint32_t sh = src & 31u, e = sh + need;
-                    pa = (uint32_t)(uintptr_t)(s_bits + (src >> 5));
-                    pm0 = (e >= 32u ? ~0u : ((1u << e) - 1u)) & (~0u << sh);
-                    pm1 = e > 32u ? ((1u << (e - 32u)) - 1u) : 0u;
+                    S.pa = (uint32_t)(uintptr_t)(s_bits + (src >> 5));
+                    S.pm0 = (e >= 32u ? ~0u : ((1u << e) - 1u)) & (~0u << sh);
+                    S.pm1 = e > 32u ? ((1u << (e - 32u)) - 1u) : 0u;
                     const uint32_t dh = dst & 31u, de = dh + m;
-                    qa = (uint32_t)(uintptr_t)(s_bits + (dst >> 5));
-                    qm0 = (de >= 32u ? ~0u : ((1u << de) - 1u)) & (~0u << dh);
-                    qm1 = de > 32u ? ((1u << (de - 32u)) - 1u) : 0u;
+                    S.qa = (uint32_t)(uintptr_t)(s_bits + (dst >> 5));
+                    S.qm0 = (de >= 32u ? ~0u : ((1u << de) - 1u)) & (~0u << dh);
+                    S.qm1 = de > 32u ? ((1u << (de - 32u)) - 1u) : 0u;
                 }
                 // copy plan: pieces at [0] and [m - 8] (m >= 8; 8 bytes each), or [0] and [m - 4] (m < 8; 4 bytes each); m > 16: also [8], [m - 16]
-                const uint32_t as0 = a_out + src, ad0 = a_out + dst;
+                S.as0 = a_out + src; S.ad0 = a_out + dst;
                 const uint32_t o1 = m >= 8u ? m - 8u : m - 4u, o3 = m > 16u ? m - 16u : 0u;
-                const uint32_t as1 = as0 + o1, ad1 = ad0 + o1, as3 = as0 + o3, ad3 = ad0 + o3;
-                uint64_t mp = ballot64(fast);                                  // fast lanes still waiting
-                const uint64_t mA = ballot64(fast && m > 16u), mB = ballot64(fast && m >= 8u), mC = ballot64(fast && m < 8u);
-                const bool any_slow = ballot64(pending && !fast) != 0ull;
-                bool spend = pending && !fast;
-                uint32_t spins = 0;
-                while (mp != 0ull || (any_slow && ballot64(spend) != 0ull)) {
-                    if (mp != 0ull) {
-                        uint32_t w0, w1, t0, t1, c0, c1;
-                        uint64_t r0, r1, r2, r3, sv, sr, st;
-                        asm volatile(
-                            "s_mov_b64 %[sv], exec\n\t"
-                            "s_mov_b64 exec, %[mp]\n\t"
-                            "ds_read_b32 %[w0], %[pa]\n\t"
-                            "ds_read_b32 %[w1], %[pa] offset:4\n\t"
-                            "s_waitcnt lgkmcnt(0)\n\t"
-                            "v_bfi_b32 %[t0], %[w0], 0, %[pm0]\n\t"              // pm0 & ~w0: needed bits that are not set yet
-                            "v_bfi_b32 %[t1], %[w1], 0, %[pm1]\n\t"
-                            "v_or_b32 %[t0], %[t0], %[t1]\n\t"
-                            "v_cmpx_eq_u32 0, %[t0]\n\t"                         // exec = ready lanes
-                            "s_cbranch_execz 1f\n\t"
-                            "s_mov_b64 %[sr], exec\n\t"
-                            "s_and_b64 exec, %[sr], %[mB]\n\t"                   // 8..32 bytes: first and last 8
-                            "ds_read_b64 %[r0], %[as0]\n\t"
-                            "ds_read_b64 %[r1], %[as1]\n\t"
-                            "s_and_b64 exec, %[sr], %[mA]\n\t"                   // 17..32: the two middle pieces
-                            "ds_read_b64 %[r2], %[as0] offset:8\n\t"
-                            "ds_read_b64 %[r3], %[as3]\n\t"
-                            "s_and_b64 exec, %[sr], %[mC]\n\t"                   // 4..7 bytes: first and last 4
-                            "ds_read_b32 %[c0], %[as0]\n\t"
-                            "ds_read_b32 %[c1], %[as1]\n\t"
-                            "s_waitcnt lgkmcnt(0)\n\t"
-                            "ds_write_b32 %[ad0], %[c0]\n\t"
-                            "ds_write_b32 %[ad1], %[c1]\n\t"
-                            "s_and_b64 exec, %[sr], %[mA]\n\t"
-                            "ds_write_b64 %[ad0], %[r2] offset:8\n\t"
-                            "ds_write_b64 %[ad3], %[r3]\n\t"
-                            "s_and_b64 exec, %[sr], %[mB]\n\t"
-                            "ds_write_b64 %[ad0], %[r0]\n\t"
-                            "ds_write_b64 %[ad1], %[r1]\n\t"
-                            "s_mov_b64 exec, %[sr]\n\t"
-                            "ds_or_b32 %[qa], %[qm0]\n\t"                        // publish: behind the copy's writes in the wave's DS queue
-                            "ds_or_b32 %[qa], %[qm1] offset:4\n\t"
-                            "s_andn2_b64 %[mp], %[mp], %[sr]\n"
-                            "1:\n\t"
-                            "s_mov_b64 exec, %[sv]"
-                            : [mp] "+s"(mp), [sv] "=&s"(sv), [sr] "=&s"(sr), [st] "=&s"(st), [w0] "=&v"(w0), [w1] "=&v"(w1), [t0] "=&v"(t0), [t1] "=&v"(t1),
-                              [c0] "=&v"(c0), [c1] "=&v"(c1), [r0] "=&v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3)
-                            : [pa] "v"(pa), [pm0] "v"(pm0), [pm1] "v"(pm1), [qa] "v"(qa), [qm0] "v"(qm0), [qm1] "v"(qm1),
-                              [as0] "v"(as0), [as1] "v"(as1), [as3] "v"(as3), [ad0] "v"(ad0), [ad1] "v"(ad1), [ad3] "v"(ad3),
-                              [mA] "s"(mA), [mB] "s"(mB), [mC] "s"(mC)
-                            : "memory", "vcc", "scc");
-                    }
-                    if (any_slow) {
-                        bool sready = false;
-                        if (spend) sready = bits_ready(s_bits, src, src + need);
-                        if (sready && m <= 64u && off >= m && m >= 4u) {
-                            lds_store_tier<64>(lds_ld_aligned18(as0 & ~3u), ad0, as0 & 3u, m, dm);
-                            bits_set(s_bits, dst, dst + m);
-                            spend = false;
-                        } else if (sready && m < kLongRun) {
-                            const uint8_t* sp = s_out + src;
-                            if (off >= 8u) {
-                                uint32_t k = 0;
-                                for (; k + 8u <= m; k += 8u) {
-                                    uint8_t t[8];
+                S.as1 = S.as0 + o1; S.ad1 = S.ad0 + o1; S.as3 = S.as0 + o3; S.ad3 = S.ad0 + o3;
+                S.dst = dst; S.off = off; S.m = m;
+                S.mp = ballot64(fast);
+                S.mA = ballot64(fast && m > 16u); S.mB = ballot64(fast && m >= 8u); S.mC = ballot64(fast && m < 8u);
+                S.spend = pending && !fast;
+                S.any_slow = ballot64(S.spend) != 0ull;
+                S.live = S.mp != 0ull || S.any_slow;
+            };
+            uint32_t spins = 0;
+            const auto d3_step = [&](D3Slot& S) __attribute__((always_inline)) {
+                if (S.mp != 0ull) {
+                    // The poll LOOP as one block: it leaves only when no fast lane waits any more or after `lim` trips that found
+                    // nothing (1 while the batch has lanes of the general path, which must be looked after between trips).
+                    // Fixed registers: v[112:113] the bitmap words, v114/v115 scratch, v[116:123] the four 8-byte pieces — a piece's low
+                    // half is what a 4..7-byte match stores, and inline asm cannot name half of an operand.
+                    //   every ready lane: pieces [0] and [m - 8] (m >= 8) or [m - 4] (m < 8; the 8-byte read runs 4 bytes past the
+                    //   source, harmless); m > 16: also [8] and [m - 16]
+                    uint64_t sv, sr;
+                    uint32_t ic;
+                    const uint32_t lim = S.any_slow ? 1u : 1024u;
+                    asm volatile(
+                        "s_mov_b64 %[sv], exec\n\t"
+                        "s_mov_b32 %[ic], 0\n"
+                        "0:\n\t"
+                        "s_mov_b64 exec, %[mp]\n\t"
+                        "ds_read2_b32 v[112:113], %[pa] offset1:1\n\t"
+                        "s_waitcnt lgkmcnt(0)\n\t"
+                        "v_bfi_b32 v114, v112, 0, %[pm0]\n\t"              // pm0 & ~w0: needed bits that are not set yet
+                        "v_bfi_b32 v115, v113, 0, %[pm1]\n\t"
+                        "v_or_b32 v114, v114, v115\n\t"
+                        "v_cmpx_eq_u32 0, v114\n\t"                        // exec = ready lanes
+                        "s_cbranch_execz 1f\n\t"
+                        "s_mov_b64 %[sr], exec\n\t"
+                        "ds_read_b64 v[116:117], %[as0]\n\t"
+                        "ds_read_b64 v[118:119], %[as1]\n\t"
+                        "s_and_b64 exec, %[sr], %[mA]\n\t"                   // 17..32 bytes: the two middle pieces
+                        "ds_read_b64 v[120:121], %[as0] offset:8\n\t"
+                        "ds_read_b64 v[122:123], %[as3]\n\t"
+                        "s_waitcnt lgkmcnt(0)\n\t"
+                        "ds_write_b64 %[ad0], v[120:121] offset:8\n\t"
+                        "ds_write_b64 %[ad3], v[122:123]\n\t"
+                        "s_and_b64 exec, %[sr], %[mB]\n\t"                   // 8..32 bytes: first and last 8
+                        "ds_write_b64 %[ad0], v[116:117]\n\t"
+                        "ds_write_b64 %[ad1], v[118:119]\n\t"
+                        "s_and_b64 exec, %[sr], %[mC]\n\t"                   // 4..7 bytes: first and last 4
+                        "ds_write_b32 %[ad0], v116\n\t"
+                        "ds_write_b32 %[ad1], v118\n\t"
+                        "s_mov_b64 exec, %[sr]\n\t"
+                        "ds_or_b32 %[qa], %[qm0]\n\t"                        // publish: behind the copy's writes in the wave's DS queue
+                        "ds_or_b32 %[qa], %[qm1] offset:4\n\t"
+                        "s_andn2_b64 %[mp], %[mp], %[sr]\n\t"
+                        "s_cbranch_scc1 0b\n\t"                              // lanes left: poll again
+                        "s_branch 2f\n"
+                        "1:\n\t"
+                        "s_add_u32 %[ic], %[ic], 1\n\t"
+                        "s_cmp_lt_u32 %[ic], %[lim]\n\t"
+                        "s_cbranch_scc1 0b\n"
+                        "2:\n\t"
+                        "s_mov_b64 exec, %[sv]"
+                        : [mp] "+s"(S.mp), [sv] "=&s"(sv), [sr] "=&s"(sr), [ic] "=&s"(ic)
+                        : [pa] "v"(S.pa), [pm0] "v"(S.pm0), [pm1] "v"(S.pm1), [qa] "v"(S.qa), [qm0] "v"(S.qm0), [qm1] "v"(S.qm1),
+                          [as0] "v"(S.as0), [as1] "v"(S.as1), [as3] "v"(S.as3), [ad0] "v"(S.ad0), [ad1] "v"(S.ad1), [ad3] "v"(S.ad3),
+                          [mA] "s"(S.mA), [mB] "s"(S.mB), [mC] "s"(S.mC), [lim] "s"(lim)
+                        : "memory", "vcc", "scc", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123");
+                    spins += ic;
+                }
+                if (S.any_slow) {
+                    // (the values pass through an empty asm: left alone, the compiler hoists everything the copy routines below derive
+                    //  from them — ~200 instructions of store addresses and tail selectors — out of the poll loop into the batch
+                    //  setup, where EVERY batch pays for them, with or without such a lane)
+                    uint32_t dst = S.dst, off = S.off, m = S.m, as0 = S.as0, ad0 = S.ad0;
+                    asm volatile("" : "+v"(dst), "+v"(off), "+v"(m), "+v"(as0), "+v"(ad0));
+                    const uint32_t src = dst - off, need = off < m ? off : m;
+                    bool sready = false;
+                    if (S.spend) sready = bits_ready(s_bits, src, src + need);
+                    if (sready && m <= 64u && off >= m && m >= 4u) {
+                        lds_store_tier<64>(lds_ld_aligned18(as0 & ~3u), ad0, as0 & 3u, m, dm);
+                        bits_set(s_bits, dst, dst + m);
+                        S.spend = false;
+                    } else if (sready && m < kLongRun) {
+                        const uint8_t* sp = s_out + src;
+                        if (off >= 8u) {
+                            uint32_t k = 0;
+                            for (; k + 8u <= m; k += 8u) {
+                                uint8_t t[8];
 #pragma unroll
-                                    for (int q = 0; q < 8; q++) t[q] = sp[k + q];
+                                for (int q = 0; q < 8; q++) t[q] = sp[k + q];
 #pragma unroll
-                                    for (int q = 0; q < 8; q++) s_out[dst + k + q] = t[q];
-                                }
-                                for (; k < m; k++) s_out[dst + k] = sp[k];
-                            } else {
-                                for (uint32_t k = 0; k < m; k++) s_out[dst + k] = sp[k];
+                                for (int q = 0; q < 8; q++) s_out[dst + k + q] = t[q];
                             }
-                            bits_set(s_bits, dst, dst + m);
-                            spend = false;
+                            for (; k < m; k++) s_out[dst + k] = sp[k];
+                        } else {
+                            for (uint32_t k = 0; k < m; k++) s_out[dst + k] = sp[k];
                         }
-                        uint64_t longm = ballot64(sready && m >= kLongRun);
-                        while (longm) {
-                            const uint32_t l = ctz64(longm);
-                            longm &= longm - 1ull;
-                            const uint32_t lmm = rdlane(m, l), lo = rdlane(off, l), ld = rdlane(dst, l);
-                            const uint8_t* sb = s_out + (ld - lo);
-                            if (lo == 1u || lo == 2u || lo == 4u) {
-                                const uint32_t h = (0u - ld) & 15u, hh = h < lmm ? h : lmm;
-                                if (lane < hh) s_out[ld + lane] = sb[lane % lo];
-                                uint32_t wv = 0;
-#pragma unroll
-                                for (uint32_t i = 0; i < 4u; i++) wv |= (uint32_t)sb[(hh + i) % lo] << (8u * i);
-                                const uint32_t nv = (lmm - hh) >> 4;
-                                uint4* dv = reinterpret_cast<uint4*>(s_out + ld + hh);
-                                for (uint32_t q = lane; q < nv; q += 64u) dv[q] = make_uint4(wv, wv, wv, wv);
-                                const uint32_t t0 = hh + (nv << 4);
-                                if (t0 + lane < lmm) s_out[ld + t0 + lane] = sb[(t0 + lane) % lo];
-                            } else {
-                                uint32_t rr = lane, step = 64u;
-                                if (lo <= 64u) { rr = lane % lo; step = 64u % lo; }
-                                for (uint32_t k = lane; k < lmm; k += 64u) {
-                                    s_out[ld + k] = sb[lo >= lmm ? k : rr];
-                                    rr += step;
-                                    if (rr >= lo) rr -= lo;
-                                }
-                            }
-                            wave_bits_set(s_bits, ld, ld + lmm);
-                            if (lane == l) spend = false;
-                        }
+                        bits_set(s_bits, dst, dst + m);
+                        S.spend = false;
                     }
+                    uint64_t longm = ballot64(sready && m >= kLongRun);
+                    while (longm) {
+                        const uint32_t l = ctz64(longm);
+                        longm &= longm - 1ull;
+                        const uint32_t lmm = rdlane(m, l), lo = rdlane(off, l), ld = rdlane(dst, l);
+                        const uint8_t* sb = s_out + (ld - lo);
+                        if (lo == 1u || lo == 2u || lo == 4u) {
+                            const uint32_t h = (0u - ld) & 15u, hh = h < lmm ? h : lmm;
+                            if (lane < hh) s_out[ld + lane] = sb[lane % lo];
+                            uint32_t wv = 0;
+#pragma unroll
+                            for (uint32_t i = 0; i < 4u; i++) wv |= (uint32_t)sb[(hh + i) % lo] << (8u * i);
+                            const uint32_t nv = (lmm - hh) >> 4;
+                            uint4* dv = reinterpret_cast<uint4*>(s_out + ld + hh);
+                            for (uint32_t q = lane; q < nv; q += 64u) dv[q] = make_uint4(wv, wv, wv, wv);
+                            const uint32_t t0 = hh + (nv << 4);
+                            if (t0 + lane < lmm) s_out[ld + t0 + lane] = sb[(t0 + lane) % lo];
+                        } else {
+                            uint32_t rr = lane, step = 64u;
+                            if (lo <= 64u) { rr = lane % lo; step = 64u % lo; }
+                            for (uint32_t k = lane; k < lmm; k += 64u) {
+                                s_out[ld + k] = sb[lo >= lmm ? k : rr];
+                                rr += step;
+                                if (rr >= lo) rr -= lo;
+                            }
+                        }
+                        wave_bits_set(s_bits, ld, ld + lmm);
+                        if (lane == l) S.spend = false;
+                    }
+                    S.any_slow = ballot64(S.spend) != 0ull;
+                }
+                S.live = S.mp != 0ull || S.any_slow;
+            };
+            D3Slot A;
+#ifdef CJ_D3_STATS
+            uint32_t st_trips = 0, st_prod = 0, st_batches = 0, st_slow = 0, st_nslow = 0, st_tprod = 0, st_tidle = 0, st_nrdy = 0;
+            const unsigned long long st_t0 = __builtin_readcyclecounter();
+#endif
+            for (uint32_t base = wave * 64u; base < nrec_all; base += kL2Threads) {
+                d3_fill(A, rec_view(raw_nx, base + lane, nseq, nrec_all));
+                spins = 0;
+#ifdef CJ_D3_STATS
+                st_nslow += (uint32_t)__builtin_popcountll(ballot64(A.spend));
+#endif
+                if (base + kL2Threads < nrec_all) raw_nx = rec_fetch(base + kL2Threads + lane, nseq, nrec_all);
+                while (A.live) {
+#ifdef CJ_D3_STATS
+                    const uint64_t mp0 = A.mp; const bool st_as = A.any_slow;
+                    const unsigned long long st_a = __builtin_readcyclecounter();
+#endif
+                    d3_step(A);
+#ifdef CJ_D3_STATS
+                    const uint32_t st_d = (uint32_t)(__builtin_readcyclecounter() - st_a);
+                    st_trips++; st_prod += mp0 != A.mp ? 1u : 0u; st_slow += st_as ? 1u : 0u;
+                    if (mp0 != A.mp) st_tprod += st_d; else st_tidle += st_d;
+#endif
                     if (++spins > kSpinLimit) { *s_fail = 1u; break; }
                 }
+#ifdef CJ_D3_STATS
+                st_batches++;
+#endif
             }
+#ifdef CJ_D3_STATS
+            if (prof && tid == 0) { s_prof[6] += st_trips; s_prof[7] += st_prod; s_prof[8] += st_batches; s_prof[9] += (uint32_t)(__builtin_readcyclecounter() - st_t0); s_prof[10] += st_slow; s_prof[11] += st_nslow; s_prof[12] += st_tprod; s_prof[13] += st_tidle; }
+#endif
         } else
         // raw_nx = the wave's first batch (requested by D2's last iteration, or by D2's prologue if the wave has no batch)
         for (uint32_t base = wave * 64u;; base += kL2Threads) {
@@ -1079,7 +1141,9 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                     if (sready && cross && !cross_full) {
                         // done above
                     } else if (sready && m <= 64u && off >= m) {        // 33..64 bytes, no self-overlap (Snappy copies reach 64): one tier copy
-                        lds_store_tier<64>(lds_ld_aligned18(asrc & ~3u), a_out + dst, asrc & 3u, m, dm);
+                        uint32_t t_src = asrc, t_dst = a_out + dst, t_m = m;       // (through an empty asm: or the routine's ~200 address / selector
+                        asm volatile("" : "+v"(t_src), "+v"(t_dst), "+v"(t_m));  //  instructions are hoisted into every batch's setup)
+                        lds_store_tier<64>(lds_ld_aligned18(t_src & ~3u), t_dst, t_src & 3u, t_m, dm);
                         bits_set(s_bits, dst, dst + m);
                         pending = false;
                     } else if (sready && m < kLongRun) {

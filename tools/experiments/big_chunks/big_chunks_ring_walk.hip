@@ -24,6 +24,7 @@ namespace cj {
 
 constexpr uint32_t kBigLead = 1024;                 // bytes in front of its boundary where a lane starts looking for the chain
 constexpr uint32_t kBigSegMin = 2048;               // shortest segment
+constexpr uint32_t kBigAhead = 32;                  // cached bytes a lane must have ahead before a step (lz4_parse_kernel)
 constexpr uint32_t kBigNone = 0xFFFFFFFEu, kBigNoLink = 0xFFu;      // (0xFFFFFFFF, the scratch's memset value: no candidate yet)
 constexpr uint32_t kBigListHdr = 4;
 constexpr uint32_t kBigWaves = 4;                   // wavefronts per block of the parse kernel
@@ -70,107 +71,127 @@ __global__ __launch_bounds__(256) void big_list_kernel(BatchArgs a, uint32_t* li
     if (idx < list[1]) list[kBigListHdr + idx] = c;
 }
 
-// The lanes' view of their streams: a 16-byte WINDOW in registers, loaded straight from global memory at the position of the field
-// the lane reads next.  A sequence is two fields — token + literal length bytes at ip, offset + match length bytes behind the
-// literals at ip2 — and the window loaded at ip2 also holds the next token (at most 5 + 4 bytes): ONE round trip per sequence, none
-// when the literals are so short that the next fields still lie inside the window.  (The first version walked on 128-byte rings in
-// LDS refilled cooperatively, like the small-chunk parse kernels: that pays where a lane walks tens of KiB in short steps.  Here a
-// lane walks 7 KiB, the streams of 256 KiB chunks are literal-heavy — 80 bytes per sequence on the benchmark data, so nearly every
-// step left its ring — and the refill bookkeeping cost 700 - 2 000 wave-instructions per step: 2.9 ms per 8 192 chunks.  What covers
-// a round trip is the other fifteen wavefronts of the CU.)
-struct Win {
-    uint32_t d0, d1, d2, d3;   // the bytes [wb, wb + 16) of the stream
-    uint32_t wb;               // st-position of the window (0xFFFFFFFF: nothing loaded)
-    __device__ __forceinline__ bool covers(uint32_t p, uint32_t nbytes) const { return p >= wb && p + nbytes <= wb + 16u; }
-    // [p, p + 16), moved back where that would leave the last 16-byte granule of the stream (st-positions: base is 128-byte aligned)
-    __device__ __forceinline__ void load(const uint8_t* base, uint32_t p, uint32_t safe_end) {
-        wb = p + 16u <= safe_end ? p : safe_end - 16u;
-        const uint4 v = ld16u(base + wb);
-        d0 = v.x; d1 = v.y; d2 = v.z; d3 = v.w;
+// The lanes' view of their streams: a 128-byte ring per lane in LDS (two 64-byte units), refilled cooperatively like the 256-byte
+// rings of the small-chunk parse kernels (lane_stream.hpp) — 4 lanes fetch one lane's next unit with aligned 16-byte loads, 16
+// units per load instruction — at half the size: 9 KiB per wavefront, sixteen wavefronts per CU.  This walk is bound by memory
+// latency (a chunk of 256 KiB has long literal runs: most steps need a line of the stream that nobody has touched), and what
+// covers a round trip is other wavefronts.
+constexpr uint32_t kSsRing = 128, kSsUnit = 64;
+constexpr uint32_t kSsStride = kSsRing + 16u;           // 16-byte aligned rings (one ds_write_b128 per fetched piece)
+constexpr uint32_t kSsWaveBytes = 64u * kSsStride;
+constexpr uint32_t kSsLanesPerUnit = kSsUnit / 16u, kSsTargets = 64u / kSsLanesPerUnit, kSsLoads = 64u / kSsTargets;
+
+struct SegStream {
+    const uint8_t* base;    // 128-byte aligned address at or below the first stream byte
+    uint32_t lo, hi;        // cached window [lo, hi): multiples of 64, hi - lo <= 128
+    uint32_t end;           // offset of the end of the stream
+    uint32_t ring;          // LDS byte offset of this lane's ring
+    __device__ __forceinline__ uint32_t ring32(uint32_t p) const {        // the 4 bytes at p, read from the ring whether or not they are cached
+        const uint32_t a0 = ring + (p & (kSsRing - 4u)), a1 = ring + ((p + 4u) & (kSsRing - 4u));
+        uint32_t w0, w1;
+        asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(w0), "=&v"(w1) : "v"(a0), "v"(a1) : "memory");
+        return __builtin_amdgcn_alignbyte(w1, w0, p & 3u);
     }
-    // the 4 / 8 bytes at p (p >= wb; bytes past the window read as zero)
-    __device__ __forceinline__ uint32_t x32(uint32_t p) const {
-        const uint32_t o = p - wb, k = o >> 2;
-        const uint32_t lo = k == 0u ? d0 : k == 1u ? d1 : k == 2u ? d2 : k == 3u ? d3 : 0u;
-        const uint32_t hi = k == 0u ? d1 : k == 1u ? d2 : k == 2u ? d3 : 0u;
-        return __builtin_amdgcn_alignbyte(hi, lo, o & 3u);
-    }
-    __device__ __forceinline__ uint2 x64(uint32_t p) const {
-        const uint32_t o = p - wb, k = o >> 2;
-        const uint32_t a = k == 0u ? d0 : k == 1u ? d1 : k == 2u ? d2 : k == 3u ? d3 : 0u;
-        const uint32_t b = k == 0u ? d1 : k == 1u ? d2 : k == 2u ? d3 : 0u;
-        const uint32_t c = k == 0u ? d2 : k == 1u ? d3 : 0u;
-        return make_uint2(__builtin_amdgcn_alignbyte(b, a, o & 3u), __builtin_amdgcn_alignbyte(c, b, o & 3u));
+    __device__ __forceinline__ bool in_window(uint32_t p) const { return p >= lo && p + 4u <= hi && p + 4u <= end; }
+    __device__ __forceinline__ uint32_t ld32(uint32_t p) const {           // anywhere in the stream (zero-filled past its end)
+        if (in_window(p)) return ring32(p);
+        const uint32_t v = ld_le_tail(base, p, end);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                               // vmcnt(0): here, not on the common path behind the branch
+        return v;
     }
 };
+
+// what a lane needs to know about the lanes it fetches for (lane t = 16 r + lane / 4 in load r): their stream base and end never change
+struct SegPlan { uint32_t blo[kSsLoads], bhi[kSsLoads], end[kSsLoads]; };
+__device__ __forceinline__ SegPlan seg_plan(const SegStream& st) {
+    SegPlan p;
+    const uint32_t lane = lane_id();
+    const uint32_t blo = (uint32_t)(uintptr_t)st.base, bhi = (uint32_t)((uintptr_t)st.base >> 32);
+#pragma unroll
+    for (uint32_t r = 0; r < kSsLoads; r++) {
+        const int t = (int)(kSsTargets * r + lane / kSsLanesPerUnit);
+        p.blo[r] = (uint32_t)__shfl((int)blo, t); p.bhi[r] = (uint32_t)__shfl((int)bhi, t); p.end[r] = (uint32_t)__shfl((int)st.end, t);
+    }
+    return p;
+}
+// one wave-convergent refill round: every lane that has room gets its next 64-byte unit
+__device__ __forceinline__ void seg_refill(SegStream& st, bool want, uint32_t wave_ring, const SegPlan& plan) {
+    const uint32_t lane = lane_id(), piece = lane % kSsLanesPerUnit;
+    const uint32_t mine = st.hi | (want ? 1u : 0u);                    // hi is a multiple of 64
+    uint4 v[kSsLoads];
+    uint32_t dsta[kSsLoads];
+#pragma unroll
+    for (uint32_t r = 0; r < kSsLoads; r++) {
+        const uint32_t t = kSsTargets * r + lane / kSsLanesPerUnit;
+        const uint32_t th = (uint32_t)__shfl((int)mine, (int)t);
+        const uint32_t off = (th & ~1u) + 16u * piece;
+        v[r] = make_uint4(0, 0, 0, 0);
+        dsta[r] = 0xffffffffu;
+        if ((th & 1u) && off < plan.end[r]) {
+            const uint8_t* src = reinterpret_cast<const uint8_t*>(((uint64_t)plan.bhi[r] << 32) | plan.blo[r]) + off;
+            v[r] = *reinterpret_cast<const uint4*>(src);               // 16-byte aligned, never crosses into a page past the stream
+            dsta[r] = wave_ring + t * kSsStride + (off & (kSsRing - 1u));
+        }
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < kSsLoads; r++) {
+        if (dsta[r] != 0xffffffffu) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 q = {v[r].x, v[r].y, v[r].z, v[r].w};
+            asm volatile("ds_write_b128 %0, %1" :: "v"(dsta[r]), "v"(q) : "memory");
+        }
+    }
+    if (want) {
+        if (st.hi - st.lo >= kSsRing) st.lo += kSsUnit;
+        st.hi += kSsUnit;
+    }
+}
 
 struct BigElem { uint32_t lit, lit_at, mlen, offset, next; bool ok, last; };
 
 // one element at st-position ip (straight-line for the common shape, the grammar's general function for the lanes that meet
 // anything else): the step of lz4_parse_kernel / snappy_parse_kernel without the checks that need the output position
 template <int kCodec>
-__device__ __forceinline__ BigElem big_elem(Win& w, const uint8_t* base, uint32_t ip, uint32_t iend, uint32_t safe_end, bool going) {
+__device__ __forceinline__ BigElem big_elem(const SegStream& st, uint32_t ip, uint32_t iend, bool going) {
     BigElem e;
     bool fast = false;
-    {   // field A at ip: normally inside the window that was loaded for the previous sequence's field B
-        const bool cold = going && !w.covers(ip, 4u);
-        if (ballot64(cold) != 0ull) { if (cold) w.load(base, ip, safe_end); }
-    }
-    const uint32_t t4 = w.x32(ip);
-    uint32_t ip2, nxf;                       // field B's position; bytes of field B
-    bool fa;                                 // field A has the common shape
     if constexpr (kCodec == CJ_CODEC_LZ4_BLOCK) {
-        const uint32_t token = t4 & 0xffu, e1 = (t4 >> 8) & 0xffu, e2 = (t4 >> 16) & 0xffu, e3 = t4 >> 24;
-        const bool x1 = (token >> 4) == 15u, x2 = x1 && e1 == 255u, x3 = x2 && e2 == 255u;
-        const uint32_t lit = (token >> 4) + (x1 ? e1 : 0u) + (x2 ? e2 : 0u) + (x3 ? e3 : 0u);
-        const uint32_t ip1 = ip + 1u + (x1 ? 1u : 0u) + (x2 ? 1u : 0u) + (x3 ? 1u : 0u);
-        ip2 = ip1 + lit;
-        fa = !(x3 && e3 == 255u) && ip2 + 8u <= iend;                   // (iend - ip1 >= lit + 8: not the block's last sequences)
-        e.lit = lit; e.lit_at = ip1; e.mlen = token & 15u;
+        const uint32_t t4 = st.ring32(ip);
+        const uint32_t token = t4 & 0xffu, e1 = (t4 >> 8) & 0xffu;
+        const bool x1 = (token >> 4) == 15u;
+        const uint32_t lit = (token >> 4) + (x1 ? e1 : 0u);
+        const uint32_t ip1 = ip + 1u + (x1 ? 1u : 0u), ip2 = ip1 + lit;
+        const bool w1 = st.in_window(ip), w2 = ip2 + 4u <= st.hi && ip2 + 4u <= iend;
+        const uint32_t o4 = st.ring32(ip2);
+        const uint32_t mc = token & 15u, e2 = (o4 >> 16) & 0xffu;
+        const bool x2 = mc == 15u;
+        fast = w1 && w2 && !(x1 && e1 == 255u) && !(x2 && e2 == 255u) && iend - ip1 >= lit + 8u;
+        e.lit = lit; e.lit_at = ip1; e.offset = o4 & 0xffffu; e.mlen = mc + (x2 ? e2 : 0u) + 4u;
+        e.next = ip2 + 2u + (x2 ? 1u : 0u); e.ok = true; e.last = false;
     } else {
+        const uint32_t t4 = st.ring32(ip);
         const uint32_t tag = t4 & 0xffu, l6 = tag >> 2;
         const bool is_lit = (tag & 3u) == 0u;
         const uint32_t lhdr = is_lit ? (l6 == 60u ? 2u : 1u) : 0u;
         const uint32_t lit = is_lit ? (l6 == 60u ? ((t4 >> 8) & 0xffu) + 1u : l6 + 1u) : 0u;
-        ip2 = ip + lhdr + lit;
-        fa = !(is_lit && l6 > 60u) && ip2 + 8u <= iend;
-        e.lit = lit; e.lit_at = ip + lhdr; e.mlen = 0u;
-    }
-    {   // field B at ip2 and the field A behind it (at most 5 + 4 bytes)
-        const bool far = going && fa && !w.covers(ip2, 9u);
-        if (ballot64(far) != 0ull) { if (far) w.load(base, ip2, safe_end); }
-    }
-    const uint2 o8 = w.x64(ip2);
-    if constexpr (kCodec == CJ_CODEC_LZ4_BLOCK) {
-        const uint32_t f1 = (o8.x >> 16) & 0xffu, f2 = o8.x >> 24, f3 = o8.y & 0xffu;
-        const bool y1 = e.mlen == 15u, y2 = y1 && f1 == 255u, y3 = y2 && f2 == 255u;
-        fast = fa && !(y3 && f3 == 255u);
-        e.offset = o8.x & 0xffffu;
-        e.mlen = e.mlen + (y1 ? f1 : 0u) + (y2 ? f2 : 0u) + (y3 ? f3 : 0u) + 4u;
-        e.next = ip2 + 2u + (y1 ? 1u : 0u) + (y2 ? 1u : 0u) + (y3 ? 1u : 0u);
-        nxf = 0u;
-    } else {
-        const uint32_t c4 = o8.x, ctag = c4 & 0xffu, kind = ctag & 3u;
+        const uint32_t ip2 = ip + lhdr + lit;
+        const bool w1 = st.in_window(ip), w2 = ip2 + 4u <= st.hi && ip2 + 4u <= iend;
+        const uint32_t c4 = st.ring32(ip2);
+        const uint32_t ctag = c4 & 0xffu, kind = ctag & 3u;
         const uint32_t ip3 = ip2 + (kind == 1u ? 2u : 3u);
-        fast = fa && (kind == 1u || kind == 2u) && ip3 < iend;
+        fast = w1 && w2 && !(is_lit && l6 > 60u) && (kind == 1u || kind == 2u) && ip3 < iend;
+        e.lit = lit; e.lit_at = ip + lhdr;
         e.mlen = kind == 1u ? 4u + ((ctag >> 2) & 7u) : 1u + (ctag >> 2);
         e.offset = kind == 1u ? ((ctag >> 5) << 8) | ((c4 >> 8) & 0xffu) : (c4 >> 8) & 0xffffu;
-        e.next = ip3;
-        nxf = 0u;
+        e.next = ip3; e.ok = true; e.last = false;
     }
-    (void)nxf;
-    e.ok = true; e.last = false;
     if (ballot64(going && !fast) != 0ull) {
         if (going && !fast) {
             using G = typename std::conditional<kCodec == CJ_CODEC_SNAPPY_RAW, SnappyGrammar, Lz4Grammar>::type;
-            const auto rd = [base, iend](uint32_t q) {                  // anywhere in the stream (zero-filled past its end)
-                const uint32_t v = ld_le_tail(base, q, iend);
-                __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
-                return v;
-            };
-            Seq sq;
-            e.ok = G::at(rd, ip, iend, sq, base);
-            e.lit = sq.lit; e.lit_at = sq.lit_at; e.mlen = sq.mlen; e.offset = sq.offset; e.next = sq.next; e.last = sq.last;
+            const auto rd = [&st](uint32_t p) { return st.ld32(p); };
+            Seq s;
+            e.ok = G::at(rd, ip, iend, s, st.base);
+            e.lit = s.lit; e.lit_at = s.lit_at; e.mlen = s.mlen; e.offset = s.offset; e.next = s.next; e.last = s.last;
         }
     }
     return e;
@@ -190,9 +211,12 @@ constexpr uint32_t kBigLaneBad = 1u, kBigLaneLast = 2u;
 // does past a wrong candidate: never wrong, only double work.
 template <int kCodec>
 __global__ __launch_bounds__(64 * kBigWaves) void big_walk_kernel(BatchArgs a, const uint32_t* list, uint32_t capr, uint4* recs, uint32_t* cands, BigLane* lanes) {
+    __shared__ __attribute__((aligned(16))) uint8_t rings[kBigWaves * kSsWaveBytes];
     constexpr uint32_t k = kBigLanes;
     const uint32_t gl = blockIdx.x * (64u * kBigWaves) + threadIdx.x;
     const uint32_t j = gl / capr, bi = gl % capr;                // (capr is a multiple of 64: a wavefront has one j)
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t wave_ring = (uint32_t)(uintptr_t)rings + wave * kSsWaveBytes;
     const uint32_t listed = list[0] < list[1] ? list[0] : list[1];
     const bool exists = bi < listed && j < k;
     const uint32_t c = exists ? list[kBigListHdr + bi] : 0u;
@@ -206,13 +230,16 @@ __global__ __launch_bounds__(64 * kBigWaves) void big_walk_kernel(BatchArgs a, c
     const uint32_t bj = j * seg;
     bool done = !(walk && bj < n);
     const uint32_t mis = done ? 0u : (uint32_t)(reinterpret_cast<uintptr_t>(in) & 127u);
-    const uint8_t* base = done ? nullptr : in - mis;               // 128-byte aligned
-    const uint32_t iend = done ? 0u : mis + n;
-    const uint32_t safe_end = (iend + 15u) & ~15u;                  // reads stay inside the stream's last 16-byte granule (cramjam_hip.h)
-    Win w = {0u, 0u, 0u, 0u, 0xFFFFFFFFu};
-    // positions below are st-positions (offsets from base): stream position + mis
+    SegStream st;
+    st.base = done ? nullptr : in - mis;
+    st.end = done ? 0u : mis + n;
+    st.ring = wave_ring + lane * kSsStride;
+    const uint32_t iend = st.end;
+    // positions below are st-positions (offsets from st.base): stream position + mis
     const uint32_t my_b = mis + bj;
     uint32_t ip = mis + (j == 0u || bj <= kBigLead ? 0u : bj - kBigLead);
+    st.lo = st.hi = ip & ~(kSsUnit - 1u);
+    const SegPlan plan = seg_plan(st);
     bool lead = !done && j != 0u, retried = false;
     uint32_t lsteps = 0;                                         // elements walked in the lead-in
     uint32_t tb = j + 1u;
@@ -230,6 +257,13 @@ __global__ __launch_bounds__(64 * kBigWaves) void big_walk_kernel(BatchArgs a, c
     bool grp = false;
 
     for (;;) {
+        if (!done && ip >= st.hi) st.lo = st.hi = ip & ~(kSsUnit - 1u);      // jumped past the window (long literal run): re-anchor
+        for (;;) {
+            const bool want = !done && st.hi < iend && (st.hi - st.lo < kSsRing || ip >= st.lo + kSsUnit);
+            const bool urgent = want && ip + kBigAhead > st.hi;
+            if (ballot64(urgent) == 0ull) break;
+            seg_refill(st, want, wave_ring, plan);
+        }
         if (ballot64(!done) == 0ull) break;
         bool go = !done && !fin;
         bool emit = false;
@@ -243,7 +277,7 @@ __global__ __launch_bounds__(64 * kBigWaves) void big_walk_kernel(BatchArgs a, c
                 else { tb += 1u; next_b = tb < k ? next_b + seg : 0xFFFFFFFFu; }        // another position, or not known yet: walk on
             }
         }
-        const BigElem e = big_elem<kCodec>(w, base, ip, iend, safe_end, go);
+        const BigElem e = big_elem<kCodec>(st, ip, iend, go);
         if (ballot64(go && lead) != 0ull) {
             if (go && lead) {
                 uint32_t nx = e.ok && !e.last ? e.next : ip + 1u;          // malformed here = this was no token: try the next byte
@@ -258,6 +292,7 @@ __global__ __launch_bounds__(64 * kBigWaves) void big_walk_kernel(BatchArgs a, c
                     uint32_t back = 32u * kBigLead / lsteps;
                     back = back < 2u * kBigLead ? 2u * kBigLead : (back > 8u * kBigLead ? 8u * kBigLead : back);
                     ip = mis + (bj > back ? bj - back : 0u);
+                    st.lo = st.hi = ip & ~(kSsUnit - 1u);
                     lsteps = 0u;
                 } else
                 if (ip >= my_b) {

@@ -155,7 +155,14 @@ __device__ __forceinline__ void lds_store_own(const uint32_t* w, uint32_t a, uin
     const uint32_t h = (0u - a) & 3u;
     const int32_t r = (int32_t)n - (int32_t)h;              // literal bytes from the first aligned address on
     const uint32_t ah = a + h, dummy = dm.w - 28u;          // (dm.w - 28 + 4i stays inside the dummy slots)
+#ifdef CJ_OWN_HEAD_EXACT
     lds_st32(n ? a : dm.w, v[0]);
+#else
+    // the <= 3 bytes in front of the first aligned address as one byte and one halfword store, both aligned (a misaligned dword
+    // store of a full wave is replayed lane by lane: 64 cycles of the LDS pipe against ~10 for each of these)
+    asm volatile("ds_write_b8 %0, %1" :: "v"((h & 1u) && n ? a : dm.b), "v"(v[0]) : "memory");
+    asm volatile("ds_write_b16 %0, %1" :: "v"((h & 2u) && n ? a + (h & 1u) : (dm.w & ~1u)), "v"(v[0] >> (8u * (h & 1u))) : "memory");
+#endif
     own_dwords<0, T / 4>(v, h, r, ah, dummy);
 }
 // the ready bits of [lo, lo + n), n <= 32: two words, no loop (n = 0: two ORs of nothing)

@@ -131,10 +131,10 @@ __device__ __forceinline__ void lds_store_tier(const Loaded& r, uint32_t dst, ui
 
 // ---- D2 for a sequence that OWNS the bytes behind its literals --------------------------------------------------------
 // A sequence whose match this lane writes later (D3, same wavefront, program order) may spill up to 3 bytes past the end of its
-// literals: they land in its own match region, which no other lane reads before the bitmap says so.  That removes everything
-// lds_store_tier spends on exactness: bytes 0..3 go out as ONE store at the exact address (misaligned: replayed lane by lane, ~64
-// cycles of the LDS pipe, but one instruction), the rest as aligned dwords from the first aligned address on, each predicated on
-// holding at least one literal byte — no head / tail byte stores, no tail dword selection.  n <= T; n = 0: nothing is stored.
+// literals: they land in its own match region, which no other lane reads before the bitmap says so.  That removes what
+// lds_store_tier spends on the exact END: the <= 3 bytes in front of the first aligned address go out as one byte and one
+// halfword store, the rest as aligned dwords, each predicated on holding at least one literal byte — no tail byte stores, no tail
+// dword selection (14 -> 6 or 10 stores per batch; the LDS pipe is what bounds this kernel).  n <= T; n = 0: nothing is stored.
 template <int OFF>
 __device__ __forceinline__ void lds_st32_off(uint32_t a, uint32_t v) {
     asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(a), "v"(v), "n"(OFF) : "memory");
@@ -155,14 +155,10 @@ __device__ __forceinline__ void lds_store_own(const uint32_t* w, uint32_t a, uin
     const uint32_t h = (0u - a) & 3u;
     const int32_t r = (int32_t)n - (int32_t)h;              // literal bytes from the first aligned address on
     const uint32_t ah = a + h, dummy = dm.w - 28u;          // (dm.w - 28 + 4i stays inside the dummy slots)
-#ifdef CJ_OWN_HEAD_EXACT
-    lds_st32(n ? a : dm.w, v[0]);
-#else
     // the <= 3 bytes in front of the first aligned address as one byte and one halfword store, both aligned (a misaligned dword
     // store of a full wave is replayed lane by lane: 64 cycles of the LDS pipe against ~10 for each of these)
     asm volatile("ds_write_b8 %0, %1" :: "v"((h & 1u) && n ? a : dm.b), "v"(v[0]) : "memory");
     asm volatile("ds_write_b16 %0, %1" :: "v"((h & 2u) && n ? a + (h & 1u) : (dm.w & ~1u)), "v"(v[0] >> (8u * (h & 1u))) : "memory");
-#endif
     own_dwords<0, T / 4>(v, h, r, ah, dummy);
 }
 // the ready bits of [lo, lo + n), n <= 32: two words, no loop (n = 0: two ORs of nothing)

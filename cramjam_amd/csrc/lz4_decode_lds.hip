@@ -540,7 +540,6 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         if constexpr (kCompact && !kFused) { if (tid == 0) table2[nseq] = make_uint2(0u, U & 0xffffu); }      // sentinel: where the last record's match ends
         __syncthreads();
         CJ_PHASE_MARK(1);
-        bool fwd_taken = false;                              // (uniform) D1f ran: the records were rewritten, extra literal copies appended
 #ifndef CJ_NO_FORWARD
         // ---- D1f: MATCH FORWARDING.  D3 resolves matches as a dependency DAG and pays its latency per LEVEL; real data
         //      (text, logs, records) is deep: a phrase is copied from its previous occurrence, which was copied from the one
@@ -559,7 +558,6 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             // when the slab waits for bytes of earlier slabs — the forwarding runs before that wait, what it removes from
             // the dependency depth comes off the serial chain through the slabs
             if (nseq <= kFwdMaxRecords && staged && (*s_small * CJ_FWD_SHARE_NUM > nseq || (kSlab && *s_ncross > 0u))) {
-                fwd_taken = true;
                 uint32_t* f_w0 = reinterpret_cast<uint32_t*>(s_out);
                 uint32_t* f_st = f_w0 + kFwdMaxRecords;
                 uint16_t* f_ls = reinterpret_cast<uint16_t*>(f_st + kFwdMaxRecords);      // literal source of every record (16 bits: the chunk is staged)
@@ -730,7 +728,6 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         const uint32_t i0 = wave * 64u + lane;
         const auto fetch_batch = [&](uint32_t b) { return rec_fetch(b < nrec_all ? b + lane : i0, nseq, nrec_all); };   // past the wave's last batch: its FIRST again — D3 starts on it
         uint4 raw_nx = rec_fetch(i0, nseq, nrec_all);
-#ifndef CJ_NO_OWN_D2
         if constexpr (kCompact) {
             // A sequence whose match this lane copies in D3 OWNS the bytes behind its literals (lds_store_own): up to 32 literal
             // bytes per sequence go the lean way, and their 32 source bytes are requested one batch ahead (two loads per record,
@@ -766,7 +763,6 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 own_place(B);
             }
         } else
-#endif
         for (uint32_t base = wave * 64u; base < nrec_all; base += kL2Threads) {
             const uint4 rec = rec_view(raw_nx, base + lane, nseq, nrec_all);
             raw_nx = fetch_batch(base + kL2Threads);
@@ -833,10 +829,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         // with four wavefronts on a SIMD) issue ahead of the wavefronts that poll in D3 — the polls fill the gaps that remain.
         // profiles/r04/experiments p01: D1 11.6 k -> 10.6 k, D2 23.9 k -> 21.6 k, D3 52.9 k -> 54.5 k cycles per chunk, 617.6 -> 627.4 GB/s
         // (the opposite assignment: 611 GB/s).
-#ifndef CJ_D3_PRIO
-#define CJ_D3_PRIO 0
-#endif
-        if constexpr (!kSlab && !kLinked) __builtin_amdgcn_s_setprio(CJ_D3_PRIO);
+        if constexpr (!kSlab && !kLinked) __builtin_amdgcn_s_setprio(0);
 
         // ---- D3: matches (same resolver as variant 1).  No barrier after D2: readiness is exact per byte through the
         //      bitmap, so a wave starts on its matches while other waves are still placing literals ----
@@ -908,7 +901,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                     //   source, harmless); m > 16: also [8] and [m - 16]
                     uint64_t sv, sr;
                     uint32_t ic;
-                    const uint32_t lim = S.any_slow ? 1u : 1024u;
+                    const uint32_t lim = S.any_slow ? 1u : 1024u;          // (2 / 4 / 8 trips between two looks at the general-path lanes: corpus 177.4 -> 176.8 / 175.9 / 173.2 GB/s)
                     asm volatile(
                         "s_mov_b64 %[sv], exec\n\t"
                         "s_mov_b32 %[ic], 0\n"
@@ -1020,37 +1013,15 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 S.live = S.mp != 0ull || S.any_slow;
             };
             D3Slot A;
-#ifdef CJ_D3_STATS
-            uint32_t st_trips = 0, st_prod = 0, st_batches = 0, st_slow = 0, st_nslow = 0, st_tprod = 0, st_tidle = 0, st_nrdy = 0;
-            const unsigned long long st_t0 = __builtin_readcyclecounter();
-#endif
             for (uint32_t base = wave * 64u; base < nrec_all; base += kL2Threads) {
                 d3_fill(A, rec_view(raw_nx, base + lane, nseq, nrec_all));
                 spins = 0;
-#ifdef CJ_D3_STATS
-                st_nslow += (uint32_t)__builtin_popcountll(ballot64(A.spend));
-#endif
                 if (base + kL2Threads < nrec_all) raw_nx = rec_fetch(base + kL2Threads + lane, nseq, nrec_all);
                 while (A.live) {
-#ifdef CJ_D3_STATS
-                    const uint64_t mp0 = A.mp; const bool st_as = A.any_slow;
-                    const unsigned long long st_a = __builtin_readcyclecounter();
-#endif
                     d3_step(A);
-#ifdef CJ_D3_STATS
-                    const uint32_t st_d = (uint32_t)(__builtin_readcyclecounter() - st_a);
-                    st_trips++; st_prod += mp0 != A.mp ? 1u : 0u; st_slow += st_as ? 1u : 0u;
-                    if (mp0 != A.mp) st_tprod += st_d; else st_tidle += st_d;
-#endif
                     if (++spins > kSpinLimit) { *s_fail = 1u; break; }
                 }
-#ifdef CJ_D3_STATS
-                st_batches++;
-#endif
             }
-#ifdef CJ_D3_STATS
-            if (prof && tid == 0) { s_prof[6] += st_trips; s_prof[7] += st_prod; s_prof[8] += st_batches; s_prof[9] += (uint32_t)(__builtin_readcyclecounter() - st_t0); s_prof[10] += st_slow; s_prof[11] += st_nslow; s_prof[12] += st_tprod; s_prof[13] += st_tidle; }
-#endif
         } else
         // raw_nx = the wave's first batch (requested by D2's last iteration, or by D2's prologue if the wave has no batch)
         for (uint32_t base = wave * 64u;; base += kL2Threads) {

@@ -139,33 +139,37 @@ template <int OFF>
 __device__ __forceinline__ void lds_st32_off(uint32_t a, uint32_t v) {
     asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(a), "v"(v), "n"(OFF) : "memory");
 }
+// (predicated by the exec mask, not by a dummy address: the LDS pipe charges a scattered store by its ACTIVE lanes — 13.8 cycles
+//  with 64, 7.7 with 32, 5.1 with 16 (tools/lds_throughput_probe.hip) — and the later dwords of a batch belong to few lanes)
 template <int I, int N>
-__device__ __forceinline__ void own_dwords(const uint32_t* v, uint32_t h, int32_t r, uint32_t ah, uint32_t dummy) {
+__device__ __forceinline__ void own_dwords(const uint32_t* v, uint32_t h, int32_t r, uint32_t ah) {
     if constexpr (I < N) {
-        lds_st32_off<4 * I>(r > 4 * I ? ah : dummy, __builtin_amdgcn_alignbyte(v[I + 1], v[I], h));
-        own_dwords<I + 1, N>(v, h, r, ah, dummy);
+        const uint32_t mi = __builtin_amdgcn_alignbyte(v[I + 1], v[I], h);
+        if (r > 4 * I) lds_st32_off<4 * I>(ah, mi);
+        own_dwords<I + 1, N>(v, h, r, ah);
     }
 }
 template <int T>
-__device__ __forceinline__ void lds_store_own(const uint32_t* w, uint32_t a, uint32_t n, Dummies dm) {      // w: source bytes 0 .. T-1 (T / 4 dwords)
+__device__ __forceinline__ void lds_store_own(const uint32_t* w, uint32_t a, uint32_t n) {      // w: source bytes 0 .. T-1 (T / 4 dwords)
     uint32_t v[T / 4 + 1];
 #pragma unroll
     for (int i = 0; i < T / 4; i++) v[i] = w[i];
     v[T / 4] = 0u;
     const uint32_t h = (0u - a) & 3u;
     const int32_t r = (int32_t)n - (int32_t)h;              // literal bytes from the first aligned address on
-    const uint32_t ah = a + h, dummy = dm.w - 28u;          // (dm.w - 28 + 4i stays inside the dummy slots)
+    const uint32_t ah = a + h;
     // the <= 3 bytes in front of the first aligned address as one byte and one halfword store, both aligned (a misaligned dword
-    // store of a full wave is replayed lane by lane: 64 cycles of the LDS pipe against ~10 for each of these)
-    asm volatile("ds_write_b8 %0, %1" :: "v"((h & 1u) && n ? a : dm.b), "v"(v[0]) : "memory");
-    asm volatile("ds_write_b16 %0, %1" :: "v"((h & 2u) && n ? a + (h & 1u) : (dm.w & ~1u)), "v"(v[0] >> (8u * (h & 1u))) : "memory");
-    own_dwords<0, T / 4>(v, h, r, ah, dummy);
+    // store of a full wave is replayed lane by lane: 64 cycles of the LDS pipe against 14 for each of these)
+    if ((h & 1u) && n) asm volatile("ds_write_b8 %0, %1" :: "v"(a), "v"(v[0]) : "memory");
+    if ((h & 2u) && n) asm volatile("ds_write_b16 %0, %1" :: "v"(a + (h & 1u)), "v"(v[0] >> (8u * (h & 1u))) : "memory");
+    own_dwords<0, T / 4>(v, h, r, ah);
 }
 // the ready bits of [lo, lo + n), n <= 32: two words, no loop (n = 0: two ORs of nothing)
 __device__ __forceinline__ void bits_set32(uint32_t* bits, uint32_t lo, uint32_t n) {
     const uint64_t m = ((1ull << n) - 1ull) << (lo & 31u);
     const uint32_t wa = (uint32_t)(uintptr_t)bits + ((lo >> 5) << 2);
-    asm volatile("ds_or_b32 %0, %1\n\tds_or_b32 %0, %2 offset:4" :: "v"(wa), "v"((uint32_t)m), "v"((uint32_t)(m >> 32)) : "memory");
+    if (n) asm volatile("ds_or_b32 %0, %1" :: "v"(wa), "v"((uint32_t)m) : "memory");
+    if ((uint32_t)(m >> 32)) asm volatile("ds_or_b32 %0, %1 offset:4" :: "v"(wa), "v"((uint32_t)(m >> 32)) : "memory");
 }
 
 // copy n (<= tier, tier in {16,32,64} wave-uniform) bytes src -> dst, both LDS byte addresses; [src, src+n) is

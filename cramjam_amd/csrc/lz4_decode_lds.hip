@@ -745,8 +745,8 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 L.v[0] = q0.x; L.v[1] = q0.y; L.v[2] = q0.z; L.v[3] = q0.w; L.v[4] = q1.x; L.v[5] = q1.y; L.v[6] = q1.z; L.v[7] = q1.w;
             };
             const auto own_place = [&](OwnLit& L) {
-                if (ballot64(L.nl > 16u)) lds_store_own<32>(L.v, a_out + L.dst, L.nl, dm);
-                else lds_store_own<16>(L.v, a_out + L.dst, L.nl, dm);
+                if (ballot64(L.nl > 16u)) lds_store_own<32>(L.v, a_out + L.dst, L.nl);
+                else lds_store_own<16>(L.v, a_out + L.dst, L.nl);
                 bits_set32(s_bits, L.dst, L.nl);
                 if (ballot64(L.n > L.nl)) place_from_global(L.n - L.nl, L.src + L.nl, L.dst + L.nl);
             };

@@ -37,11 +37,11 @@ __global__ __launch_bounds__(1024) void probe(unsigned long long* out, int iters
     h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
     const uint32_t base = (uint32_t)(uintptr_t)s + ((h % 4000u) * 16u);          // 16 B aligned, scattered over 64 KiB
     int slot = 0;
-    for (int k = 1; k <= 64; k *= 4) {
-        for (int mis = 0; mis < 2; mis++) {
+    for (int k = 1; k <= 64; k *= 2) {
+        for (int mis = 0; mis < 3; mis++) {
             const bool act = (int)lane < k;
-            const uint32_t a = base + (mis ? 3u : 0u);
-#define RUN(OP) { const uint32_t aa = (mis && (OP == 3 || OP == 6)) ? base + 8u : (mis && OP == 9) ? base + 2u : (OP == 1 || OP == 8) ? base : a; __syncthreads(); unsigned long long t0 = __builtin_readcyclecounter(); if (act) run<OP>(aa, iters); __syncthreads(); unsigned long long t1 = __builtin_readcyclecounter(); if (threadIdx.x == 0) out[slot * 16 + OP] = t1 - t0; }
+            const uint32_t a = base + (mis == 1 ? 3u : mis == 2 ? 4u : 0u);
+#define RUN(OP) { const uint32_t aa = (mis && (OP == 3 || OP == 6)) ? base + 8u : (mis && OP == 9) ? base + 2u : (OP == 1 || OP == 8) ? base + (mis == 2 ? 4u : 0u) : a; __syncthreads(); unsigned long long t0 = __builtin_readcyclecounter(); if (act) run<OP>(aa, iters); __syncthreads(); unsigned long long t1 = __builtin_readcyclecounter(); if (threadIdx.x == 0) out[slot * 16 + OP] = t1 - t0; }
             RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9)
             slot++;
         }
@@ -49,19 +49,19 @@ __global__ __launch_bounds__(1024) void probe(unsigned long long* out, int iters
 }
 
 int main() {
-    unsigned long long* c; hipMalloc(&c, 16 * 16 * 8); hipMemset(c, 0, 16 * 16 * 8);
+    unsigned long long* c; hipMalloc(&c, 32 * 16 * 8); hipMemset(c, 0, 32 * 16 * 8);
     const int iters = 64;
     hipFuncSetAttribute((const void*)probe, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 64);
     hipLaunchKernelGGL(probe, dim3(1), dim3(1024), 65536 + 64, 0, c, iters);
-    unsigned long long h[16 * 16];
+    unsigned long long h[32 * 16];
     hipMemcpy(h, c, sizeof h, hipMemcpyDeviceToHost);
     const char* names[10] = {"rd_b32", "rd2_b32", "rd_b64", "rd_b128", "wr_b32", "wr_b64", "wr_b128", "wr_b8", "or_b32", "wr_b16"};
     printf("LDS pipe cycles per wave-instruction (16 waves x %d x 8 ops each, one CU)\n%-22s", iters, "");
     for (int o = 0; o < 10; o++) printf("%9s", names[o]);
     printf("\n");
     int slot = 0;
-    for (int k = 1; k <= 64; k *= 4) for (int mis = 0; mis < 2; mis++, slot++) {
-        printf("lanes %2d %-13s", k, mis ? "misaligned+3" : "aligned");
+    for (int k = 1; k <= 64; k *= 2) for (int mis = 0; mis < 3; mis++, slot++) {
+        printf("lanes %2d %-13s", k, mis == 1 ? "misaligned+3" : mis == 2 ? "dword+4" : "aligned");
         for (int o = 0; o < 10; o++) printf("%9.1f", (double)h[slot * 16 + o] / (16.0 * iters * 8));
         printf("\n");
     }

@@ -214,6 +214,70 @@ __device__ __forceinline__ void lds_copy_sparse(uint32_t dst, uint32_t src, uint
     }
 }
 
+// ---- dense exact copy (D3, many lanes ready at once) -----------------------------------------------------------
+// m = 8 .. 32 bytes from LDS address src to dst, [src, src + m) final, no overlap, with ALIGNED accesses only: the pipe charges an
+// aligned 8-byte access of n scattered lanes 3 - 9 cycles (16.5 for a full wave's store), a misaligned one n + 1 whatever its width
+// (tools/lds_throughput_probe.hip).  Up to five aligned 8-byte reads around the source; the bytes in front of the destination's
+// first 8-byte boundary as byte / halfword / dword pieces; whole aligned 8-byte words (source shifted by (src & 7) + (-dst & 7)
+// bytes: whole dwords by two conditional register moves, the rest by v_alignbyte); the tail as dword / halfword / byte pieces.
+// Nothing outside [dst, dst + m) is written, up to 7 bytes outside [src, src + m) are read.  Lanes with on = false do nothing.
+__device__ __forceinline__ void lds_copy_dense(uint32_t src, uint32_t dst, uint32_t m, bool on) {
+    const uint32_t sa = src & ~7u, so = src & 7u;
+    uint32_t S[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) S[i] = 0u;
+    const uint32_t span = so + m;                        // bytes from sa that matter (<= 39)
+    if (on) {
+        uint64_t r0, r1;
+        asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8" : "=&v"(r0), "=&v"(r1) : "v"(sa) : "memory");
+        uint64_t r2 = 0, r3 = 0, r4 = 0;
+        if (span > 16u) asm volatile("ds_read_b64 %0, %1 offset:16" : "=v"(r2) : "v"(sa) : "memory");
+        if (span > 24u) asm volatile("ds_read_b64 %0, %1 offset:24" : "=v"(r3) : "v"(sa) : "memory");
+        if (span > 32u) asm volatile("ds_read_b64 %0, %1 offset:32" : "=v"(r4) : "v"(sa) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4) :: "memory");
+        S[0] = (uint32_t)r0; S[1] = (uint32_t)(r0 >> 32); S[2] = (uint32_t)r1; S[3] = (uint32_t)(r1 >> 32); S[4] = (uint32_t)r2; S[5] = (uint32_t)(r2 >> 32);
+        S[6] = (uint32_t)r3; S[7] = (uint32_t)(r3 >> 32); S[8] = (uint32_t)r4; S[9] = (uint32_t)(r4 >> 32);
+    }
+    const uint32_t hb = (0u - dst) & 7u;                 // bytes in front of the destination's first 8-byte boundary (< m)
+    const uint32_t rem = m - hb, K = rem >> 3, tb = rem & 7u;
+    // head: stream bytes 0 .. 7 = the 8 bytes at byte `so` of S
+    {
+        const uint32_t q = 0u - (so >> 2);
+        const uint32_t h0 = (q & S[1]) | (~q & S[0]), h1 = (q & S[2]) | (~q & S[1]), h2 = (q & S[3]) | (~q & S[2]);
+        const uint32_t lo = __builtin_amdgcn_alignbyte(h1, h0, so & 3u), hi = __builtin_amdgcn_alignbyte(h2, h1, so & 3u);
+        if (on && (hb & 1u)) asm volatile("ds_write_b8 %0, %1" :: "v"(dst), "v"(lo) : "memory");
+        if (on && (hb & 2u)) asm volatile("ds_write_b16 %0, %1" :: "v"(dst + (hb & 1u)), "v"(lo >> (8u * (hb & 1u))) : "memory");
+        if (on && (hb & 4u)) asm volatile("ds_write_b32 %0, %1" :: "v"(dst + (hb & 3u)), "v"(__builtin_amdgcn_alignbyte(hi, lo, hb & 3u)) : "memory");
+    }
+    // body: stream byte hb + 8 k = byte T + 8 k of S
+    const uint32_t T = so + hb;                          // 0 .. 14
+    uint32_t B[11], C[9], E[8];
+    // (bit selects, not ?: — the compiler turns a run of conditional element picks into a dynamically indexed scratch array)
+    const uint32_t m4 = 0u - ((T >> 2) & 1u), m8 = 0u - ((T >> 3) & 1u);
+#pragma unroll
+    for (int i = 0; i < 11; i++) B[i] = (m4 & S[i + 1]) | (~m4 & S[i]);
+#pragma unroll
+    for (int i = 0; i < 9; i++) C[i] = (m8 & B[i + 2]) | (~m8 & B[i]);
+#pragma unroll
+    for (int i = 0; i < 8; i++) E[i] = __builtin_amdgcn_alignbyte(C[i + 1], C[i], T & 3u);
+    const uint32_t d8 = dst + hb;
+    if (on && K > 0u) asm volatile("ds_write_b64 %0, %1" :: "v"(d8), "v"(((uint64_t)E[1] << 32) | E[0]) : "memory");
+    if (on && K > 1u) asm volatile("ds_write_b64 %0, %1 offset:8" :: "v"(d8), "v"(((uint64_t)E[3] << 32) | E[2]) : "memory");
+    if (on && K > 2u) asm volatile("ds_write_b64 %0, %1 offset:16" :: "v"(d8), "v"(((uint64_t)E[5] << 32) | E[4]) : "memory");
+    if (on && K > 3u) asm volatile("ds_write_b64 %0, %1 offset:24" :: "v"(d8), "v"(((uint64_t)E[7] << 32) | E[6]) : "memory");
+    // tail: word K (K <= 3 when tb > 0)
+    {
+        const uint32_t k0 = 0u - (uint32_t)(K == 0u), k1 = 0u - (uint32_t)(K == 1u), k2 = 0u - (uint32_t)(K == 2u), k3 = 0u - (uint32_t)(K >= 3u);
+        const uint32_t tl = (E[0] & k0) | (E[2] & k1) | (E[4] & k2) | (E[6] & k3);
+        const uint32_t th = (E[1] & k0) | (E[3] & k1) | (E[5] & k2) | (E[7] & k3);
+        const uint32_t ta = d8 + 8u * K;
+        const uint32_t w = (tb & 4u) ? th : tl;           // the word the 2- and 1-byte pieces come from
+        if (on && (tb & 4u)) asm volatile("ds_write_b32 %0, %1" :: "v"(ta), "v"(tl) : "memory");
+        if (on && (tb & 2u)) asm volatile("ds_write_b16 %0, %1" :: "v"(ta + (tb & 4u)), "v"(w) : "memory");
+        if (on && (tb & 1u)) asm volatile("ds_write_b8 %0, %1" :: "v"(ta + (tb & 6u)), "v"(w >> (8u * (tb & 2u))) : "memory");
+    }
+}
+
 __device__ __forceinline__ uint32_t wave_tier(uint32_t n, bool active) {       // wave-uniform tier for the active lanes
     if (ballot64(active && n > 32u)) return 64u;
     if (ballot64(active && n > 16u)) return 32u;

@@ -56,6 +56,9 @@ constexpr uint32_t kL2Threads = CJ_L2_THREADS;
 constexpr uint32_t kL2OffBits = 65536;
 constexpr uint32_t kL2OffVars = kL2OffBits + 8192;         // [0] fail flag, [8] current chunk, [64,128) dummy bytes, [128,384) dummy dwords
 constexpr uint32_t kL2Bytes = kL2OffVars + 384 + 128;      // 74880 B (the last 128: phase counters, the next chunk's descriptors): two workgroups fit one CU's LDS
+#ifndef CJ_DENSE_LANES
+#define CJ_DENSE_LANES 24u
+#endif
 constexpr uint32_t kL2TabRecords = 3u * kSyncStride * kSyncEvery;   // records of a chunk (the parse kernel routes chunks with more than 16 384 sequences elsewhere) + the extra literal copies of D1f (at most two per record, D1f takes at most 6 144 records)
 
 
@@ -891,6 +894,24 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 S.live = S.mp != 0ull || S.any_slow;
             };
             uint32_t spins = 0;
+            // The FIRST look at a batch finds most of its 64 matches ready (two thirds of a chunk's matches are copied in trips with 16
+            // lanes or more), and the pipe charges a misaligned access by its active lanes — 8 x (lanes + 1) cycles for the sparse copy
+            // plan below.  With kDenseLanes lanes or more the copy is done with aligned accesses instead (lds_copy_dense); later trips
+            // find a handful of lanes and keep the exact-address plan.  (threshold 16 / 24 / 32 / 40 lanes: 689.4 / 689.3 / 689.1 / 685.1 GB/s against 668
+            // without it; the same test inside the asm loop — every trip — gave 681 and cost the corpus 1.5 %.)
+            const auto d3_first = [&](D3Slot& S) __attribute__((always_inline)) {
+                const bool f = ((S.mp >> lane) & 1ull) != 0ull;
+                bool ready = false;
+                if (f) { const uint2 w = lds_ld64(S.pa); ready = (w.x & S.pm0) == S.pm0 && (w.y & S.pm1) == S.pm1; }
+                const uint64_t rm = ballot64(ready);
+                if ((uint32_t)__builtin_popcountll(rm) >= CJ_DENSE_LANES) {
+                    lds_copy_dense(S.as0, S.ad0, S.m, ready && S.m >= 8u);
+                    if (ready && S.m < 8u) lds_copy_sparse(S.ad0, S.as0, S.m);
+                    if (ready) asm volatile("ds_or_b32 %0, %1\n\tds_or_b32 %0, %2 offset:4" :: "v"(S.qa), "v"(S.qm0), "v"(S.qm1) : "memory");
+                    S.mp &= ~rm;
+                    S.live = S.mp != 0ull || S.any_slow;
+                }
+            };
             const auto d3_step = [&](D3Slot& S) __attribute__((always_inline)) {
                 if (S.mp != 0ull) {
                     // The poll LOOP as one block: it leaves only when no fast lane waits any more or after `lim` trips that found
@@ -1016,6 +1037,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             for (uint32_t base = wave * 64u; base < nrec_all; base += kL2Threads) {
                 d3_fill(A, rec_view(raw_nx, base + lane, nseq, nrec_all));
                 spins = 0;
+                if (A.mp != 0ull) d3_first(A);
                 if (base + kL2Threads < nrec_all) raw_nx = rec_fetch(base + kL2Threads + lane, nseq, nrec_all);
                 while (A.live) {
                     d3_step(A);

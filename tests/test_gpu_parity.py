@@ -556,3 +556,87 @@ def test_chunks_of_up_to_16384_sequences_take_the_workgroup_decoder(eng):
             res, outs = eng.batch_host(codec, DEC, flags, blobs, [len(c) for c in chunks])
             assert [int(r) for r in res] == [len(c) for c in chunks], (codec, flags)
             assert all(bytes(o) == c for o, c in zip(outs, chunks)), (codec, flags)
+
+
+def _lz4_block(seqs, tail):
+    """an LZ4 block from (literal bytes, offset, match length) triples + the final literals — written by hand so that the
+    test chooses every length and alignment itself"""
+    out = bytearray()
+    def ext(v):
+        while v >= 255: out.append(255); v -= 255
+        out.append(v)
+    for lit, off, m in seqs:
+        out.append((min(len(lit), 15) << 4) | min(m - 4, 15))
+        if len(lit) >= 15: ext(len(lit) - 15)
+        out += lit
+        out += bytes((off & 255, off >> 8))
+        if m - 4 >= 15: ext(m - 4 - 15)
+    out.append(min(len(tail), 15) << 4)
+    if len(tail) >= 15: ext(len(tail) - 15)
+    out += tail
+    return bytes(out)
+
+
+def _snappy_raw(n, seqs, tail):
+    out = bytearray()
+    v = n
+    while v >= 128: out.append((v & 127) | 128); v >>= 7
+    out.append(v)
+    def lit(b):
+        if not b: return
+        k = len(b) - 1
+        if k < 60: out.append(k << 2)
+        else: out.append(61 << 2); out.extend((k & 255, k >> 8))
+        out.extend(b)
+    for l, off, m in seqs:
+        lit(l)
+        while m > 0:                                  # copies of at most 64 bytes, 2-byte offsets
+            k = min(m, 64) if m - min(m, 64) == 0 or m - min(m, 64) >= 4 else m - 4
+            out.append(((k - 1) << 2) | 2); out.extend((off & 255, off >> 8))
+            m -= k
+    lit(tail)
+    return bytes(out)
+
+
+@pytest.mark.parametrize("codec", [LZ4, SNAPPY])
+def test_every_alignment_and_length_of_literals_and_matches(eng, codec):
+    """hand-written streams in which every literal length 0..40 meets every destination alignment, and every match length
+    4..40 every combination of source and destination alignment modulo 8 — far matches (ready at the resolver's first look:
+    the aligned dense copy) and near ones (the exact-address copy), through the workgroup decoder and the default pipeline"""
+    rng = np.random.default_rng(5)
+    chunks = []
+    for variant in range(6):
+        data = bytearray(rng.integers(0, 256, 4096, dtype=np.uint8).tobytes())
+        seqs = []
+        first = bytes(data)
+        pending_lit = first
+        combos = [(m, sa, ll) for m in range(4, 41) for sa in range(8) for ll in (0, 1, 2, 3, 5, 7, 11, 17, 29, 40)]
+        rng.shuffle(combos)
+        for m, sa, ll in combos:
+            if len(data) + ll + m > 65000: break
+            lit = bytes(rng.integers(0, 256, ll, dtype=np.uint8).tobytes()) if seqs else pending_lit
+            if seqs: data += lit
+            dst = len(data)
+            if variant % 2 == 0:                              # far: somewhere in the first half of what exists, aligned as asked
+                src = (int(rng.integers(0, max(8, dst // 2 - 64))) & ~7) + sa
+            else:                                             # near: within the last 200 bytes, not overlapping
+                src = max(0, ((dst - m - int(rng.integers(0, 160))) & ~7) + sa - 8)
+            if src + m > dst: src = ((dst - m) & ~7)
+            if src < 0 or dst - src > 65535 or dst - src < m: continue
+            data += data[src:src + m]
+            seqs.append((lit, dst - src, m))
+        tail = bytes(rng.integers(0, 256, 12 + variant, dtype=np.uint8).tobytes())
+        data += tail
+        raw = bytes(data)
+        blob = _lz4_block(seqs, tail) if codec == LZ4 else _snappy_raw(len(raw), seqs, tail)
+        want = oracle.lz4_decompress_raw(blob, len(raw)) if codec == LZ4 else oracle.snappy_decompress(blob)
+        assert want == (len(raw), raw), (variant, want[0], len(raw))      # the hand-written stream is valid and means what was meant
+        assert len(seqs) >= 600
+        chunks.append((blob, raw))
+    for flag in (N.FLAG_FORCE_LDS_PER_CHUNK, 0, N.FLAG_FORCE_WAVE_PER_CHUNK):
+        for extra in (0, 19):
+            streams = [c[0] for c in chunks] * 40                 # (a batch large enough for the parse kernel + decoder pipeline as well)
+            raws = [c[1] for c in chunks] * 40
+            res, outs = eng.batch_host(codec, DEC, flag, streams, [len(r) + extra for r in raws])
+            bad = [i for i, (r, o, raw) in enumerate(zip(res, outs, raws)) if r != len(raw) or o != raw]
+            assert not bad, (codec, flag, extra, bad[:8])

@@ -278,6 +278,40 @@ __device__ __forceinline__ void lds_copy_dense(uint32_t src, uint32_t dst, uint3
     }
 }
 
+// ---- the general path's copy (D3: matches above 32 bytes, self-overlapping ones; below kLongRun) ----------------------------
+// m bytes from LDS address src to dst, `off` bytes apart in the output (off < 8: dst = src + off in the same window), the source final
+// up to dst, the lane alone on this match.  In 8-byte pieces at
+// their exact addresses — a handful of lanes, so the misaligned accesses are cheap — instead of byte by byte (a 200-byte match
+// was 400 dependent LDS instructions; the corpus has 38 matches of 65 - 511 bytes per chunk, on the chain).  The DS queue of a
+// wavefront executes in order, so a piece may read what the piece before it wrote:
+//   off >= 8   pieces at 0, 8, 16 ... and a last one at m - 8 (m >= 8);
+//   off <  8   the bytes repeat with period off: the first D - off bytes one by one (D = the multiple of off that is >= 8: at most
+//              13 bytes), from there on pieces that read D bytes back.
+// Fewer than 8 bytes in all: byte by byte.
+__device__ __forceinline__ void lds_copy_serial(uint32_t src, uint32_t dst, uint32_t off, uint32_t m) {
+    const auto piece = [](uint32_t s, uint32_t d) {
+        uint64_t r;
+        asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(s) : "memory");
+        asm volatile("ds_write_b64 %0, %1" :: "v"(d), "v"(r) : "memory");
+    };
+    const auto byte1 = [](uint32_t s, uint32_t d) {
+        uint32_t r;
+        asm volatile("ds_read_u8 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(s) : "memory");
+        asm volatile("ds_write_b8 %0, %1" :: "v"(d), "v"(r) : "memory");
+    };
+    if (m < 8u) { for (uint32_t k = 0; k < m; k++) byte1(src + k, dst + k); return; }
+    uint32_t k = 0;
+    if (off < 8u) {                                              // (src = dst - off, same window)
+        const uint32_t back = off * ((8u + off - 1u) / off);     // pieces read `back` bytes behind where they write
+        const uint32_t pro = back - off < m ? back - off : m;
+        for (; k < pro; k++) byte1(src + k, dst + k);
+        if (m - k < 8u) { for (; k < m; k++) byte1(dst + k - off, dst + k); return; }
+        src = dst - back;
+    }
+    for (; k + 8u <= m; k += 8u) piece(src + k, dst + k);
+    if (k < m) piece(src + m - 8u, dst + m - 8u);                // (m - 8 >= the bytes done one by one: m - k < 8 was handled above)
+}
+
 __device__ __forceinline__ uint32_t wave_tier(uint32_t n, bool active) {       // wave-uniform tier for the active lanes
     if (ballot64(active && n > 32u)) return 64u;
     if (ballot64(active && n > 16u)) return 32u;

@@ -978,25 +978,8 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                     const uint32_t src = dst - off, need = off < m ? off : m;
                     bool sready = false;
                     if (S.spend) sready = bits_ready(s_bits, src, src + need);
-                    if (sready && m <= 64u && off >= m && m >= 4u) {
-                        lds_store_tier<64>(lds_ld_aligned18(as0 & ~3u), ad0, as0 & 3u, m, dm);
-                        bits_set(s_bits, dst, dst + m);
-                        S.spend = false;
-                    } else if (sready && m < kLongRun) {
-                        const uint8_t* sp = s_out + src;
-                        if (off >= 8u) {
-                            uint32_t k = 0;
-                            for (; k + 8u <= m; k += 8u) {
-                                uint8_t t[8];
-#pragma unroll
-                                for (int q = 0; q < 8; q++) t[q] = sp[k + q];
-#pragma unroll
-                                for (int q = 0; q < 8; q++) s_out[dst + k + q] = t[q];
-                            }
-                            for (; k < m; k++) s_out[dst + k] = sp[k];
-                        } else {
-                            for (uint32_t k = 0; k < m; k++) s_out[dst + k] = sp[k];
-                        }
+                    if (sready && m < kLongRun) {
+                        lds_copy_serial(as0, ad0, off, m);
                         bits_set(s_bits, dst, dst + m);
                         S.spend = false;
                     }
@@ -1133,27 +1116,8 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                     }
                     if (sready && cross && !cross_full) {
                         // done above
-                    } else if (sready && m <= 64u && off >= m) {        // 33..64 bytes, no self-overlap (Snappy copies reach 64): one tier copy
-                        uint32_t t_src = asrc, t_dst = a_out + dst, t_m = m;       // (through an empty asm: or the routine's ~200 address / selector
-                        asm volatile("" : "+v"(t_src), "+v"(t_dst), "+v"(t_m));  //  instructions are hoisted into every batch's setup)
-                        lds_store_tier<64>(lds_ld_aligned18(t_src & ~3u), t_dst, t_src & 3u, t_m, dm);
-                        bits_set(s_bits, dst, dst + m);
-                        pending = false;
                     } else if (sready && m < kLongRun) {
-                        const uint8_t* sp = cross ? smem + (a_prev - (uint32_t)(uintptr_t)smem) + 65536u - (off - dst) : s_out + src;
-                        if (off >= 8u) {
-                            uint32_t k = 0;
-                            for (; k + 8u <= m; k += 8u) {
-                                uint8_t t[8];
-#pragma unroll
-                                for (int q = 0; q < 8; q++) t[q] = sp[k + q];
-#pragma unroll
-                                for (int q = 0; q < 8; q++) s_out[dst + k + q] = t[q];
-                            }
-                            for (; k < m; k++) s_out[dst + k] = sp[k];
-                        } else {
-                            for (uint32_t k = 0; k < m; k++) s_out[dst + k] = sp[k];
-                        }
+                        lds_copy_serial(asrc, a_out + dst, off, m);
                         bits_set(s_bits, dst, dst + m);
                         pending = false;
                     }

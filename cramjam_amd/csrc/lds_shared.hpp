@@ -308,6 +308,15 @@ __device__ __forceinline__ void lds_copy_serial(uint32_t src, uint32_t dst, uint
         if (m - k < 8u) { for (; k < m; k++) byte1(dst + k - off, dst + k); return; }
         src = dst - back;
     }
+    if (off >= 32u) {                                            // four pieces per wait: what they read was written before they started
+        for (; k + 32u <= m; k += 32u) {
+            uint64_t r0, r1, r2, r3;
+            asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:16\n\tds_read_b64 %3, %4 offset:24\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(src + k) : "memory");
+            asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:8\n\tds_write_b64 %0, %3 offset:16\n\tds_write_b64 %0, %4 offset:24"
+                         :: "v"(dst + k), "v"(r0), "v"(r1), "v"(r2), "v"(r3) : "memory");
+        }
+    }
     for (; k + 8u <= m; k += 8u) piece(src + k, dst + k);
     if (k < m) piece(src + m - 8u, dst + m - 8u);                // (m - 8 >= the bytes done one by one: m - k < 8 was handled above)
 }

@@ -56,6 +56,10 @@ constexpr uint32_t kL2Threads = CJ_L2_THREADS;
 constexpr uint32_t kL2OffBits = 65536;
 constexpr uint32_t kL2OffVars = kL2OffBits + 8192;         // [0] fail flag, [8] current chunk, [64,128) dummy bytes, [128,384) dummy dwords
 constexpr uint32_t kL2Bytes = kL2OffVars + 384 + 128;      // 74880 B (the last 128: phase counters, the next chunk's descriptors): two workgroups fit one CU's LDS
+#ifndef CJ_D2_LONG
+#define CJ_D2_LONG 256u
+#endif
+constexpr uint32_t kD2LongRun = CJ_D2_LONG;      // literal runs at least this long are placed by the whole wavefront (512 / 256 / 128: x-ray 249.8 / 262.4 / 262.5 GB/s, whole corpus 212.5 / 213.8 / 213.6)
 #ifndef CJ_DENSE_LANES
 #define CJ_DENSE_LANES 24u
 #endif
@@ -696,7 +700,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         // ---- D2: literals, one lane per sequence -> LDS window ----
         // what is left of a run after its first bytes were taken from LDS / the whole run (old path): global -> window
         const auto place_from_global = [&](uint32_t n, uint32_t src, uint32_t dst) {
-            uint64_t lm = ballot64(n >= kLongRun);
+            uint64_t lm = ballot64(n >= kD2LongRun);
             while (lm) {
                 const uint32_t l = ctz64(lm);
                 lm &= lm - 1ull;
@@ -739,7 +743,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             const uint8_t* lit_base = iend >= 32u ? in : reinterpret_cast<const uint8_t*>(table);      // 32 readable bytes for the lanes that load nothing
             const auto own_issue = [&](const uint4& rec, OwnLit& L) {
                 L.n = rec.y; L.src = rec.x; L.dst = rec.z - rec.y;
-                const bool own = (rec.w & 0xffffu) != 0u && (rec.w >> 16) >= 4u && L.src + 32u <= safe_end && L.n < kLongRun;
+                const bool own = (rec.w & 0xffffu) != 0u && (rec.w >> 16) >= 4u && L.src + 32u <= safe_end && L.n < kD2LongRun;
                 L.nl = own ? (L.n < 32u ? L.n : 32u) : 0u;
                 const uint8_t* g = lit_base + (L.nl ? L.src : 0u);
                 uint4 q0, q1;

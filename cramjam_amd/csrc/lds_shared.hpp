@@ -468,8 +468,12 @@ __device__ __forceinline__ DW<T / 4 + 2> gl_ld_exact(const uint8_t* g) {
 // Anything that is not a clean chunk of kLdsMinSeq .. kSyncStride * kSyncEvery (256 .. 16 384) sequences (any violation, too few or too many sequences) is handed to
 // the wavefront-per-chunk kernel, which decodes every valid chunk and names every error exactly: returns false then.
 // =====================================================================================================
-constexpr uint32_t kFusedLanes = 256;
-constexpr uint32_t kFusedAux = 6u * kFusedLanes * 4u;              // merge, next, mark, entry, count, bytes: 6 KiB behind the decoder's LDS
+#ifndef CJ_FUSED_LANES
+#define CJ_FUSED_LANES 512
+#endif
+constexpr uint32_t kFusedLanes = CJ_FUSED_LANES;          // every thread of the workgroup walks a segment (256, wavefronts 0-3 only: 137 k cycles per chunk)
+constexpr uint32_t kFusedAux = 6144u;                               // merge, next, mark, entry (16 bits per lane each) + totals: behind the decoder's LDS
+static_assert(4u * kFusedLanes * 2u + 128u <= kFusedAux, "aux");
 
 __device__ __forceinline__ uint32_t wave_excl_scan_add32(uint32_t v, uint32_t& total) {
     const uint32_t lane = lane_id();
@@ -489,11 +493,12 @@ template <class G, uint32_t kThreads>
 __device__ __forceinline__ bool fused_parse(uint32_t a_in, uint32_t iend, uint32_t cap, uint32_t* bits, uint32_t* aux, uint2* table2,
                                             uint32_t* s_near, uint32_t& nseq_out, uint32_t& U_out) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    uint32_t* s_merge = aux;
-    uint32_t* s_next = aux + kFusedLanes;
-    uint32_t* s_mark = aux + 2u * kFusedLanes;
-    uint32_t* s_entry = aux + 3u * kFusedLanes;
-    uint32_t* s_tot = aux + 4u * kFusedLanes;            // [0..8): per-wave totals (count, bytes); [16..24): verdict words
+    // (positions fit 16 bits: a staged chunk ends below 65 520; 0xFFFF / 0xFFFE stand for kPosErr / kPosEnd)
+    uint16_t* s_merge = reinterpret_cast<uint16_t*>(aux);
+    uint16_t* s_next = s_merge + kFusedLanes;
+    uint16_t* s_mark = s_merge + 2u * kFusedLanes;
+    uint16_t* s_entry = s_merge + 3u * kFusedLanes;
+    uint32_t* s_tot = aux + 2u * kFusedLanes;            // [0..8): per-wave counts, [8..16): per-wave bytes, [16..24): verdict words
     const uint32_t a_bits = (uint32_t)(uintptr_t)bits;
     const auto rd = [a_in](uint32_t q) { return lds_ld32a(a_in + q); };
     const bool plane = tid < kFusedLanes;                  // the parse lanes (wavefronts 0-3); everyone takes the barriers
@@ -535,14 +540,14 @@ __device__ __forceinline__ bool fused_parse(uint32_t a_in, uint32_t iend, uint32
         }
         if (active && merge_pos >= iend && merge_pos != kPosEnd) merge_pos = kPosErr;
         const uint32_t nx0 = merge_pos < iend ? merge_pos / seg : tid;       // a piece that ends the stream points at itself
-        s_merge[tid] = merge_pos;
-        s_next[tid] = active ? nx0 : tid;
+        s_merge[tid] = (uint16_t)(merge_pos >= 0xFFFEu ? (merge_pos == kPosEnd ? 0xFFFEu : 0xFFFFu) : merge_pos);
+        s_next[tid] = (uint16_t)(active ? nx0 : tid);
         s_mark[tid] = tid == 0u ? 1u : 0u;
         s_entry[tid] = 0u;
     }
     __syncthreads();
     // ---- P2: mark the chain from lane 0 by pointer doubling ----
-    for (uint32_t round = 0; round < 8u; round++) {
+    for (uint32_t round = 0; (1u << round) < kFusedLanes; round++) {
         uint32_t n1 = 0, n2 = 0;
         if (plane) {
             n1 = s_next[tid];
@@ -556,7 +561,7 @@ __device__ __forceinline__ bool fused_parse(uint32_t a_in, uint32_t iend, uint32
     bool on_chain = false;
     if (plane) {
         on_chain = active && s_mark[tid] != 0u;
-        if (on_chain && merge_pos < iend) s_entry[merge_pos / seg] = merge_pos;
+        if (on_chain && merge_pos < iend) s_entry[merge_pos / seg] = (uint16_t)merge_pos;
     }
     __syncthreads();
     const uint32_t entry = plane ? s_entry[tid] : 0u;       // lane 0 enters at 0
@@ -579,13 +584,14 @@ __device__ __forceinline__ bool fused_parse(uint32_t a_in, uint32_t iend, uint32
         uint32_t tc, tb;
         base_idx = wave_excl_scan_add32(cnt, tc);
         base_op = wave_excl_scan_add32(outb, tb);
-        if (lane == 0) { s_tot[wave] = tc; s_tot[4u + wave] = tb; }
+        if (lane == 0) { s_tot[wave] = tc; s_tot[8u + wave] = tb; }
     }
     __syncthreads();
     if (plane) {
-        for (uint32_t w = 0; w < wave; w++) { base_idx += s_tot[w]; base_op += s_tot[4u + w]; }
+        for (uint32_t w = 0; w < wave; w++) { base_idx += s_tot[w]; base_op += s_tot[8u + w]; }
     }
-    const uint32_t total_seq = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
+    uint32_t total_seq = 0;
+    for (uint32_t w = 0; w < kFusedLanes / 64u; w++) total_seq += s_tot[w];
     // (a valid chunk's pieces add up to at most `cap` output bytes; a wild count is caught by the checks of P4)
     if (total_seq < kLdsMinSeq || total_seq > kSyncStride * kSyncEvery) return false;       // uniform: too few / too many sequences for this decoder
 

@@ -306,6 +306,37 @@ __global__ __launch_bounds__(64 * kParseWaves) void snappy_parse_kernel(BatchArg
                       && lit_len <= dn - op && offset != 0u && offset <= op2 && clen <= dn - op2 && ip3 < iend;
             if (fast_ok) { ip = ip3; op = op2 + clen; }
         }
+        // ---- more records in the same trip where the first went the straight way and the next does too (lz4_parse_kernel): the
+        //      trip's fixed cost once for all of them; nothing is committed — not even the sync point — unless the record holds ----
+#ifndef CJ_SN_PARSE_EXTRA
+#define CJ_SN_PARSE_EXTRA 7
+#endif
+        bool more = fast_ok;
+        for (int rep = 0; rep < CJ_SN_PARSE_EXTRA; rep++) {
+            if (ballot64(more) == 0ull) break;
+            if (more) {
+                const uint32_t t4 = st.ring32(ip);
+                const uint32_t tag = t4 & 0xffu, l6 = tag >> 2;
+                const bool is_lit = (tag & 3u) == 0u;
+                const uint32_t lhdr = is_lit ? (l6 == 60u ? 2u : 1u) : 0u;
+                const uint32_t lit_len = is_lit ? (l6 == 60u ? ((t4 >> 8) & 0xffu) + 1u : l6 + 1u) : 0u;
+                const uint32_t ip2 = ip + lhdr + lit_len;
+                const bool w1 = st.in_window(ip), w2 = ip2 + 4u <= st.hi && ip2 + 4u <= iend;
+                const uint32_t c4 = st.ring32(ip2);
+                const uint32_t ctag = c4 & 0xffu, kind = ctag & 3u;
+                const uint32_t clen = kind == 1u ? 4u + ((ctag >> 2) & 7u) : 1u + (ctag >> 2);
+                const uint32_t offset = kind == 1u ? ((ctag >> 5) << 8) | ((c4 >> 8) & 0xffu) : (c4 >> 8) & 0xffffu;
+                const uint32_t ip3 = ip2 + (kind == 1u ? 2u : 3u), op2 = op + lit_len;
+                const bool ok2 = w1 && w2 && !(is_lit && l6 > 60u) && (kind == 1u || kind == 2u)
+                                 && lit_len <= dn - op && offset != 0u && offset <= op2 && clen <= dn - op2 && ip3 < iend;
+                if (ok2) {
+                    if ((nrec % kSyncEvery) == 0u) sb.put(csync, nrec / kSyncEvery, make_uint2(ip - mis, op));
+                    nrec += 1;
+                    ip = ip3; op = op2 + clen;
+                }
+                more = ok2;
+            }
+        }
         if (!done && !fast_ok) {
             SnRecord rec;
             if (snappy_record_step(rd, ip, op, iend, dn, rec) != 0) { r = CJ_E_SNAPPY_CORRUPT; done = true; }

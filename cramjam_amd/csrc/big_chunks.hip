@@ -223,23 +223,45 @@ __global__ __launch_bounds__(64 * kBigWaves) void big_walk_kernel(BatchArgs a, c
     int32_t need = 0;                                            // how far in front of this lane's first output byte its matches reach
     bool bad = false, saw_last = false, fin = false;
     uint4* region = recs + (size_t)bi * kBigRecPitch + (size_t)j * kBigRegion;
-    // records leave in groups of two slots = one aligned 32-byte store, in the WAVE's phase (iteration `it` fills slot it & 1): a lane
-    // that turns to its real walk in an odd iteration begins its region at slot 1 (`pad`)
-    uint4 p0 = make_uint4(0, 0, 0, 0), p1 = p0;
-    uint32_t it = 0, it_base = 0, pad = 0;
-    bool grp = false;
+    // records leave in groups of two slots = one aligned 32-byte store, per lane: record k of the lane in slot k, the region's
+    // sentinel behind the last one
+    uint4 p0 = make_uint4(0, 0, 0, 0);
+    uint32_t nput = 0;
+    const auto put = [&](const uint4& v, bool last_one) {
+        if ((nput & 1u) == 0u) { p0 = v; if (last_one) region[nput] = v; }
+        else { region[nput - 1u] = p0; region[nput] = v; }
+        nput += 1u;
+    };
+    // one element of the real walk: the checks that do not need the absolute output position, its record
+    const auto take = [&](const BigElem& e) {
+        const uint32_t op2 = r + e.lit;
+        const bool has_match = kCodec == CJ_CODEC_LZ4_BLOCK ? !e.last : e.mlen != 0u;
+        const uint32_t off16 = e.offset & 0xffffu;
+        // (a Snappy copy that reaches further back than 65 535 bytes needs more than the previous slab: wavefront kernel)
+        const bool bad_now = !e.ok || (has_match && (e.offset == 0u || e.offset > 0xffffu)) || cnt + 4u > kBigRegion
+                             || (!e.last && e.next >= iend) || e.lit > kBigInMax || e.mlen > 0x00ffffffu;
+        const int32_t reach = has_match ? (int32_t)off16 - (int32_t)op2 : need;
+        need = reach > need ? reach : need;
+        if (kCodec == CJ_CODEC_LZ4_BLOCK && has_match) lim = op2 + (e.mlen + 5u > 12u ? e.mlen + 5u : 12u);
+        const uint32_t mlen = has_match ? e.mlen : 0u;
+        put(make_uint4((e.lit_at - mis) | ((mlen >> 16) << 24), e.lit, r, (has_match ? off16 : 0u) | ((mlen & 0xffffu) << 16)), false);
+        cnt += 1u;
+        r = op2 + mlen;
+        ip = e.next;
+        saw_last = e.last;
+        fin = e.last;
+        if (bad_now || r > kBigOutMax) { bad = true; done = true; }
+    };
 
     for (;;) {
         if (ballot64(!done) == 0ull) break;
         bool go = !done && !fin;
-        bool emit = false;
-        uint4 slot = make_uint4(0u, 0u, r, 0u);                  // the region's sentinel
         if (ballot64(!done && (fin || (!lead && ip >= next_b))) != 0ull) {
-            if (!done && fin) { emit = true; done = true; }      // the sentinel behind the last record
+            if (!done && fin) { put(make_uint4(0u, 0u, r, 0u), true); done = true; }      // the sentinel behind the last record
             else if (go && !lead && ip >= next_b) {              // across a boundary, on a token: the candidate of the segment it is in now?
                 while (tb + 1u < k && ip >= next_b + seg) { tb += 1u; next_b += seg; }
                 const uint32_t cm = __hip_atomic_load(ccand + tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (cm == ip) { link = tb; done = true; go = false; emit = true; }      // the region's sentinel
+                if (cm == ip) { link = tb; done = true; go = false; put(make_uint4(0u, 0u, r, 0u), true); }      // the region's sentinel
                 else { tb += 1u; next_b = tb < k ? next_b + seg : 0xFFFFFFFFu; }        // another position, or not known yet: walk on
             }
         }
@@ -265,45 +287,19 @@ __global__ __launch_bounds__(64 * kBigWaves) void big_walk_kernel(BatchArgs a, c
                     const uint32_t cand = ip < iend ? ip : kBigNone;
                     __hip_atomic_store(ccand + j, cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (cand == kBigNone) done = true;
-                    it_base = (it + 1u) & ~1u; pad = (it + 1u) & 1u;      // the first slot is put in the next iteration
                 }
                 go = false;
             }
         }
-        if (go) {
-            const uint32_t op2 = r + e.lit;
-            const bool has_match = kCodec == CJ_CODEC_LZ4_BLOCK ? !e.last : e.mlen != 0u;
-            const uint32_t off16 = e.offset & 0xffffu;
-            // (a Snappy copy that reaches further back than 65 535 bytes needs more than the previous slab: wavefront kernel)
-            const bool bad_now = !e.ok || (has_match && (e.offset == 0u || e.offset > 0xffffu)) || it - it_base + 4u > kBigRegion
-                                 || (!e.last && e.next >= iend) || e.lit > kBigInMax || e.mlen > 0x00ffffffu;
-            const int32_t reach = has_match ? (int32_t)off16 - (int32_t)op2 : need;
-            need = reach > need ? reach : need;
-            if (kCodec == CJ_CODEC_LZ4_BLOCK && has_match) lim = op2 + (e.mlen + 5u > 12u ? e.mlen + 5u : 12u);
-            const uint32_t mlen = has_match ? e.mlen : 0u;
-            emit = true;
-            slot = make_uint4((e.lit_at - mis) | ((mlen >> 16) << 24), e.lit, r, (has_match ? off16 : 0u) | ((mlen & 0xffffu) << 16));
-            cnt += 1u;
-            r = op2 + mlen;
-            ip = e.next;
-            saw_last = e.last;
-            fin = e.last;
-            if (bad_now || r > kBigOutMax) { bad = true; done = true; }
-        }
-        const uint32_t q = it & 1u;                               // (uniform)
-        if (q == 0u) p0 = emit ? slot : p0;
-        else p1 = emit ? slot : p1;
-        grp = grp || emit;
-        if (q == 1u) {
-            if (grp) { region[it - 1u - it_base] = p0; region[it - it_base] = p1; }
-            grp = false;
-        }
-        it += 1u;
+        if (go) take(e);
+        // (more elements per trip, the parse kernels' trick, LOSE here: 1 / 2 / 3 / 7 more 2.39 / 2.71 / 2.78 / 3.73 ms against 2.25 — this
+        //  element function carries two window tests with their ballots, it is no cheaper than the trip)
     }
-    if (grp) { region[(it & ~1u) - it_base] = p0; region[(it & ~1u) - it_base + 1u] = p1; }
+    if ((nput & 1u) != 0u && !done) region[nput - 1u] = p0;      // (cannot happen: every lane that wrote a record ends with its sentinel or as bad)
 
     if (exists) {
-        const BigLane bl = {cnt, r, lim, link, need, (bad ? kBigLaneBad : 0u) | (saw_last ? kBigLaneLast : 0u), pad, 0u};
+        if (bad && (nput & 1u) != 0u) region[nput - 1u] = p0;      // (a bad lane's records are never used; kept complete for debugging)
+        const BigLane bl = {cnt, r, lim, link, need, (bad ? kBigLaneBad : 0u) | (saw_last ? kBigLaneLast : 0u), 0u, 0u};
         lanes[(size_t)bi * k + j] = bl;
     }
 }

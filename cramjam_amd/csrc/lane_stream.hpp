@@ -11,9 +11,12 @@ namespace cj {
 #ifndef CJ_PARSE_WAVES
 #define CJ_PARSE_WAVES 2
 #endif
+#ifndef CJ_REFILL_TOUCH
+#define CJ_REFILL_TOUCH 1
+#endif
 constexpr uint32_t kParseWaves = CJ_PARSE_WAVES;                    // waves per block (ring storage 2 x 64 x 272 B = 34 KiB static LDS)
 constexpr uint32_t kRingBytes = 256;                   // two 128 B lines per lane
-constexpr uint32_t kRingStride = kRingBytes + 16;      // 16 B aligned rings (one ds_write_b128 per fetched piece); the lanes read at unrelated
+constexpr uint32_t kRingStride = kRingBytes + 16;      // 16 B aligned rings (one ds_write_b128 per fetched piece; the first 8 of the 16 spare bytes mirror the ring's first 8); the lanes read at unrelated
                                                        // offsets anyway, so the exact skew between rings does not matter for bank conflicts
 
 struct LaneStream {
@@ -21,6 +24,9 @@ struct LaneStream {
     uint32_t lo, hi;        // cached window [lo, hi) in offsets from base; multiples of 128, hi - lo <= kRingBytes
     uint32_t end;           // offset of the end of the stream
     uint32_t ring;          // LDS byte offset of this lane's ring
+#if CJ_REFILL_TOUCH
+    uint32_t touch;         // a word of the line the lane will ask for next, requested when the current one arrived (see refill_round)
+#endif
 
     __device__ __forceinline__ uint32_t ld32(uint32_t p) const {        // 4 bytes at offset p (little endian)
         if (p >= lo && p + 4u <= hi && p + 4u <= end) {
@@ -41,12 +47,29 @@ struct LaneStream {
     // the straight-line form for the parse kernels' common case: is [p, p + 4) cached, and the 4 bytes at p read from the ring
     // whether or not it is (the address never leaves the lane's ring; the value only means something if in_window(p))
     __device__ __forceinline__ bool in_window(uint32_t p) const { return p >= lo && p + 4u <= hi && p + 4u <= end; }
+    // (the ring's first 8 bytes are mirrored behind its end by refill_round: the 8 / 12 bytes from any dword of the ring are read without a wrap)
     __device__ __forceinline__ uint32_t ring32(uint32_t p) const {
-        const uint32_t a0 = ring + (p & (kRingBytes - 4u)), a1 = ring + ((p + 4u) & (kRingBytes - 4u));
-        uint32_t w0, w1;
-        asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(w0), "=&v"(w1) : "v"(a0), "v"(a1) : "memory");
-        return __builtin_amdgcn_alignbyte(w1, w0, p & 3u);
+        uint64_t w;
+        asm volatile("ds_read2_b32 %0, %1 offset1:1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(ring + (p & (kRingBytes - 4u))) : "memory");
+        return __builtin_amdgcn_alignbyte((uint32_t)(w >> 32), (uint32_t)w, p & 3u);
+    }
+    // two positions under one wait (the parse kernels: a sequence's offset field and the NEXT sequence's token — where that token sits
+    // follows from the current token alone, so a sequence costs one dependent LDS round trip instead of two)
+    __device__ __forceinline__ void ring32x2(uint32_t p, uint32_t q, uint32_t& vp, uint32_t& vq) const {
+        uint64_t w, x;
+        asm volatile("ds_read2_b32 %0, %2 offset1:1\n\tds_read2_b32 %1, %3 offset1:1\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(w), "=&v"(x) : "v"(ring + (p & (kRingBytes - 4u))), "v"(ring + (q & (kRingBytes - 4u))) : "memory");
+        vp = __builtin_amdgcn_alignbyte((uint32_t)(w >> 32), (uint32_t)w, p & 3u);
+        vq = __builtin_amdgcn_alignbyte((uint32_t)(x >> 32), (uint32_t)x, q & 3u);
+    }
+    // 8 bytes at p (three dwords of the ring; the Snappy parse: a copy element and the tag bytes of the record behind it)
+    __device__ __forceinline__ void ring64(uint32_t p, uint32_t& lo8, uint32_t& hi8) const {
+        uint64_t w;
+        uint32_t w2;
+        asm volatile("ds_read2_b32 %0, %2 offset1:1\n\tds_read_b32 %1, %2 offset:8\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(w), "=&v"(w2) : "v"(ring + (p & (kRingBytes - 4u))) : "memory");
+        lo8 = __builtin_amdgcn_alignbyte((uint32_t)(w >> 32), (uint32_t)w, p & 3u);
+        hi8 = __builtin_amdgcn_alignbyte(w2, (uint32_t)(w >> 32), p & 3u);
     }
 };
 
@@ -71,6 +94,9 @@ __device__ __forceinline__ RefillPlan refill_plan(const LaneStream& st) {
 
 __device__ __forceinline__ void refill_round(LaneStream& st, bool want, uint32_t wave_ring, const RefillPlan& plan) {
     const uint32_t lane = lane_id(), piece = lane & 7u;
+#if CJ_REFILL_TOUCH
+    asm volatile("" :: "v"(st.touch));                                 // the previous round's touch is accounted for here, not earlier
+#endif
     const uint32_t mine = st.hi | (want ? 1u : 0u);                    // hi is a multiple of 128
     uint32_t th[8];
 #pragma unroll
@@ -95,12 +121,23 @@ __device__ __forceinline__ void refill_round(LaneStream& st, bool want, uint32_t
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
             const u32x4 q = {v[r].x, v[r].y, v[r].z, v[r].w};
             asm volatile("ds_write_b128 %0, %1" :: "v"(dsta[r]), "v"(q) : "memory");
+            if (dsta[r] == wave_ring + (uint32_t)(8 * r + (int)(lane >> 3)) * kRingStride) {        // the ring's first piece: its first 8 bytes again behind the ring's end
+                const uint64_t head = ((uint64_t)v[r].y << 32) | v[r].x;
+                asm volatile("ds_write_b64 %0, %1" :: "v"(dsta[r] + kRingBytes), "v"(head) : "memory");
+            }
         }
     }
     if (want) {
         if (st.hi - st.lo >= kRingBytes) st.lo += 128u;
         st.hi += 128u;
     }
+#if CJ_REFILL_TOUCH
+    {   // one word of the line this lane asks for next (its round is a trip or two away): that round finds the line in the L2
+        const uint32_t last = st.end ? (st.end - 1u) & ~127u : 0u, nx = st.hi + 128u * (CJ_REFILL_TOUCH - 1u);
+        typedef const uint32_t __attribute__((address_space(1)))* GlobalWord;     // (a flat load would also count against the LDS reads' lgkmcnt)
+        st.touch = *(GlobalWord)(uintptr_t)(st.base + (nx < last ? nx : last));
+    }
+#endif
 }
 
 

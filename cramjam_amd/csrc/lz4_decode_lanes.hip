@@ -79,8 +79,11 @@ __global__ __launch_bounds__(64 * kParseWaves) void lz4_parse_kernel(BatchArgs a
     const uint32_t cap = (uint32_t)cap64;
     LaneStream st;
     const uint32_t mis = done ? 0u : (uint32_t)(reinterpret_cast<uintptr_t>(in) & 127u);
-    st.base = done ? nullptr : in - mis;
+    st.base = done ? (CJ_REFILL_TOUCH ? a.in_base : nullptr) : in - mis;
     st.lo = 0; st.hi = 0;
+#if CJ_REFILL_TOUCH
+    st.touch = 0;
+#endif
     st.end = done ? 0u : mis + (uint32_t)n64;
     st.ring = wave_ring + lane * kRingStride;
     const uint32_t iend = st.end;
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(64 * kParseWaves) void lz4_parse_kernel(BatchArgs a
     uint2* csync = sync + (size_t)c * kSyncPitch;
 
     uint32_t ip = mis, op = 0, nseq = 0;
-    SyncBatch sb = {make_uint2(0, 0), make_uint2(0, 0), make_uint2(0, 0), make_uint2(0, 0)};
+    SyncBatch sb = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     // ---- wave-convergent walk: refill rounds, then one sequence per active lane ----
     while (ballot64(!done) != 0ull) {
         if (!done && ip >= st.hi) st.lo = st.hi = ip & ~127u;      // jumped past the window (long literal run): re-anchor
@@ -113,25 +116,39 @@ __global__ __launch_bounds__(64 * kParseWaves) void lz4_parse_kernel(BatchArgs a
         //      sequence (and every error) takes the general walk below from the same state.  The general walk alone is ~235
         //      instructions per step, half of them scalar mask bookkeeping for its ~30 conditional blocks, and the kernel is
         //      bound by exactly that ----
-        bool fast_ok = false;
-        if (!done) {
-            const uint32_t t4 = st.ring32(ip);
+        // One dependent LDS round trip per sequence: where the NEXT token sits follows from the current token alone (the extension bytes
+        // that would move it further are exactly the ones this path refuses), so the offset field and the next token are read together.
+        struct FastSeq { bool ok; uint32_t ip3, op3, t4n; };
+        // the trip's bounds: [ip, ip + 4) cached and inside the block; the offset field cached and at least 8 bytes before the block's end
+        // (rem_in >= lit + 8 implies every bound the general walk checks while it reads one-byte extensions); the output margins
+        const uint32_t win_end = st.hi < iend ? st.hi : iend;
+        const int32_t ip2_max = (int32_t)win_end - 4 < (int32_t)iend - 8 ? (int32_t)win_end - 4 : (int32_t)iend - 8;      // (signed: a short block makes it negative)
+        const bool ip_low_ok = ip >= st.lo;                       // (the position only moves forward during the trip)
+        const auto fast_seq = [&](uint32_t t4) __attribute__((always_inline)) -> FastSeq {
             const uint32_t token = t4 & 0xffu, e1 = (t4 >> 8) & 0xffu;
             const bool x1 = (token >> 4) == 15u;
             const uint32_t lit = (token >> 4) + (x1 ? e1 : 0u);
-            const uint32_t ip1 = ip + 1u + (x1 ? 1u : 0u), ip2 = ip1 + lit;
-            const bool w1 = st.in_window(ip), w2 = ip2 + 4u <= st.hi && ip2 + 4u <= iend;
-            const uint32_t o4 = st.ring32(ip2);
-            const uint32_t offset = o4 & 0xffffu, mc = token & 15u, e2 = (o4 >> 16) & 0xffu;
+            const uint32_t ip2 = ip + (x1 ? 2u : 1u) + lit;
+            const uint32_t mc = token & 15u;
             const bool x2 = mc == 15u;
-            const uint32_t mlen = mc + (x2 ? e2 : 0u) + 4u;
-            const uint32_t ip3 = ip2 + 2u + (x2 ? 1u : 0u);
-            const uint32_t op2 = op + lit;
-            // rem_in >= lit + 8 implies every bound the general walk checks while it reads one-byte extensions
-            fast_ok = w1 && w2 && !(x1 && e1 == 255u) && !(x2 && e2 == 255u)
-                      && cap - op >= lit + 12u && iend - ip1 >= lit + 8u
-                      && offset != 0u && offset <= op2 + hist && cap - op2 >= mlen + 5u;
-            if (fast_ok) { ip = ip3; op = op2 + mlen; }
+            const uint32_t ip3 = ip2 + (x2 ? 3u : 2u);
+            uint32_t o4, t4n;
+            st.ring32x2(ip2, ip3, o4, t4n);
+            const uint32_t offset = o4 & 0xffffu, e2 = (o4 >> 16) & 0xffu;
+            const uint32_t op2 = op + lit, op3 = op2 + mc + (x2 ? e2 : 0u) + 4u;
+            // (bitwise: as a chain of && this compiles to nested branches, four or five per sequence)
+            const bool ok = ip_low_ok & ((int32_t)(ip + 4u) <= (int32_t)win_end) & ((int32_t)ip2 <= ip2_max)
+                            & !(x1 & (e1 == 255u)) & !(x2 & (e2 == 255u))
+                            & ((int32_t)(op2 + 12u) <= (int32_t)cap) & ((int32_t)(op3 + 5u) <= (int32_t)cap)
+                            & (offset != 0u) & (offset <= op2 + hist);
+            return FastSeq{ok, ip3, op3, t4n};
+        };
+        bool fast_ok = false;
+        uint32_t t4_next = 0;
+        if (!done) {
+            const FastSeq f = fast_seq(st.ring32(ip));
+            fast_ok = f.ok; t4_next = f.t4n;
+            if (f.ok) { ip = f.ip3; op = f.op3; }
         }
 #ifndef CJ_PARSE_SINGLE
         // ---- MORE sequences in the same trip where the first went the straight way and the next one does too (token and offset
@@ -146,27 +163,13 @@ __global__ __launch_bounds__(64 * kParseWaves) void lz4_parse_kernel(BatchArgs a
         for (int rep = 0; rep < CJ_PARSE_EXTRA; rep++) {
             if (ballot64(more) == 0ull) break;
             if (more) {
-                const uint32_t t4 = st.ring32(ip);
-                const uint32_t token = t4 & 0xffu, e1 = (t4 >> 8) & 0xffu;
-                const bool x1 = (token >> 4) == 15u;
-                const uint32_t lit = (token >> 4) + (x1 ? e1 : 0u);
-                const uint32_t ip1 = ip + 1u + (x1 ? 1u : 0u), ip2 = ip1 + lit;
-                const bool w1 = st.in_window(ip), w2 = ip2 + 4u <= st.hi && ip2 + 4u <= iend;
-                const uint32_t o4 = st.ring32(ip2);
-                const uint32_t offset = o4 & 0xffffu, mc = token & 15u, e2 = (o4 >> 16) & 0xffu;
-                const bool x2 = mc == 15u;
-                const uint32_t mlen = mc + (x2 ? e2 : 0u) + 4u;
-                const uint32_t ip3 = ip2 + 2u + (x2 ? 1u : 0u);
-                const uint32_t op2 = op + lit;
-                const bool ok2 = w1 && w2 && !(x1 && e1 == 255u) && !(x2 && e2 == 255u)
-                                 && cap - op >= lit + 12u && iend - ip1 >= lit + 8u
-                                 && offset != 0u && offset <= op2 + hist && cap - op2 >= mlen + 5u;
-                if (ok2) {
+                const FastSeq f = fast_seq(t4_next);
+                if (f.ok) {
                     if ((nseq % kSyncEvery) == 0u) sb.put(csync, nseq / kSyncEvery, make_uint2(ip - mis, op));
                     nseq += 1;
-                    ip = ip3; op = op2 + mlen;
+                    ip = f.ip3; op = f.op3;
                 }
-                more = ok2;
+                more = f.ok; t4_next = f.t4n;
             }
         }
 #endif

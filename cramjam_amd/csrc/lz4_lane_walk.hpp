@@ -36,23 +36,23 @@ constexpr uint32_t kRouteStored = 0x20000000u;   // linked-frame parse: the bloc
 // a wave's 64 lanes belong to 64 chunks, so every 8-byte store used to dirty a 32-byte sector of its own (PMC: 1.86 GB written per
 // 100 k chunks for 0.27 GB of sync points).  A chunk's region starts 128-byte aligned (kSyncPitch) and holds a multiple of 4 slots.
 struct SyncBatch {
-    uint2 p0, p1, p2, p3;
+    uint32_t x0, y0, x1, y1, x2, y2, x3, y3;
     __device__ __forceinline__ void put(uint2* csync, uint32_t slot, uint2 v) {
-        const uint32_t k = slot & 3u;
-        p0 = k == 0u ? v : p0; p1 = k == 1u ? v : p1; p2 = k == 2u ? v : p2; p3 = k == 3u ? v : p3;
-        if (k == 3u && slot < kSyncStride) {
+        // a shift register: no slot selection (put runs in nearly every step of a wave: some lane is at a multiple of 8)
+        x0 = x1; y0 = y1; x1 = x2; y1 = y2; x2 = x3; y2 = y3; x3 = v.x; y3 = v.y;
+        if ((slot & 3u) == 3u && slot < kSyncStride) {
             uint4* g = reinterpret_cast<uint4*>(csync + (slot - 3u));
-            g[0] = make_uint4(p0.x, p0.y, p1.x, p1.y);
-            g[1] = make_uint4(p2.x, p2.y, p3.x, p3.y);
+            g[0] = make_uint4(x0, y0, x1, y1);
+            g[1] = make_uint4(x2, y2, x3, y3);
         }
     }
-    // n = sync points put so far: the group that was not completed
+    // n = sync points put so far: the group that was not completed (its k newest entries sit at the register's end: 3 | 2 3 | 1 2 3)
     __device__ __forceinline__ void flush(uint2* csync, uint32_t n) {
         const uint32_t k = n & 3u, base = n & ~3u;
         if (base >= kSyncStride) return;
-        if (k >= 1u) csync[base] = p0;
-        if (k >= 2u) csync[base + 1u] = p1;
-        if (k >= 3u) csync[base + 2u] = p2;
+        if (k >= 1u) csync[base] = k == 1u ? make_uint2(x3, y3) : k == 2u ? make_uint2(x2, y2) : make_uint2(x1, y1);
+        if (k >= 2u) csync[base + 1u] = k == 2u ? make_uint2(x3, y3) : make_uint2(x2, y2);
+        if (k >= 3u) csync[base + 2u] = make_uint2(x3, y3);
     }
 };
 

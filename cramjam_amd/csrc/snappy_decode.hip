@@ -260,8 +260,11 @@ __global__ __launch_bounds__(64 * kParseWaves) void snappy_parse_kernel(BatchArg
     }
     LaneStream st;
     const uint32_t mis = done ? 0u : (uint32_t)(reinterpret_cast<uintptr_t>(in + hdr) & 127u);
-    st.base = done ? nullptr : in + hdr - mis;
+    st.base = done ? (CJ_REFILL_TOUCH ? a.in_base : nullptr) : in + hdr - mis;
     st.lo = 0; st.hi = 0;
+#if CJ_REFILL_TOUCH
+    st.touch = 0;
+#endif
     st.end = done ? 0u : mis + (uint32_t)n64 - hdr;
     st.ring = wave_ring + lane * kRingStride;
     const uint32_t iend = st.end;
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(64 * kParseWaves) void snappy_parse_kernel(BatchArg
     const auto rd = [&st](uint32_t p) { return st.ld32(p); };
 
     uint32_t ip = mis, op = 0, nrec = 0;
-    SyncBatch sb = {make_uint2(0, 0), make_uint2(0, 0), make_uint2(0, 0), make_uint2(0, 0)};
+    SyncBatch sb = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     while (ballot64(!done) != 0ull) {
         if (!done && ip >= st.hi) st.lo = st.hi = ip & ~127u;      // jumped past the window (long literal): re-anchor
         for (;;) {
@@ -288,23 +291,35 @@ __global__ __launch_bounds__(64 * kParseWaves) void snappy_parse_kernel(BatchArg
         // ---- the common record as straight-line code (same idea as in lz4_parse_kernel): an optional literal with a one- or
         //      two-byte header followed by a 1- or 2-byte-offset copy, everything cached, valid and not the stream's last record.
         //      Nothing is committed unless all of that holds; every other record takes snappy_record_step from the same state ----
-        bool fast_ok = false;
-        if (!done) {
-            const uint32_t t4 = st.ring32(ip);
+        // One dependent LDS round trip per record: the read at the copy element brings 8 bytes, and the record behind it starts 2 or 3
+        // bytes further — its tag (and a literal's length byte) come with the copy element.
+        struct FastRec { bool ok; uint32_t ip3, op3, t4n; };
+        const uint32_t win_end = st.hi < iend ? st.hi : iend;            // [p, p + 4) cached and inside the stream: p + 4 <= win_end (and p >= lo: the position only moves forward)
+        const bool ip_low_ok = ip >= st.lo;
+        const auto fast_rec = [&](uint32_t t4) __attribute__((always_inline)) -> FastRec {
             const uint32_t tag = t4 & 0xffu, l6 = tag >> 2;
             const bool is_lit = (tag & 3u) == 0u;
             const uint32_t lhdr = is_lit ? (l6 == 60u ? 2u : 1u) : 0u;
             const uint32_t lit_len = is_lit ? (l6 == 60u ? ((t4 >> 8) & 0xffu) + 1u : l6 + 1u) : 0u;
             const uint32_t ip2 = ip + lhdr + lit_len;                        // the copy element
-            const bool w1 = st.in_window(ip), w2 = ip2 + 4u <= st.hi && ip2 + 4u <= iend;
-            const uint32_t c4 = st.ring32(ip2);
+            uint32_t c4, c8;
+            st.ring64(ip2, c4, c8);
             const uint32_t ctag = c4 & 0xffu, kind = ctag & 3u;
             const uint32_t clen = kind == 1u ? 4u + ((ctag >> 2) & 7u) : 1u + (ctag >> 2);
             const uint32_t offset = kind == 1u ? ((ctag >> 5) << 8) | ((c4 >> 8) & 0xffu) : (c4 >> 8) & 0xffffu;
             const uint32_t ip3 = ip2 + (kind == 1u ? 2u : 3u), op2 = op + lit_len;
-            fast_ok = w1 && w2 && !(is_lit && l6 > 60u) && (kind == 1u || kind == 2u)
-                      && lit_len <= dn - op && offset != 0u && offset <= op2 && clen <= dn - op2 && ip3 < iend;
-            if (fast_ok) { ip = ip3; op = op2 + clen; }
+            const uint32_t t4n = __builtin_amdgcn_alignbyte(c8, c4, kind == 1u ? 2u : 3u);
+            // (bitwise: a chain of && compiles to nested branches)
+            const bool ok = ip_low_ok & (ip + 4u <= win_end) & (ip2 + 4u <= win_end) & !(is_lit & (l6 > 60u)) & ((kind == 1u) | (kind == 2u))
+                            & (lit_len <= dn - op) & (offset != 0u) & (offset <= op2) & (clen <= dn - op2) & (ip3 < iend);
+            return FastRec{ok, ip3, op2 + clen, t4n};
+        };
+        bool fast_ok = false;
+        uint32_t t4_next = 0;
+        if (!done) {
+            const FastRec f = fast_rec(st.ring32(ip));
+            fast_ok = f.ok; t4_next = f.t4n;
+            if (f.ok) { ip = f.ip3; op = f.op3; }
         }
         // ---- more records in the same trip where the first went the straight way and the next does too (lz4_parse_kernel): the
         //      trip's fixed cost once for all of them; nothing is committed — not even the sync point — unless the record holds ----
@@ -315,26 +330,13 @@ __global__ __launch_bounds__(64 * kParseWaves) void snappy_parse_kernel(BatchArg
         for (int rep = 0; rep < CJ_SN_PARSE_EXTRA; rep++) {
             if (ballot64(more) == 0ull) break;
             if (more) {
-                const uint32_t t4 = st.ring32(ip);
-                const uint32_t tag = t4 & 0xffu, l6 = tag >> 2;
-                const bool is_lit = (tag & 3u) == 0u;
-                const uint32_t lhdr = is_lit ? (l6 == 60u ? 2u : 1u) : 0u;
-                const uint32_t lit_len = is_lit ? (l6 == 60u ? ((t4 >> 8) & 0xffu) + 1u : l6 + 1u) : 0u;
-                const uint32_t ip2 = ip + lhdr + lit_len;
-                const bool w1 = st.in_window(ip), w2 = ip2 + 4u <= st.hi && ip2 + 4u <= iend;
-                const uint32_t c4 = st.ring32(ip2);
-                const uint32_t ctag = c4 & 0xffu, kind = ctag & 3u;
-                const uint32_t clen = kind == 1u ? 4u + ((ctag >> 2) & 7u) : 1u + (ctag >> 2);
-                const uint32_t offset = kind == 1u ? ((ctag >> 5) << 8) | ((c4 >> 8) & 0xffu) : (c4 >> 8) & 0xffffu;
-                const uint32_t ip3 = ip2 + (kind == 1u ? 2u : 3u), op2 = op + lit_len;
-                const bool ok2 = w1 && w2 && !(is_lit && l6 > 60u) && (kind == 1u || kind == 2u)
-                                 && lit_len <= dn - op && offset != 0u && offset <= op2 && clen <= dn - op2 && ip3 < iend;
-                if (ok2) {
+                const FastRec f = fast_rec(t4_next);
+                if (f.ok) {
                     if ((nrec % kSyncEvery) == 0u) sb.put(csync, nrec / kSyncEvery, make_uint2(ip - mis, op));
                     nrec += 1;
-                    ip = ip3; op = op2 + clen;
+                    ip = f.ip3; op = f.op3;
                 }
-                more = ok2;
+                more = f.ok; t4_next = f.t4n;
             }
         }
         if (!done && !fast_ok) {

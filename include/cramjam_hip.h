@@ -170,8 +170,10 @@ typedef enum { CJ_OP_DECOMPRESS = 0, CJ_OP_COMPRESS = 1 } cj_op;
 #define CJ_FLAG_DEBUG_PROFILE        0x1000u
 /* decode batches up to this many chunks run parse + decode as ONE kernel (the segmented parse inside the workgroup decoder:
  * 1 chunk 0.16 ms instead of 0.25, 8 192 chunks 348 instead of 178 GB/s); above, a lane-per-chunk parse kernel in front of the
- * decoder is cheaper per chunk (measured crossover between 16 384 and 32 768 chunks, profiles/r02) */
-#define CJ_FUSED_MAX_CHUNKS 24576
+ * decoder is cheaper per chunk.  The crossover depends on the data — the parse kernel's fixed latency is one lane walking one
+ * chunk, i.e. its sequence count: benchmark data (2.7 k sequences per 64 KiB) ~13 000 chunks for LZ4 and ~10 500 for Snappy,
+ * the reference's corpus (~8 k) above 24 000 (profiles/r04/experiments, c02); 16 384 loses at most ~11 % on either side */
+#define CJ_FUSED_MAX_CHUNKS 16384
 /* decode batches larger than this are submitted in slices of this many chunks (env CJ_SLICE_CHUNKS) */
 #define CJ_SLICE_CHUNKS_DEFAULT 131072
 

@@ -197,7 +197,7 @@ def test_device_batch_synth_roundtrip(eng, chunk, mapping):
             assert d == (len(r), r), (codec, i, res[i])
 
 
-# both sides of CJ_FUSED_MAX_CHUNKS (24 576): parse + decode in one kernel below it, parse pass + workgroup decoder above
+# both sides of CJ_FUSED_MAX_CHUNKS (16 384): parse + decode in one kernel below it, parse pass + workgroup decoder above
 PIPELINE_BATCHES = [8192 + 37, 24576 + 41]
 
 

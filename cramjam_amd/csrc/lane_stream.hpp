@@ -53,23 +53,34 @@ struct LaneStream {
         asm volatile("ds_read2_b32 %0, %1 offset1:1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(ring + (p & (kRingBytes - 4u))) : "memory");
         return __builtin_amdgcn_alignbyte((uint32_t)(w >> 32), (uint32_t)w, p & 3u);
     }
-    // two positions under one wait (the parse kernels: a sequence's offset field and the NEXT sequence's token — where that token sits
-    // follows from the current token alone, so a sequence costs one dependent LDS round trip instead of two)
-    __device__ __forceinline__ void ring32x2(uint32_t p, uint32_t q, uint32_t& vp, uint32_t& vq) const {
-        uint64_t w, x;
-        asm volatile("ds_read2_b32 %0, %2 offset1:1\n\tds_read2_b32 %1, %3 offset1:1\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(w), "=&v"(x) : "v"(ring + (p & (kRingBytes - 4u))), "v"(ring + (q & (kRingBytes - 4u))) : "memory");
-        vp = __builtin_amdgcn_alignbyte((uint32_t)(w >> 32), (uint32_t)w, p & 3u);
-        vq = __builtin_amdgcn_alignbyte((uint32_t)(x >> 32), (uint32_t)x, q & 3u);
+    // Two positions under one wait (the parse kernels: a sequence's offset field and the NEXT sequence's token — where that token sits
+    // follows from the current token alone, so a sequence costs one dependent LDS round trip instead of two), as request + arrival: what
+    // does not depend on the bytes (window tests, output margins) is written between the two and runs during the round trip.  (As plain
+    // LDS loads the compiler issued the two reads a block apart, each with its own wait.)
+    struct Pair { uint64_t w, x; };
+    __device__ __forceinline__ Pair ring32x2_request(uint32_t p, uint32_t q) const {
+        Pair r;
+        asm volatile("ds_read2_b32 %0, %2 offset1:1\n\tds_read2_b32 %1, %3 offset1:1"
+                     : "=&v"(r.w), "=&v"(r.x) : "v"(ring + (p & (kRingBytes - 4u))), "v"(ring + (q & (kRingBytes - 4u))) : "memory");
+        return r;
+    }
+    __device__ __forceinline__ void ring32x2_arrive(Pair r, uint32_t p, uint32_t q, uint32_t& vp, uint32_t& vq) const {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.w), "+v"(r.x) :: "memory");
+        vp = __builtin_amdgcn_alignbyte((uint32_t)(r.w >> 32), (uint32_t)r.w, p & 3u);
+        vq = __builtin_amdgcn_alignbyte((uint32_t)(r.x >> 32), (uint32_t)r.x, q & 3u);
     }
     // 8 bytes at p (three dwords of the ring; the Snappy parse: a copy element and the tag bytes of the record behind it)
-    __device__ __forceinline__ void ring64(uint32_t p, uint32_t& lo8, uint32_t& hi8) const {
-        uint64_t w;
-        uint32_t w2;
-        asm volatile("ds_read2_b32 %0, %2 offset1:1\n\tds_read_b32 %1, %2 offset:8\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(w), "=&v"(w2) : "v"(ring + (p & (kRingBytes - 4u))) : "memory");
-        lo8 = __builtin_amdgcn_alignbyte((uint32_t)(w >> 32), (uint32_t)w, p & 3u);
-        hi8 = __builtin_amdgcn_alignbyte(w2, (uint32_t)(w >> 32), p & 3u);
+    struct Trio { uint64_t w; uint32_t w2; };
+    __device__ __forceinline__ Trio ring64_request(uint32_t p) const {
+        Trio r;
+        asm volatile("ds_read2_b32 %0, %2 offset1:1\n\tds_read_b32 %1, %2 offset:8"
+                     : "=&v"(r.w), "=&v"(r.w2) : "v"(ring + (p & (kRingBytes - 4u))) : "memory");
+        return r;
+    }
+    __device__ __forceinline__ void ring64_arrive(Trio r, uint32_t p, uint32_t& lo8, uint32_t& hi8) const {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.w), "+v"(r.w2) :: "memory");
+        lo8 = __builtin_amdgcn_alignbyte((uint32_t)(r.w >> 32), (uint32_t)r.w, p & 3u);
+        hi8 = __builtin_amdgcn_alignbyte(r.w2, (uint32_t)(r.w >> 32), p & 3u);
     }
 };
 

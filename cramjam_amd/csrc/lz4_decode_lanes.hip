@@ -104,11 +104,15 @@ __global__ __launch_bounds__(64 * kParseWaves) void lz4_parse_kernel(BatchArgs a
             if (ballot64(urgent) == 0ull) break;
             refill_round(st, want, wave_ring, plan);
         }
+        // A trip takes at most eight consecutive sequences of a lane, so at most ONE of them starts a sync group: it is only noted where
+        // it occurs (three selects) and handed to the sync batch once, at the end of the trip — put() is a branch with a dozen moves and
+        // the group's stores behind it, and some lane of the wave is at a multiple of 8 in nearly every step.
+        bool sp_hit = false;
+        uint32_t sp_ip = 0, sp_op = 0, sp_slot = 0;
         if (!done) {
             // one sequence; mirrors lz4_lane_walk<false> with reads through the line cache
-            if ((nseq % kSyncEvery) == 0u) {
-                sb.put(csync, nseq / kSyncEvery, make_uint2(ip - mis, op));
-            }
+            sp_hit = (nseq % kSyncEvery) == 0u;
+            sp_ip = ip - mis; sp_op = op; sp_slot = nseq / kSyncEvery;
             nseq += 1;
         }
         // ---- the common case as straight-line code: token and offset both in the line cache, length extensions of at most one
@@ -132,14 +136,16 @@ __global__ __launch_bounds__(64 * kParseWaves) void lz4_parse_kernel(BatchArgs a
             const uint32_t mc = token & 15u;
             const bool x2 = mc == 15u;
             const uint32_t ip3 = ip2 + (x2 ? 3u : 2u);
-            uint32_t o4, t4n;
-            st.ring32x2(ip2, ip3, o4, t4n);
-            const uint32_t offset = o4 & 0xffffu, e2 = (o4 >> 16) & 0xffu;
-            const uint32_t op2 = op + lit, op3 = op2 + mc + (x2 ? e2 : 0u) + 4u;
+            const LaneStream::Pair rq = st.ring32x2_request(ip2, ip3);
             // (bitwise: as a chain of && this compiles to nested branches, four or five per sequence)
-            const bool ok = ip_low_ok & ((int32_t)(ip + 4u) <= (int32_t)win_end) & ((int32_t)ip2 <= ip2_max)
-                            & !(x1 & (e1 == 255u)) & !(x2 & (e2 == 255u))
-                            & ((int32_t)(op2 + 12u) <= (int32_t)cap) & ((int32_t)(op3 + 5u) <= (int32_t)cap)
+            const uint32_t op2 = op + lit;
+            const bool ok_early = ip_low_ok & ((int32_t)(ip + 4u) <= (int32_t)win_end) & ((int32_t)ip2 <= ip2_max)
+                                  & !(x1 & (e1 == 255u)) & ((int32_t)(op2 + 12u) <= (int32_t)cap);
+            uint32_t o4, t4n;
+            st.ring32x2_arrive(rq, ip2, ip3, o4, t4n);
+            const uint32_t offset = o4 & 0xffffu, e2 = (o4 >> 16) & 0xffu;
+            const uint32_t op3 = op2 + mc + (x2 ? e2 : 0u) + 4u;
+            const bool ok = ok_early & !(x2 & (e2 == 255u)) & ((int32_t)(op3 + 5u) <= (int32_t)cap)
                             & (offset != 0u) & (offset <= op2 + hist);
             return FastSeq{ok, ip3, op3, t4n};
         };
@@ -159,13 +165,17 @@ __global__ __launch_bounds__(64 * kParseWaves) void lz4_parse_kernel(BatchArgs a
 #ifndef CJ_PARSE_EXTRA
 #define CJ_PARSE_EXTRA 7
 #endif
+        static_assert(CJ_PARSE_EXTRA + 1 <= (int)kSyncEvery, "a trip must not cross two sync groups: the deferred put holds one");
         bool more = fast_ok;                          // (fast_ok itself still says whether the FIRST sequence needs the general walk below)
+#pragma unroll
         for (int rep = 0; rep < CJ_PARSE_EXTRA; rep++) {
             if (ballot64(more) == 0ull) break;
             if (more) {
                 const FastSeq f = fast_seq(t4_next);
                 if (f.ok) {
-                    if ((nseq % kSyncEvery) == 0u) sb.put(csync, nseq / kSyncEvery, make_uint2(ip - mis, op));
+                    const bool hit = (nseq % kSyncEvery) == 0u;
+                    sp_ip = hit ? ip - mis : sp_ip; sp_op = hit ? op : sp_op; sp_slot = hit ? nseq / kSyncEvery : sp_slot;
+                    sp_hit = sp_hit | hit;
                     nseq += 1;
                     ip = f.ip3; op = f.op3;
                 }
@@ -231,6 +241,7 @@ __global__ __launch_bounds__(64 * kParseWaves) void lz4_parse_kernel(BatchArgs a
                 }
             }
         }
+        if (sp_hit) sb.put(csync, sp_slot, make_uint2(sp_ip, sp_op));
     }
     if (exists) {
         sb.flush(csync, (nseq + kSyncEvery - 1u) / kSyncEvery);

@@ -282,10 +282,13 @@ __global__ __launch_bounds__(64 * kParseWaves) void snappy_parse_kernel(BatchArg
             if (ballot64(urgent) == 0ull) break;
             refill_round(st, want, wave_ring, plan);
         }
+        // (at most one of a trip's eight records starts a sync group: noted where it occurs, handed to the sync batch at the trip's end —
+        //  lz4_parse_kernel)
+        bool sp_hit = false;
+        uint32_t sp_ip = 0, sp_op = 0, sp_slot = 0;
         if (!done) {
-            if ((nrec % kSyncEvery) == 0u) {
-                sb.put(csync, nrec / kSyncEvery, make_uint2(ip - mis, op));
-            }
+            sp_hit = (nrec % kSyncEvery) == 0u;
+            sp_ip = ip - mis; sp_op = op; sp_slot = nrec / kSyncEvery;
             nrec += 1;
         }
         // ---- the common record as straight-line code (same idea as in lz4_parse_kernel): an optional literal with a one- or
@@ -302,16 +305,18 @@ __global__ __launch_bounds__(64 * kParseWaves) void snappy_parse_kernel(BatchArg
             const uint32_t lhdr = is_lit ? (l6 == 60u ? 2u : 1u) : 0u;
             const uint32_t lit_len = is_lit ? (l6 == 60u ? ((t4 >> 8) & 0xffu) + 1u : l6 + 1u) : 0u;
             const uint32_t ip2 = ip + lhdr + lit_len;                        // the copy element
+            const LaneStream::Trio rq = st.ring64_request(ip2);
+            const uint32_t op2 = op + lit_len;
+            // (bitwise: a chain of && compiles to nested branches)
+            const bool ok_early = ip_low_ok & (ip + 4u <= win_end) & (ip2 + 4u <= win_end) & !(is_lit & (l6 > 60u)) & (lit_len <= dn - op);
             uint32_t c4, c8;
-            st.ring64(ip2, c4, c8);
+            st.ring64_arrive(rq, ip2, c4, c8);
             const uint32_t ctag = c4 & 0xffu, kind = ctag & 3u;
             const uint32_t clen = kind == 1u ? 4u + ((ctag >> 2) & 7u) : 1u + (ctag >> 2);
             const uint32_t offset = kind == 1u ? ((ctag >> 5) << 8) | ((c4 >> 8) & 0xffu) : (c4 >> 8) & 0xffffu;
-            const uint32_t ip3 = ip2 + (kind == 1u ? 2u : 3u), op2 = op + lit_len;
+            const uint32_t ip3 = ip2 + (kind == 1u ? 2u : 3u);
             const uint32_t t4n = __builtin_amdgcn_alignbyte(c8, c4, kind == 1u ? 2u : 3u);
-            // (bitwise: a chain of && compiles to nested branches)
-            const bool ok = ip_low_ok & (ip + 4u <= win_end) & (ip2 + 4u <= win_end) & !(is_lit & (l6 > 60u)) & ((kind == 1u) | (kind == 2u))
-                            & (lit_len <= dn - op) & (offset != 0u) & (offset <= op2) & (clen <= dn - op2) & (ip3 < iend);
+            const bool ok = ok_early & ((kind == 1u) | (kind == 2u)) & (offset != 0u) & (offset <= op2) & (clen <= dn - op2) & (ip3 < iend);
             return FastRec{ok, ip3, op2 + clen, t4n};
         };
         bool fast_ok = false;
@@ -326,13 +331,17 @@ __global__ __launch_bounds__(64 * kParseWaves) void snappy_parse_kernel(BatchArg
 #ifndef CJ_SN_PARSE_EXTRA
 #define CJ_SN_PARSE_EXTRA 7
 #endif
+        static_assert(CJ_SN_PARSE_EXTRA + 1 <= (int)kSyncEvery, "a trip must not cross two sync groups: the deferred put holds one");
         bool more = fast_ok;
+#pragma unroll
         for (int rep = 0; rep < CJ_SN_PARSE_EXTRA; rep++) {
             if (ballot64(more) == 0ull) break;
             if (more) {
                 const FastRec f = fast_rec(t4_next);
                 if (f.ok) {
-                    if ((nrec % kSyncEvery) == 0u) sb.put(csync, nrec / kSyncEvery, make_uint2(ip - mis, op));
+                    const bool hit = (nrec % kSyncEvery) == 0u;
+                    sp_ip = hit ? ip - mis : sp_ip; sp_op = hit ? op : sp_op; sp_slot = hit ? nrec / kSyncEvery : sp_slot;
+                    sp_hit = sp_hit | hit;
                     nrec += 1;
                     ip = f.ip3; op = f.op3;
                 }
@@ -352,6 +361,7 @@ __global__ __launch_bounds__(64 * kParseWaves) void snappy_parse_kernel(BatchArg
                 }
             }
         }
+        if (sp_hit) sb.put(csync, sp_slot, make_uint2(sp_ip, sp_op));
     }
     if (exists) {
         sb.flush(csync, (nrec + kSyncEvery - 1u) / kSyncEvery);

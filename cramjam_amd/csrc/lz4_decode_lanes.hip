@@ -12,6 +12,7 @@
 //                             decoder cannot take (capacity > 64 KiB, > 16 384 sequences) are routed to the wavefront kernel.
 #include "lz4_lane_walk.hpp"
 #include "lane_stream.hpp"
+#include <cstdlib>
 
 namespace cj {
 

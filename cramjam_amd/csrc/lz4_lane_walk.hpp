@@ -50,9 +50,12 @@ struct SyncBatch {
     __device__ __forceinline__ void flush(uint2* csync, uint32_t n) {
         const uint32_t k = n & 3u, base = n & ~3u;
         if (base >= kSyncStride) return;
-        if (k >= 1u) csync[base] = k == 1u ? make_uint2(x3, y3) : k == 2u ? make_uint2(x2, y2) : make_uint2(x1, y1);
-        if (k >= 2u) csync[base + 1u] = k == 2u ? make_uint2(x3, y3) : make_uint2(x2, y2);
-        if (k >= 3u) csync[base + 2u] = make_uint2(x3, y3);
+        // (values first, then the selects: a conditional between MEMBERS becomes a select of addresses, and a batch that lives inside a
+        //  larger object is then never split into registers — seen as 552 bytes of scratch in the dual parse kernel)
+        const uint32_t a1 = x1, b1 = y1, a2 = x2, b2 = y2, a3 = x3, b3 = y3;
+        if (k >= 1u) csync[base] = make_uint2(k == 1u ? a3 : k == 2u ? a2 : a1, k == 1u ? b3 : k == 2u ? b2 : b1);
+        if (k >= 2u) csync[base + 1u] = make_uint2(k == 2u ? a3 : a2, k == 2u ? b3 : b2);
+        if (k >= 3u) csync[base + 2u] = make_uint2(a3, b3);
     }
 };
 

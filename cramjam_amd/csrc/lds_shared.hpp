@@ -33,6 +33,13 @@ __device__ __forceinline__ uint32_t lds_ld32a(uint32_t a) {
     asm volatile("ds_read2_b32 %0, %1 offset1:1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a & ~3u) : "memory");
     return __builtin_amdgcn_alignbyte((uint32_t)(v >> 32), (uint32_t)v, a & 3u);
 }
+// 8 bytes at any byte address as three aligned dwords (x = bytes 0..3, y = bytes 4..7); may read up to 4 bytes past them
+__device__ __forceinline__ uint2 lds_ld64a(uint32_t a) {
+    uint64_t v;
+    uint32_t v2;
+    asm volatile("ds_read2_b32 %0, %2 offset1:1\n\tds_read_b32 %1, %2 offset:8\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v), "=&v"(v2) : "v"(a & ~3u) : "memory");
+    return make_uint2(__builtin_amdgcn_alignbyte((uint32_t)(v >> 32), (uint32_t)v, a & 3u), __builtin_amdgcn_alignbyte(v2, (uint32_t)(v >> 32), a & 3u));
+}
 __device__ __forceinline__ uint2 lds_ld64(uint32_t a) {
     uint2 v;
     asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:4\n\ts_waitcnt lgkmcnt(0)"

@@ -60,6 +60,9 @@ constexpr uint32_t kL2Bytes = kL2OffVars + 384 + 128;      // 74880 B (the last 
 #define CJ_D2_LONG 256u
 #endif
 constexpr uint32_t kD2LongRun = CJ_D2_LONG;      // literal runs at least this long are placed by the whole wavefront (512 / 256 / 128: x-ray 249.8 / 262.4 / 262.5 GB/s, whole corpus 212.5 / 213.8 / 213.6)
+#ifndef CJ_SN_D1_FAST
+#define CJ_SN_D1_FAST 1
+#endif
 #ifndef CJ_DENSE_LANES
 #define CJ_DENSE_LANES 24u
 #endif
@@ -499,12 +502,42 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 uint32_t ip = p.x, op = p.y;
                 uint32_t s = sp * kSyncEvery;
                 uint32_t near = 0;
+#if CJ_SN_D1_FAST
+                // The common record — an optional literal with a one-byte header, then a copy with a 1- or 2-byte offset — as straight-line
+                // code with ONE dependent LDS read: the copy element is read as 8 bytes, and the tag of the record behind it (2 or 3 bytes
+                // further) comes with it (snappy_parse_kernel's fast_rec without its checks: the parse accepted this stream).  Every other
+                // shape takes snappy_record_step from the same state.
+                uint32_t t4 = rd(ip);
+                for (uint32_t j = 0; j < kSyncEvery && s < nseq; j++, s++) {
+                    const uint32_t tag = t4 & 0xffu, l6 = tag >> 2;
+                    const bool is_lit = (tag & 3u) == 0u;
+                    const uint32_t lhdr = is_lit ? 1u : 0u, lit_len = is_lit ? l6 + 1u : 0u;
+                    const uint32_t ip2 = ip + lhdr + lit_len;
+                    const uint2 c8 = lds_ld64a(a_in + ip2);
+                    const uint32_t ctag = c8.x & 0xffu, kind = ctag & 3u;
+                    const bool fast = !(is_lit & (l6 >= 60u)) & ((kind == 1u) | (kind == 2u)) & (ip2 < iend);
+                    SnRecord rec;
+                    if (fast) {
+                        const uint32_t clen = kind == 1u ? 4u + ((ctag >> 2) & 7u) : 1u + (ctag >> 2);
+                        const uint32_t offset = kind == 1u ? ((ctag >> 5) << 8) | ((c8.x >> 8) & 0xffu) : (c8.x >> 8) & 0xffffu;
+                        rec.lit_src = is_lit ? ip + 1u : 0u; rec.lit_len = lit_len; rec.dst = op + lit_len; rec.w = offset | (clen << 16);
+                        ip = ip2 + (kind == 1u ? 2u : 3u); op = rec.dst + clen;
+                        t4 = __builtin_amdgcn_alignbyte(c8.y, c8.x, kind == 1u ? 2u : 3u);
+                    } else {
+                        (void)snappy_record_step(rd, ip, op, iend, U, rec);     // the parse kernel accepted this stream
+                        t4 = rd(ip);
+                    }
+                    rec_store(s, rec.lit_src, rec.lit_len, rec.dst, rec.w);
+                    near += (rec.w != 0u && (rec.w & 0xffffu) < kFwdNear) ? 1u : 0u;
+                }
+#else
                 for (uint32_t j = 0; j < kSyncEvery && s < nseq; j++, s++) {
                     SnRecord rec;
                     (void)snappy_record_step(rd, ip, op, iend, U, rec);     // the parse kernel accepted this stream
                     rec_store(s, rec.lit_src, rec.lit_len, rec.dst, rec.w);
                     near += (rec.w != 0u && (rec.w & 0xffffu) < kFwdNear) ? 1u : 0u;
                 }
+#endif
                 if (near) atomicAdd(s_small, near);
             }
         } else

@@ -60,6 +60,9 @@ constexpr uint32_t kL2Bytes = kL2OffVars + 384 + 128;      // 74880 B (the last 
 #define CJ_D2_LONG 256u
 #endif
 constexpr uint32_t kD2LongRun = CJ_D2_LONG;      // literal runs at least this long are placed by the whole wavefront (512 / 256 / 128: x-ray 249.8 / 262.4 / 262.5 GB/s, whole corpus 212.5 / 213.8 / 213.6)
+#ifndef CJ_D3_MASK64
+#define CJ_D3_MASK64 1
+#endif
 #ifndef CJ_SN_D1_FAST
 #define CJ_SN_D1_FAST 1
 #endif
@@ -910,6 +913,14 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 const bool fast = pending && m >= 4u && m <= 32u && off >= m;
                 S.pa = 0; S.pm0 = 0; S.pm1 = 0; S.qa = 0; S.qm0 = 0; S.qm1 = 0;
                 if (fast) {
+#if CJ_D3_MASK64
+                    // (need, m in 4 .. 32: the run of bits as one 64-bit shift — two instructions per mask instead of nine)
+                    const uint64_t pmask = (~0ull >> (64u - need)) << (src & 31u), qmask = (~0ull >> (64u - m)) << (dst & 31u);
+                    S.pa = (uint32_t)(uintptr_t)(s_bits + (src >> 5));
+                    S.pm0 = (uint32_t)pmask; S.pm1 = (uint32_t)(pmask >> 32);
+                    S.qa = (uint32_t)(uintptr_t)(s_bits + (dst >> 5));
+                    S.qm0 = (uint32_t)qmask; S.qm1 = (uint32_t)(qmask >> 32);
+#else
                     const uint32_t sh = src & 31u, e = sh + need;
                     S.pa = (uint32_t)(uintptr_t)(s_bits + (src >> 5));
                     S.pm0 = (e >= 32u ? ~0u : ((1u << e) - 1u)) & (~0u << sh);
@@ -918,6 +929,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                     S.qa = (uint32_t)(uintptr_t)(s_bits + (dst >> 5));
                     S.qm0 = (de >= 32u ? ~0u : ((1u << de) - 1u)) & (~0u << dh);
                     S.qm1 = de > 32u ? ((1u << (de - 32u)) - 1u) : 0u;
+#endif
                 }
                 // copy plan: pieces at [0] and [m - 8] (m >= 8; 8 bytes each), or [0] and [m - 4] (m < 8; 4 bytes each); m > 16: also [8], [m - 16]
                 S.as0 = a_out + src; S.ad0 = a_out + dst;

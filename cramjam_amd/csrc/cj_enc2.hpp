@@ -1,0 +1,390 @@
+// cj_enc2.hpp — the round-based LZ77 matcher of the LZ4-block and Snappy-raw encoders (gfx950, one wavefront per chunk).
+//
+// What a round does (tests/hostsim/enc2_model.c states the same thing as scalar C; the kernels emit exactly its bytes):
+//   probe    kR consecutive positions — lane l owns the FOUR CONSECUTIVE positions 4 l .. 4 l + 3 of every group of 256, so two
+//            dwords per lane yield the four position dwords with three v_alignbyte — against the 8192 x u16 hash table as it was
+//            when the round began: hash, table read, candidate dword, compare.  Straight-line code, no branches.
+//   heads    a verified position whose left neighbour is verified with the SAME offset lies inside its neighbour's match: only
+//            the first position of such a run (its head) is a candidate.  On match-heavy data half of all positions verify and
+//            one in fifteen is a head; the heads are compacted into consecutive lanes (ranks from v_mbcnt, a 256-byte LDS list).
+//   extend   ONE pass over the compacted heads measures every candidate forwards (4 + 64 bytes at most, 16-byte blocks) and
+//            backwards (16 bytes) — the previous matcher ran this code once per 64 positions with a lane or two active.
+//   select   greedy walk over the heads in position order: the first head whose interval still has four bytes past the end of the
+//            previous match wins (a head the previous match ran over still offers its tail).  The chain carries `cur` only:
+//            v_cmp + s_ff1 + v_readlane + v_writelane per selected match; starts, lengths and sizes follow lane-parallel.
+//   queue    selected sequences are appended to a 64-entry queue in LDS and emitted lane-parallel when it is full — one emission
+//            pass per ~64 sequences instead of one per round.
+//   insert   positions that are not strictly inside an emitted match (its last kTail positions count as outside) enter the table:
+//            a toggle bitmap in LDS written by the selected lanes, read back as a parity prefix by the position lanes.
+// Windows of heads that hold a capped forward extension, a selected literal run of 256 bytes or a selected match of 259 bytes and
+// more are redone by a serial cooperative path (same decisions, whole-wave extension and emission).
+#pragma once
+#include "cj_match.hpp"
+
+#if defined(__HIPCC__)
+// v_writelane_b32: clang has no builtin for it; a declaration with the intrinsic's name as its assembler name is lowered to the
+// intrinsic (the compiler then also places the hazard no-ops a hand-written instruction would need)
+extern "C" __device__ int cj_llvm_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+#endif
+
+namespace cj {
+#if defined(__HIPCC__)
+namespace enc2 {
+
+#ifndef CJ_ENC2_GROUPS
+#define CJ_ENC2_GROUPS 1
+#endif
+constexpr int kG = CJ_ENC2_GROUPS;                  // groups of 256 positions per round
+constexpr uint32_t kR = 256u * kG;
+constexpr uint32_t kTail = 2u;                      // the last kTail positions of a match are inserted (text +1..4 %, benchmark data -0.4 % against none)
+constexpr uint32_t kQueueCap = 64u;
+// LDS scratch of one wavefront, in dwords: heads [0, 64) · toggle bitmap [64, 64 + kR / 32 + 1) · queue [96, 96 + 128)
+constexpr uint32_t kScratchWords = 256u;
+constexpr uint32_t kHeadsAt = 0u, kTogAt = 64u, kQueueAt = 96u;
+static_assert(kTogAt + kR / 32u + 1u <= kQueueAt && kQueueAt + 2u * kQueueCap <= kScratchWords, "scratch layout");
+constexpr uint32_t kFwdBlocks = 4u;                 // forward measurement cap: 4 + 64 bytes, longer matches are finished cooperatively
+constexpr uint32_t kFlagFwdMore = 1u, kFlagBackMore = 2u;
+constexpr uint32_t kMaxLit = 256u, kMaxCode = 255u; // a queue entry packs lit < 256 and mlen - 4 < 255 into a byte each
+
+__device__ __forceinline__ uint32_t g32(const uint8_t* b, uint32_t off) { uint32_t v; __builtin_memcpy(&v, b + off, 4); return v; }
+__device__ __forceinline__ uint2 g64(const uint8_t* b, uint32_t off) { uint2 v; __builtin_memcpy(&v, b + off, 8); return v; }
+__device__ __forceinline__ uint4 g128(const uint8_t* b, uint32_t off) { uint4 v; __builtin_memcpy(&v, b + off, 16); return v; }
+__device__ __forceinline__ void s8(uint8_t* b, uint32_t off, uint32_t v) { b[off] = (uint8_t)v; }
+__device__ __forceinline__ void s32(uint8_t* b, uint32_t off, uint32_t v) { __builtin_memcpy(b + off, &v, 4); }
+__device__ __forceinline__ void s64(uint8_t* b, uint32_t off, uint2 v) { __builtin_memcpy(b + off, &v, 8); }
+__device__ __forceinline__ void s128(uint8_t* b, uint32_t off, uint4 v) { __builtin_memcpy(b + off, &v, 16); }
+
+// v_ffbl_b32 / v_ffbh_u32 as the hardware defines them: ~0 for a zero operand (the C builtins are undefined there, and a
+// select around them costs a compare and a v_cndmask per dword)
+__device__ __forceinline__ uint32_t ffbl_raw(uint32_t x) { uint32_t r; asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+__device__ __forceinline__ uint32_t ffbh_raw(uint32_t x) { uint32_t r; asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+// index of the first differing byte of two 16-byte blocks (16: none), branch-free: OR-ing the dword's bit offset into ~0 keeps
+// ~0, so an unsigned minimum picks the first dword that differs
+__device__ __forceinline__ uint32_t first_diff(const uint4& x, const uint4& y) {
+    const uint32_t b0 = ffbl_raw(x.x ^ y.x), b1 = ffbl_raw(x.y ^ y.y) | 32u, b2 = ffbl_raw(x.z ^ y.z) | 64u, b3 = ffbl_raw(x.w ^ y.w) | 96u;
+    return umin(umin(umin(b0, b1), umin(b2, b3)) >> 3, 16u);
+}
+// equal bytes counted from the END of two 16-byte blocks (16: all)
+__device__ __forceinline__ uint32_t last_same(const uint4& x, const uint4& y) {
+    const uint32_t b3 = ffbh_raw(x.w ^ y.w), b2 = ffbh_raw(x.z ^ y.z) | 32u, b1 = ffbh_raw(x.y ^ y.y) | 64u, b0 = ffbh_raw(x.x ^ y.x) | 96u;
+    return umin(umin(umin(b0, b1), umin(b2, b3)) >> 3, 16u);
+}
+
+// exact n-byte copy by ONE lane, n < 256 (a queued literal run): 16-byte blocks, then the remainder as two overlapping pieces
+// of the largest power of two that fits (the second one ends exactly at n) — never a byte beyond [0, n) on either side
+__device__ __forceinline__ void lane_copy(uint8_t* out, uint32_t o, const uint8_t* in, uint32_t i, uint32_t n) {
+    if (n >= 16u) {
+        for (uint32_t k = 0; k + 16u <= n; k += 16u) s128(out, o + k, g128(in, i + k));
+        s128(out, o + n - 16u, g128(in, i + n - 16u));
+    } else if (n >= 8u) {
+        const uint2 a = g64(in, i), b = g64(in, i + n - 8u);
+        s64(out, o, a); s64(out, o + n - 8u, b);
+    } else if (n >= 4u) {
+        const uint32_t a = g32(in, i), b = g32(in, i + n - 4u);
+        s32(out, o, a); s32(out, o + n - 4u, b);
+    } else if (n > 0u) {
+        const uint32_t a = in[i], b = in[i + (n >> 1)], c = in[i + n - 1u];
+        s8(out, o, a); s8(out, o + (n >> 1), b); s8(out, o + n - 1u, c);
+    }
+}
+
+// The per-wavefront state of one chunk's walk.  Fmt supplies the stream format:
+//   Fmt::last_start(n), Fmt::limit(n)          last position a match may start at / must end by
+//   Fmt::seq_size(lit, code, off)               encoded bytes of one queued sequence (code = mlen - 4)
+//   Fmt::emit_lane(in, out, o, lit0, lit, code, off)   one lane writes one queued sequence at output offset o
+//   Fmt::emit_wave(in, out, op, lit0, lit, off, mlen) -> new op   the whole wavefront writes one sequence of any size
+template <class Fmt, bool kGlobalTable>
+struct Walk {
+    const uint8_t* in;      // position 0 (start of the piece)
+    uint8_t* out;
+    uint32_t n;             // end of this wavefront's range
+    uint32_t last_start, limit;
+    uint32_t* scr;          // kScratchWords dwords of LDS
+    HashTab<kGlobalTable> ht;
+    uint32_t op;            // output position after the last EMITTED sequence (queued ones are not counted yet)
+    uint32_t q_n;           // queued sequences
+
+    __device__ __forceinline__ void flush() {
+        if (q_n == 0u) return;
+        const uint32_t lane = lane_id();
+        const bool on = lane < q_n;
+        const uint32_t lit0 = scr[kQueueAt + 2u * lane], pk = scr[kQueueAt + 2u * lane + 1u];
+        const uint32_t off = pk & 0xffffu, lit = (pk >> 16) & 0xffu, code = pk >> 24;
+        uint32_t total;
+        const uint32_t before = wave_excl_add(on ? Fmt::seq_size(lit, code, off) : 0u, total);
+        if (on) Fmt::emit_lane(in, out, op + before, lit0, lit, code, off);
+        op += total;
+        q_n = 0u;
+    }
+
+    // one round over [pos, pos + span); cur = end of the last selected match on entry and exit
+    __device__ __forceinline__ void round(uint32_t pos, uint32_t span, const uint32_t (&D0)[kG], const uint32_t (&D1)[kG], uint32_t& cur) {
+        const uint32_t lane = lane_id();
+        const uint32_t round_last = umin(last_start, pos + span - 1u);
+        // ---- probe ----
+        uint32_t hs[kG][4], dd[kG][4];
+        {
+            uint32_t v[kG][4], t[kG][4];
+#pragma unroll
+            for (int g = 0; g < kG; g++) {
+                v[g][0] = D0[g];
+                v[g][1] = __builtin_amdgcn_alignbyte(D1[g], D0[g], 1);
+                v[g][2] = __builtin_amdgcn_alignbyte(D1[g], D0[g], 2);
+                v[g][3] = __builtin_amdgcn_alignbyte(D1[g], D0[g], 3);
+#pragma unroll
+                for (int k = 0; k < 4; k++) { hs[g][k] = hash_slot(v[g][k]); t[g][k] = ht.get(hs[g][k]); }
+            }
+            uint32_t w[kG][4], c[kG][4];
+            bool okd[kG][4];
+#pragma unroll
+            for (int g = 0; g < kG; g++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t p = pos + 256u * g + 4u * lane + k;
+                    const uint32_t d = (p - t[g][k]) & 0xffffu;          // distance to the slot's position, modulo the 64 KiB lap
+                    okd[g][k] = d != 0u && d <= p && p <= round_last;
+                    dd[g][k] = d;
+                    c[g][k] = okd[g][k] ? p - d : 0u;
+                    w[g][k] = g32(in, c[g][k]);                          // every lane loads (position 0 when there is no candidate): no branch
+                }
+#pragma unroll
+            for (int g = 0; g < kG; g++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) dd[g][k] = (okd[g][k] && w[g][k] == v[g][k]) ? dd[g][k] : 0u;      // 0 = not verified
+        }
+        // ---- heads: verified, and the left neighbour is not verified with the same offset ----
+        uint64_t hm[kG][4];
+        uint32_t total_heads = 0;
+#pragma unroll
+        for (int g = 0; g < kG; g++) {
+            const uint32_t left0 = dpp_from<kDppWaveShr1>(0u, dd[g][3]);            // lane l - 1's last position; lane 0 of a group starts afresh
+            hm[g][0] = ballot64(dd[g][0] != 0u && dd[g][0] != left0);
+            hm[g][1] = ballot64(dd[g][1] != 0u && dd[g][1] != dd[g][0]);
+            hm[g][2] = ballot64(dd[g][2] != 0u && dd[g][2] != dd[g][1]);
+            hm[g][3] = ballot64(dd[g][3] != 0u && dd[g][3] != dd[g][2]);
+#pragma unroll
+            for (int k = 0; k < 4; k++) total_heads += (uint32_t)__builtin_popcountll(hm[g][k]);
+        }
+        // toggle bitmap of this round: cleared before the first window writes into it
+        if (lane < kR / 32u + 1u) scr[kTogAt + lane] = 0u;
+        // ---- windows of up to 64 heads in position order ----
+        for (uint32_t w0 = 0; w0 < total_heads; w0 += 64u) {
+            {   // ranks: heads of earlier groups, of lower lanes of this group, of this lane's lower positions
+                uint32_t base = 0;
+#pragma unroll
+                for (int g = 0; g < kG; g++) {
+                    uint32_t r = base;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) r += bits_below_lane(hm[g][k]);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const bool h = ((hm[g][k] >> lane) & 1ull) != 0ull;
+                        if (h && r - w0 < 64u) scr[kHeadsAt + r - w0] = (dd[g][k] << 16) | (256u * g + 4u * lane + k);
+                        r += h ? 1u : 0u;
+                        base += (uint32_t)__builtin_popcountll(hm[g][k]);
+                    }
+                }
+            }
+            const uint32_t mw = umin(total_heads - w0, 64u);
+            const bool is_head = lane < mw;
+            const uint32_t hv = is_head ? scr[kHeadsAt + lane] : (1u << 16);
+            const uint32_t P = pos + (hv & 0xffffu), d = hv >> 16, C = P - d;
+            // ---- forward: equal bytes after the four verified ones ----
+            uint32_t fwd = 0;
+            bool more = is_head;
+            const uint32_t a = P + 4u;
+            for (uint32_t it = 0; it < kFwdBlocks; it++) {
+                if (ballot64(more) == 0ull) break;
+                const bool blk = more && a + fwd + 16u <= n;
+                uint4 x = make_uint4(0, 0, 0, 0), y = make_uint4(0, 0, 0, 1);
+                if (blk) { x = g128(in, a + fwd); y = g128(in, a + fwd - d); }
+                if (more && !blk) {                                  // within 16 bytes of the end of the input: byte by byte
+                    while (a + fwd < limit && in[a + fwd] == in[a + fwd - d]) fwd += 1u;
+                    more = false;
+                }
+                if (blk) {
+                    const uint32_t e = first_diff(x, y);
+                    fwd += e;
+                    more = e == 16u;
+                }
+            }
+            if (a + fwd >= limit) { fwd = limit - a; more = false; }      // (a <= limit: P <= last_start)
+            uint32_t E = is_head ? a + fwd : 0u;                     // E = 0: never selected
+            // ---- backward: equal bytes before position and candidate, within the literals pending at the start of the round ----
+            uint32_t back = 0;
+            bool back_more = false;
+            {
+                const uint32_t room = P - cur;                       // P >= pos >= cur
+                const uint32_t blim = umin(room, C);
+                const bool on = is_head && blim > 0u;
+                if (on && C >= 16u) {
+                    const uint32_t sm = last_same(g128(in, P - 16u), g128(in, C - 16u));
+                    back = umin(sm, blim);
+                    back_more = sm == 16u && blim > 16u;
+                } else if (on) {                                     // candidate within the first 16 bytes of the piece
+                    while (back < blim && in[P - 1u - back] == in[C - 1u - back]) back += 1u;
+                }
+            }
+            const uint32_t BS = P - back;
+            const uint64_t fwd_more_mask = ballot64(is_head && more);
+            // ---- greedy walk: the chain carries `cur` only ----
+            const uint32_t cur0 = cur;
+            uint64_t sel = 0ull;
+            uint32_t PE = 0u;
+            bool slow = fwd_more_mask != 0ull;
+            if (!slow) {
+                for (;;) {
+                    if (cur > last_start) break;
+                    const uint64_t m = ballot64(E >= cur + 4u);
+                    if (m == 0ull) break;
+                    const uint32_t first = ctz64(m);
+                    PE = (uint32_t)cj_llvm_writelane((int)cur, (int)first, (int)PE);
+                    sel |= 1ull << first;
+                    cur = rdlane(E, first);
+                }
+                const bool selected = ((sel >> lane) & 1ull) != 0ull;
+                const uint32_t s = umax(BS, PE);
+                const uint32_t lit = s - PE, code = E - s - 4u;
+                const bool needs_wave = selected && (lit >= kMaxLit || code >= kMaxCode || (back_more && P >= PE && P - PE > 16u));
+                slow = ballot64(needs_wave) != 0ull;
+                if (!slow) {
+                    const uint32_t ns = (uint32_t)__builtin_popcountll(sel);
+                    if (q_n + ns > kQueueCap) flush();
+                    if (selected) {
+                        const uint32_t slot = kQueueAt + 2u * (q_n + bits_below_lane(sel));
+                        scr[slot] = PE;
+                        scr[slot + 1u] = d | (lit << 16) | (code << 24);
+                        // coverage toggles: positions s + 1 .. E - kTail - 1 (relative to pos, clamped to the round) are inside this match
+                        const uint32_t sx = s + 1u > pos ? s + 1u - pos : 0u;
+                        const uint32_t ex = umin(E - kTail - pos, kR);                    // E - kTail > s + 1 >= ... may lie before pos: then ex wraps — excluded below
+                        if (E - kTail > pos && ex > sx) {
+                            atomicXor(&scr[kTogAt + (sx >> 5)], 1u << (sx & 31u));
+                            atomicXor(&scr[kTogAt + (ex >> 5)], 1u << (ex & 31u));
+                        }
+                    }
+                    q_n += ns;
+                }
+            }
+            if (slow) {
+                // ---- serial cooperative path: same decisions, extensions finished by the whole wavefront, every selected sequence
+                //      of this window emitted by the whole wavefront ----
+                cur = cur0;
+                const uint32_t flags = (more ? kFlagFwdMore : 0u) | (back_more ? kFlagBackMore : 0u);
+                for (uint32_t i = 0; i < mw; i++) {
+                    if (cur > last_start) break;
+                    const uint32_t Pi = rdlane(P, i), di = rdlane(d, i), fl = rdlane(flags, i);
+                    uint32_t Ei = rdlane(E, i);
+                    if (fl & kFlagFwdMore) Ei += wave_extend(in, Ei, Ei - di, limit);
+                    if (Ei < cur + 4u) continue;
+                    uint32_t s = cur;
+                    if (Pi >= cur) {
+                        const uint32_t room = Pi - cur;
+                        uint32_t bk = umin(Pi - rdlane(BS, i), room);
+                        if ((fl & kFlagBackMore) && bk == 16u && room > 16u) bk += wave_extend_back(in, Pi - 16u, Pi - di - 16u, room - 16u);
+                        s = Pi - bk;
+                    }
+                    flush();
+                    op = Fmt::emit_wave(in, out, op, cur, s - cur, di, Ei - s);
+                    if (lane == 0u) {
+                        const uint32_t sx = s + 1u > pos ? s + 1u - pos : 0u;
+                        const uint32_t ex = umin(Ei - kTail - pos, kR);
+                        if (Ei - kTail > pos && ex > sx) {
+                            scr[kTogAt + (sx >> 5)] ^= 1u << (sx & 31u);
+                            scr[kTogAt + (ex >> 5)] ^= 1u << (ex & 31u);
+                        }
+                    }
+                    cur = Ei;
+                }
+            }
+        }
+        // ---- insert the positions that are not inside an emitted match ----
+        {
+            uint32_t carry = 0;          // parity of the toggles before this group
+#pragma unroll
+            for (int g = 0; g < kG; g++) {
+                const uint32_t word = scr[kTogAt + 8u * g + (lane >> 3)];
+                const uint32_t bits = (word >> (4u * (lane & 7u))) & 15u;
+                const uint32_t pre = bits ^ (bits << 1) ^ (bits << 2) ^ (bits << 3);               // bit k = parity of the toggles at positions 4 l .. 4 l + k
+                const uint64_t odd = ballot64((__builtin_popcount(bits) & 1) != 0);
+                const uint32_t before = (bits_below_lane(odd) + carry) & 1u;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t p = pos + 256u * g + 4u * lane + k;
+                    const bool covered = (((pre >> k) ^ before) & 1u) != 0u;
+                    if (p <= round_last && !covered) ht.set(hs[g][k], p);
+                }
+                carry += (uint32_t)__builtin_popcountll(odd);
+            }
+            ht.settle();
+            if constexpr (kGlobalTable) {
+                // a table in global memory does not order the lanes of a store instruction: read back and let the entry win that the
+                // LDS table would keep — the last instruction (group, k), within it the highest lane
+                for (;;) {
+                    bool again = false;
+                    uint32_t carry2 = 0;
+#pragma unroll
+                    for (int g = 0; g < kG; g++) {
+                        const uint32_t word = scr[kTogAt + 8u * g + (lane >> 3)];
+                        const uint32_t bits = (word >> (4u * (lane & 7u))) & 15u;
+                        const uint32_t pre = bits ^ (bits << 1) ^ (bits << 2) ^ (bits << 3);
+                        const uint64_t odd = ballot64((__builtin_popcount(bits) & 1) != 0);
+                        const uint32_t before = (bits_below_lane(odd) + carry2) & 1u;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const uint32_t rel = 256u * g + 4u * lane + k, p = pos + rel;
+                            const bool covered = (((pre >> k) ^ before) & 1u) != 0u;
+                            if (p <= round_last && !covered) {
+                                const uint32_t there = (ht.get(hs[g][k]) - pos) & 0xffffu;      // the slot holds a position of this round
+                                const uint32_t key_there = ((there >> 8) << 8) | ((there & 3u) << 6) | ((there >> 2) & 63u);
+                                const uint32_t key_mine = ((uint32_t)g << 8) | ((uint32_t)k << 6) | lane;
+                                if (there < kR && key_there < key_mine) { ht.set(hs[g][k], p); again = true; }
+                            }
+                        }
+                        carry2 += (uint32_t)__builtin_popcountll(odd);
+                    }
+                    if (ballot64(again) == 0ull) break;
+                    ht.settle();
+                }
+            }
+        }
+    }
+
+    // the whole range [q0, n): rounds, then the queue; returns the end of the last match (the final literals start there)
+    __device__ __forceinline__ uint32_t run(uint32_t q0) {
+        const uint32_t lane = lane_id();
+        uint32_t pos = q0, cur = q0;
+        uint32_t span = q0 == 0u ? 64u : kR;          // short first rounds while the table is empty (a sub-piece's table is pre-indexed)
+        uint32_t D0[kG], D1[kG], own_pos = ~0u;
+        while (pos <= last_start) {
+            if (own_pos != pos) {
+#pragma unroll
+                for (int g = 0; g < kG; g++) {
+                    const uint32_t b = pos + 256u * g + 4u * lane;
+                    D0[g] = D1[g] = 0u;
+                    if (b <= last_start) { D0[g] = g32(in, b); D1[g] = g32(in, b + 4u); }
+                }
+            }
+            // the next round's dwords travel while this round runs
+            const uint32_t round_end = pos + span;
+            uint32_t N0[kG], N1[kG];
+#pragma unroll
+            for (int g = 0; g < kG; g++) {
+                const uint32_t b = round_end + 256u * g + 4u * lane;
+                N0[g] = N1[g] = 0u;
+                if (b <= last_start) { N0[g] = g32(in, b); N1[g] = g32(in, b + 4u); }
+            }
+            round(pos, span, D0, D1, cur);
+#pragma unroll
+            for (int g = 0; g < kG; g++) { D0[g] = N0[g]; D1[g] = N1[g]; }
+            own_pos = round_end;
+            span = span * 2u < kR ? span * 2u : kR;
+            pos = cur > round_end ? cur : round_end;
+        }
+        flush();
+        return cur;
+    }
+};
+
+}  // namespace enc2
+#endif
+}  // namespace cj

@@ -15,6 +15,7 @@
 #error "cj_match.hpp: the encoders are written for gfx950 (gfx9 wave64: vmcnt-acknowledged stores, DPP row_bcast, DS same-address store order)"
 #endif
 #include "cj_common.hpp"
+#include <cstdlib>
 
 namespace cj {
 #if defined(__HIPCC__)
@@ -535,13 +536,13 @@ static_assert(kHashSize * 2u <= kEncTableBytes, "table slot");
 #define CJ_ENC_TABLE_WAVES_PER_EU 3
 #endif
 template <class Enc, bool kGlobalTable>
-__device__ __forceinline__ void encode_persistent_body(const BatchArgs& a, uint32_t* counter, uint16_t* ht) {
+__device__ __forceinline__ void encode_persistent_body(const BatchArgs& a, uint32_t* counter, uint16_t* ht, uint32_t* scr) {
     for (;;) {
         uint32_t c = 0;
         if (threadIdx.x == 0) c = atomicAdd(counter, 1u);
         const uint32_t chunk = uni(c);                               // lane 0's value (one wavefront per block)
         if (chunk >= a.n_chunks) return;
-        Enc::template chunk<kGlobalTable>(a, chunk, HashTab<kGlobalTable>{ht});
+        Enc::template chunk<kGlobalTable>(a, chunk, HashTab<kGlobalTable>{ht}, scr);
     }
 }
 // (four wavefronts per SIMD as the register target.  The compiler notes that 16 KiB of LDS per block allow only 2.5 per SIMD —
@@ -554,15 +555,20 @@ __device__ __forceinline__ void encode_persistent_body(const BatchArgs& a, uint3
 #endif
 template <class Enc>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CJ_ENC_LDS_WAVES_PER_EU, CJ_ENC_LDS_WAVES_PER_EU))) void encode_lds_blocks_kernel(BatchArgs a, uint32_t* counter) {
-    __shared__ uint16_t ht_lds[kHashSize];                           // exactly 16 KiB: one more word and only nine blocks fit a CU
-    encode_persistent_body<Enc, false>(a, counter, ht_lds);
+    __shared__ uint16_t ht_lds[kHashSize];                           // 16 KiB + the matcher's scratch: nine blocks per CU
+    __shared__ uint32_t scr[Enc::kScratchWords];
+    encode_persistent_body<Enc, false>(a, counter, ht_lds, scr);
 }
 #pragma clang diagnostic pop
 template <class Enc>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CJ_ENC_TABLE_WAVES_PER_EU, CJ_ENC_TABLE_WAVES_PER_EU)))
 void encode_table_blocks_kernel(BatchArgs a, uint32_t* counter, uint16_t* tables) {
-    encode_persistent_body<Enc, true>(a, counter, tables + (size_t)blockIdx.x * (kEncTableBytes / 2u));
+    __shared__ uint32_t scr[Enc::kScratchWords];
+    encode_persistent_body<Enc, true>(a, counter, tables + (size_t)blockIdx.x * (kEncTableBytes / 2u), scr);
 }
+
+// CJ_ENC_V1=1 in the environment: the position-per-lane matcher of rounds 1-4 (A/B runs only)
+inline bool encoder_v1() { static const bool v = [] { const char* e = getenv("CJ_ENC_V1"); return e && e[0] == '1'; }(); return v; }
 
 template <class Enc>
 inline void launch_encode_filled(const BatchArgs& a, hipStream_t s, const EncFill& f) {

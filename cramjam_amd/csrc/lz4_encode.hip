@@ -7,7 +7,7 @@
 // at least 12 bytes before the end, the last 5 bytes are literals, inputs < 13 bytes are one literal
 // run.  Every emitted block decodes with LZ4_decompress_safe at exact capacity (tests check this
 // against the CPU oracle).
-#include "cj_match.hpp"
+#include "cj_enc2.hpp"
 
 namespace cj {
 
@@ -206,12 +206,106 @@ __global__ __launch_bounds__(kSplit ? 256 : kEncThreads) void lz4_encode_kernel(
 }
 
 struct Lz4Enc {
+    static constexpr uint32_t kScratchWords = 1;
     template <bool kGlobalTable>
-    static __device__ __forceinline__ void chunk(const BatchArgs& a, uint32_t c, const HashTab<kGlobalTable>& ht) { lz4_encode_chunk<false, kGlobalTable>(a, c, ht); }
+    static __device__ __forceinline__ void chunk(const BatchArgs& a, uint32_t c, const HashTab<kGlobalTable>& ht, uint32_t*) { lz4_encode_chunk<false, kGlobalTable>(a, c, ht); }
+};
+
+// ---- round-based matcher (cj_enc2.hpp): the encoder of every batch and of the split pieces of large buffers ----
+struct Lz4Fmt {
+    static __device__ __forceinline__ uint32_t last_start(uint32_t n) { return n - 12u; }      // a match may start here at the latest
+    static __device__ __forceinline__ uint32_t limit(uint32_t n) { return n - 5u; }            // and must end here at the latest
+    static __device__ __forceinline__ uint32_t seq_size(uint32_t lit, uint32_t code, uint32_t) {
+        return 3u + lit + (lit >= 15u ? 1u : 0u) + (code >= 15u ? 1u : 0u);                    // lit < 256, code < 255: one length byte at most
+    }
+    static __device__ __forceinline__ void emit_lane(const uint8_t* in, uint8_t* out, uint32_t o, uint32_t lit0, uint32_t lit, uint32_t code, uint32_t off) {
+        enc2::s8(out, o, ((lit < 15u ? lit : 15u) << 4) | (code < 15u ? code : 15u));
+        uint32_t q = o + 1u;
+        if (lit >= 15u) { enc2::s8(out, q, lit - 15u); q += 1u; }
+        enc2::lane_copy(out, q, in, lit0, lit);
+        q += lit;
+        enc2::s8(out, q, off); enc2::s8(out, q + 1u, off >> 8);
+        if (code >= 15u) enc2::s8(out, q + 2u, code - 15u);
+    }
+    static __device__ __forceinline__ uint32_t emit_wave(const uint8_t* in, uint8_t* out, uint32_t op, uint32_t lit0, uint32_t lit, uint32_t off, uint32_t mlen) {
+        const uint32_t lane = lane_id(), mcode = mlen - 4u;
+        if (lane == 0) out[op] = (uint8_t)(((lit < 15u ? lit : 15u) << 4) | (mcode < 15u ? mcode : 15u));
+        op += 1;
+        if (lit >= 15u) op = emit_len_ext(out, op, lit - 15u);
+        wave_copy(out + op, in + lit0, lit);
+        op += lit;
+        if (lane < 2) out[op + lane] = (uint8_t)(off >> (8u * lane));
+        op += 2;
+        if (mcode >= 15u) op = emit_len_ext(out, op, mcode - 15u);
+        return op;
+    }
+};
+
+template <bool kSplit, bool kGlobalTable>
+__device__ __forceinline__ void lz4_encode2_chunk(const BatchArgs& a, uint32_t chunk, const HashTab<kGlobalTable>& ht, uint32_t* scr) {
+    const uint64_t base_off = kSplit ? a.in_off[chunk & ~(split_per(a.flags) - 1u)] : a.in_off[chunk];      // the piece's first sub-piece
+    const uint8_t* in = a.in_base + base_off;               // position 0 = start of the piece
+    const uint32_t q0 = (uint32_t)(a.in_off[chunk] - base_off);      // this wave's range = [q0, n)
+    const uint64_t n64 = q0 + a.in_len[chunk];
+    uint8_t* out = a.out_base + a.out_off[chunk];
+    const uint64_t cap64 = a.out_cap[chunk];
+    const uint32_t lane = lane_id();
+    const bool prefix = (a.flags & CJ_FLAG_LZ4_SIZE_PREFIX) != 0;
+
+    if (n64 > 0x7E000000ull) { if (lane == 0) a.result[chunk] = CJ_E_INPUT_TOO_LARGE; return; }
+    const uint32_t n = (uint32_t)n64;
+    // the engine only launches with capacity >= LZ4_compressBound(n) (+4); anything smaller is refused here
+    const uint64_t need = (uint64_t)(n - q0) + (n - q0) / 255u + 16u + (prefix ? 4u : 0u);
+    if (cap64 < need) { if (lane == 0) a.result[chunk] = CJ_E_COMPRESS_FAILED; return; }
+    if (prefix) {
+        if (lane < 4) out[lane] = (uint8_t)(n >> (8u * lane));
+        out += 4;
+    }
+    uint32_t anchor = q0, op = 0;
+    if (n - q0 >= 13u) {
+        ht.clear();
+        if constexpr (kSplit) ht.preindex(in, q0);
+        ht.settle();
+        enc2::Walk<Lz4Fmt, kGlobalTable> w{in, out, n, Lz4Fmt::last_start(n), Lz4Fmt::limit(n), scr, ht, 0u, 0u};
+        anchor = w.run(q0);
+        op = w.op;
+    }
+    uint64_t tail_report = 0;
+    {   // last literals
+        const uint32_t lit = n - anchor;
+        if (a.flags & kFlagReportTail) tail_report = (uint64_t)lit << 32;
+        if (lane == 0) out[op] = (uint8_t)((lit < 15u ? lit : 15u) << 4);
+        op += 1;
+        if (lit >= 15u) op = emit_len_ext(out, op, lit - 15u);
+        wave_copy(out + op, in + anchor, lit);
+        op += lit;
+    }
+    if (lane == 0) a.result[chunk] = (int64_t)(((uint64_t)op + (prefix ? 4u : 0u)) | tail_report);
+}
+
+template <bool kSplit>
+__global__ __launch_bounds__(64) void lz4_encode2_kernel(BatchArgs a) {
+    __shared__ uint16_t ht_lds[kHashSize];
+    __shared__ uint32_t scr[enc2::kScratchWords];
+    const uint32_t chunk = blockIdx.x;
+    if (chunk >= a.n_chunks) return;
+    lz4_encode2_chunk<kSplit, false>(a, chunk, HashTab<false>{ht_lds}, scr);
+}
+
+struct Lz4Enc2 {
+    static constexpr uint32_t kScratchWords = enc2::kScratchWords;
+    template <bool kGlobalTable>
+    static __device__ __forceinline__ void chunk(const BatchArgs& a, uint32_t c, const HashTab<kGlobalTable>& ht, uint32_t* scr) { lz4_encode2_chunk<false, kGlobalTable>(a, c, ht, scr); }
 };
 
 void launch_lz4_encode(const BatchArgs& a, hipStream_t s, const EncFill* fill) {
     if (a.n_chunks == 0) return;
+    if (!encoder_v1()) {
+        if (fill && !(a.flags & kFlagSplitPieces)) { launch_encode_filled<Lz4Enc2>(a, s, *fill); return; }
+        if (a.flags & kFlagSplitPieces) hipLaunchKernelGGL(lz4_encode2_kernel<true>, dim3(a.n_chunks), dim3(64), 0, s, a);
+        else hipLaunchKernelGGL(lz4_encode2_kernel<false>, dim3(a.n_chunks), dim3(64), 0, s, a);
+        return;
+    }
     if (fill && !(a.flags & kFlagSplitPieces)) { launch_encode_filled<Lz4Enc>(a, s, *fill); return; }
     dim3 grid((a.n_chunks + kEncWaves - 1) / kEncWaves), block(kEncThreads);
     if (a.flags & kFlagSplitPieces) {

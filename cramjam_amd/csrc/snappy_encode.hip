@@ -5,7 +5,7 @@
 // preamble + literal / copy-1 / copy-2 elements (format_description.txt); copies longer than 64
 // are split exactly like the CPU encoders do (64,64,...,[60],rest) so every element is canonical.
 // The 64 KiB window of the match finder keeps every offset < 65536, so copy-4 is never emitted.
-#include "cj_match.hpp"
+#include "cj_enc2.hpp"
 
 namespace cj {
 
@@ -232,12 +232,100 @@ __global__ __launch_bounds__(kSplit ? 256 : kEncThreads) void snappy_encode_kern
 }
 
 struct SnappyEnc {
+    static constexpr uint32_t kScratchWords = 1;
     template <bool kGlobalTable>
-    static __device__ __forceinline__ void chunk(const BatchArgs& a, uint32_t c, const HashTab<kGlobalTable>& ht) { snappy_encode_chunk<false, kGlobalTable>(a, c, ht); }
+    static __device__ __forceinline__ void chunk(const BatchArgs& a, uint32_t c, const HashTab<kGlobalTable>& ht, uint32_t*) { snappy_encode_chunk<false, kGlobalTable>(a, c, ht); }
+};
+
+// ---- round-based matcher (cj_enc2.hpp): the encoder of every batch and of the split pieces of large buffers ----
+struct SnappyFmt {
+    // a copy may start in the last 8 bytes of the input neither here nor (for its last 15) in the CPU encoders: the matcher's
+    // position lanes read 8 bytes at a time
+    static __device__ __forceinline__ uint32_t last_start(uint32_t n) { return n - 8u; }
+    static __device__ __forceinline__ uint32_t limit(uint32_t n) { return n; }
+    static __device__ __forceinline__ uint32_t seq_size(uint32_t lit, uint32_t code, uint32_t off) {
+        return snappy_literal_size(lit) + snappy_copy_size(off, code + 4u);
+    }
+    static __device__ __forceinline__ void emit_lane(const uint8_t* in, uint8_t* out, uint32_t o, uint32_t lit0, uint32_t lit, uint32_t code, uint32_t off) {
+        if (lit) {          // lit < 256: one or two header bytes
+            const uint32_t n1 = lit - 1u;
+            if (n1 < 60u) { enc2::s8(out, o, n1 << 2); o += 1u; }
+            else { enc2::s8(out, o, 60u << 2); enc2::s8(out, o + 1u, n1); o += 2u; }
+            enc2::lane_copy(out, o, in, lit0, lit);
+            o += lit;
+        }
+        uint32_t len = code + 4u;
+        while (len >= 68u) { enc2::s8(out, o, 2u | (63u << 2)); enc2::s8(out, o + 1u, off); enc2::s8(out, o + 2u, off >> 8); o += 3u; len -= 64u; }
+        if (len > 64u) { enc2::s8(out, o, 2u | (59u << 2)); enc2::s8(out, o + 1u, off); enc2::s8(out, o + 2u, off >> 8); o += 3u; len -= 60u; }
+        if (len < 12u && off < 2048u) { enc2::s8(out, o, 1u | ((len - 4u) << 2) | ((off >> 8) << 5)); enc2::s8(out, o + 1u, off); }
+        else { enc2::s8(out, o, 2u | ((len - 1u) << 2)); enc2::s8(out, o + 1u, off); enc2::s8(out, o + 2u, off >> 8); }
+    }
+    static __device__ __forceinline__ uint32_t emit_wave(const uint8_t* in, uint8_t* out, uint32_t op, uint32_t lit0, uint32_t lit, uint32_t off, uint32_t mlen) {
+        if (lit) op = emit_snappy_literal(out, op, in + lit0, lit);
+        return emit_snappy_copy(out, op, off, mlen);
+    }
+};
+
+template <bool kSplit, bool kGlobalTable>
+__device__ __forceinline__ void snappy_encode2_chunk(const BatchArgs& a, uint32_t chunk, const HashTab<kGlobalTable>& ht, uint32_t* scr) {
+    const uint64_t base_off = kSplit ? a.in_off[chunk & ~(split_per(a.flags) - 1u)] : a.in_off[chunk];      // the piece's first sub-piece
+    const uint8_t* in = a.in_base + base_off;               // position 0 = start of the piece
+    const uint32_t q0 = (uint32_t)(a.in_off[chunk] - base_off);      // this wave's range = [q0, n)
+    const uint64_t n64 = q0 + a.in_len[chunk];
+    uint8_t* out = a.out_base + a.out_off[chunk];
+    const uint64_t cap64 = a.out_cap[chunk];
+    const uint32_t lane = lane_id();
+
+    // snap: TooBig above u32::MAX (we also keep positions in 32 bits); BufferTooSmall below max_compress_len
+    if (n64 > 0xFFFFFFFFull - 64u) { if (lane == 0) a.result[chunk] = CJ_E_SNAPPY_TOO_BIG; return; }
+    const uint64_t need = 32u + (n64 - q0) + (n64 - q0) / 6u;
+    if (need > 0xFFFFFFFFull) { if (lane == 0) a.result[chunk] = CJ_E_SNAPPY_TOO_BIG; return; }
+    if (cap64 < need) { if (lane == 0) a.result[chunk] = CJ_E_SNAPPY_BUF_SMALL; return; }
+    const uint32_t n = (uint32_t)n64;
+
+    uint32_t op = 0;
+    {   // varint preamble
+        uint32_t v = n - q0;
+        while (v >= 0x80u) { if (lane == 0) out[op] = (uint8_t)(v | 0x80u); op += 1; v >>= 7; }
+        if (lane == 0) out[op] = (uint8_t)v;
+        op += 1;
+    }
+    uint32_t anchor = q0;
+    if (n - q0 >= 8u) {
+        ht.clear();
+        if constexpr (kSplit) ht.preindex(in, q0);
+        ht.settle();
+        enc2::Walk<SnappyFmt, kGlobalTable> w{in, out, n, SnappyFmt::last_start(n), SnappyFmt::limit(n), scr, ht, op, 0u};
+        anchor = w.run(q0);
+        op = w.op;
+    }
+    if (anchor < n) op = emit_snappy_literal(out, op, in + anchor, n - anchor);
+    if (lane == 0) a.result[chunk] = (int64_t)op;
+}
+
+template <bool kSplit>
+__global__ __launch_bounds__(64) void snappy_encode2_kernel(BatchArgs a) {
+    __shared__ uint16_t ht_lds[kHashSize];
+    __shared__ uint32_t scr[enc2::kScratchWords];
+    const uint32_t chunk = blockIdx.x;
+    if (chunk >= a.n_chunks) return;
+    snappy_encode2_chunk<kSplit, false>(a, chunk, HashTab<false>{ht_lds}, scr);
+}
+
+struct SnappyEnc2 {
+    static constexpr uint32_t kScratchWords = enc2::kScratchWords;
+    template <bool kGlobalTable>
+    static __device__ __forceinline__ void chunk(const BatchArgs& a, uint32_t c, const HashTab<kGlobalTable>& ht, uint32_t* scr) { snappy_encode2_chunk<false, kGlobalTable>(a, c, ht, scr); }
 };
 
 void launch_snappy_encode(const BatchArgs& a, hipStream_t s, const EncFill* fill) {
     if (a.n_chunks == 0) return;
+    if (!encoder_v1()) {
+        if (fill && !(a.flags & kFlagSplitPieces)) { launch_encode_filled<SnappyEnc2>(a, s, *fill); return; }
+        if (a.flags & kFlagSplitPieces) hipLaunchKernelGGL(snappy_encode2_kernel<true>, dim3(a.n_chunks), dim3(64), 0, s, a);
+        else hipLaunchKernelGGL(snappy_encode2_kernel<false>, dim3(a.n_chunks), dim3(64), 0, s, a);
+        return;
+    }
     if (fill && !(a.flags & kFlagSplitPieces)) { launch_encode_filled<SnappyEnc>(a, s, *fill); return; }
     dim3 grid((a.n_chunks + kEncWaves - 1) / kEncWaves), block(kEncThreads);
     if (a.flags & kFlagSplitPieces) {

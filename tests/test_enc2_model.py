@@ -1,0 +1,71 @@
+"""The scalar model of the round-based matcher (tests/hostsim/enc2_model.c — what cramjam_amd/csrc/cj_enc2.hpp computes, written as
+plain C): every stream it emits must decode with the oracle's decoders, and its ratio must stay with the CPU encoders'
+(LZ4_compress_default / snappy::RawCompress as restated by the oracle).  CPU only; tests/test_enc2_gpu.py holds the kernels to the
+model byte for byte."""
+import ctypes as C
+import os
+import subprocess
+
+import pytest
+
+import oracle
+from conftest import ROOT
+from enc2_cases import cases, synth
+
+SIM_DIR = os.path.join(ROOT, "tests", "hostsim")
+SIM_SO = os.path.join(SIM_DIR, "libsim_enc2.so")
+
+
+def model_lib():
+    src = os.path.join(SIM_DIR, "enc2_model.c")
+    if not os.path.exists(SIM_SO) or os.path.getmtime(SIM_SO) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-o", SIM_SO, src])
+    L = C.CDLL(SIM_SO)
+    for f in (L.enc2_model_lz4, L.enc2_model_snappy):
+        f.restype = C.c_int64
+        f.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32]
+    return L
+
+
+def model_lz4(L, raw, R=256):
+    out = C.create_string_buffer(len(raw) + len(raw) // 255 + 32)
+    n = L.enc2_model_lz4(raw, len(raw), out, R)
+    return out.raw[:n]
+
+
+def model_snappy(L, raw, R=256):
+    out = C.create_string_buffer(64 + len(raw) + len(raw) // 6)
+    n = L.enc2_model_snappy(raw, len(raw), out, R)
+    return out.raw[:n]
+
+
+@pytest.mark.parametrize("R", [256, 512])
+def test_model_streams_decode_with_the_oracle(R):
+    L = model_lib()
+    for name, raw in cases():
+        blk = model_lz4(L, raw, R)
+        r, d = oracle.lz4_decompress_raw(blk, len(raw))          # exact capacity: the end-of-block rules bite
+        assert r == len(raw) and d == raw, ("lz4", name, r)
+        blk = model_snappy(L, raw, R)
+        r, d = oracle.snappy_decompress(blk)
+        assert r == len(raw) and d == raw, ("snappy", name, r)
+
+
+def test_model_keeps_the_cpu_encoders_ratio_on_the_benchmark_data():
+    L = model_lib()
+    tot = gl = gs = cl = cs = 0
+    for i in range(40):
+        raw = synth(100 + i)
+        tot += len(raw)
+        gl += len(model_lz4(L, raw)); gs += len(model_snappy(L, raw))
+        cl += oracle.lz4_compress_raw(raw)[0]; cs += oracle.snappy_compress(raw)[0]
+    assert tot / gl >= 1.62 and tot / gs >= 1.62, (tot / gl, tot / gs)
+    assert gl <= cl * 1.005 and gs <= cs * 1.005, (tot / gl, tot / cl, tot / gs, tot / cs)
+
+
+def test_all_literal_known_answers():
+    # /root/reference/tests/test_variants.py:329-334: the bytes of an all-literal block are pinned by the reference
+    L = model_lib()
+    assert model_lz4(L, b"howdy neighbor") == b"\xe0howdy neighbor"
+    assert model_snappy(L, b"howdy neighbor") == b"\x0e4howdy neighbor"
+    assert model_lz4(L, b"") == b"\x00" and model_snappy(L, b"") == b"\x00"

@@ -1,0 +1,187 @@
+// issue_rate_probe.hip — how many wave-instructions per cycle does ONE CU of gfx950 issue?
+//
+// Round 4 concluded "a CU retires ~0.94 wave-instructions per cycle once it holds 16 wavefronts" from three latency-bound kernels
+// and treated it as a ceiling; the round-4 verdict asked for a measurement.  One workgroup per CU (the LDS request forces it), W
+// wavefronts per workgroup (4 / 8 / 16 = 1 / 2 / 4 per SIMD), every wavefront runs the same straight-line body `iters` times:
+//   independent streams (eight accumulators, distance 8 between dependent instructions) and fully dependent ones (one chain),
+//   VALU only, VALU + SALU, VALU + SALU + ds_read_b32, and single instruction kinds the encoders and decoders lean on
+//   (v_mul_lo_u32, v_readlane, DPP moves, v_cmp -> SGPR, v_cndmask, v_alignbyte, ds_bpermute, scattered ds_read_u16).
+// Reported: wave-instructions per cycle and CU = W x instructions per wavefront / (latest end - earliest start) of the CU's
+// wavefronts, in s_memtime ticks and, as a cross-check, in shader cycles derived from the kernel's wall time.
+// Build: hipcc --offload-arch=gfx950 -O2 tools/issue_rate_probe.hip -o tools/_bin/issue_rate_probe
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+#define R4(x) x x x x
+#define R8(x) R4(x) R4(x)
+#define R16(x) R8(x) R8(x)
+#define R32(x) R16(x) R16(x)
+
+// eight independent accumulators %0..%7; %8 = a VGPR operand, %9 = an SGPR operand
+#define V8_INDEP(op) op " %0, %0, %8\n" op " %1, %1, %8\n" op " %2, %2, %8\n" op " %3, %3, %8\n" op " %4, %4, %8\n" op " %5, %5, %8\n" op " %6, %6, %8\n" op " %7, %7, %8\n"
+#define V8_DEP(op) op " %0, %0, %8\n" op " %0, %0, %8\n" op " %0, %0, %8\n" op " %0, %0, %8\n" op " %0, %0, %8\n" op " %0, %0, %8\n" op " %0, %0, %8\n" op " %0, %0, %8\n"
+
+struct Mode { const char* name; int valu, salu, lds; };
+static const Mode kModes[] = {
+    {"v_add_u32 x32, independent", 32, 0, 0},
+    {"v_add_u32 x32, one dependent chain", 32, 0, 0},
+    {"v_add_u32 x32 + s_add_u32 x16, independent", 32, 16, 0},
+    {"v_add_u32 x32 + s_add_u32 x16, dependent chains", 32, 16, 0},
+    {"v_add x32 + s_add x16 + ds_read_b32 x8, independent", 32, 16, 8},
+    {"v_add x40 + s_add x16 + ds_read_b32 x8, dependent (pointer chase feeds the chain)", 40, 16, 8},
+    {"v_mul_lo_u32 x32, independent", 32, 0, 0},
+    {"v_readlane_b32 x32 (to 8 SGPRs)", 32, 0, 0},
+    {"v_mov_b32 dpp row_shr:1 x32, independent", 32, 0, 0},
+    {"v_cmp_lt_u32 -> SGPR pair x32", 32, 0, 0},
+    {"v_cndmask_b32 (vcc) x32, independent", 32, 0, 0},
+    {"v_alignbyte_b32 x32, independent", 32, 0, 0},
+    {"ds_bpermute_b32 x8 + v_add x8", 8, 0, 8},
+    {"ds_read_u16 x8 at scattered addresses + v_add x8", 8, 0, 8},
+    {"v_xor/v_ffbl/v_or/v_min mix x32 (first-difference ladder), independent", 32, 0, 0},
+    {"v_mbcnt_lo + v_mbcnt_hi x16 pairs", 32, 0, 0},
+};
+constexpr int kNumModes = sizeof(kModes) / sizeof(kModes[0]);
+
+template <int MODE>
+__global__ __launch_bounds__(1024) void probe(uint64_t* times, uint32_t* sink, int iters) {
+    extern __shared__ uint32_t lds[];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < 8192; i += blockDim.x) lds[i] = (i * 2654435761u) & 0x7ffcu;      // pointer-chase table: byte offsets into itself
+    __syncthreads();
+    uint32_t a0 = tid, a1 = tid + 1, a2 = tid + 2, a3 = tid + 3, a4 = tid + 4, a5 = tid + 5, a6 = tid + 6, a7 = tid + 7;
+    uint32_t vb = tid | 1u, addr = (tid * 4u) & 0x7ffcu;
+    uint32_t s0 = 1, s1 = 2, s2 = 3, s3 = 4;
+    const uint32_t sk = (uint32_t)iters | 1u;
+    uint64_t t0, t1;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_barrier\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");
+    for (int it = 0; it < iters; it++) {
+        if constexpr (MODE == 0) {
+            asm volatile(R4(V8_INDEP("v_add_u32")) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk));
+        } else if constexpr (MODE == 1) {
+            asm volatile(R4(V8_DEP("v_add_u32")) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk));
+        } else if constexpr (MODE == 2) {
+            asm volatile(R4(V8_INDEP("v_add_u32") "s_add_u32 %[s0], %[s0], %9\n s_add_u32 %[s1], %[s1], %9\n s_add_u32 %[s2], %[s2], %9\n s_add_u32 %[s3], %[s3], %9\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk), [s0] "s"(s0), [s1] "s"(s1), [s2] "s"(s2), [s3] "s"(s3) : "scc");
+        } else if constexpr (MODE == 3) {
+            asm volatile(R4(V8_DEP("v_add_u32") "s_add_u32 %[s0], %[s0], %9\n s_add_u32 %[s0], %[s0], %9\n s_add_u32 %[s0], %[s0], %9\n s_add_u32 %[s0], %[s0], %9\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk), [s0] "s"(s0) : "scc");
+        } else if constexpr (MODE == 4) {
+            uint32_t r0 = 0, r1 = 0;
+            asm volatile(R4(V8_INDEP("v_add_u32") "s_add_u32 %[s0], %[s0], %9\n s_add_u32 %[s1], %[s1], %9\n s_add_u32 %[s2], %[s2], %9\n s_add_u32 %[s3], %[s3], %9\n"
+                            "ds_read_b32 %[r0], %[addr]\n ds_read_b32 %[r1], %[addr] offset:256\n")
+                         "s_waitcnt lgkmcnt(0)\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                         : "v"(vb), "s"(sk), [s0] "s"(s0), [s1] "s"(s1), [s2] "s"(s2), [s3] "s"(s3), [r0] "v"(r0), [r1] "v"(r1), [addr] "v"(addr) : "scc", "memory");
+        } else if constexpr (MODE == 5) {
+            // the chase: addr = lds[addr]; 8 reads per body, each waits for the one before; the VALU and SALU chains run beside it
+            asm volatile(R8(R4("v_add_u32 %0, %0, %8\n") "s_add_u32 %[s0], %[s0], %9\n s_add_u32 %[s0], %[s0], %9\n"
+                            "ds_read_b32 %[addr], %[addr]\n s_waitcnt lgkmcnt(0)\n v_add_u32 %0, %0, %[addr]\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk), [s0] "s"(s0), [addr] "v"(addr) : "scc", "memory");
+        } else if constexpr (MODE == 6) {
+            asm volatile(R4(V8_INDEP("v_mul_lo_u32")) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk));
+        } else if constexpr (MODE == 7) {
+            uint32_t q0, q1, q2, q3, q4, q5, q6, q7;
+            asm volatile(R4("v_readlane_b32 %0, %8, 1\n v_readlane_b32 %1, %9, 2\n v_readlane_b32 %2, %10, 3\n v_readlane_b32 %3, %11, 4\n"
+                            "v_readlane_b32 %4, %12, 5\n v_readlane_b32 %5, %13, 6\n v_readlane_b32 %6, %14, 7\n v_readlane_b32 %7, %15, 8\n")
+                         : "=s"(q0), "=s"(q1), "=s"(q2), "=s"(q3), "=s"(q4), "=s"(q5), "=s"(q6), "=s"(q7) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7));
+            s0 += q0 ^ q7;
+        } else if constexpr (MODE == 8) {
+            asm volatile(R4("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                            "v_mov_b32_dpp %2, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                            "v_mov_b32_dpp %4, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                            "v_mov_b32_dpp %6, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        } else if constexpr (MODE == 9) {
+            uint64_t m0, m1, m2, m3;
+            asm volatile(R8("v_cmp_lt_u32 %0, %4, %5\n v_cmp_lt_u32 %1, %5, %6\n v_cmp_lt_u32 %2, %6, %7\n v_cmp_lt_u32 %3, %7, %4\n")
+                         : "=s"(m0), "=s"(m1), "=s"(m2), "=s"(m3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+            s0 += (uint32_t)(m0 ^ m3);
+        } else if constexpr (MODE == 10) {
+            asm volatile("v_cmp_lt_u32 vcc, %8, %0\n" R4(V8_INDEP("v_cndmask_b32")) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk) : "vcc");
+        } else if constexpr (MODE == 11) {
+            asm volatile(R4("v_alignbyte_b32 %0, %0, %8, 1\n v_alignbyte_b32 %1, %1, %8, 2\n v_alignbyte_b32 %2, %2, %8, 3\n v_alignbyte_b32 %3, %3, %8, 1\n"
+                            "v_alignbyte_b32 %4, %4, %8, 2\n v_alignbyte_b32 %5, %5, %8, 3\n v_alignbyte_b32 %6, %6, %8, 1\n v_alignbyte_b32 %7, %7, %8, 2\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk));
+        } else if constexpr (MODE == 12) {
+            asm volatile(R8("ds_bpermute_b32 %0, %8, %1\n v_add_u32 %2, %2, %8\n") "s_waitcnt lgkmcnt(0)\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(addr), "s"(sk) : "memory");
+        } else if constexpr (MODE == 13) {
+            asm volatile(R8("ds_read_u16 %0, %1\n v_add_u32 %2, %2, %8\n") "s_waitcnt lgkmcnt(0)\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk) : "memory");
+            a1 = (a1 * 5u + 2u) & 0x7ffeu;
+        } else if constexpr (MODE == 14) {
+            asm volatile(R4("v_xor_b32 %0, %1, %8\n v_ffbl_b32 %2, %0\n v_or_b32 %3, 32, %2\n v_min_u32 %4, %3, %2\n"
+                            "v_xor_b32 %5, %6, %8\n v_ffbl_b32 %7, %5\n v_or_b32 %1, 64, %7\n v_min_u32 %6, %1, %7\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk));
+        } else if constexpr (MODE == 15) {
+            asm volatile(R4("v_mbcnt_lo_u32_b32 %0, %9, 0\n v_mbcnt_hi_u32_b32 %0, %9, %0\n v_mbcnt_lo_u32_b32 %1, %9, 0\n v_mbcnt_hi_u32_b32 %1, %9, %1\n"
+                            "v_mbcnt_lo_u32_b32 %2, %9, 0\n v_mbcnt_hi_u32_b32 %2, %9, %2\n v_mbcnt_lo_u32_b32 %3, %9, 0\n v_mbcnt_hi_u32_b32 %3, %9, %3\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk));
+        }
+    }
+    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
+    const uint32_t wave = tid >> 6;
+    if ((tid & 63u) == 0) { times[(blockIdx.x * 16 + wave) * 2] = t0; times[(blockIdx.x * 16 + wave) * 2 + 1] = t1; }
+    sink[blockIdx.x * blockDim.x + tid] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ s0 ^ s1 ^ s2 ^ s3 ^ addr;
+}
+
+template <int MODE>
+static void run_mode(int n_cu, uint64_t* d_times, uint32_t* d_sink, double clock_ghz) {
+    const Mode& m = kModes[MODE];
+    const int iters = 4000;
+    const size_t lds_bytes = 96 * 1024;          // one workgroup per CU
+    CHECK(hipFuncSetAttribute((const void*)probe<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    for (int waves : {4, 8, 16}) {
+        hipEvent_t e0, e1;
+        CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(probe<MODE>, dim3(n_cu), dim3(64 * waves), lds_bytes, 0, d_times, d_sink, 10);      // warm-up
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(probe<MODE>, dim3(n_cu), dim3(64 * waves), lds_bytes, 0, d_times, d_sink, iters);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipDeviceSynchronize());
+        float ms = 0;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        std::vector<uint64_t> t((size_t)n_cu * 32);
+        CHECK(hipMemcpy(t.data(), d_times, t.size() * 8, hipMemcpyDeviceToHost));
+        std::vector<double> span;
+        for (int b = 0; b < n_cu; b++) {
+            uint64_t lo = ~0ull, hi = 0;
+            for (int w = 0; w < waves; w++) { lo = std::min(lo, t[(b * 16 + w) * 2]); hi = std::max(hi, t[(b * 16 + w) * 2 + 1]); }
+            span.push_back((double)(hi - lo));
+        }
+        std::sort(span.begin(), span.end());
+        const double ticks = span[span.size() / 2];
+        const double per_wave = (double)iters * (m.valu + m.salu + m.lds);
+        const double wall_cycles = ms * 1e-3 * clock_ghz * 1e9;
+        printf("mode %2d  %-86s waves/CU %2d  instr/tick/CU %6.3f (VALU %5.3f SALU %5.3f LDS %5.3f)  ticks/iter/wave %8.1f  by wall clock @%.2f GHz: %6.3f instr/cycle/CU\n",
+               MODE, m.name, waves, waves * per_wave / ticks, waves * (double)iters * m.valu / ticks, waves * (double)iters * m.salu / ticks,
+               waves * (double)iters * m.lds / ticks, ticks / iters, clock_ghz, waves * per_wave / wall_cycles);
+        CHECK(hipEventDestroy(e0)); CHECK(hipEventDestroy(e1));
+    }
+}
+
+template <int M>
+static void run_all(int n_cu, uint64_t* d_times, uint32_t* d_sink, double ghz) {
+    run_mode<M>(n_cu, d_times, d_sink, ghz);
+    if constexpr (M + 1 < kNumModes) run_all<M + 1>(n_cu, d_times, d_sink, ghz);
+}
+
+int main() {
+    hipDeviceProp_t p;
+    CHECK(hipGetDeviceProperties(&p, 0));
+    const int n_cu = p.multiProcessorCount;
+    const double ghz = p.clockRate * 1e-6;
+    printf("device %s, %d CUs, clockRate %.3f GHz (s_memtime tick = ? compare the two columns)\n", p.name, n_cu, ghz);
+    uint64_t* d_times; uint32_t* d_sink;
+    CHECK(hipMalloc(&d_times, (size_t)n_cu * 32 * 8));
+    CHECK(hipMalloc(&d_sink, (size_t)n_cu * 1024 * 4));
+    run_all<0>(n_cu, d_times, d_sink, ghz);
+    return 0;
+}

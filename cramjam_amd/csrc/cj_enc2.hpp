@@ -46,13 +46,31 @@ constexpr uint32_t kFwdBlocks = 4u;                 // forward measurement cap: 
 constexpr uint32_t kFlagFwdMore = 1u, kFlagBackMore = 2u;
 constexpr uint32_t kMaxLit = 256u, kMaxCode = 255u; // a queue entry packs lit < 256 and mlen - 4 < 255 into a byte each
 
-__device__ __forceinline__ uint32_t g32(const uint8_t* b, uint32_t off) { uint32_t v; __builtin_memcpy(&v, b + off, 4); return v; }
-__device__ __forceinline__ uint2 g64(const uint8_t* b, uint32_t off) { uint2 v; __builtin_memcpy(&v, b + off, 8); return v; }
-__device__ __forceinline__ uint4 g128(const uint8_t* b, uint32_t off) { uint4 v; __builtin_memcpy(&v, b + off, 16); return v; }
-__device__ __forceinline__ void s8(uint8_t* b, uint32_t off, uint32_t v) { b[off] = (uint8_t)v; }
-__device__ __forceinline__ void s32(uint8_t* b, uint32_t off, uint32_t v) { __builtin_memcpy(b + off, &v, 4); }
-__device__ __forceinline__ void s64(uint8_t* b, uint32_t off, uint2 v) { __builtin_memcpy(b + off, &v, 8); }
-__device__ __forceinline__ void s128(uint8_t* b, uint32_t off, uint4 v) { __builtin_memcpy(b + off, &v, 16); }
+// the wave mask of a condition straight from the compare (HIP's __ballot goes through an integer: v_cndmask + v_cmp per call)
+__device__ __forceinline__ uint64_t bal(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// Input and output are addressed as (uniform base in SGPRs) + (32-bit offset in a VGPR): global_load/store ... v_off, s[base:base+1].
+// The compiler does that only for a pointer it KNOWS to be uniform and global: both halves through v_readfirstlane, and the
+// address space spelled out (a pointer rebuilt from integers is a flat pointer otherwise: flat_load + 64-bit VALU address arithmetic).
+#define CJ_GAS __attribute__((address_space(1)))
+typedef const CJ_GAS uint8_t* gcptr;
+typedef CJ_GAS uint8_t* gptr;
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+typedef uint32_t v2raw __attribute__((ext_vector_type(2)));
+typedef uint32_t v4raw __attribute__((ext_vector_type(4)));
+typedef v2raw v2_unaligned __attribute__((aligned(1)));
+typedef v4raw v4_unaligned __attribute__((aligned(1)));
+__device__ __forceinline__ gcptr uniform_gptr(const uint8_t* p) {
+    const uint64_t v = (uint64_t)p;
+    return (gcptr)(((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v));
+}
+__device__ __forceinline__ uint32_t g8(gcptr b, uint32_t off) { return b[off]; }
+__device__ __forceinline__ uint32_t g32(gcptr b, uint32_t off) { return *(const CJ_GAS u32_unaligned*)(b + off); }
+__device__ __forceinline__ uint2 g64(gcptr b, uint32_t off) { const v2raw v = *(const CJ_GAS v2_unaligned*)(b + off); return make_uint2(v.x, v.y); }
+__device__ __forceinline__ uint4 g128(gcptr b, uint32_t off) { const v4raw v = *(const CJ_GAS v4_unaligned*)(b + off); return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void s8(gptr b, uint32_t off, uint32_t v) { b[off] = (uint8_t)v; }
+__device__ __forceinline__ void s32(gptr b, uint32_t off, uint32_t v) { *(CJ_GAS u32_unaligned*)(b + off) = v; }
+__device__ __forceinline__ void s64(gptr b, uint32_t off, uint2 v) { v2raw r; r.x = v.x; r.y = v.y; *(CJ_GAS v2_unaligned*)(b + off) = r; }
+__device__ __forceinline__ void s128(gptr b, uint32_t off, uint4 v) { v4raw r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; *(CJ_GAS v4_unaligned*)(b + off) = r; }
 
 // v_ffbl_b32 / v_ffbh_u32 as the hardware defines them: ~0 for a zero operand (the C builtins are undefined there, and a
 // select around them costs a compare and a v_cndmask per dword)
@@ -72,7 +90,7 @@ __device__ __forceinline__ uint32_t last_same(const uint4& x, const uint4& y) {
 
 // exact n-byte copy by ONE lane, n < 256 (a queued literal run): 16-byte blocks, then the remainder as two overlapping pieces
 // of the largest power of two that fits (the second one ends exactly at n) — never a byte beyond [0, n) on either side
-__device__ __forceinline__ void lane_copy(uint8_t* out, uint32_t o, const uint8_t* in, uint32_t i, uint32_t n) {
+__device__ __forceinline__ void lane_copy(gptr out, uint32_t o, gcptr in, uint32_t i, uint32_t n) {
     if (n >= 16u) {
         for (uint32_t k = 0; k + 16u <= n; k += 16u) s128(out, o + k, g128(in, i + k));
         s128(out, o + n - 16u, g128(in, i + n - 16u));
@@ -83,7 +101,7 @@ __device__ __forceinline__ void lane_copy(uint8_t* out, uint32_t o, const uint8_
         const uint32_t a = g32(in, i), b = g32(in, i + n - 4u);
         s32(out, o, a); s32(out, o + n - 4u, b);
     } else if (n > 0u) {
-        const uint32_t a = in[i], b = in[i + (n >> 1)], c = in[i + n - 1u];
+        const uint32_t a = g8(in, i), b = g8(in, i + (n >> 1)), c = g8(in, i + n - 1u);
         s8(out, o, a); s8(out, o + (n >> 1), b); s8(out, o + n - 1u, c);
     }
 }
@@ -95,8 +113,8 @@ __device__ __forceinline__ void lane_copy(uint8_t* out, uint32_t o, const uint8_
 //   Fmt::emit_wave(in, out, op, lit0, lit, off, mlen) -> new op   the whole wavefront writes one sequence of any size
 template <class Fmt, bool kGlobalTable>
 struct Walk {
-    const uint8_t* in;      // position 0 (start of the piece)
-    uint8_t* out;
+    gcptr in;               // position 0 (start of the piece), uniform
+    gptr out;               // uniform
     uint32_t n;             // end of this wavefront's range
     uint32_t last_start, limit;
     uint32_t* scr;          // kScratchWords dwords of LDS
@@ -113,13 +131,17 @@ struct Walk {
         uint32_t total;
         const uint32_t before = wave_excl_add(on ? Fmt::seq_size(lit, code, off) : 0u, total);
         if (on) Fmt::emit_lane(in, out, op + before, lit0, lit, code, off);
-        op += total;
+        op = uni(op + total);
         q_n = 0u;
     }
 
     // one round over [pos, pos + span); cur = end of the last selected match on entry and exit
-    __device__ __forceinline__ void round(uint32_t pos, uint32_t span, const uint32_t (&D0)[kG], const uint32_t (&D1)[kG], uint32_t& cur) {
+    __device__ __forceinline__ void round(uint32_t pos, uint32_t span, const uint32_t (&D0)[kG], const uint32_t (&D1)[kG], uint32_t& cur_io) {
         const uint32_t lane = lane_id();
+        // wave-uniform state is TOLD to be uniform (v_readfirstlane): the compiler cannot see it through the chunk bookkeeping, and a
+        // walk it believes divergent becomes an exec-masked loop with `cur` in a VGPR (measured: twice the scalar instructions)
+        uint32_t cur = uni(cur_io);
+        pos = uni(pos); span = uni(span);
         const uint32_t round_last = umin(last_start, pos + span - 1u);
         // ---- probe ----
         uint32_t hs[kG][4], dd[kG][4];
@@ -154,16 +176,17 @@ struct Walk {
         }
         // ---- heads: verified, and the left neighbour is not verified with the same offset ----
         uint64_t hm[kG][4];
+        bool hd[kG][4];
         uint32_t total_heads = 0;
 #pragma unroll
         for (int g = 0; g < kG; g++) {
             const uint32_t left0 = dpp_from<kDppWaveShr1>(0u, dd[g][3]);            // lane l - 1's last position; lane 0 of a group starts afresh
-            hm[g][0] = ballot64(dd[g][0] != 0u && dd[g][0] != left0);
-            hm[g][1] = ballot64(dd[g][1] != 0u && dd[g][1] != dd[g][0]);
-            hm[g][2] = ballot64(dd[g][2] != 0u && dd[g][2] != dd[g][1]);
-            hm[g][3] = ballot64(dd[g][3] != 0u && dd[g][3] != dd[g][2]);
+            hd[g][0] = dd[g][0] != 0u && dd[g][0] != left0;
+            hd[g][1] = dd[g][1] != 0u && dd[g][1] != dd[g][0];
+            hd[g][2] = dd[g][2] != 0u && dd[g][2] != dd[g][1];
+            hd[g][3] = dd[g][3] != 0u && dd[g][3] != dd[g][2];
 #pragma unroll
-            for (int k = 0; k < 4; k++) total_heads += (uint32_t)__builtin_popcountll(hm[g][k]);
+            for (int k = 0; k < 4; k++) { hm[g][k] = bal(hd[g][k]); total_heads += (uint32_t)__builtin_popcountll(hm[g][k]); }
         }
         // toggle bitmap of this round: cleared before the first window writes into it
         if (lane < kR / 32u + 1u) scr[kTogAt + lane] = 0u;
@@ -178,7 +201,7 @@ struct Walk {
                     for (int k = 0; k < 4; k++) r += bits_below_lane(hm[g][k]);
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        const bool h = ((hm[g][k] >> lane) & 1ull) != 0ull;
+                        const bool h = hd[g][k];
                         if (h && r - w0 < 64u) scr[kHeadsAt + r - w0] = (dd[g][k] << 16) | (256u * g + 4u * lane + k);
                         r += h ? 1u : 0u;
                         base += (uint32_t)__builtin_popcountll(hm[g][k]);
@@ -189,44 +212,50 @@ struct Walk {
             const bool is_head = lane < mw;
             const uint32_t hv = is_head ? scr[kHeadsAt + lane] : (1u << 16);
             const uint32_t P = pos + (hv & 0xffffu), d = hv >> 16, C = P - d;
-            // ---- forward: equal bytes after the four verified ones ----
-            uint32_t fwd = 0;
-            bool more = is_head;
+            // ---- measure: ONE round trip carries the first two forward blocks and the backward block of every head ----
             const uint32_t a = P + 4u;
-            for (uint32_t it = 0; it < kFwdBlocks; it++) {
-                if (ballot64(more) == 0ull) break;
-                const bool blk = more && a + fwd + 16u <= n;
-                uint4 x = make_uint4(0, 0, 0, 0), y = make_uint4(0, 0, 0, 1);
-                if (blk) { x = g128(in, a + fwd); y = g128(in, a + fwd - d); }
-                if (more && !blk) {                                  // within 16 bytes of the end of the input: byte by byte
-                    while (a + fwd < limit && in[a + fwd] == in[a + fwd - d]) fwd += 1u;
+            uint32_t fwd = 0, back = 0;
+            bool more = is_head, back_more = false;
+            {
+                const bool blk0 = is_head && a + 16u <= n, blk1 = is_head && a + 32u <= n;
+                const uint32_t room = P - cur;                       // P >= pos >= cur in the first window; a later window may start behind cur (BS is not used then)
+                const uint32_t blim = umin(room, C);
+                const bool bk_on = is_head && blim > 0u, bk_blk = bk_on && C >= 16u;
+                uint4 x0 = make_uint4(0, 0, 0, 0), y0 = make_uint4(0, 0, 0, 1), x1 = x0, y1 = y0, bx = x0, by = y0;
+                if (blk0) { x0 = g128(in, a); y0 = g128(in, a - d); }
+                if (blk1) { x1 = g128(in, a + 16u); y1 = g128(in, a + 16u - d); }
+                if (bk_blk) { bx = g128(in, P - 16u); by = g128(in, C - 16u); }
+                if (blk0) {
+                    const uint32_t e0 = first_diff(x0, y0), e1 = first_diff(x1, y1);
+                    fwd = e0 == 16u && blk1 ? 16u + e1 : e0;       // (no second block this close to the end: the loop below goes on from 16)
+                    more = fwd == (blk1 ? 32u : 16u);
+                }
+                if (bk_blk) {
+                    const uint32_t sm = last_same(bx, by);
+                    back = umin(sm, blim);
+                    back_more = sm == 16u && blim > 16u;
+                } else if (bk_on) {                                  // candidate within the first 16 bytes of the piece
+                    while (back < blim && g8(in, P - 1u - back) == g8(in, C - 1u - back)) back += 1u;
+                }
+            }
+            // the rare rest: matches beyond 4 + 32 bytes block by block, the last 16 bytes of the input byte by byte
+            for (uint32_t it = 2; it <= kFwdBlocks; it++) {
+                if (bal(more) == 0ull) break;
+                const bool blk = more && it < kFwdBlocks && a + fwd + 16u <= n;
+                if (more && !blk && a + fwd + 16u > n) {
+                    while (a + fwd < limit && g8(in, a + fwd) == g8(in, a + fwd - d)) fwd += 1u;
                     more = false;
                 }
                 if (blk) {
-                    const uint32_t e = first_diff(x, y);
+                    const uint32_t e = first_diff(g128(in, a + fwd), g128(in, a + fwd - d));
                     fwd += e;
                     more = e == 16u;
                 }
             }
             if (a + fwd >= limit) { fwd = limit - a; more = false; }      // (a <= limit: P <= last_start)
             uint32_t E = is_head ? a + fwd : 0u;                     // E = 0: never selected
-            // ---- backward: equal bytes before position and candidate, within the literals pending at the start of the round ----
-            uint32_t back = 0;
-            bool back_more = false;
-            {
-                const uint32_t room = P - cur;                       // P >= pos >= cur
-                const uint32_t blim = umin(room, C);
-                const bool on = is_head && blim > 0u;
-                if (on && C >= 16u) {
-                    const uint32_t sm = last_same(g128(in, P - 16u), g128(in, C - 16u));
-                    back = umin(sm, blim);
-                    back_more = sm == 16u && blim > 16u;
-                } else if (on) {                                     // candidate within the first 16 bytes of the piece
-                    while (back < blim && in[P - 1u - back] == in[C - 1u - back]) back += 1u;
-                }
-            }
             const uint32_t BS = P - back;
-            const uint64_t fwd_more_mask = ballot64(is_head && more);
+            const uint64_t fwd_more_mask = bal(is_head && more);
             // ---- greedy walk: the chain carries `cur` only ----
             const uint32_t cur0 = cur;
             uint64_t sel = 0ull;
@@ -235,7 +264,7 @@ struct Walk {
             if (!slow) {
                 for (;;) {
                     if (cur > last_start) break;
-                    const uint64_t m = ballot64(E >= cur + 4u);
+                    const uint64_t m = bal(E >= cur + 4u);
                     if (m == 0ull) break;
                     const uint32_t first = ctz64(m);
                     PE = (uint32_t)cj_llvm_writelane((int)cur, (int)first, (int)PE);
@@ -246,7 +275,7 @@ struct Walk {
                 const uint32_t s = umax(BS, PE);
                 const uint32_t lit = s - PE, code = E - s - 4u;
                 const bool needs_wave = selected && (lit >= kMaxLit || code >= kMaxCode || (back_more && P >= PE && P - PE > 16u));
-                slow = ballot64(needs_wave) != 0ull;
+                slow = bal(needs_wave) != 0ull;
                 if (!slow) {
                     const uint32_t ns = (uint32_t)__builtin_popcountll(sel);
                     if (q_n + ns > kQueueCap) flush();
@@ -262,7 +291,7 @@ struct Walk {
                             atomicXor(&scr[kTogAt + (ex >> 5)], 1u << (ex & 31u));
                         }
                     }
-                    q_n += ns;
+                    q_n = uni(q_n + ns);
                 }
             }
             if (slow) {
@@ -274,13 +303,13 @@ struct Walk {
                     if (cur > last_start) break;
                     const uint32_t Pi = rdlane(P, i), di = rdlane(d, i), fl = rdlane(flags, i);
                     uint32_t Ei = rdlane(E, i);
-                    if (fl & kFlagFwdMore) Ei += wave_extend(in, Ei, Ei - di, limit);
+                    if (fl & kFlagFwdMore) Ei += wave_extend((const uint8_t*)in, Ei, Ei - di, limit);
                     if (Ei < cur + 4u) continue;
                     uint32_t s = cur;
                     if (Pi >= cur) {
                         const uint32_t room = Pi - cur;
                         uint32_t bk = umin(Pi - rdlane(BS, i), room);
-                        if ((fl & kFlagBackMore) && bk == 16u && room > 16u) bk += wave_extend_back(in, Pi - 16u, Pi - di - 16u, room - 16u);
+                        if ((fl & kFlagBackMore) && bk == 16u && room > 16u) bk += wave_extend_back((const uint8_t*)in, Pi - 16u, Pi - di - 16u, room - 16u);
                         s = Pi - bk;
                     }
                     flush();
@@ -305,7 +334,7 @@ struct Walk {
                 const uint32_t word = scr[kTogAt + 8u * g + (lane >> 3)];
                 const uint32_t bits = (word >> (4u * (lane & 7u))) & 15u;
                 const uint32_t pre = bits ^ (bits << 1) ^ (bits << 2) ^ (bits << 3);               // bit k = parity of the toggles at positions 4 l .. 4 l + k
-                const uint64_t odd = ballot64((__builtin_popcount(bits) & 1) != 0);
+                const uint64_t odd = bal((__builtin_popcount(bits) & 1) != 0);
                 const uint32_t before = (bits_below_lane(odd) + carry) & 1u;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -327,7 +356,7 @@ struct Walk {
                         const uint32_t word = scr[kTogAt + 8u * g + (lane >> 3)];
                         const uint32_t bits = (word >> (4u * (lane & 7u))) & 15u;
                         const uint32_t pre = bits ^ (bits << 1) ^ (bits << 2) ^ (bits << 3);
-                        const uint64_t odd = ballot64((__builtin_popcount(bits) & 1) != 0);
+                        const uint64_t odd = bal((__builtin_popcount(bits) & 1) != 0);
                         const uint32_t before = (bits_below_lane(odd) + carry2) & 1u;
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
@@ -342,16 +371,18 @@ struct Walk {
                         }
                         carry2 += (uint32_t)__builtin_popcountll(odd);
                     }
-                    if (ballot64(again) == 0ull) break;
+                    if (bal(again) == 0ull) break;
                     ht.settle();
                 }
             }
         }
+        cur_io = cur;
     }
 
     // the whole range [q0, n): rounds, then the queue; returns the end of the last match (the final literals start there)
     __device__ __forceinline__ uint32_t run(uint32_t q0) {
         const uint32_t lane = lane_id();
+        q0 = uni(q0); n = uni(n); last_start = uni(last_start); limit = uni(limit); op = uni(op);
         uint32_t pos = q0, cur = q0;
         uint32_t span = q0 == 0u ? 64u : kR;          // short first rounds while the table is empty (a sub-piece's table is pre-indexed)
         uint32_t D0[kG], D1[kG], own_pos = ~0u;
@@ -378,6 +409,7 @@ struct Walk {
             for (int g = 0; g < kG; g++) { D0[g] = N0[g]; D1[g] = N1[g]; }
             own_pos = round_end;
             span = span * 2u < kR ? span * 2u : kR;
+            cur = uni(cur);
             pos = cur > round_end ? cur : round_end;
         }
         flush();

@@ -533,7 +533,7 @@ __device__ __forceinline__ void insert_round(const HashTab<kGlobal>& ht, uint32_
 // one chunk; HashTab<true> makes the global table behave exactly like the LDS one (same bytes out whichever block takes a chunk).
 static_assert(kHashSize * 2u <= kEncTableBytes, "table slot");
 #ifndef CJ_ENC_TABLE_WAVES_PER_EU
-#define CJ_ENC_TABLE_WAVES_PER_EU 3
+#define CJ_ENC_TABLE_WAVES_PER_EU 4
 #endif
 template <class Enc, bool kGlobalTable>
 __device__ __forceinline__ void encode_persistent_body(const BatchArgs& a, uint32_t* counter, uint16_t* ht, uint32_t* scr) {

@@ -127,7 +127,10 @@ int launch_encode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a, hipStrea
         if (lz4) cj::launch_lz4_encode(a, s); else cj::launch_snappy_encode(a, s);
         return 0;
     }
-    const uint32_t table_blocks = kEncTableBlocksPerCu * (uint32_t)e->n_cu;
+    // (experiment knobs of round 5, removed once the sweep is in: blocks of either kind per CU)
+    static const uint32_t env_tab = [] { const char* v = std::getenv("CJ_ENC_TABLE_BLOCKS"); return v ? (uint32_t)std::atoi(v) : kEncTableBlocksPerCu; }();
+    static const uint32_t env_lds = [] { const char* v = std::getenv("CJ_ENC_LDS_BLOCKS"); return v ? (uint32_t)std::atoi(v) : kEncLdsBlocksPerCu; }();
+    const uint32_t table_blocks = env_tab * (uint32_t)e->n_cu;
     if (!e->enc_aux) {
         HIP_TRY(hipStreamCreateWithFlags(&e->enc_aux, hipStreamNonBlocking), CJ_E_NO_DEVICE);
         HIP_TRY(hipEventCreateWithFlags(&e->enc_fork, hipEventDisableTiming), CJ_E_NO_DEVICE);
@@ -139,7 +142,7 @@ int launch_encode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a, hipStrea
     cj::EncFill f;
     f.aux = e->enc_aux; f.fork = e->enc_fork; f.join = e->enc_join;
     f.counter = (uint32_t*)e->d_enc.p; f.tables = (uint16_t*)((uint8_t*)e->d_enc.p + 256);
-    f.lds_blocks = kEncLdsBlocksPerCu * (uint32_t)e->n_cu; f.table_blocks = table_blocks;
+    f.lds_blocks = env_lds * (uint32_t)e->n_cu; f.table_blocks = table_blocks;
     if (lz4) cj::launch_lz4_encode(a, s, &f); else cj::launch_snappy_encode(a, s, &f);
     HIP_TRY(hipEventRecord(e->enc_free, s), CJ_E_NO_DEVICE);
     return 0;

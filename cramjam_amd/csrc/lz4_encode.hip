@@ -218,7 +218,7 @@ struct Lz4Fmt {
     static __device__ __forceinline__ uint32_t seq_size(uint32_t lit, uint32_t code, uint32_t) {
         return 3u + lit + (lit >= 15u ? 1u : 0u) + (code >= 15u ? 1u : 0u);                    // lit < 256, code < 255: one length byte at most
     }
-    static __device__ __forceinline__ void emit_lane(const uint8_t* in, uint8_t* out, uint32_t o, uint32_t lit0, uint32_t lit, uint32_t code, uint32_t off) {
+    static __device__ __forceinline__ void emit_lane(enc2::gcptr in, enc2::gptr out, uint32_t o, uint32_t lit0, uint32_t lit, uint32_t code, uint32_t off) {
         enc2::s8(out, o, ((lit < 15u ? lit : 15u) << 4) | (code < 15u ? code : 15u));
         uint32_t q = o + 1u;
         if (lit >= 15u) { enc2::s8(out, q, lit - 15u); q += 1u; }
@@ -227,7 +227,8 @@ struct Lz4Fmt {
         enc2::s8(out, q, off); enc2::s8(out, q + 1u, off >> 8);
         if (code >= 15u) enc2::s8(out, q + 2u, code - 15u);
     }
-    static __device__ __forceinline__ uint32_t emit_wave(const uint8_t* in, uint8_t* out, uint32_t op, uint32_t lit0, uint32_t lit, uint32_t off, uint32_t mlen) {
+    static __device__ __forceinline__ uint32_t emit_wave(enc2::gcptr gin, enc2::gptr gout, uint32_t op, uint32_t lit0, uint32_t lit, uint32_t off, uint32_t mlen) {
+        const uint8_t* in = (const uint8_t*)gin; uint8_t* out = (uint8_t*)gout;
         const uint32_t lane = lane_id(), mcode = mlen - 4u;
         if (lane == 0) out[op] = (uint8_t)(((lit < 15u ? lit : 15u) << 4) | (mcode < 15u ? mcode : 15u));
         op += 1;
@@ -266,7 +267,7 @@ __device__ __forceinline__ void lz4_encode2_chunk(const BatchArgs& a, uint32_t c
         ht.clear();
         if constexpr (kSplit) ht.preindex(in, q0);
         ht.settle();
-        enc2::Walk<Lz4Fmt, kGlobalTable> w{in, out, n, Lz4Fmt::last_start(n), Lz4Fmt::limit(n), scr, ht, 0u, 0u};
+        enc2::Walk<Lz4Fmt, kGlobalTable> w{enc2::uniform_gptr(in), (enc2::gptr)enc2::uniform_gptr(out), n, Lz4Fmt::last_start(n), Lz4Fmt::limit(n), scr, ht, 0u, 0u};
         anchor = w.run(q0);
         op = w.op;
     }

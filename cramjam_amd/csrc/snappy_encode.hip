@@ -246,7 +246,7 @@ struct SnappyFmt {
     static __device__ __forceinline__ uint32_t seq_size(uint32_t lit, uint32_t code, uint32_t off) {
         return snappy_literal_size(lit) + snappy_copy_size(off, code + 4u);
     }
-    static __device__ __forceinline__ void emit_lane(const uint8_t* in, uint8_t* out, uint32_t o, uint32_t lit0, uint32_t lit, uint32_t code, uint32_t off) {
+    static __device__ __forceinline__ void emit_lane(enc2::gcptr in, enc2::gptr out, uint32_t o, uint32_t lit0, uint32_t lit, uint32_t code, uint32_t off) {
         if (lit) {          // lit < 256: one or two header bytes
             const uint32_t n1 = lit - 1u;
             if (n1 < 60u) { enc2::s8(out, o, n1 << 2); o += 1u; }
@@ -260,7 +260,8 @@ struct SnappyFmt {
         if (len < 12u && off < 2048u) { enc2::s8(out, o, 1u | ((len - 4u) << 2) | ((off >> 8) << 5)); enc2::s8(out, o + 1u, off); }
         else { enc2::s8(out, o, 2u | ((len - 1u) << 2)); enc2::s8(out, o + 1u, off); enc2::s8(out, o + 2u, off >> 8); }
     }
-    static __device__ __forceinline__ uint32_t emit_wave(const uint8_t* in, uint8_t* out, uint32_t op, uint32_t lit0, uint32_t lit, uint32_t off, uint32_t mlen) {
+    static __device__ __forceinline__ uint32_t emit_wave(enc2::gcptr gin, enc2::gptr gout, uint32_t op, uint32_t lit0, uint32_t lit, uint32_t off, uint32_t mlen) {
+        const uint8_t* in = (const uint8_t*)gin; uint8_t* out = (uint8_t*)gout;
         if (lit) op = emit_snappy_literal(out, op, in + lit0, lit);
         return emit_snappy_copy(out, op, off, mlen);
     }
@@ -295,7 +296,7 @@ __device__ __forceinline__ void snappy_encode2_chunk(const BatchArgs& a, uint32_
         ht.clear();
         if constexpr (kSplit) ht.preindex(in, q0);
         ht.settle();
-        enc2::Walk<SnappyFmt, kGlobalTable> w{in, out, n, SnappyFmt::last_start(n), SnappyFmt::limit(n), scr, ht, op, 0u};
+        enc2::Walk<SnappyFmt, kGlobalTable> w{enc2::uniform_gptr(in), (enc2::gptr)enc2::uniform_gptr(out), n, SnappyFmt::last_start(n), SnappyFmt::limit(n), scr, ht, op, 0u};
         anchor = w.run(q0);
         op = w.op;
     }

@@ -54,6 +54,12 @@ def cases():
     out.append(("back_ext", b"x" * 40 + bytes(rnd.getrandbits(8) for _ in range(5000)) + b"x" * 40 + b"yz" * 30))
     long_lit_then_match = bytes(rnd.getrandbits(8) for _ in range(300))
     out.append(("lit300_match", long_lit_then_match + long_lit_then_match[10:90] + bytes(20)))
+    base = bytes(rnd.getrandbits(8) for _ in range(2000))
+    for t in range(0, 72, 3):                                    # a match that runs into the end-of-block zone, every distance from the end
+        out.append(("tail_match_%d" % t, base + base[100:140 + t]))
+        out.append(("tail_match_lit_%d" % t, base + base[100:170] + bytes(rnd.getrandbits(8) for _ in range(t))))
+    for k in range(24):                                          # ragged sizes: the last round's positions end anywhere in a lane's four
+        out.append(("synth_ragged_%d" % k, synth(300 + k, 30000 + 37 * k + k * k)))
     for n in (0, 1, 4, 7, 8, 9, 12, 13, 14, 15, 16, 17, 20, 31, 63, 64, 65, 67, 68, 255, 256, 257, 260, 511, 512, 513, 1023, 1024):
         out.append(("abab_%d" % n, (b"abcab" * 300)[:n]))
         out.append(("text_%d" % n, text[1000:1000 + n]))

@@ -2,6 +2,8 @@
 (tests/hostsim/enc2_model.c): byte-identical streams on every input shape, through the one-block-per-chunk kernels (small
 batch) and through the persistent blocks of both kinds (large batch: hash table in LDS / in global memory).  The model's own
 streams are checked against the oracle's decoders in tests/test_enc2_model.py; here the kernels' bytes are decoded once more."""
+import os
+
 import pytest
 
 import oracle
@@ -20,9 +22,12 @@ def caps_for(codec, raws):
     return [L.cj_lz4_block_compress_bound(len(r), 0) if codec == LZ4 else L.cj_snappy_raw_max_compress_len(len(r)) for r in raws]
 
 
+R = int(os.environ.get("CJ_TEST_ENC2_R", "256"))          # positions per round of the library under test (a -DCJ_ENC2_GROUPS=2 variant: 512)
+
+
 def expected(codec, raws):
     M = model_lib()
-    return [model_lz4(M, r) if codec == LZ4 else model_snappy(M, r) for r in raws]
+    return [model_lz4(M, r, R) if codec == LZ4 else model_snappy(M, r, R) for r in raws]
 
 
 def decode(codec, blk, n):

@@ -45,11 +45,30 @@ static const Mode kModes[] = {
     {"ds_read_u16 x8 at scattered addresses + v_add x8", 8, 0, 8},
     {"v_xor/v_ffbl/v_or/v_min mix x32 (first-difference ladder), independent", 32, 0, 0},
     {"v_mbcnt_lo + v_mbcnt_hi x16 pairs", 32, 0, 0},
+    {"v_cndmask_b32_e64 (SGPR-pair mask) x32, independent", 32, 0, 0},
+    {"v_add_u32 with an SGPR operand x32, independent", 32, 0, 0},
+    {"v_add_co_u32 (carry to vcc) x32, independent", 32, 0, 0},
+    {"v_lshlrev_b32 x32, independent", 32, 0, 0},
+    {"v_mad_u32_u24 x32, independent", 32, 0, 0},
+    {"v_lshl_add_u32 x32, independent", 32, 0, 0},
+    {"v_add3_u32 x32, independent", 32, 0, 0},
+    {"v_bfe_u32 x32, independent", 32, 0, 0},
+    {"v_ffbl_b32 x32, independent", 32, 0, 0},
+    {"v_min_u32 x32, independent", 32, 0, 0},
+    {"v_xor_b32 x32, independent", 32, 0, 0},
+    {"v_readfirstlane_b32 x32", 32, 0, 0},
+    {"v_cmp_lt_u32_e32 (vcc) x32", 32, 0, 0},
+    {"s_and_saveexec_b64 + s_or_b64 exec x16 pairs + v_add x32", 32, 32, 0},
+    {"v_lshl_add_u64 x32, independent", 32, 0, 0},
+    {"v_cndmask_b32_e32 (vcc), vcc written once BEFORE the loop, x32", 32, 0, 0},
+    {"global_load_dword x8 scattered in 64 KiB per wave (cache-resident) + v_add x8", 8, 0, 0},
+    {"global_load_dwordx4 x8 scattered in 64 KiB per wave + v_add x8", 8, 0, 0},
+    {"ds_write_b16 x8 scattered + v_add x8", 8, 0, 8},
 };
 constexpr int kNumModes = sizeof(kModes) / sizeof(kModes[0]);
 
 template <int MODE>
-__global__ __launch_bounds__(1024) void probe(uint64_t* times, uint32_t* sink, int iters) {
+__global__ __launch_bounds__(1024) void probe(uint64_t* times, uint32_t* sink, int iters, const uint8_t* gmem) {
     extern __shared__ uint32_t lds[];
     const uint32_t tid = threadIdx.x;
     for (uint32_t i = tid; i < 8192; i += blockDim.x) lds[i] = (i * 2654435761u) & 0x7ffcu;      // pointer-chase table: byte offsets into itself
@@ -58,6 +77,12 @@ __global__ __launch_bounds__(1024) void probe(uint64_t* times, uint32_t* sink, i
     uint32_t vb = tid | 1u, addr = (tid * 4u) & 0x7ffcu;
     uint32_t s0 = 1, s1 = 2, s2 = 3, s3 = 4;
     const uint32_t sk = (uint32_t)iters | 1u;
+    const uint64_t mask64 = 0x5555aaaa3333ccccull ^ (uint64_t)iters;
+    const uint64_t gb_ = (uint64_t)(gmem + ((size_t)blockIdx.x * 16 + (tid >> 6)) * 65536);      // 64 KiB per wavefront
+    const uint64_t gbase = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(gb_ >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)gb_);
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    v4 r4 = {0, 0, 0, 0};
+    if (MODE == 31) asm volatile("v_cmp_lt_u32 vcc, %0, %1" :: "v"(a0), "v"(vb) : "vcc");
     uint64_t t0, t1;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_barrier\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");
     for (int it = 0; it < iters; it++) {
@@ -123,6 +148,75 @@ __global__ __launch_bounds__(1024) void probe(uint64_t* times, uint32_t* sink, i
             asm volatile(R4("v_mbcnt_lo_u32_b32 %0, %9, 0\n v_mbcnt_hi_u32_b32 %0, %9, %0\n v_mbcnt_lo_u32_b32 %1, %9, 0\n v_mbcnt_hi_u32_b32 %1, %9, %1\n"
                             "v_mbcnt_lo_u32_b32 %2, %9, 0\n v_mbcnt_hi_u32_b32 %2, %9, %2\n v_mbcnt_lo_u32_b32 %3, %9, 0\n v_mbcnt_hi_u32_b32 %3, %9, %3\n")
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk));
+        } else if constexpr (MODE == 16) {
+            asm volatile(R4("v_cndmask_b32_e64 %0, %0, %8, %[m]\n v_cndmask_b32_e64 %1, %1, %8, %[m]\n v_cndmask_b32_e64 %2, %2, %8, %[m]\n v_cndmask_b32_e64 %3, %3, %8, %[m]\n"
+                            "v_cndmask_b32_e64 %4, %4, %8, %[m]\n v_cndmask_b32_e64 %5, %5, %8, %[m]\n v_cndmask_b32_e64 %6, %6, %8, %[m]\n v_cndmask_b32_e64 %7, %7, %8, %[m]\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk), [m] "s"(mask64));
+        } else if constexpr (MODE == 17) {
+            asm volatile(R4("v_add_u32 %0, %9, %0\n v_add_u32 %1, %9, %1\n v_add_u32 %2, %9, %2\n v_add_u32 %3, %9, %3\n v_add_u32 %4, %9, %4\n v_add_u32 %5, %9, %5\n v_add_u32 %6, %9, %6\n v_add_u32 %7, %9, %7\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk));
+        } else if constexpr (MODE == 18) {
+            asm volatile(R4("v_add_co_u32 %0, vcc, %0, %8\n v_add_co_u32 %1, vcc, %1, %8\n v_add_co_u32 %2, vcc, %2, %8\n v_add_co_u32 %3, vcc, %3, %8\n"
+                            "v_add_co_u32 %4, vcc, %4, %8\n v_add_co_u32 %5, vcc, %5, %8\n v_add_co_u32 %6, vcc, %6, %8\n v_add_co_u32 %7, vcc, %7, %8\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk) : "vcc");
+        } else if constexpr (MODE == 19) {
+            asm volatile(R4("v_lshlrev_b32 %0, 1, %0\n v_lshlrev_b32 %1, 1, %1\n v_lshlrev_b32 %2, 1, %2\n v_lshlrev_b32 %3, 1, %3\n v_lshlrev_b32 %4, 1, %4\n v_lshlrev_b32 %5, 1, %5\n v_lshlrev_b32 %6, 1, %6\n v_lshlrev_b32 %7, 1, %7\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk));
+        } else if constexpr (MODE == 20) {
+            asm volatile(R4("v_mad_u32_u24 %0, %0, %8, %8\n v_mad_u32_u24 %1, %1, %8, %8\n v_mad_u32_u24 %2, %2, %8, %8\n v_mad_u32_u24 %3, %3, %8, %8\n"
+                            "v_mad_u32_u24 %4, %4, %8, %8\n v_mad_u32_u24 %5, %5, %8, %8\n v_mad_u32_u24 %6, %6, %8, %8\n v_mad_u32_u24 %7, %7, %8, %8\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk));
+        } else if constexpr (MODE == 21) {
+            asm volatile(R4("v_lshl_add_u32 %0, %0, 1, %8\n v_lshl_add_u32 %1, %1, 1, %8\n v_lshl_add_u32 %2, %2, 1, %8\n v_lshl_add_u32 %3, %3, 1, %8\n"
+                            "v_lshl_add_u32 %4, %4, 1, %8\n v_lshl_add_u32 %5, %5, 1, %8\n v_lshl_add_u32 %6, %6, 1, %8\n v_lshl_add_u32 %7, %7, 1, %8\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk));
+        } else if constexpr (MODE == 22) {
+            asm volatile(R4("v_add3_u32 %0, %0, %8, %8\n v_add3_u32 %1, %1, %8, %8\n v_add3_u32 %2, %2, %8, %8\n v_add3_u32 %3, %3, %8, %8\n"
+                            "v_add3_u32 %4, %4, %8, %8\n v_add3_u32 %5, %5, %8, %8\n v_add3_u32 %6, %6, %8, %8\n v_add3_u32 %7, %7, %8, %8\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk));
+        } else if constexpr (MODE == 23) {
+            asm volatile(R4("v_bfe_u32 %0, %0, 1, 31\n v_bfe_u32 %1, %1, 1, 31\n v_bfe_u32 %2, %2, 1, 31\n v_bfe_u32 %3, %3, 1, 31\n v_bfe_u32 %4, %4, 1, 31\n v_bfe_u32 %5, %5, 1, 31\n v_bfe_u32 %6, %6, 1, 31\n v_bfe_u32 %7, %7, 1, 31\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk));
+        } else if constexpr (MODE == 24) {
+            asm volatile(R4("v_ffbl_b32 %0, %0\n v_ffbl_b32 %1, %1\n v_ffbl_b32 %2, %2\n v_ffbl_b32 %3, %3\n v_ffbl_b32 %4, %4\n v_ffbl_b32 %5, %5\n v_ffbl_b32 %6, %6\n v_ffbl_b32 %7, %7\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk));
+        } else if constexpr (MODE == 25) {
+            asm volatile(R4(V8_INDEP("v_min_u32")) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk));
+        } else if constexpr (MODE == 26) {
+            asm volatile(R4(V8_INDEP("v_xor_b32")) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk));
+        } else if constexpr (MODE == 27) {
+            uint32_t q0, q1, q2, q3, q4, q5, q6, q7;
+            asm volatile(R4("v_readfirstlane_b32 %0, %8\n v_readfirstlane_b32 %1, %9\n v_readfirstlane_b32 %2, %10\n v_readfirstlane_b32 %3, %11\n"
+                            "v_readfirstlane_b32 %4, %12\n v_readfirstlane_b32 %5, %13\n v_readfirstlane_b32 %6, %14\n v_readfirstlane_b32 %7, %15\n")
+                         : "=s"(q0), "=s"(q1), "=s"(q2), "=s"(q3), "=s"(q4), "=s"(q5), "=s"(q6), "=s"(q7) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7));
+            s0 += q0 ^ q7;
+        } else if constexpr (MODE == 28) {
+            asm volatile(R8("v_cmp_lt_u32 vcc, %0, %1\n v_cmp_lt_u32 vcc, %1, %2\n v_cmp_lt_u32 vcc, %2, %3\n v_cmp_lt_u32 vcc, %3, %0\n")
+                         :: "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "vcc");
+        } else if constexpr (MODE == 29) {
+            uint64_t sv;
+            asm volatile(R16("s_and_saveexec_b64 %[sv], %[m]\n v_add_u32 %0, %0, %[vb]\n v_add_u32 %1, %1, %[vb]\n s_or_b64 exec, exec, %[sv]\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), [sv] "=&s"(sv) : [vb] "v"(vb), "s"(sk), [m] "s"(mask64) : "scc");
+        } else if constexpr (MODE == 30) {
+            uint64_t b0 = a0, b1 = a1, b2 = a2, b3 = a3;
+            asm volatile(R8("v_lshl_add_u64 %0, %0, 0, %4\n v_lshl_add_u64 %1, %1, 0, %4\n v_lshl_add_u64 %2, %2, 0, %4\n v_lshl_add_u64 %3, %3, 0, %4\n")
+                         : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3) : "v"(b0));
+            a0 ^= (uint32_t)(b0 ^ b1 ^ b2 ^ b3);
+        } else if constexpr (MODE == 31) {
+            asm volatile(R4(V8_INDEP("v_cndmask_b32")) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk));
+        } else if constexpr (MODE == 32) {
+            asm volatile(R8("global_load_dword %0, %1, %[gb]\n v_add_u32 %2, %2, %8\n") "s_waitcnt vmcnt(0)\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk), [gb] "s"(gbase) : "memory");
+            a1 = (a1 * 5u + 2u * tid + 1u) & 0xfffcu;
+        } else if constexpr (MODE == 33) {
+            uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+            asm volatile(R8("global_load_dwordx4 %[r], %1, %[gb]\n v_add_u32 %2, %2, %8\n") "s_waitcnt vmcnt(0)\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk), [gb] "s"(gbase), [r] "v"(r4) : "memory");
+            a1 = (a1 * 5u + 2u * tid + 1u) & 0xfff0u;
+        } else if constexpr (MODE == 34) {
+            asm volatile(R8("ds_write_b16 %1, %0\n v_add_u32 %2, %2, %8\n") "s_waitcnt lgkmcnt(0)\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk) : "memory");
+            a1 = (a1 * 5u + 2u) & 0x7ffeu;
         }
     }
     asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
@@ -131,6 +225,7 @@ __global__ __launch_bounds__(1024) void probe(uint64_t* times, uint32_t* sink, i
     sink[blockIdx.x * blockDim.x + tid] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ s0 ^ s1 ^ s2 ^ s3 ^ addr;
 }
 
+static const uint8_t* d_gmem;
 template <int MODE>
 static void run_mode(int n_cu, uint64_t* d_times, uint32_t* d_sink, double clock_ghz) {
     const Mode& m = kModes[MODE];
@@ -140,10 +235,10 @@ static void run_mode(int n_cu, uint64_t* d_times, uint32_t* d_sink, double clock
     for (int waves : {4, 8, 16}) {
         hipEvent_t e0, e1;
         CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-        hipLaunchKernelGGL(probe<MODE>, dim3(n_cu), dim3(64 * waves), lds_bytes, 0, d_times, d_sink, 10);      // warm-up
+        hipLaunchKernelGGL(probe<MODE>, dim3(n_cu), dim3(64 * waves), lds_bytes, 0, d_times, d_sink, 10, d_gmem);      // warm-up
         CHECK(hipDeviceSynchronize());
         CHECK(hipEventRecord(e0));
-        hipLaunchKernelGGL(probe<MODE>, dim3(n_cu), dim3(64 * waves), lds_bytes, 0, d_times, d_sink, iters);
+        hipLaunchKernelGGL(probe<MODE>, dim3(n_cu), dim3(64 * waves), lds_bytes, 0, d_times, d_sink, iters, d_gmem);
         CHECK(hipEventRecord(e1));
         CHECK(hipDeviceSynchronize());
         float ms = 0;
@@ -182,6 +277,10 @@ int main() {
     uint64_t* d_times; uint32_t* d_sink;
     CHECK(hipMalloc(&d_times, (size_t)n_cu * 32 * 8));
     CHECK(hipMalloc(&d_sink, (size_t)n_cu * 1024 * 4));
+    uint8_t* g;
+    CHECK(hipMalloc(&g, (size_t)n_cu * 16 * 65536 + 4096));
+    CHECK(hipMemset(g, 1, (size_t)n_cu * 16 * 65536 + 4096));
+    d_gmem = g;
     run_all<0>(n_cu, d_times, d_sink, ghz);
     return 0;
 }

@@ -145,6 +145,7 @@ struct Walk {
         const uint32_t round_last = umin(last_start, pos + span - 1u);
         // ---- probe ----
         uint32_t hs[kG][4], dd[kG][4];
+        bool hd[kG][4];
         {
             uint32_t v[kG][4], t[kG][4];
 #pragma unroll
@@ -156,38 +157,44 @@ struct Walk {
 #pragma unroll
                 for (int k = 0; k < 4; k++) { hs[g][k] = hash_slot(v[g][k]); t[g][k] = ht.get(hs[g][k]); }
             }
-            uint32_t w[kG][4], c[kG][4];
-            bool okd[kG][4];
+            // distance to the slot's position, modulo the 64 KiB lap of the 16-bit table; 0 = no candidate
 #pragma unroll
             for (int g = 0; g < kG; g++)
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const uint32_t p = pos + 256u * g + 4u * lane + k;
-                    const uint32_t d = (p - t[g][k]) & 0xffffu;          // distance to the slot's position, modulo the 64 KiB lap
-                    okd[g][k] = d != 0u && d <= p && p <= round_last;
-                    dd[g][k] = d;
-                    c[g][k] = okd[g][k] ? p - d : 0u;
-                    w[g][k] = g32(in, c[g][k]);                          // every lane loads (position 0 when there is no candidate): no branch
+                    const uint32_t d = (p - t[g][k]) & 0xffffu;
+                    dd[g][k] = (d != 0u && d <= p && p <= round_last) ? d : 0u;
+                }
+            // Only the FIRST position of a run of equal distances is verified: its followers lie inside its match if it is one, and a
+            // candidate dword is a scattered access — the vector memory path takes ~1.5 cycles per lane for those (64 lanes: ~94 cycles
+            // per instruction and CU, tools/issue_rate_probe.hip), which is what bounds this kernel.  On match-heavy data half of all
+            // positions are followers.
+#pragma unroll
+            for (int g = 0; g < kG; g++) {
+                const uint32_t left0 = dpp_from<kDppWaveShr1>(0u, dd[g][3]);            // lane l - 1's last position; lane 0 of a group starts afresh
+                bool pre[4];
+                pre[0] = dd[g][0] != 0u && dd[g][0] != left0;
+                pre[1] = dd[g][1] != 0u && dd[g][1] != dd[g][0];
+                pre[2] = dd[g][2] != 0u && dd[g][2] != dd[g][1];
+                pre[3] = dd[g][3] != 0u && dd[g][3] != dd[g][2];
+                uint32_t w[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    w[k] = ~v[g][k];
+                    if (pre[k]) w[k] = g32(in, pos + 256u * g + 4u * lane + k - dd[g][k]);
                 }
 #pragma unroll
-            for (int g = 0; g < kG; g++)
-#pragma unroll
-                for (int k = 0; k < 4; k++) dd[g][k] = (okd[g][k] && w[g][k] == v[g][k]) ? dd[g][k] : 0u;      // 0 = not verified
+                for (int k = 0; k < 4; k++) hd[g][k] = pre[k] && w[k] == v[g][k];
+            }
         }
-        // ---- heads: verified, and the left neighbour is not verified with the same offset ----
+        // ---- heads: the verified first positions of runs ----
         uint64_t hm[kG][4];
-        bool hd[kG][4];
         uint32_t total_heads = 0;
 #pragma unroll
-        for (int g = 0; g < kG; g++) {
-            const uint32_t left0 = dpp_from<kDppWaveShr1>(0u, dd[g][3]);            // lane l - 1's last position; lane 0 of a group starts afresh
-            hd[g][0] = dd[g][0] != 0u && dd[g][0] != left0;
-            hd[g][1] = dd[g][1] != 0u && dd[g][1] != dd[g][0];
-            hd[g][2] = dd[g][2] != 0u && dd[g][2] != dd[g][1];
-            hd[g][3] = dd[g][3] != 0u && dd[g][3] != dd[g][2];
+        for (int g = 0; g < kG; g++)
 #pragma unroll
             for (int k = 0; k < 4; k++) { hm[g][k] = bal(hd[g][k]); total_heads += (uint32_t)__builtin_popcountll(hm[g][k]); }
-        }
         // toggle bitmap of this round: cleared before the first window writes into it
         if (lane < kR / 32u + 1u) scr[kTogAt + lane] = 0u;
         // ---- windows of up to 64 heads in position order ----

@@ -1,8 +1,7 @@
 /* enc2_model.c — scalar CPU statement of the round-based matcher of cramjam_amd/csrc/cj_enc2.hpp (TEST INFRASTRUCTURE).
  *
  * The GPU encoders are specified by this model: a round probes R consecutive positions against the hash table as it was when the
- * round began; of the verified positions only the HEADS of runs (a verified position whose left neighbour is not verified with the
- * same offset) become candidates; every head is extended to its true length forwards and backwards; the heads are walked in
+ * round began; only the HEADS of runs of equal candidate distances are verified and become candidates; every head is extended to its true length forwards and backwards; the heads are walked in
  * position order, greedily (the first head whose interval still has four bytes after the previous match ends wins); positions that
  * are not strictly inside an emitted match — its last TAIL positions count as outside — are inserted into the table.  tests/test_enc2_gpu.py asserts that the kernels emit
  * exactly these bytes, tests/test_enc2_model.py that the streams decode with the oracle and keep the CPU encoders' ratio.
@@ -29,23 +28,28 @@ static int model_round(const uint8_t* in, uint32_t n, uint16_t* tab, uint32_t po
     static uint8_t ok[RMAX], valid[RMAX], covered[RMAX];
     (void)n;
     const uint32_t anchor = *cur_io;
+    /* candidates: the slot's position, as a distance modulo the 64 KiB lap of the 16-bit table */
     for (uint32_t i = 0; i < R; i++) {
         const uint32_t p = pos + i;
         valid[i] = i < span && p <= last_start;
         ok[i] = 0; d[i] = 0; covered[i] = 0;
         if (!valid[i]) continue;
-        const uint32_t v = ld32(in + p);
-        hs[i] = hash_slot(v);
-        uint32_t c = (p & 0xFFFF0000u) | tab[hs[i]];
-        if (c >= p) c -= 65536u;
-        if (c < p && p - c <= 65535u && ld32(in + c) == v) { ok[i] = 1; d[i] = p - c; }
+        hs[i] = hash_slot(ld32(in + p));
+        const uint32_t dist = (p - tab[hs[i]]) & 0xffffu;
+        if (dist != 0u && dist <= p) d[i] = dist;
+    }
+    /* Only the FIRST position of a run of equal distances is verified (its left neighbour IN THE SAME GROUP OF 256 has another distance or
+     * no candidate): the positions behind it lie inside its match if it is one, and a candidate dword costs a scattered memory access
+     * each — on match-heavy data half of all positions are such followers. */
+    for (uint32_t i = 0; i < R; i++) {
+        if (d[i] == 0u) continue;
+        if ((i & 255u) != 0u && d[i - 1] == d[i]) continue;
+        if (ld32(in + pos + i - d[i]) == ld32(in + pos + i)) ok[i] = 1;
     }
     uint32_t cur = anchor;
     int ns = 0;
     for (uint32_t i = 0; i < R; i++) {
-        if (!ok[i]) continue;
-        /* head: the left neighbour IN THE SAME GROUP OF 256 is not verified with the same offset (position 256 g of a round starts afresh) */
-        if ((i & 255u) != 0u && ok[i - 1] && d[i - 1] == d[i]) continue;
+        if (!ok[i]) continue;            /* a verified head */
         const uint32_t p = pos + i, c = p - d[i];
         uint32_t e = p + 4u;
         while (e < limit && in[e] == in[e - d[i]]) e++;

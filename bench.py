@@ -556,8 +556,8 @@ def encode_kernel_names(N, codec, nch):
     import torch
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     tag = "Lz4Enc" if codec == "lz4" else "SnappyEnc"
-    if nch >= 10 * cus:
-        return "encode_lds_blocks_kernel<%s>+encode_table_blocks_kernel<%s> (concurrent streams)" % (tag, tag)
+    if nch >= 9 * cus:
+        return "encode_blocks_kernel<%s>" % tag
     return "%s_encode_kernel" % codec
 
 

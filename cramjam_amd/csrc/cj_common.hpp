@@ -50,17 +50,12 @@ void launch_lz4_decode_fused(const BatchArgs& a, void* meta, void* tabs, uint32_
 size_t lz4_lds2_tab_bytes(uint32_t grid);
 size_t lz4_lds_scratch_sync_bytes(size_t n_chunks);
 size_t lz4_lds_scratch_meta_bytes(size_t n_chunks);
-// Encoders, large batches: besides the ten LDS-table wavefronts that fit a CU, `table_blocks` more wavefronts with their hash
-// table in a slot of global memory take chunks from the same counter (cj_match.hpp: encode_persistent_kernel).  They are
-// launched on `aux` between the two events, so that they are resident together with the LDS blocks.
+// Encoders, large batches: persistent one-wavefront blocks (nine per CU, what the LDS holds) take chunks from one counter
+// (cj_match.hpp: encode_blocks_kernel)
 struct EncFill {
-    hipStream_t aux;
-    hipEvent_t fork, join;
-    uint32_t* counter;          // one zeroed word per launch (this struct's owner serialises launches)
-    uint16_t* tables;           // table_blocks x kEncTableBytes
-    uint32_t lds_blocks, table_blocks;
+    uint32_t* counter;          // one word, zeroed per launch (this struct's owner serialises launches)
+    uint32_t blocks;
 };
-constexpr size_t kEncTableBytes = 16384;
 void launch_lz4_encode(const BatchArgs& a, hipStream_t s, const EncFill* fill = nullptr);
 void launch_snappy_decode(const BatchArgs& a, hipStream_t s);                                   // one wavefront per chunk
 void launch_snappy_decode_lanes(const BatchArgs& a, hipStream_t s);                            // one lane per chunk

@@ -111,14 +111,14 @@ __device__ __forceinline__ void lane_copy(gptr out, uint32_t o, gcptr in, uint32
 //   Fmt::seq_size(lit, code, off)               encoded bytes of one queued sequence (code = mlen - 4)
 //   Fmt::emit_lane(in, out, o, lit0, lit, code, off)   one lane writes one queued sequence at output offset o
 //   Fmt::emit_wave(in, out, op, lit0, lit, off, mlen) -> new op   the whole wavefront writes one sequence of any size
-template <class Fmt, bool kGlobalTable>
+template <class Fmt>
 struct Walk {
     gcptr in;               // position 0 (start of the piece), uniform
     gptr out;               // uniform
     uint32_t n;             // end of this wavefront's range
     uint32_t last_start, limit;
     uint32_t* scr;          // kScratchWords dwords of LDS
-    HashTab<kGlobalTable> ht;
+    HashTab ht;
     uint32_t op;            // output position after the last EMITTED sequence (queued ones are not counted yet)
     uint32_t q_n;           // queued sequences
 
@@ -352,36 +352,6 @@ struct Walk {
                 carry += (uint32_t)__builtin_popcountll(odd);
             }
             ht.settle();
-            if constexpr (kGlobalTable) {
-                // a table in global memory does not order the lanes of a store instruction: read back and let the entry win that the
-                // LDS table would keep — the last instruction (group, k), within it the highest lane
-                for (;;) {
-                    bool again = false;
-                    uint32_t carry2 = 0;
-#pragma unroll
-                    for (int g = 0; g < kG; g++) {
-                        const uint32_t word = scr[kTogAt + 8u * g + (lane >> 3)];
-                        const uint32_t bits = (word >> (4u * (lane & 7u))) & 15u;
-                        const uint32_t pre = bits ^ (bits << 1) ^ (bits << 2) ^ (bits << 3);
-                        const uint64_t odd = bal((__builtin_popcount(bits) & 1) != 0);
-                        const uint32_t before = (bits_below_lane(odd) + carry2) & 1u;
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const uint32_t rel = 256u * g + 4u * lane + k, p = pos + rel;
-                            const bool covered = (((pre >> k) ^ before) & 1u) != 0u;
-                            if (p <= round_last && !covered) {
-                                const uint32_t there = (ht.get(hs[g][k]) - pos) & 0xffffu;      // the slot holds a position of this round
-                                const uint32_t key_there = ((there >> 8) << 8) | ((there & 3u) << 6) | ((there >> 2) & 63u);
-                                const uint32_t key_mine = ((uint32_t)g << 8) | ((uint32_t)k << 6) | lane;
-                                if (there < kR && key_there < key_mine) { ht.set(hs[g][k], p); again = true; }
-                            }
-                        }
-                        carry2 += (uint32_t)__builtin_popcountll(odd);
-                    }
-                    if (bal(again) == 0ull) break;
-                    ht.settle();
-                }
-            }
         }
         cur_io = cur;
     }

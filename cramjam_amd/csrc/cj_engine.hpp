@@ -94,9 +94,8 @@ struct cj_engine {
     cj::DevBuf d_tab;              // LDS decoder variant 2: per-workgroup record tables
     cj::DevBuf d_bigrecs, d_bigmisc, d_bigslabtab;   // chunks of 64 KiB .. 256 KiB in a device batch (big_chunks.hpp, CJ_FLAG_BIG_CHUNKS): record areas; list + summaries + slab items; the slab decoder's tables
     cj::DevBuf d_big, d_bigtab;    // large.hip: parse scratch / record tables of one large stream (under `mu`)
-    // encoders, large batches (cj::EncFill): second stream for the global-table blocks, their tables + the chunk counter
-    hipStream_t enc_aux = nullptr;
-    hipEvent_t enc_fork = nullptr, enc_join = nullptr, enc_free = nullptr;
+    // encoders, large batches (cj::EncFill): the persistent blocks' chunk counter
+    hipEvent_t enc_free = nullptr;
     cj::DevBuf d_enc;
     int n_cu = 0;
 };

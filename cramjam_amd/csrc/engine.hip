@@ -108,41 +108,25 @@ int launch_decode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a, hipStrea
     return 0;
 }
 
-// LZ4 block / Snappy raw encode of a batch of independent chunks, one wavefront per chunk.  A CU holds ten wavefronts with a
-// 16 KiB hash table in LDS.  A batch with at least that many chunks (fewer: every chunk gets an LDS wavefront at once, 2 048
-// chunks 2.24 ms against 2.58) runs as persistent blocks — ten LDS-table blocks per CU on `s` plus kEncTableBlocksPerCu blocks
-// per CU whose table lives in global memory, on the engine's second stream, all taking chunks from one counter
-// (cj_match.hpp).  100 k chunks: LZ4 66 -> 75 GB/s, Snappy 61 -> 73; 2 560 chunks 4.0 -> 3.0 ms (the counter also evens out
-// the CUs); 4 or 6 table blocks per CU give what 3 give.
-#ifndef CJ_ENC_TABLE_BLOCKS
-#define CJ_ENC_TABLE_BLOCKS 3
-#endif
-constexpr uint32_t kEncLdsBlocksPerCu = 10, kEncTableBlocksPerCu = CJ_ENC_TABLE_BLOCKS;
+// LZ4 block / Snappy raw encode of a batch of independent chunks, one wavefront per chunk.  A CU holds nine wavefronts with a 16 KiB
+// hash table + 1 KiB of matcher scratch in LDS.  A batch with at least that many chunks (fewer: every chunk gets its wavefront at
+// once) runs as persistent blocks, nine per CU, all taking chunks from one counter (cj_match.hpp), which also evens out the CUs.
+constexpr uint32_t kEncBlocksPerCu = 9;
 
 int launch_encode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a, hipStream_t s) {
     const bool lz4 = codec == CJ_CODEC_LZ4_BLOCK;
     std::lock_guard<std::mutex> lock(e->scratch_mu);
     if (e->n_cu == 0) HIP_TRY(hipDeviceGetAttribute(&e->n_cu, hipDeviceAttributeMultiprocessorCount, e->device), CJ_E_NO_DEVICE);
-    if (a.n_chunks < kEncLdsBlocksPerCu * (uint32_t)e->n_cu || (a.flags & cj::kFlagSplitPieces)) {
+    if (a.n_chunks < kEncBlocksPerCu * (uint32_t)e->n_cu || (a.flags & cj::kFlagSplitPieces)) {
         if (lz4) cj::launch_lz4_encode(a, s); else cj::launch_snappy_encode(a, s);
         return 0;
     }
-    // (experiment knobs of round 5, removed once the sweep is in: blocks of either kind per CU)
-    static const uint32_t env_tab = [] { const char* v = std::getenv("CJ_ENC_TABLE_BLOCKS"); return v ? (uint32_t)std::atoi(v) : kEncTableBlocksPerCu; }();
-    static const uint32_t env_lds = [] { const char* v = std::getenv("CJ_ENC_LDS_BLOCKS"); return v ? (uint32_t)std::atoi(v) : kEncLdsBlocksPerCu; }();
-    const uint32_t table_blocks = env_tab * (uint32_t)e->n_cu;
-    if (!e->enc_aux) {
-        HIP_TRY(hipStreamCreateWithFlags(&e->enc_aux, hipStreamNonBlocking), CJ_E_NO_DEVICE);
-        HIP_TRY(hipEventCreateWithFlags(&e->enc_fork, hipEventDisableTiming), CJ_E_NO_DEVICE);
-        HIP_TRY(hipEventCreateWithFlags(&e->enc_join, hipEventDisableTiming), CJ_E_NO_DEVICE);
-    }
     if (!e->enc_free) HIP_TRY(hipEventCreateWithFlags(&e->enc_free, hipEventDisableTiming), CJ_E_NO_DEVICE);
-    else HIP_TRY(hipStreamWaitEvent(s, e->enc_free, 0), CJ_E_NO_DEVICE);      // the previous batch (maybe on another stream) is done with the counter and the tables
-    if (!e->d_enc.reserve(256 + (size_t)table_blocks * cj::kEncTableBytes)) return CJ_E_OOM;   // (sized once: n_cu is fixed)
+    else HIP_TRY(hipStreamWaitEvent(s, e->enc_free, 0), CJ_E_NO_DEVICE);      // the previous batch (maybe on another stream) is done with the counter
+    if (!e->d_enc.reserve(256)) return CJ_E_OOM;
     cj::EncFill f;
-    f.aux = e->enc_aux; f.fork = e->enc_fork; f.join = e->enc_join;
-    f.counter = (uint32_t*)e->d_enc.p; f.tables = (uint16_t*)((uint8_t*)e->d_enc.p + 256);
-    f.lds_blocks = env_lds * (uint32_t)e->n_cu; f.table_blocks = table_blocks;
+    f.counter = (uint32_t*)e->d_enc.p;
+    f.blocks = kEncBlocksPerCu * (uint32_t)e->n_cu;
     if (lz4) cj::launch_lz4_encode(a, s, &f); else cj::launch_snappy_encode(a, s, &f);
     HIP_TRY(hipEventRecord(e->enc_free, s), CJ_E_NO_DEVICE);
     return 0;
@@ -317,8 +301,7 @@ void cj_engine_destroy(cj_engine* e) {
     e->h_in.release(); e->h_out.release();
     if (e->scratch_free) (void)hipEventDestroy(e->scratch_free);
     e->d_enc.release();
-    for (hipEvent_t ev : {e->enc_fork, e->enc_join, e->enc_free}) if (ev) (void)hipEventDestroy(ev);
-    if (e->enc_aux) (void)hipStreamDestroy(e->enc_aux);
+    if (e->enc_free) (void)hipEventDestroy(e->enc_free);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }

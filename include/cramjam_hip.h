@@ -192,8 +192,6 @@ CJ_API int  cj_engine_device(const cj_engine* e);
  * allocation: true for every chunk of a buffer that comes from hipMalloc / a caching allocator (allocations start on
  * 256-byte boundaries and are padded to their granule), NOT for a chunk that begins or ends flush with a page the
  * caller carved up itself.  cj_batch_host pads to 16 bytes on its own staging buffers. */
-/* Compress batches of >= 10 chunks per CU also use a second stream owned by the engine (global-table encoder blocks, forked
- * from / joined to `hip_stream` with events): the call is still ordered on `hip_stream` alone. */
 CJ_API int cj_batch_device(cj_engine* e, cj_codec codec, cj_op op, uint32_t flags, size_t n_chunks,
                     const uint8_t* in_base, const uint64_t* in_off, const uint64_t* in_len,
                     uint8_t* out_base, const uint64_t* out_off, const uint64_t* out_cap,

@@ -66,8 +66,14 @@ __global__ __launch_bounds__(256) void big_list_kernel(BatchArgs a, uint32_t* li
     if (c >= a.n_chunks) return;
     const uint8_t* in; uint32_t n, cap, skip;
     if (!big_prologue<kCodec>(a, c, in, n, cap, skip)) return;
-    const uint32_t idx = atomicAdd(&list[0], 1u);
-    if (idx < list[1]) list[kBigListHdr + idx] = c;
+    list[kBigListHdr + atomicAdd(&list[0], 1u)] = c;            // (the list holds one slot per chunk of the batch)
+}
+
+// the listed chunks of one GROUP: entries [base, base + cap) of the list (the engine walks the list in groups of as many chunks as
+// it has record areas for)
+__device__ __forceinline__ uint32_t big_group_count(const uint32_t* list, uint32_t base, uint32_t cap) {
+    const uint32_t listed = list[0];
+    return listed > base ? (listed - base < cap ? listed - base : cap) : 0u;
 }
 
 // The lanes' view of their streams: a 16-byte WINDOW in registers, loaded straight from global memory at the position of the field
@@ -189,13 +195,13 @@ constexpr uint32_t kBigLaneBad = 1u, kBigLaneLast = 2u;
 // scope load) — and if that lane has not got that far yet (its wavefront may not even have started), it simply WALKS ON as it
 // does past a wrong candidate: never wrong, only double work.
 template <int kCodec>
-__global__ __launch_bounds__(64 * kBigWaves) void big_walk_kernel(BatchArgs a, const uint32_t* list, uint32_t capr, uint4* recs, uint32_t* cands, BigLane* lanes) {
+__global__ __launch_bounds__(64 * kBigWaves) void big_walk_kernel(BatchArgs a, const uint32_t* list, uint32_t base_i, uint32_t cap_g, uint32_t capr, uint4* recs, uint32_t* cands, BigLane* lanes) {
     constexpr uint32_t k = kBigLanes;
     const uint32_t gl = blockIdx.x * (64u * kBigWaves) + threadIdx.x;
     const uint32_t j = gl / capr, bi = gl % capr;                // (capr is a multiple of 64: a wavefront has one j)
-    const uint32_t listed = list[0] < list[1] ? list[0] : list[1];
+    const uint32_t listed = big_group_count(list, base_i, cap_g);
     const bool exists = bi < listed && j < k;
-    const uint32_t c = exists ? list[kBigListHdr + bi] : 0u;
+    const uint32_t c = exists ? list[kBigListHdr + base_i + bi] : 0u;
     uint32_t* ccand = cands + (size_t)bi * k;
 
     const uint8_t* in = nullptr;
@@ -307,16 +313,16 @@ __global__ __launch_bounds__(64 * kBigWaves) void big_walk_kernel(BatchArgs a, c
 // THE EPILOGUE, 32 lanes per listed chunk: which lanes does the chain run through, what lies in front of each, the checks that
 // needed absolute positions, and for every 64 KiB boundary of the output the record that holds it
 template <int kCodec>
-__global__ __launch_bounds__(256) void big_sum_kernel(BatchArgs a, const uint32_t* list, const uint4* recs, const BigLane* lanes, BigMeta* bigmeta, ParseMeta* meta) {
+__global__ __launch_bounds__(256) void big_sum_kernel(BatchArgs a, const uint32_t* list, uint32_t base_i, uint32_t cap_g, const uint4* recs, const BigLane* lanes, BigMeta* bigmeta, ParseMeta* meta) {
     __shared__ volatile uint32_t s_live[256];
     constexpr uint32_t k = kBigLanes;
     const uint32_t gl = blockIdx.x * 256u + threadIdx.x;
     const uint32_t bi = gl >> kBigLanesLog, j = gl & (k - 1u);
     const uint32_t lane = lane_id();
     const uint32_t g0 = threadIdx.x & ~(k - 1u);
-    const uint32_t listed = list[0] < list[1] ? list[0] : list[1];
+    const uint32_t listed = big_group_count(list, base_i, cap_g);
     const bool exists = bi < listed;
-    const uint32_t c = exists ? list[kBigListHdr + bi] : 0u;
+    const uint32_t c = exists ? list[kBigListHdr + base_i + bi] : 0u;
     const uint8_t* in = nullptr;
     uint32_t n = 0, cap = 0, skip = 0;
     const bool walk = exists && big_prologue<kCodec>(a, c, in, n, cap, skip);
@@ -360,10 +366,12 @@ __global__ __launch_bounds__(256) void big_sum_kernel(BatchArgs a, const uint32_
 
     // ---- the record that holds output byte 65536 * s: the live lane whose output range contains it searches its region ----
     BigMeta* bm = bigmeta + bi;
-    if (exists && chunk_ok && live) {
-        for (uint32_t sb = 1; sb < kBigSlabs; sb++) {
-            const uint32_t b = sb * 65536u;
-            if (b >= total || b < opb || b >= opb + r) continue;      // not in this chunk / not in this lane's part (r > 0 here)
+    uint32_t sf[kBigSlabs];                                      // slab s's first record, known to all 32 lanes of the chunk after the reduction
+    sf[0] = 0u;
+    for (uint32_t sb = 1; sb < kBigSlabs; sb++) {
+        uint32_t mine = 0xFFFFFFFFu;
+        const uint32_t b = sb * 65536u;
+        if (exists && chunk_ok && live && b < total && b >= opb && b < opb + r) {      // in this lane's part (r > 0 here)
             const uint32_t rel = b - opb;
             uint32_t lo = 0, hi = cnt;                             // largest idx in [0, cnt) with lit_start[idx] <= rel (idx 0 has lit_start 0)
             while (hi - lo > 1u) {
@@ -371,9 +379,24 @@ __global__ __launch_bounds__(256) void big_sum_kernel(BatchArgs a, const uint32_
                 const uint32_t z = __hip_atomic_load(&reinterpret_cast<const uint32_t*>(region + pad + mid)[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (z <= rel) lo = mid; else hi = mid;
             }
-            bm->slab_first[sb] = first + lo;
+            mine = first + lo;
         }
+        for (uint32_t d = 1; d < k; d <<= 1) {                   // minimum over the chunk's 32 lanes (they sit side by side in one wavefront)
+            const uint32_t o = (uint32_t)__shfl_xor((int)mine, (int)d, 64);
+            mine = o < mine ? o : mine;
+        }
+        sf[sb] = mine;
     }
+    // The slab decoder's record table and cross list hold kBigSlabRecs records per slab: an LZ4 sequence with a match covers at least
+    // four output bytes, so a 64 KiB slab never has more — a Snappy stream may (copies and literals of one byte): such a chunk
+    // stays with the wavefront kernel.
+    for (uint32_t sb = 0; sb < kBigSlabs; sb++) {
+        if (sb * 65536u >= total) break;
+        const uint32_t r0 = sf[sb], r1 = (sb + 1u) * 65536u < total ? sf[sb + 1u] : nseq - 1u;
+        if (r0 == 0xFFFFFFFFu || r1 == 0xFFFFFFFFu || r1 < r0 || r1 - r0 + 1u > kBigSlabRecs) chunk_ok = false;
+    }
+    if (exists && chunk_ok && j == 0u)
+        for (uint32_t sb = 1; sb < kBigSlabs; sb++) if (sb * 65536u < total) bm->slab_first[sb] = sf[sb];
     if (exists) {
         if (chunk_ok) {
             bm->first[j] = first;
@@ -390,12 +413,12 @@ __global__ __launch_bounds__(256) void big_sum_kernel(BatchArgs a, const uint32_
     }
 }
 
-__global__ __launch_bounds__(256) void big_items_kernel(BatchArgs a, const uint32_t* list, const BigMeta* bigmeta, uint32_t cap,
+__global__ __launch_bounds__(256) void big_items_kernel(BatchArgs a, const uint32_t* list, uint32_t base_i, const BigMeta* bigmeta, uint32_t cap,
                                                         uint64_t* rows, ParseMeta* item_meta, uint32_t* done) {
     const uint32_t w = blockIdx.x * 256u + threadIdx.x, items = kBigSlabs * cap;
     if (w >= items) return;
     const uint32_t bi = w % cap, sl = w / cap;
-    const uint32_t listed = list[0] < list[1] ? list[0] : list[1];
+    const uint32_t listed = big_group_count(list, base_i, cap);
     uint64_t in_off = 0, in_len = 0, out_off = 0, out_cap = 0, res = 0;
     uint32_t nrec = 0;
     if (bi < listed) {
@@ -415,9 +438,9 @@ __global__ __launch_bounds__(256) void big_items_kernel(BatchArgs a, const uint3
     done[w] = 0u;
 }
 
-void launch_big_items(const BatchArgs& a, const uint32_t* list, const void* bigmeta, uint32_t cap, uint64_t* rows, void* item_meta, uint32_t* done, hipStream_t s) {
+void launch_big_items(const BatchArgs& a, const uint32_t* list, uint32_t base, const void* bigmeta, uint32_t cap, uint64_t* rows, void* item_meta, uint32_t* done, hipStream_t s) {
     if (cap == 0) return;
-    hipLaunchKernelGGL(big_items_kernel, dim3((kBigSlabs * cap + 255u) / 256u), dim3(256), 0, s, a, list, (const BigMeta*)bigmeta, cap, rows, (ParseMeta*)item_meta, done);
+    hipLaunchKernelGGL(big_items_kernel, dim3((kBigSlabs * cap + 255u) / 256u), dim3(256), 0, s, a, list, base, (const BigMeta*)bigmeta, cap, rows, (ParseMeta*)item_meta, done);
 }
 
 size_t big_recs_bytes(size_t cap) { return cap * (size_t)kBigRecPitch * sizeof(uint4); }
@@ -425,24 +448,30 @@ size_t big_meta_bytes(size_t cap) { return cap * sizeof(BigMeta); }
 
 size_t big_walk_scratch_bytes(size_t cap) { const size_t capr = (cap + 63) & ~(size_t)63; return capr * kBigLanes * (4 + sizeof(BigLane)); }
 
-// scratch: big_walk_scratch_bytes(cap) bytes (the lanes' candidates and summaries)
-void launch_big_parse(const BatchArgs& a, int codec, uint32_t* list, uint32_t cap, void* recs, void* bigmeta, void* meta, void* scratch, hipStream_t s) {
+// list[0] = number of listed chunks (zeroed here, counted on the device), list[4 + i] = chunk index; room for every chunk of the batch
+void launch_big_list(const BatchArgs& a, int codec, uint32_t* list, hipStream_t s) {
+    if (a.n_chunks == 0) return;
+    (void)hipMemsetAsync(list, 0, 16, s);
+    const dim3 lgrid((a.n_chunks + 255u) / 256u);
+    if (codec == CJ_CODEC_SNAPPY_RAW) hipLaunchKernelGGL((big_list_kernel<CJ_CODEC_SNAPPY_RAW>), lgrid, dim3(256), 0, s, a, list);
+    else hipLaunchKernelGGL((big_list_kernel<CJ_CODEC_LZ4_BLOCK>), lgrid, dim3(256), 0, s, a, list);
+}
+
+// one group of the list: entries [base, base + cap).  scratch: big_walk_scratch_bytes(cap) bytes (the lanes' candidates and summaries)
+void launch_big_parse(const BatchArgs& a, int codec, const uint32_t* list, uint32_t base, uint32_t cap, void* recs, void* bigmeta, void* meta, void* scratch, hipStream_t s) {
     if (a.n_chunks == 0 || cap == 0) return;
     const uint32_t capr = (cap + 63u) & ~63u;
     uint32_t* cands = (uint32_t*)scratch;
     BigLane* lanes = (BigLane*)((uint8_t*)scratch + (size_t)capr * kBigLanes * 4);
     (void)hipMemsetAsync(cands, 0xFF, (size_t)capr * kBigLanes * 4, s);          // 0xFFFFFFFF = no candidate yet
-    const dim3 lgrid((a.n_chunks + 255u) / 256u);
     const dim3 wgrid((capr * kBigLanes + 64u * kBigWaves - 1u) / (64u * kBigWaves)), wblock(64u * kBigWaves);
     const dim3 sgrid((cap * kBigLanes + 255u) / 256u);
     if (codec == CJ_CODEC_SNAPPY_RAW) {
-        hipLaunchKernelGGL((big_list_kernel<CJ_CODEC_SNAPPY_RAW>), lgrid, dim3(256), 0, s, a, list);
-        hipLaunchKernelGGL((big_walk_kernel<CJ_CODEC_SNAPPY_RAW>), wgrid, wblock, 0, s, a, (const uint32_t*)list, capr, (uint4*)recs, cands, lanes);
-        hipLaunchKernelGGL((big_sum_kernel<CJ_CODEC_SNAPPY_RAW>), sgrid, dim3(256), 0, s, a, (const uint32_t*)list, (const uint4*)recs, (const BigLane*)lanes, (BigMeta*)bigmeta, (ParseMeta*)meta);
+        hipLaunchKernelGGL((big_walk_kernel<CJ_CODEC_SNAPPY_RAW>), wgrid, wblock, 0, s, a, list, base, cap, capr, (uint4*)recs, cands, lanes);
+        hipLaunchKernelGGL((big_sum_kernel<CJ_CODEC_SNAPPY_RAW>), sgrid, dim3(256), 0, s, a, list, base, cap, (const uint4*)recs, (const BigLane*)lanes, (BigMeta*)bigmeta, (ParseMeta*)meta);
     } else {
-        hipLaunchKernelGGL((big_list_kernel<CJ_CODEC_LZ4_BLOCK>), lgrid, dim3(256), 0, s, a, list);
-        hipLaunchKernelGGL((big_walk_kernel<CJ_CODEC_LZ4_BLOCK>), wgrid, wblock, 0, s, a, (const uint32_t*)list, capr, (uint4*)recs, cands, lanes);
-        hipLaunchKernelGGL((big_sum_kernel<CJ_CODEC_LZ4_BLOCK>), sgrid, dim3(256), 0, s, a, (const uint32_t*)list, (const uint4*)recs, (const BigLane*)lanes, (BigMeta*)bigmeta, (ParseMeta*)meta);
+        hipLaunchKernelGGL((big_walk_kernel<CJ_CODEC_LZ4_BLOCK>), wgrid, wblock, 0, s, a, list, base, cap, capr, (uint4*)recs, cands, lanes);
+        hipLaunchKernelGGL((big_sum_kernel<CJ_CODEC_LZ4_BLOCK>), sgrid, dim3(256), 0, s, a, list, base, cap, (const uint4*)recs, (const BigLane*)lanes, (BigMeta*)bigmeta, (ParseMeta*)meta);
     }
 }
 

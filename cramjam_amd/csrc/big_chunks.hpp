@@ -26,6 +26,7 @@ constexpr uint32_t kBigInMax = kBigOutMax + kBigOutMax / 128u + 64u;         // 
 constexpr uint32_t kBigRegion = 2048u;                                       // record slots per region (a chunk of text has ~1 300 sequences per lane); a lane with more hands the chunk to the wavefront kernel
 constexpr uint32_t kBigRecPitch = kBigLanes * kBigRegion;                    // record slots per chunk (16 bytes each: 1 MiB)
 constexpr uint32_t kBigSlabs = kBigOutMax / 65536u;
+constexpr uint32_t kBigSlabRecs = 16384u;                                  // records per 64 KiB slab the slab decoder's tables are sized for (+ 64 of slack): a slab with more keeps its chunk off this path
 
 struct BigMeta {                 // one per listed chunk, written by the parse kernel
     uint32_t chunk;              // index of the chunk in the batch
@@ -40,14 +41,16 @@ struct BigMeta {                 // one per listed chunk, written by the parse k
 // the engine's scratch for a batch that may hold big chunks (CJ_FLAG_BIG_CHUNKS): a list of at most `cap` chunks gets record areas
 size_t big_recs_bytes(size_t cap);
 size_t big_meta_bytes(size_t cap);
-// list[0] = number of listed chunks (counted on the device), list[1] = capacity, list[4 + i] = chunk index.  The small-chunk
+// list[0] = number of listed chunks (counted on the device), list[4 + i] = chunk index, one slot per chunk of the batch.  The engine
+// walks the list in GROUPS of `cap` chunks (as many as it has record areas for): entries [base, base + cap).  The small-chunk
 // pipeline has flagged every chunk above 64 KiB kRouteWave in `meta`; a chunk this stage takes gets meta = {0, 0} and its result.
 size_t big_walk_scratch_bytes(size_t cap);
-void launch_big_parse(const BatchArgs& a, int codec, uint32_t* list, uint32_t cap, void* recs, void* bigmeta, void* meta, void* scratch, hipStream_t s);
+void launch_big_list(const BatchArgs& a, int codec, uint32_t* list, hipStream_t s);
+void launch_big_parse(const BatchArgs& a, int codec, const uint32_t* list, uint32_t base, uint32_t cap, void* recs, void* bigmeta, void* meta, void* scratch, hipStream_t s);
 // the slab work items of the listed chunks in slab-major order (item w = slab w / cap of listed chunk w % cap): descriptor rows
 // in_off | in_len | out_off | out_cap | result (8 bytes x items each, in that order from `rows`), their ParseMeta, zeroed flags
 constexpr size_t kBigItemRows = 5;
-void launch_big_items(const BatchArgs& a, const uint32_t* list, const void* bigmeta, uint32_t cap, uint64_t* rows, void* item_meta, uint32_t* done, hipStream_t s);
+void launch_big_items(const BatchArgs& a, const uint32_t* list, uint32_t base, const void* bigmeta, uint32_t cap, uint64_t* rows, void* item_meta, uint32_t* done, hipStream_t s);
 void launch_lz4_decode_big_slabs(const BatchArgs& items, const void* meta, const void* recs, const void* bigmeta, uint32_t cap, void* tabs, uint32_t* counter,
                                  uint32_t* done, void* cross, uint32_t tab_stride, uint32_t cross_stride, uint32_t grid, hipStream_t s, int codec);
 

@@ -92,7 +92,8 @@ struct cj_engine {
     std::vector<uint64_t> h_meta;
     cj::DevBuf d_frame;            // frame.hip: assembled / staged framed stream
     cj::DevBuf d_tab;              // LDS decoder variant 2: per-workgroup record tables
-    cj::DevBuf d_bigrecs, d_bigmisc, d_bigslabtab;   // chunks of 64 KiB .. 256 KiB in a device batch (big_chunks.hpp, CJ_FLAG_BIG_CHUNKS): record areas; list + summaries + slab items; the slab decoder's tables
+    cj::DevBuf d_biglist, d_bigrecs, d_bigmisc, d_bigslabtab;   // chunks of 64 KiB .. 256 KiB in a device batch (big_chunks.hpp, CJ_FLAG_BIG_CHUNKS): record areas; list + summaries + slab items; the slab decoder's tables
+    uint32_t* h_count = nullptr;   // pinned word: the number of big chunks of a batch above kBigCap chunks (engine.hip launch_decode)
     cj::DevBuf d_big, d_bigtab;    // large.hip: parse scratch / record tables of one large stream (under `mu`)
     // encoders, large batches (cj::EncFill): the persistent blocks' chunk counter
     hipEvent_t enc_free = nullptr;

@@ -47,7 +47,7 @@ int lds_scratch(cj_engine* e, const cj::BatchArgs& a, hipStream_t s, bool with_s
 //                      pass over the input (100 k chunks: 18 ms fused, 10.6 ms with the parse kernel)
 //   then               the wavefront-per-chunk kernel on what the parse left over (errors, chunks above 64 KiB, few long runs)
 //   flags              CJ_FLAG_FORCE_WAVE_PER_CHUNK / _LANE_PER_CHUNK: one mapping for every chunk (tests, comparisons)
-constexpr size_t kBigCap = 8192;          // big chunks (CJ_FLAG_BIG_CHUNKS) that get a record area per slice (1 MiB each); the rest take the wavefront kernel
+constexpr size_t kBigCap = 8192;          // big chunks (CJ_FLAG_BIG_CHUNKS) decoded per group: each holds a record area of 1 MiB while its group is in flight
 
 int launch_decode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a, hipStream_t s) {
     const bool lz4 = codec == CJ_CODEC_LZ4_BLOCK;
@@ -62,6 +62,23 @@ int launch_decode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a, hipStrea
     static const int force_fused = [] { const char* v = std::getenv("CJ_FUSED"); return v ? std::atoi(v) : -1; }();
     const bool fused = force_fused >= 0 ? force_fused != 0 : a.n_chunks <= (uint32_t)CJ_FUSED_MAX_CHUNKS;
     std::lock_guard<std::mutex> lock(e->scratch_mu);
+    // CJ_FLAG_BIG_CHUNKS: which chunks lie in (64 KiB, 256 KiB], and how many?  Listed on the device first; a batch of up to kBigCap
+    // chunks needs no count (one group, sized by the batch), a larger one reads the count back — the one place where a decode
+    // call waits for the stream (it sizes the record areas, 1 MiB per chunk, and the number of groups).
+    uint32_t n_big = 0;
+    const size_t big_list_bytes = ((4 + (size_t)a.n_chunks) * 4 + 255) & ~(size_t)255;
+    uint32_t* big_list = nullptr;
+    if ((a.flags & CJ_FLAG_BIG_CHUNKS) && e->d_biglist.reserve(big_list_bytes)) {
+        big_list = (uint32_t*)e->d_biglist.p;
+        cj::launch_big_list(a, codec, big_list, s);
+        n_big = a.n_chunks;
+        if (a.n_chunks > kBigCap) {
+            if (!e->h_count) HIP_TRY(hipHostMalloc((void**)&e->h_count, 64, hipHostMallocDefault), CJ_E_OOM);
+            HIP_TRY(hipMemcpyAsync(e->h_count, big_list, 4, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
+            HIP_TRY(hipStreamSynchronize(s), CJ_E_NO_DEVICE);
+            n_big = *e->h_count;
+        }
+    } else if (a.flags & CJ_FLAG_BIG_CHUNKS) (void)hipGetLastError();
     const int rc = lds_scratch(e, a, s, !fused);
     if (rc != 0) return rc;
     uint32_t* lists = (uint32_t*)e->d_lanelist.p;
@@ -75,32 +92,34 @@ int launch_decode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a, hipStrea
         else cj::launch_snappy_parse(a, e->d_sync.p, e->d_pmeta.p, s);
         cj::launch_lz4_decode_lds2(a, e->d_sync.p, e->d_pmeta.p, e->d_tab.p, lists + 2, grid, s, codec);
     }
-    if (a.flags & CJ_FLAG_BIG_CHUNKS) {
-        // chunks of 64 KiB .. 256 KiB (flagged kRouteWave above): listed, parsed by eight lanes each into records, decoded slab by slab
-        // with two workgroups per CU (big_chunks.hpp); what that stage does not take stays flagged for the wavefront kernel
-        const uint32_t cap = (uint32_t)std::min<size_t>(a.n_chunks, kBigCap);
+    if (n_big != 0u) {
+        // chunks of 64 KiB .. 256 KiB (flagged kRouteWave above): listed, parsed by 32 lanes each into records, decoded slab by slab
+        // with two workgroups per CU (big_chunks.hpp) — in GROUPS of `cap` listed chunks, as many as there are record areas for
+        // (1 MiB each); what that stage does not take stays flagged for the wavefront kernel
+        const uint32_t cap = (uint32_t)std::min<size_t>(n_big, kBigCap);
         const uint32_t items = cj::kBigSlabs * cap;
-        const uint32_t tab_stride = 4u * (16384u + 64u), cross_stride = 3u * (16384u + 64u);
-        // d_bigmisc: list (4 + cap words) | BigMeta x cap | item rows (5 x 8 bytes x items) | item meta | done flags | counter
-        const size_t o_meta = ((4 + (size_t)cap) * 4 + 255) & ~(size_t)255, o_rows = (o_meta + cj::big_meta_bytes(cap) + 255) & ~(size_t)255,
+        const uint32_t tab_stride = 4u * (cj::kBigSlabRecs + 64u), cross_stride = 3u * (cj::kBigSlabRecs + 64u);
+        // d_bigmisc: BigMeta x cap | item rows (5 x 8 bytes x items) | item meta | done flags | counter | walk scratch
+        const size_t o_meta = 0, o_rows = (o_meta + cj::big_meta_bytes(cap) + 255) & ~(size_t)255,
                      o_imeta = o_rows + cj::kBigItemRows * 8 * (size_t)items, o_done = o_imeta + 8 * (size_t)items, o_ctr = o_done + 4 * (size_t)items,
                      o_walk = o_ctr + 256, total = o_walk + cj::big_walk_scratch_bytes(cap);
-        if (!e->d_bigrecs.reserve_exact(cj::big_recs_bytes(cap)) || !e->d_bigmisc.reserve(total)
-            || !e->d_bigslabtab.reserve((size_t)grid * tab_stride * 16 + (size_t)grid * cross_stride * 16 + (size_t)grid * (tab_stride + 512u) * 4)) return CJ_E_OOM;
+        // no room for the record areas: the chunks stay with the wavefront kernel (slower, never wrong)
+        const bool room = e->d_bigrecs.reserve_exact(cj::big_recs_bytes(cap)) && e->d_bigmisc.reserve(total)
+            && e->d_bigslabtab.reserve((size_t)grid * tab_stride * 16 + (size_t)grid * cross_stride * 16 + (size_t)grid * (tab_stride + 512u) * 4);
+        if (!room) (void)hipGetLastError();
         uint8_t* m = (uint8_t*)e->d_bigmisc.p;
-        uint32_t* list = (uint32_t*)m;
-        const uint32_t hdr[4] = {0u, cap, 0u, 0u};
-        HIP_TRY(hipMemcpyAsync(list, hdr, sizeof hdr, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
-        HIP_TRY(hipMemsetAsync(m + o_ctr, 0, 256, s), CJ_E_NO_DEVICE);
-        cj::launch_big_parse(a, codec, list, cap, e->d_bigrecs.p, m + o_meta, e->d_pmeta.p, m + o_walk, s);
-        uint64_t* rows = (uint64_t*)(m + o_rows);
-        cj::launch_big_items(a, list, m + o_meta, cap, rows, m + o_imeta, (uint32_t*)(m + o_done), s);
-        cj::BatchArgs it = a;
-        it.in_off = rows; it.in_len = rows + items; it.out_off = rows + 2 * (size_t)items; it.out_cap = rows + 3 * (size_t)items;
-        it.result = (int64_t*)(rows + 4 * (size_t)items); it.n_chunks = items; it.flags = a.flags & CJ_FLAG_DEBUG_PROFILE;
-        uint8_t* t = (uint8_t*)e->d_bigslabtab.p;
-        cj::launch_lz4_decode_big_slabs(it, m + o_imeta, e->d_bigrecs.p, m + o_meta, cap, t, (uint32_t*)(m + o_ctr), (uint32_t*)(m + o_done),
-                                        t + (size_t)grid * tab_stride * 16, tab_stride, cross_stride, std::min(grid, items), s, codec);
+        for (uint32_t base = 0; room && base < n_big; base += cap) {
+            HIP_TRY(hipMemsetAsync(m + o_ctr, 0, 256, s), CJ_E_NO_DEVICE);
+            cj::launch_big_parse(a, codec, big_list, base, cap, e->d_bigrecs.p, m + o_meta, e->d_pmeta.p, m + o_walk, s);
+            uint64_t* rows = (uint64_t*)(m + o_rows);
+            cj::launch_big_items(a, big_list, base, m + o_meta, cap, rows, m + o_imeta, (uint32_t*)(m + o_done), s);
+            cj::BatchArgs it = a;
+            it.in_off = rows; it.in_len = rows + items; it.out_off = rows + 2 * (size_t)items; it.out_cap = rows + 3 * (size_t)items;
+            it.result = (int64_t*)(rows + 4 * (size_t)items); it.n_chunks = items; it.flags = a.flags & CJ_FLAG_DEBUG_PROFILE;
+            uint8_t* t = (uint8_t*)e->d_bigslabtab.p;
+            cj::launch_lz4_decode_big_slabs(it, m + o_imeta, e->d_bigrecs.p, m + o_meta, cap, t, (uint32_t*)(m + o_ctr), (uint32_t*)(m + o_done),
+                                            t + (size_t)grid * tab_stride * 16, tab_stride, cross_stride, std::min(grid, items), s, codec);
+        }
     }
     if (lz4) cj::launch_lz4_decode_routed(a, e->d_pmeta.p, s);                // few long runs / oversize chunks / errors
     else cj::launch_snappy_decode_routed(a, e->d_pmeta.p, s);
@@ -297,7 +316,7 @@ int cj_engine_create(int device, cj_engine** out) {
 void cj_engine_destroy(cj_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
-    e->d_in.release(); e->d_out.release(); e->d_meta.release(); e->d_sync.release(); e->d_bigrecs.release(); e->d_bigmisc.release(); e->d_bigslabtab.release(); e->d_pmeta.release(); e->d_lanelist.release(); e->d_frame.release(); e->d_tab.release(); e->d_big.release(); e->d_bigtab.release();
+    e->d_in.release(); e->d_out.release(); e->d_meta.release(); e->d_sync.release(); e->d_bigrecs.release(); e->d_bigmisc.release(); e->d_biglist.release(); if (e->h_count) (void)hipHostFree(e->h_count); e->d_bigslabtab.release(); e->d_pmeta.release(); e->d_lanelist.release(); e->d_frame.release(); e->d_tab.release(); e->d_big.release(); e->d_bigtab.release();
     e->h_in.release(); e->h_out.release();
     if (e->scratch_free) (void)hipEventDestroy(e->scratch_free);
     e->d_enc.release();
@@ -383,7 +402,13 @@ int cj_batch_host(cj_engine* e, cj_codec codec, cj_op op, uint32_t flags, size_t
             for (size_t k = 0; k < rest.size(); k++) result[rest[k]] = rr[k];
             return 0;
         }
-        if (!big.empty()) flags |= CJ_FLAG_BIG_CHUNKS;        // many big chunks: the batch's own big-chunk path (up to 256 KiB each; big_chunks.hpp)
+        // many big chunks: the batch's own big-chunk path takes those of up to 256 KiB (big_chunks.hpp) — asked for only if there is one
+        bool any_mid = false;
+        for (size_t i : big) {
+            const int64_t u = codec == CJ_CODEC_SNAPPY_RAW ? cj_snappy_raw_decompress_len(in_ptrs[i], in_lens[i]) : (int64_t)out_caps[i];
+            if (u > (int64_t)kLargeMin && u <= (int64_t)(4u * 65536u)) { any_mid = true; break; }
+        }
+        if (any_mid) flags |= CJ_FLAG_BIG_CHUNKS;
     }
     std::lock_guard<std::mutex> lock(e->mu);
     HIP_TRY(hipSetDevice(e->device), CJ_E_NO_DEVICE);

@@ -146,3 +146,63 @@ def test_snappy_copy_that_reaches_beyond_the_previous_slab(eng):
     res, out, off = _run(eng, SN, [stream] * 3, [len(raw)] * 3, N.FLAG_BIG_CHUNKS)
     for i in range(3):
         assert res[i] == len(raw) and out[int(off[i]):int(off[i]) + len(raw)].tobytes() == raw
+
+
+def _sn_varint(n):
+    out = bytearray()
+    while n >= 0x80: out.append((n & 0x7f) | 0x80); n >>= 7
+    out.append(n)
+    return bytes(out)
+
+
+def test_snappy_slab_with_more_records_than_the_slab_tables_hold(eng):
+    """Valid Snappy streams of tiny elements: a 64 KiB slab of OUTPUT may hold far more than the 16 384 records an LZ4 slab can
+    (min match 4) — the slab decoder's tables are sized for those, so such a chunk has to stay with the one-wavefront kernel
+    (round-4 advisor: before the check its cross list ran into the next workgroup's).  Shapes: copies of 3 bytes throughout (21 845
+    records per slab, every parse lane inside its region limit), copies of 1 byte behind a long literal, literals of 1 byte."""
+    rnd = random.Random(11)
+    streams, raws = [], []
+    seed = rnd.randbytes(16)
+    for k, (clen, off) in enumerate(((3, 3), (3, 16), (2, 5), (1, 7))):
+        cnt = 64000 if clen == 3 else 52000
+        raw = bytearray(seed)
+        body = bytearray([(len(seed) - 1) << 2]) + seed
+        for _ in range(cnt):
+            body += bytes([((clen - 1) << 2) | 2]) + off.to_bytes(2, "little")
+            for _ in range(clen): raw.append(raw[-off])
+        streams.append(_sn_varint(len(raw)) + bytes(body)); raws.append(bytes(raw))
+    # one-byte copies with offset 65 535 behind 70 000 literal bytes (the advisor's example), and one-byte literals
+    head = rnd.randbytes(70000)
+    raw = bytearray(head); body = bytearray([62 << 2]) + (len(head) - 1).to_bytes(3, "little") + head
+    for _ in range(52000):
+        body += bytes([(0 << 2) | 2]) + (65535).to_bytes(2, "little"); raw.append(raw[-65535])
+    streams.append(_sn_varint(len(raw)) + bytes(body)); raws.append(bytes(raw))
+    tiny = rnd.randbytes(90000)
+    streams.append(_sn_varint(len(tiny)) + b"".join(bytes([0, b]) for b in tiny)); raws.append(tiny)
+    for s_, r in zip(streams, raws):
+        assert oracle.snappy_decompress(s_) == (len(r), r)
+    normal = oracle.synth_v1(S, 321)
+    blobs = (streams + [oracle.snappy_compress(normal)[1]]) * 6          # between ordinary big chunks: a corrupted neighbour would show
+    want = (raws + [normal]) * 6
+    res, out, off = _run(eng, SN, blobs, [len(r) for r in want], N.FLAG_BIG_CHUNKS)
+    for i, r in enumerate(want):
+        assert res[i] == len(r), (i, int(res[i]), len(r))
+        assert out[int(off[i]):int(off[i]) + len(r)].tobytes() == r, i
+
+
+@pytest.mark.parametrize("codec", [LZ4, SN])
+def test_more_big_chunks_in_one_call_than_one_group_holds(eng, codec):
+    """The engine gives the big chunks of a call record areas in groups of 8 192 (engine.hip: kBigCap); a call with more of them
+    (round 4: the rest silently fell to one wavefront each) runs group after group — every chunk against the oracle's bytes."""
+    uniq = [oracle.synth_v1(n, 40 + n) for n in (70000, 66000, 90000, 131072, 262144, 65537)] + [_text(80000, 9)]
+    comp = (lambda r: oracle.lz4_compress_raw(r)[1]) if codec == LZ4 else (lambda r: oracle.snappy_compress(r)[1])
+    ub = [comp(r) for r in uniq]
+    small = oracle.synth_v1(40000, 77)
+    n = 8192 + 8192 + 700                                                 # three groups, the last one ragged; small chunks in between
+    blobs, want = [], []
+    for i in range(n):
+        if i % 9 == 4: blobs.append(comp(small)); want.append(small)
+        else: blobs.append(ub[i % len(ub)]); want.append(uniq[i % len(uniq)])
+    res, out, off = _run(eng, codec, blobs, [len(r) for r in want], N.FLAG_BIG_CHUNKS)
+    bad = [i for i, r in enumerate(want) if res[i] != len(r) or out[int(off[i]):int(off[i]) + len(r)].tobytes() != r]
+    assert not bad, (len(bad), bad[:8])

@@ -64,6 +64,14 @@ static const Mode kModes[] = {
     {"global_load_dword x8 scattered in 64 KiB per wave (cache-resident) + v_add x8", 8, 0, 0},
     {"global_load_dwordx4 x8 scattered in 64 KiB per wave + v_add x8", 8, 0, 0},
     {"ds_write_b16 x8 scattered + v_add x8", 8, 0, 8},
+    {"v_cndmask_b32_e64 with VCC as its mask operand x32, independent", 32, 0, 0},
+    {"v_addc_co_u32 (reads and writes vcc) x32", 32, 0, 0},
+    {"v_cndmask_b32_e32 (vcc) x32, dst != src (v_cndmask d, a, b)", 32, 0, 0},
+    {"global_load_dword x8 scattered, 16 of 64 lanes active + v_add x8", 8, 0, 0},
+    {"global_load_dword x8 consecutive dwords (coalesced) + v_add x8", 8, 0, 0},
+    {"global_load_dwordx4 x8 consecutive 16 B per lane + v_add x8", 8, 0, 0},
+    {"global_store_dword x8 scattered + v_add x8", 8, 0, 0},
+    {"global_store_byte x8 scattered + v_add x8", 8, 0, 0},
 };
 constexpr int kNumModes = sizeof(kModes) / sizeof(kModes[0]);
 
@@ -82,7 +90,9 @@ __global__ __launch_bounds__(1024) void probe(uint64_t* times, uint32_t* sink, i
     const uint64_t gbase = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(gb_ >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)gb_);
     typedef uint32_t v4 __attribute__((ext_vector_type(4)));
     v4 r4 = {0, 0, 0, 0};
-    if (MODE == 31) asm volatile("v_cmp_lt_u32 vcc, %0, %1" :: "v"(a0), "v"(vb) : "vcc");
+    const uint64_t quarter = 0x1111111111111111ull;
+    uint32_t lin = (tid & 63u) * 4u, lin4 = (tid & 63u) * 16u;
+    if (MODE == 31 || MODE == 35 || MODE == 37) asm volatile("v_cmp_lt_u32 vcc, %0, %1" :: "v"(a0), "v"(vb) : "vcc");
     uint64_t t0, t1;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_barrier\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");
     for (int it = 0; it < iters; it++) {
@@ -213,6 +223,40 @@ __global__ __launch_bounds__(1024) void probe(uint64_t* times, uint32_t* sink, i
             asm volatile(R8("global_load_dwordx4 %[r], %1, %[gb]\n v_add_u32 %2, %2, %8\n") "s_waitcnt vmcnt(0)\n"
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk), [gb] "s"(gbase), [r] "v"(r4) : "memory");
             a1 = (a1 * 5u + 2u * tid + 1u) & 0xfff0u;
+        } else if constexpr (MODE == 35) {
+            asm volatile(R4("v_cndmask_b32_e64 %0, %0, %8, vcc\n v_cndmask_b32_e64 %1, %1, %8, vcc\n v_cndmask_b32_e64 %2, %2, %8, vcc\n v_cndmask_b32_e64 %3, %3, %8, vcc\n"
+                            "v_cndmask_b32_e64 %4, %4, %8, vcc\n v_cndmask_b32_e64 %5, %5, %8, vcc\n v_cndmask_b32_e64 %6, %6, %8, vcc\n v_cndmask_b32_e64 %7, %7, %8, vcc\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk));
+        } else if constexpr (MODE == 36) {
+            asm volatile(R4("v_addc_co_u32 %0, vcc, %0, %8, vcc\n v_addc_co_u32 %1, vcc, %1, %8, vcc\n v_addc_co_u32 %2, vcc, %2, %8, vcc\n v_addc_co_u32 %3, vcc, %3, %8, vcc\n"
+                            "v_addc_co_u32 %4, vcc, %4, %8, vcc\n v_addc_co_u32 %5, vcc, %5, %8, vcc\n v_addc_co_u32 %6, vcc, %6, %8, vcc\n v_addc_co_u32 %7, vcc, %7, %8, vcc\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk) : "vcc");
+        } else if constexpr (MODE == 37) {
+            asm volatile(R4("v_cndmask_b32 %0, %1, %8\n v_cndmask_b32 %1, %2, %8\n v_cndmask_b32 %2, %3, %8\n v_cndmask_b32 %3, %4, %8\n"
+                            "v_cndmask_b32 %4, %5, %8\n v_cndmask_b32 %5, %6, %8\n v_cndmask_b32 %6, %7, %8\n v_cndmask_b32 %7, %0, %8\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk));
+        } else if constexpr (MODE == 38) {
+            uint64_t sv;
+            asm volatile("s_mov_b64 %[sv], exec\n s_mov_b64 exec, %[qm]\n"
+                         R8("global_load_dword %0, %1, %[gb]\n v_add_u32 %2, %2, %[vb]\n") "s_waitcnt vmcnt(0)\n s_mov_b64 exec, %[sv]\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), [sv] "=&s"(sv) : [vb] "v"(vb), "s"(sk), [gb] "s"(gbase), [qm] "s"(quarter) : "memory");
+            a1 = (a1 * 5u + 2u * tid + 1u) & 0xfffcu;
+        } else if constexpr (MODE == 39) {
+            asm volatile(R8("global_load_dword %0, %[lin], %[gb]\n v_add_u32 %2, %2, %8\n") "s_waitcnt vmcnt(0)\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk), [gb] "s"(gbase), [lin] "v"(lin) : "memory");
+            lin = (lin + 256u) & 0xfffcu;
+        } else if constexpr (MODE == 40) {
+            asm volatile(R8("global_load_dwordx4 %[r], %[lin], %[gb]\n v_add_u32 %2, %2, %8\n") "s_waitcnt vmcnt(0)\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk), [gb] "s"(gbase), [r] "v"(r4), [lin] "v"(lin4) : "memory");
+            lin4 = (lin4 + 1024u) & 0xfff0u;
+        } else if constexpr (MODE == 41) {
+            asm volatile(R8("global_store_dword %1, %0, %[gb]\n v_add_u32 %2, %2, %8\n") "s_waitcnt vmcnt(0)\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk), [gb] "s"(gbase) : "memory");
+            a1 = (a1 * 5u + 2u * tid + 1u) & 0xfffcu;
+        } else if constexpr (MODE == 42) {
+            asm volatile(R8("global_store_byte %1, %0, %[gb]\n v_add_u32 %2, %2, %8\n") "s_waitcnt vmcnt(0)\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk), [gb] "s"(gbase) : "memory");
+            a1 = (a1 * 5u + 2u * tid + 1u) & 0xffffu;
         } else if constexpr (MODE == 34) {
             asm volatile(R8("ds_write_b16 %1, %0\n v_add_u32 %2, %2, %8\n") "s_waitcnt lgkmcnt(0)\n"
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vb), "s"(sk) : "memory");
@@ -229,6 +273,7 @@ static const uint8_t* d_gmem;
 template <int MODE>
 static void run_mode(int n_cu, uint64_t* d_times, uint32_t* d_sink, double clock_ghz) {
     const Mode& m = kModes[MODE];
+    if (getenv("PROBE_FROM") && MODE < atoi(getenv("PROBE_FROM"))) return;
     const int iters = 4000;
     const size_t lds_bytes = 96 * 1024;          // one workgroup per CU
     CHECK(hipFuncSetAttribute((const void*)probe<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

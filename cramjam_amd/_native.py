@@ -45,6 +45,7 @@ SYMBOLS = {
     "cj_engine_device": (_int, [_vp]),
     "cj_batch_device": (_int, [_vp, _int, _int, _u32, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cj_engine_sync": (_int, [_vp]),
+    "cj_stream_sync": (_int, [_vp, _vp]),
     "cj_batch_host": (_int, [_vp, _int, _int, _u32, _sz, _vp, _vp, _vp, _vp, _vp]),
     "cj_batch_device_timed": (C.c_double, [_vp, _int, _int, _u32, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int]),
     "cj_device_alloc": (_vp, [_vp, _sz]),

@@ -351,6 +351,13 @@ int cj_engine_sync(cj_engine* e) {
     return 0;
 }
 
+int cj_stream_sync(cj_engine* e, void* hip_stream) {
+    if (!e) return CJ_E_BAD_ARG;
+    HIP_TRY(hipSetDevice(e->device), CJ_E_NO_DEVICE);
+    HIP_TRY(hipStreamSynchronize(hip_stream ? (hipStream_t)hip_stream : e->stream), CJ_E_NO_DEVICE);
+    return 0;
+}
+
 double cj_batch_device_timed(cj_engine* e, cj_codec codec, cj_op op, uint32_t flags, size_t n_chunks,
                              const uint8_t* in_base, const uint64_t* in_off, const uint64_t* in_len,
                              uint8_t* out_base, const uint64_t* out_off, const uint64_t* out_cap,

@@ -197,6 +197,9 @@ CJ_API int cj_batch_device(cj_engine* e, cj_codec codec, cj_op op, uint32_t flag
                     uint8_t* out_base, const uint64_t* out_off, const uint64_t* out_cap,
                     int64_t* result, void* hip_stream);
 CJ_API int cj_engine_sync(cj_engine* e);
+/* the same for a caller's stream (a hipStream_t; NULL = the engine's own): what a binding without its own HIP runtime handle needs
+ * to wait for a batch it submitted on a stream it was handed (cramjam_amd.batch.*_device(stream=...)) */
+CJ_API int cj_stream_sync(cj_engine* e, void* hip_stream);
 
 /* Host batch: host pointers; the engine packs inputs into pinned staging, copies H2D, runs the
  * kernels, copies D2H and scatters.  Synchronous. result[i] as above. */

@@ -156,6 +156,9 @@ def _is_device_obj(x):
 
 def _device_batch(codec, op, flags, inp, in_off, in_len, out, out_off, out_cap, result, device, stream, sync):
     import numpy as np
+    if stream is not None and int(stream) == 0:
+        raise ValueError("cramjam_amd.batch: the NULL stream (torch's default stream has handle 0) cannot be named through the C-ABI, where NULL means "
+                         "the engine's own stream — run the producer on a torch.cuda.Stream() and pass its .cuda_stream, or leave stream=None and synchronize")
     views, temps = [], []
     try:
         vin, vout = _DevView(inp), _DevView(out)
@@ -221,9 +224,11 @@ def lz4_decompress_blocks_device(inp, in_off, in_len, out, out_off, out_cap, sto
     in_off, in_len, out_off, out_cap: 64-bit integer arrays of one entry per chunk — device arrays are used in place, host
     sequences / numpy arrays are uploaded; result: optional device int64 array that receives the decoded length of every chunk
     (or a negative CJ_E_* code).  Returns `result`, or — when it was None — a numpy int64 array with the same content.
-    stream: a hipStream_t handle as an int (torch.cuda.current_stream().cuda_stream) to order the batch behind the producer of
-    the buffers; without it the caller makes sure they are ready (torch.cuda.synchronize()).  sync=False returns right after
-    submission (device-resident metadata and result only)."""
+    stream: a hipStream_t handle as an int (a torch.cuda.Stream().cuda_stream; not the default stream, whose handle 0 means "the engine's own" here) to order the
+    batch behind the producer of the buffers; without it the batch runs on the engine's own stream and the caller makes sure the
+    buffers are ready (torch.cuda.synchronize()).  sync=False returns right after submission (device-resident metadata and result
+    only).  In a process that also uses torch, import torch FIRST: both link libamdhip64.so.7, torch loads its own copy by path, and
+    two HIP runtimes in one process do not share a device."""
     return _device_batch(N.CODEC_LZ4_BLOCK, N.OP_DECOMPRESS, N.FLAG_LZ4_SIZE_PREFIX if store_size else 0,
                          inp, in_off, in_len, out, out_off, out_cap, result, device, stream, sync)
 

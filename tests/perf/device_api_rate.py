@@ -30,13 +30,17 @@ cap = np.full(n, S, np.uint64); out_off = (np.arange(n, dtype=np.uint64) * np.ui
 t_out = torch.empty(n * S, dtype=torch.uint8, device=dev)
 mk = lambda a: torch.from_numpy(a.view(np.int64)).to(dev)
 t_off, t_len, t_ooff, t_cap, t_res = mk(off), mk(ln), mk(out_off), mk(cap), torch.empty(n, dtype=torch.int64, device=dev)
-st = torch.cuda.current_stream().cuda_stream
+side = torch.cuda.Stream()
+torch.cuda.synchronize()
+st = side.cuda_stream
 for _ in range(3): batch.lz4_decompress_blocks_device(t_in, t_off, t_len, t_out, t_ooff, t_cap, result=t_res, stream=st)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 K = 20
-e0.record()
-for _ in range(K): batch.lz4_decompress_blocks_device(t_in, t_off, t_len, t_out, t_ooff, t_cap, result=t_res, stream=st, sync=False)
-e1.record(); torch.cuda.synchronize()
+with torch.cuda.stream(side):
+    e0.record()
+    for _ in range(K): batch.lz4_decompress_blocks_device(t_in, t_off, t_len, t_out, t_ooff, t_cap, result=t_res, stream=st, sync=False)
+    e1.record()
+torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / K
 assert bool((t_res == S).all())
 got = t_out.view(n, S)[:U].cpu().numpy()

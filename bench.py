@@ -425,8 +425,8 @@ def main():
 
     cpu = None
     default_case = (not mixed and dec and rt is None and args.codec == "lz4" and S == 65536 and args.lz4_mode == "auto" and args.in_flight == 1)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and dec and not mixed:
-        cpu = cpu_baseline(args, codec, b0)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, batches, args.op, rt)
     traffic = None
     kernels_ms = None
     if rank == 0 and world == 1 and (args.traffic == "on" or (args.traffic == "auto" and default_case)) and not os.environ.get("CJ_BENCH_CHILD"):
@@ -443,7 +443,7 @@ def main():
             metric = ("uncompressed GB/s (LZ4-block decomp, 64 KiB chunks)" if (dec and rt is None and args.codec == "lz4" and S == 65536)
                       else "uncompressed GB/s (%s %s, %d B chunks)" % (args.codec, args.op, S))
             workload = "%s-block %s, %d x %d B %s chunks per GPU, device-resident" % (
-                args.codec, args.op, NCH, S, "synth-v1" if corpus_files is None else "benchmark-corpus (%d unique full chunks of %d files, tiled)" % (U, len(corpus_files)))
+                args.codec, args.op, NCH, S, "synth-v1" if corpus_files is None else "benchmark-corpus (%d unique full chunks of %d files — of the corpus's 1 413: the eight large files travel as 12-chunk samples —, tiled)" % (U, len(corpus_files)))
             if dec and args.codec == "lz4":
                 kernel = {"auto": "lz4_parse_kernel+lz4_decode_lds2_kernel", "lds": "lz4_parse_kernel+lz4_decode_lds2_kernel",
                           "wave": "lz4_decode_kernel", "lane": "lz4_decode_lanes_kernel"}[args.lz4_mode]
@@ -508,46 +508,110 @@ def usable_cores():
     return n, note
 
 
-def cpu_baseline(args, codec, b):
-    """CPU decoders over the U unique chunks of this run, ONE persistent thread pool per leg (oracle/synth_batch_oracle.c):
-    the oracle's C restatement (kind "port") and the host's liblz4 / libsnappy when present (kinds "liblz4", "libsnappy"), each with
-    all cores and with one.  The top-level fields are the host library on all cores when present (else the port); `legs` lists everything."""
+def _cpu_legs(seconds, plan, n_of, run, check):
+    """time every (kind, op, threads) leg of `plan` for its share of `seconds`: a calibration pass, then `reps` passes with one pool"""
+    scale = seconds / sum(p[3] for p in plan)
+    legs = []
+    for kind, op, threads, share in plan:
+        n1 = n_of(threads)
+        t0 = time.perf_counter()
+        run(op, threads, 1, n1)
+        t1 = time.perf_counter() - t0
+        reps = max(1, min(100000, int(share * scale / max(t1, 1e-6))))
+        t0 = time.perf_counter()
+        rc = run(op, threads, reps, n1)
+        el = time.perf_counter() - t0
+        assert rc == 0, "cpu leg %s failed" % kind
+        check(kind, op, n1)
+        legs.append((kind, threads, reps, n1, el))
+    return legs
+
+
+def cpu_baseline(args, batches, op, rt_batch=None):
+    """The CPU side of the same work, on the U unique chunks of this run, ONE persistent thread pool per leg (oracle/synth_batch_oracle.c):
+    the oracle's C restatement (kind "port") and the host's liblz4 / libsnappy when present — the C code the reference executes through
+    lz4-sys, and the library its `snap` crate ports — each with all cores and with one.  decompress: the decoders over the same compressed
+    chunks the GPU reads; compress: LZ4_compress_default / snappy_compress (and the port) over the same raw chunks; roundtrip: both halves
+    (value = 1 / (1 / compress + 1 / decompress)); the mixed workload: each codec's half with its own library (value = bytes / summed time).
+    Top level: the host library on all cores when present (else the port); `legs` lists everything."""
     import numpy as np
     import oracle
     OL = oracle.lib()
-    S, U = b.S, b.U
     cores, cores_note = usable_cores()
-    out = np.empty(U * S, dtype=np.uint8)
-    res = np.zeros(U, dtype=np.int64)
-    off = np.ascontiguousarray(b.uoff, dtype=np.uint64)
-    ln = np.ascontiguousarray(b.clen, dtype=np.uint64)
-    lz4 = codec == 0
-    plan = [("port", 0 if lz4 else 2, cores, 0.35), ("port", 0 if lz4 else 2, 1, 0.15)]
-    if lz4 and OL.cjo_have_liblz4():
-        plan += [("liblz4", 4, cores, 0.35), ("liblz4", 4, 1, 0.15)]
-    if not lz4 and OL.cjo_have_libsnappy():
-        plan += [("libsnappy", 5, cores, 0.35), ("libsnappy", 5, 1, 0.15)]
-    scale = args.cpu_seconds / sum(p[3] for p in plan)
-    legs = []
-    for kind, op, threads, share in plan:
-        n1 = U if threads > 1 else min(U, 256)          # one thread: a slice of the chunks is enough for a calibration pass
-        t0 = time.perf_counter()
-        OL.cjo_batch_run_reps(op, threads, 1, n1, b.packed_h.ctypes.data, off.ctypes.data, ln.ctypes.data, out.ctypes.data, S, res.ctypes.data)
-        t1 = time.perf_counter() - t0
-        reps = max(1, min(100000, int(share * scale / max(t1, 1e-6))))
-        res[:] = 0
-        t0 = time.perf_counter()
-        rc = OL.cjo_batch_run_reps(op, threads, reps, n1, b.packed_h.ctypes.data, off.ctypes.data, ln.ctypes.data, out.ctypes.data, S, res.ctypes.data)
-        el = time.perf_counter() - t0
-        assert rc == 0 and (res[:n1] == S).all() and (out[:n1 * S] == b.raw_h[:n1 * S]).all(), "cpu decoder (%s) disagrees with the generator" % kind
-        legs.append({"kind": kind, "cores": threads, "value": reps * n1 * S / el / 1e9, "unit": "GB/s",
-                     "sample": "%d passes x %d unique %d B chunks (same inputs as the GPU run), one thread pool, %.1f s" % (reps, n1, S, el)})
-    # top level: the fastest leg of the reference's own lineage — liblz4 on all cores when the host has it (the C code the
-    # reference links through lz4-sys), else the port; every leg stays in `legs`
-    best = next((g for g in legs if g["kind"] in ("liblz4", "libsnappy") and g["cores"] > 1), legs[0])
-    top = dict(best)
-    top["host"] = cores_note
-    top["legs"] = legs
+    seconds = args.cpu_seconds / max(1, (len(batches) if op != "roundtrip" else 2))
+    all_legs, tops = [], []
+
+    def one(b, enc):
+        S, U = b.S, b.U
+        lz4 = b.codec == 0
+        raw_h = b.raw_h if b.raw_h is not None else b.raw.cpu().numpy()
+        if enc:
+            bound = (S + S // 255 + 16) if lz4 else (32 + S + S // 6)
+            stride = (bound + 15) & ~15
+            out = np.empty(U * stride, dtype=np.uint8)
+            off = np.arange(U, dtype=np.uint64) * np.uint64(S)
+            ln = np.full(U, S, np.uint64)
+            src = raw_h
+            plan = [("port", 1 if lz4 else 3, cores, 0.35), ("port", 1 if lz4 else 3, 1, 0.15)]
+            if lz4 and OL.cjo_have_liblz4():
+                plan += [("liblz4", 6, cores, 0.35), ("liblz4", 6, 1, 0.15)]
+            if not lz4 and OL.cjo_have_libsnappy():
+                plan += [("libsnappy", 7, cores, 0.35), ("libsnappy", 7, 1, 0.15)]
+        else:
+            stride = S
+            out = np.empty(U * S, dtype=np.uint8)
+            off = np.ascontiguousarray(b.uoff, dtype=np.uint64)
+            ln = np.ascontiguousarray(b.clen, dtype=np.uint64)
+            src = b.packed_h
+            plan = [("port", 0 if lz4 else 2, cores, 0.35), ("port", 0 if lz4 else 2, 1, 0.15)]
+            if lz4 and OL.cjo_have_liblz4():
+                plan += [("liblz4", 4, cores, 0.35), ("liblz4", 4, 1, 0.15)]
+            if not lz4 and OL.cjo_have_libsnappy():
+                plan += [("libsnappy", 5, cores, 0.35), ("libsnappy", 5, 1, 0.15)]
+        res = np.zeros(U, dtype=np.int64)
+
+        def run(opc, threads, reps, n1):
+            res[:] = 0
+            return OL.cjo_batch_run_reps(opc, threads, reps, n1, src.ctypes.data, off.ctypes.data, ln.ctypes.data, out.ctypes.data, stride, res.ctypes.data)
+
+        def check(kind, opc, n1):
+            if enc:
+                assert (res[:n1] > 0).all(), "cpu encoder (%s) failed" % kind
+                for i in range(0, n1, max(1, n1 // 16)):          # a sample of its streams through the oracle's decoder
+                    blk = out[i * stride:i * stride + int(res[i])].tobytes()
+                    r, d = (oracle.lz4_decompress_raw(blk, S) if lz4 else oracle.snappy_decompress(blk))
+                    assert r == S and d == raw_h[i * S:(i + 1) * S].tobytes(), "cpu encoder (%s) stream does not decode" % kind
+            else:
+                assert (res[:n1] == S).all() and (out[:n1 * S] == raw_h[:n1 * S]).all(), "cpu decoder (%s) disagrees with the generator" % kind
+        legs = _cpu_legs(seconds, plan, lambda threads: U if threads > 1 else min(U, 256), run, check)
+        what = ("%s %s" % ("lz4" if lz4 else "snappy", "compress" if enc else "decompress"))
+        outl = [{"kind": kind, "what": what, "cores": threads, "value": reps * n1 * S / el / 1e9, "unit": "GB/s",
+                 "sample": "%d passes x %d unique %d B chunks (same inputs as the GPU run), one thread pool, %.1f s" % (reps, n1, S, el)}
+                for kind, threads, reps, n1, el in legs]
+        best = next((g for g in outl if g["kind"] in ("liblz4", "libsnappy") and g["cores"] > 1), outl[0])
+        return outl, best
+
+    halves = []
+    if op == "compress":
+        halves = [(b, True) for b in batches]
+    elif op == "decompress":
+        halves = [(b, False) for b in batches]
+    else:                                                     # roundtrip: the decode batch holds the compressed chunks, rt_batch the raw ones
+        halves = [(rt_batch, True), (batches[0], False)]
+    weights = []
+    for b, enc in halves:
+        legs, best = one(b, enc)
+        all_legs += legs
+        tops.append(best)
+        weights.append(b.NCH * b.S)
+    if op == "roundtrip":
+        value = 1.0 / sum(1.0 / t["value"] for t in tops)
+    else:
+        value = sum(weights) / sum(w / t["value"] for w, t in zip(weights, tops))
+    top = {"value": value, "unit": "GB/s", "cores": tops[0]["cores"], "kind": "+".join(sorted({t["kind"] for t in tops})),
+           "sample": "; ".join("%s: %s" % (t["what"], t["sample"]) for t in tops), "host": cores_note, "legs": all_legs}
+    if top["kind"] in ("liblz4", "libsnappy", "liblz4+libsnappy"):
+        top["kind_note"] = "the host's C libraries of the codecs' own lineage (what the reference executes through lz4-sys / what its snap crate ports); SURVEY 8d kind: reference-lineage library, not the reference's Rust build"
     return top
 
 

@@ -121,7 +121,8 @@ void cjo_synth_v1(uint8_t* dst, size_t chunk_bytes, uint64_t index, uint64_t see
 int cjo_batch_run(int op, int threads, size_t n_chunks, const uint8_t* in_base, const uint64_t* in_off,
                   const uint64_t* in_len, uint8_t* out_base, size_t out_stride, int64_t* res);
 /* the same, `reps` passes over the batch with ONE pool (threads created once, barrier between passes).
- * op 4 = the host's liblz4 LZ4_decompress_safe (dlopen; res = -1 when the library is absent, see cjo_have_liblz4). */
+ * op 4 = the host's liblz4 LZ4_decompress_safe (dlopen; res = -1 when the library is absent, see cjo_have_liblz4);
+ * op 6 = its LZ4_compress_default, op 7 = the host's libsnappy snappy_compress (the compress legs of bench.py's cpu_baseline). */
 int cjo_batch_run_reps(int op, int threads, int reps, size_t n_chunks, const uint8_t* in_base, const uint64_t* in_off,
                        const uint64_t* in_len, uint8_t* out_base, size_t out_stride, int64_t* res);
 int cjo_have_liblz4(void);

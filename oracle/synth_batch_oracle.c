@@ -64,6 +64,19 @@ static lz4_safe_fn liblz4_decoder(void) {
     return g_lz4_safe;
 }
 int cjo_have_liblz4(void) { return liblz4_decoder() != 0; }
+/* LZ4_compress_default of the same library (op 6 below): the C code the reference's compress_block executes through lz4-sys */
+typedef int (*lz4_comp_fn)(const char*, char*, int, int);
+static lz4_comp_fn g_lz4_comp;
+static lz4_comp_fn liblz4_encoder(void) {
+    if (!g_lz4_comp && liblz4_decoder()) {
+        static const char* names[] = { "liblz4.so.1", "/lib/x86_64-linux-gnu/liblz4.so.1", "/opt/conda/lib/liblz4.so.1", "liblz4.so" };
+        for (unsigned k = 0; k < sizeof names / sizeof names[0] && !g_lz4_comp; k++) {
+            void* h = dlopen(names[k], RTLD_NOW | RTLD_LOCAL);
+            if (h) g_lz4_comp = (lz4_comp_fn)dlsym(h, "LZ4_compress_default");
+        }
+    }
+    return g_lz4_comp;
+}
 
 /* libsnappy's decoder through its C API (snappy-c.h: snappy_uncompress), when the host has the library: the C++ code the
  * reference's `snap` crate is a port of.  op 5 below; -1 for every chunk when it is absent. */
@@ -82,6 +95,19 @@ static snappy_unc_fn libsnappy_decoder(void) {
     return g_sn_unc;
 }
 int cjo_have_libsnappy(void) { return libsnappy_decoder() != 0; }
+/* snappy_compress of the same library (op 7 below) */
+typedef int (*snappy_comp_fn)(const char*, size_t, char*, size_t*);
+static snappy_comp_fn g_sn_comp;
+static snappy_comp_fn libsnappy_encoder(void) {
+    if (!g_sn_comp && libsnappy_decoder()) {
+        static const char* names[] = { "libsnappy.so.1", "/opt/conda/lib/libsnappy.so.1", "/usr/lib/x86_64-linux-gnu/libsnappy.so.1", "libsnappy.so" };
+        for (unsigned k = 0; k < sizeof names / sizeof names[0] && !g_sn_comp; k++) {
+            void* h = dlopen(names[k], RTLD_NOW | RTLD_LOCAL);
+            if (h) g_sn_comp = (snappy_comp_fn)dlsym(h, "snappy_compress");
+        }
+    }
+    return g_sn_comp;
+}
 
 /* A pool that lives for the whole call: `reps` passes over the batch, the threads are created ONCE and meet at a barrier
  * between passes (round 1 created and joined 255 threads per 33 ms pass and reported a tenth of what the cores can do). */
@@ -96,6 +122,8 @@ static void* worker(void* p) {
     while (atomic_load_explicit(&j->go, memory_order_acquire) == 0) sched_yield();      /* the barrier is sized once every thread exists */
     lz4_safe_fn lz4 = j->op == 4 ? liblz4_decoder() : 0;
     snappy_unc_fn snu = j->op == 5 ? libsnappy_decoder() : 0;
+    lz4_comp_fn lzc = j->op == 6 ? liblz4_encoder() : 0;
+    snappy_comp_fn snc = j->op == 7 ? libsnappy_encoder() : 0;
     for (int r = 0; r < j->reps; r++) {
         for (;;) {
             size_t i = atomic_fetch_add(&j->next[r], 8);
@@ -111,6 +139,8 @@ static void* worker(void* p) {
                 case 2: j->res[i] = cjo_snappy_decompress(in, n, out, j->out_stride); break;
                 case 3: j->res[i] = cjo_snappy_compress(in, n, out, j->out_stride); break;
                 case 5: { size_t on = j->out_stride; j->res[i] = snu && snu((const char*)in, n, (char*)out, &on) == 0 ? (int64_t)on : -1; } break;
+                case 6: j->res[i] = lzc ? lzc((const char*)in, (char*)out, (int)n, (int)j->out_stride) : -1; break;
+                case 7: { size_t on = j->out_stride; j->res[i] = snc && snc((const char*)in, n, (char*)out, &on) == 0 ? (int64_t)on : -1; } break;
                 default: j->res[i] = lz4 ? lz4((const char*)in, (char*)out, (int)n, (int)j->out_stride) : -1; break;
                 }
             }

@@ -229,9 +229,11 @@ struct Walk {
                 const uint32_t blim = umin(room, C);
                 const bool bk_on = is_head && blim > 0u, bk_blk = bk_on && C >= 16u;
                 uint4 x0 = make_uint4(0, 0, 0, 0), y0 = make_uint4(0, 0, 0, 1), x1 = x0, y1 = y0, bx = x0, by = y0;
+#ifndef CJ_EXP_NO_EXT_LOADS      // (experiment x01: what the measuring pass's loads cost — the matches come out short, the work is the same)
                 if (blk0) { x0 = g128(in, a); y0 = g128(in, a - d); }
                 if (blk1) { x1 = g128(in, a + 16u); y1 = g128(in, a + 16u - d); }
                 if (bk_blk) { bx = g128(in, P - 16u); by = g128(in, C - 16u); }
+#endif
                 if (blk0) {
                     const uint32_t e0 = first_diff(x0, y0), e1 = first_diff(x1, y1);
                     fwd = e0 == 16u && blk1 ? 16u + e1 : e0;       // (no second block this close to the end: the loop below goes on from 16)

@@ -28,6 +28,12 @@ struct Lz4Fmt {
         return 3u + lit + (lit >= 15u ? 1u : 0u) + (code >= 15u ? 1u : 0u);                    // lit < 256, code < 255: one length byte at most
     }
     static __device__ __forceinline__ void emit_lane(enc2::gcptr in, enc2::gptr out, uint32_t o, uint32_t lit0, uint32_t lit, uint32_t code, uint32_t off) {
+#ifdef CJ_EXP_NO_EMIT
+        return;             // (experiment x01: what the emission's scattered stores and literal loads cost)
+#endif
+#ifdef CJ_EXP_NO_LITCOPY
+        lit = lit > 0u ? 0u : 0u;
+#endif
         enc2::s8(out, o, ((lit < 15u ? lit : 15u) << 4) | (code < 15u ? code : 15u));
         uint32_t q = o + 1u;
         if (lit >= 15u) { enc2::s8(out, q, lit - 15u); q += 1u; }

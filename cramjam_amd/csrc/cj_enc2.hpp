@@ -31,17 +31,8 @@ namespace cj {
 #if defined(__HIPCC__)
 namespace enc2 {
 
-#ifndef CJ_ENC2_GROUPS
-#define CJ_ENC2_GROUPS 1
-#endif
-constexpr int kG = CJ_ENC2_GROUPS;                  // groups of 256 positions per round
-constexpr uint32_t kR = 256u * kG;
 constexpr uint32_t kTail = 2u;                      // the last kTail positions of a match are inserted (text +1..4 %, benchmark data -0.4 % against none)
 constexpr uint32_t kQueueCap = 64u;
-// LDS scratch of one wavefront, in dwords: heads [0, 64) · toggle bitmap [64, 64 + kR / 32 + 1) · queue [96, 96 + 128)
-constexpr uint32_t kScratchWords = 256u;
-constexpr uint32_t kHeadsAt = 0u, kTogAt = 64u, kQueueAt = 96u;
-static_assert(kTogAt + kR / 32u + 1u <= kQueueAt && kQueueAt + 2u * kQueueCap <= kScratchWords, "scratch layout");
 constexpr uint32_t kFwdBlocks = 4u;                 // forward measurement cap: 4 + 64 bytes, longer matches are finished cooperatively
 constexpr uint32_t kFlagFwdMore = 1u, kFlagBackMore = 2u;
 constexpr uint32_t kMaxLit = 256u, kMaxCode = 255u; // a queue entry packs lit < 256 and mlen - 4 < 255 into a byte each
@@ -106,21 +97,41 @@ __device__ __forceinline__ void lane_copy(gptr out, uint32_t o, gcptr in, uint32
     }
 }
 
-// The per-wavefront state of one chunk's walk.  Fmt supplies the stream format:
+// The state of one chunk's walk.  Fmt supplies the stream format:
 //   Fmt::last_start(n), Fmt::limit(n)          last position a match may start at / must end by
 //   Fmt::seq_size(lit, code, off)               encoded bytes of one queued sequence (code = mlen - 4)
 //   Fmt::emit_lane(in, out, o, lit0, lit, code, off)   one lane writes one queued sequence at output offset o
 //   Fmt::emit_wave(in, out, op, lit0, lit, off, mlen) -> new op   the whole wavefront writes one sequence of any size
-template <class Fmt>
+// kW = wavefronts per chunk (1 or 2).  With two, a round is 512 positions and wavefront w owns its group w of 256: both probe the table
+// as it was when the round began, measure their heads side by side, then select in position order — wavefront 0's heads, then
+// wavefront 1's (`cur`, the queue count and the output position travel through LDS) — and insert, group 0 first.  A wavefront issues
+// one instruction per ~5 cycles whatever it holds (tools/issue_rate_probe.hip) and a CU's LDS holds nine tables: two wavefronts per
+// table are how the CU gets more instruction streams.  tests/hostsim/enc2_model.c with R = 512 states exactly what this computes.
+template <class Fmt, int kW>
 struct Walk {
+    static constexpr uint32_t kRound = 256u * kW;
+    // LDS scratch in dwords: heads (64 per wavefront) · toggle bitmap · queue (2 per entry) · shared scalars
+    static constexpr uint32_t kHeadsAt = 0u, kTogAt = 64u * kW, kQueueAt = kTogAt + 32u, kSharedAt = kQueueAt + 2u * kQueueCap, kWords = kSharedAt + 8u;
+    static_assert(kRound / 32u + 1u <= 32u, "toggle bitmap");
+
     gcptr in;               // position 0 (start of the piece), uniform
     gptr out;               // uniform
-    uint32_t n;             // end of this wavefront's range
+    uint32_t n;             // end of this chunk's range
     uint32_t last_start, limit;
-    uint32_t* scr;          // kScratchWords dwords of LDS
+    uint32_t* scr;          // kWords dwords of LDS
     HashTab ht;
     uint32_t op;            // output position after the last EMITTED sequence (queued ones are not counted yet)
     uint32_t q_n;           // queued sequences
+    uint32_t wv;            // this wavefront's index in the chunk's workgroup (0 when kW == 1)
+
+    // both wavefronts of a chunk meet: LDS writes before it are visible behind it
+    __device__ __forceinline__ void meet() const {
+        if constexpr (kW > 1) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+    }
 
     __device__ __forceinline__ void flush() {
         if (q_n == 0u) return;
@@ -135,263 +146,280 @@ struct Walk {
         q_n = 0u;
     }
 
-    // one round over [pos, pos + span); cur = end of the last selected match on entry and exit
-    __device__ __forceinline__ void round(uint32_t pos, uint32_t span, const uint32_t (&D0)[kG], const uint32_t (&D1)[kG], uint32_t& cur_io) {
+    struct Heads {            // one wavefront's verified run heads of a round
+        uint32_t hs[4];       // hash slots of the lane's four positions
+        uint32_t dd[4];       // candidate distances (0: none)
+        bool hd[4];           // is a verified head
+        uint64_t hm[4];
+        uint32_t total;
+    };
+    struct Meas {             // one window of up to 64 heads, measured: lane i = head i
+        uint32_t mw, P, d, E, BS;
+        bool more, back_more;
+    };
+
+    // probe the 256 positions gpos + 4 lane + k against the table
+    __device__ __forceinline__ void probe(uint32_t gpos, uint32_t round_last, uint32_t D0, uint32_t D1, Heads& h) {
+        const uint32_t lane = lane_id();
+        uint32_t v[4], t[4];
+        v[0] = D0;
+        v[1] = __builtin_amdgcn_alignbyte(D1, D0, 1);
+        v[2] = __builtin_amdgcn_alignbyte(D1, D0, 2);
+        v[3] = __builtin_amdgcn_alignbyte(D1, D0, 3);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { h.hs[k] = hash_slot(v[k]); t[k] = ht.get(h.hs[k]); }
+        // distance to the slot's position, modulo the 64 KiB lap of the 16-bit table; 0 = no candidate
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t p = gpos + 4u * lane + k;
+            const uint32_t d = (p - t[k]) & 0xffffu;
+            h.dd[k] = (d != 0u && d <= p && p <= round_last) ? d : 0u;
+        }
+        // Only the FIRST position of a run of equal distances is verified: its followers lie inside its match if it is one, and a
+        // candidate dword is a scattered access — the vector memory path takes ~1.5 cycles per lane for those (64 lanes: ~94 cycles per
+        // instruction and CU, tools/issue_rate_probe.hip).  On match-heavy data half of all positions are followers.
+        const uint32_t left0 = dpp_from<kDppWaveShr1>(0u, h.dd[3]);            // lane l - 1's last position; lane 0 of a group starts afresh
+        bool pre[4];
+        pre[0] = h.dd[0] != 0u && h.dd[0] != left0;
+        pre[1] = h.dd[1] != 0u && h.dd[1] != h.dd[0];
+        pre[2] = h.dd[2] != 0u && h.dd[2] != h.dd[1];
+        pre[3] = h.dd[3] != 0u && h.dd[3] != h.dd[2];
+        uint32_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            w[k] = ~v[k];
+            if (pre[k]) w[k] = g32(in, gpos + 4u * lane + k - h.dd[k]);
+        }
+        h.total = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            h.hd[k] = pre[k] && w[k] == v[k];
+            h.hm[k] = bal(h.hd[k]);
+            h.total += (uint32_t)__builtin_popcountll(h.hm[k]);
+        }
+    }
+
+    // heads w0 .. w0 + 63 of this wavefront into consecutive lanes, measured forwards (4 + 64 bytes at most) and backwards (16)
+    __device__ __forceinline__ void measure(const Heads& h, uint32_t gpos, uint32_t w0, uint32_t cur, Meas& m) {
+        const uint32_t lane = lane_id();
+        uint32_t* heads = scr + kHeadsAt + 64u * wv;
+        {   // ranks: heads of lower lanes, of this lane's lower positions
+            uint32_t r = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) r += bits_below_lane(h.hm[k]);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (h.hd[k] && r - w0 < 64u) heads[r - w0] = (h.dd[k] << 16) | (4u * lane + k);
+                r += h.hd[k] ? 1u : 0u;
+            }
+        }
+        m.mw = umin(h.total - w0, 64u);
+        const bool is_head = lane < m.mw;
+        const uint32_t hv = is_head ? heads[lane] : (1u << 16);
+        const uint32_t P = gpos + (hv & 0xffffu), d = hv >> 16, C = P - d;
+        // ONE round trip carries the first two forward blocks and the backward block of every head
+        const uint32_t a = P + 4u;
+        uint32_t fwd = 0, back = 0;
+        bool more = is_head, back_more = false;
+        {
+            const bool blk0 = is_head && a + 16u <= n, blk1 = is_head && a + 32u <= n;
+            const uint32_t room = P - cur;                       // P >= cur for a round's first window; later windows may start behind cur (BS is not used then)
+            const uint32_t blim = umin(room, C);
+            const bool bk_on = is_head && blim > 0u, bk_blk = bk_on && C >= 16u;
+            uint4 x0 = make_uint4(0, 0, 0, 0), y0 = make_uint4(0, 0, 0, 1), x1 = x0, y1 = y0, bx = x0, by = y0;
+            if (blk0) { x0 = g128(in, a); y0 = g128(in, a - d); }
+            if (blk1) { x1 = g128(in, a + 16u); y1 = g128(in, a + 16u - d); }
+            if (bk_blk) { bx = g128(in, P - 16u); by = g128(in, C - 16u); }
+            if (blk0) {
+                const uint32_t e0 = first_diff(x0, y0), e1 = first_diff(x1, y1);
+                fwd = e0 == 16u && blk1 ? 16u + e1 : e0;       // (no second block this close to the end: the loop below goes on from 16)
+                more = fwd == (blk1 ? 32u : 16u);
+            }
+            if (bk_blk) {
+                const uint32_t sm = last_same(bx, by);
+                back = umin(sm, blim);
+                back_more = sm == 16u && blim > 16u;
+            } else if (bk_on) {                                  // candidate within the first 16 bytes of the piece
+                while (back < blim && g8(in, P - 1u - back) == g8(in, C - 1u - back)) back += 1u;
+            }
+        }
+        // the rare rest: matches beyond 4 + 32 bytes block by block, the last 16 bytes of the input byte by byte
+        for (uint32_t it = 2; it <= kFwdBlocks; it++) {
+            if (bal(more) == 0ull) break;
+            const bool blk = more && it < kFwdBlocks && a + fwd + 16u <= n;
+            if (more && !blk && a + fwd + 16u > n) {
+                while (a + fwd < limit && g8(in, a + fwd) == g8(in, a + fwd - d)) fwd += 1u;
+                more = false;
+            }
+            if (blk) {
+                const uint32_t e = first_diff(g128(in, a + fwd), g128(in, a + fwd - d));
+                fwd += e;
+                more = e == 16u;
+            }
+        }
+        if (a + fwd >= limit) { fwd = limit - a; more = false; }      // (a <= limit: P <= last_start)
+        m.P = P; m.d = d;
+        m.E = is_head ? a + fwd : 0u;                             // E = 0: never selected
+        m.BS = P - back;
+        m.more = is_head && more; m.back_more = back_more;
+    }
+
+    // the greedy walk over one measured window, its sequences into the queue, its coverage into the toggle bitmap
+    __device__ __forceinline__ void select(const Meas& m, uint32_t pos, uint32_t& cur) {
+        const uint32_t lane = lane_id();
+        const uint32_t P = m.P, d = m.d, E = m.E, BS = m.BS;
+        const uint32_t cur0 = cur;
+        uint64_t sel = 0ull;
+        uint32_t PE = 0u;
+        bool slow = bal(m.more) != 0ull;
+        if (!slow) {
+            for (;;) {                                           // the chain carries `cur` only
+                if (cur > last_start) break;
+                const uint64_t mm = bal(E >= cur + 4u);
+                if (mm == 0ull) break;
+                const uint32_t first = ctz64(mm);
+                PE = (uint32_t)cj_llvm_writelane((int)cur, (int)first, (int)PE);
+                sel |= 1ull << first;
+                cur = rdlane(E, first);
+            }
+            const bool selected = ((sel >> lane) & 1ull) != 0ull;
+            const uint32_t s = umax(BS, PE);
+            const uint32_t lit = s - PE, code = E - s - 4u;
+            const bool needs_wave = selected && (lit >= kMaxLit || code >= kMaxCode || (m.back_more && P >= PE && P - PE > 16u));
+            slow = bal(needs_wave) != 0ull;
+            if (!slow) {
+                const uint32_t ns = (uint32_t)__builtin_popcountll(sel);
+                if (q_n + ns > kQueueCap) flush();
+                if (selected) {
+                    const uint32_t slot = kQueueAt + 2u * (q_n + bits_below_lane(sel));
+                    scr[slot] = PE;
+                    scr[slot + 1u] = d | (lit << 16) | (code << 24);
+                    // coverage toggles: positions s + 1 .. E - kTail - 1 (relative to pos, clamped to the round) are inside this match
+                    const uint32_t sx = s + 1u > pos ? s + 1u - pos : 0u;
+                    const uint32_t ex = umin(E - kTail - pos, kRound);                // (E - kTail may lie before pos: ex wraps — excluded below)
+                    if (E - kTail > pos && ex > sx) {
+                        atomicXor(&scr[kTogAt + (sx >> 5)], 1u << (sx & 31u));
+                        atomicXor(&scr[kTogAt + (ex >> 5)], 1u << (ex & 31u));
+                    }
+                }
+                q_n = uni(q_n + ns);
+            }
+        }
+        if (slow) {
+            // serial cooperative path: same decisions, extensions finished by the whole wavefront, every selected sequence of this
+            // window emitted by the whole wavefront
+            cur = cur0;
+            const uint32_t flags = (m.more ? kFlagFwdMore : 0u) | (m.back_more ? kFlagBackMore : 0u);
+            for (uint32_t i = 0; i < m.mw; i++) {
+                if (cur > last_start) break;
+                const uint32_t Pi = rdlane(P, i), di = rdlane(d, i), fl = rdlane(flags, i);
+                uint32_t Ei = rdlane(E, i);
+                if (fl & kFlagFwdMore) Ei += wave_extend((const uint8_t*)in, Ei, Ei - di, limit);
+                if (Ei < cur + 4u) continue;
+                uint32_t s = cur;
+                if (Pi >= cur) {
+                    const uint32_t room = Pi - cur;
+                    uint32_t bk = umin(Pi - rdlane(BS, i), room);
+                    if ((fl & kFlagBackMore) && bk == 16u && room > 16u) bk += wave_extend_back((const uint8_t*)in, Pi - 16u, Pi - di - 16u, room - 16u);
+                    s = Pi - bk;
+                }
+                flush();
+                op = Fmt::emit_wave(in, out, op, cur, s - cur, di, Ei - s);
+                if (lane == 0u) {
+                    const uint32_t sx = s + 1u > pos ? s + 1u - pos : 0u;
+                    const uint32_t ex = umin(Ei - kTail - pos, kRound);
+                    if (Ei - kTail > pos && ex > sx) {
+                        scr[kTogAt + (sx >> 5)] ^= 1u << (sx & 31u);
+                        scr[kTogAt + (ex >> 5)] ^= 1u << (ex & 31u);
+                    }
+                }
+                cur = Ei;
+            }
+        }
+    }
+
+    // one round over [pos, pos + span); cur = end of the last selected match on entry and exit (the same in every wavefront of the chunk)
+    __device__ __forceinline__ void round(uint32_t pos, uint32_t span, uint32_t D0, uint32_t D1, uint32_t& cur_io) {
         const uint32_t lane = lane_id();
         // wave-uniform state is TOLD to be uniform (v_readfirstlane): the compiler cannot see it through the chunk bookkeeping, and a
         // walk it believes divergent becomes an exec-masked loop with `cur` in a VGPR (measured: twice the scalar instructions)
         uint32_t cur = uni(cur_io);
         pos = uni(pos); span = uni(span);
+        const uint32_t gpos = pos + 256u * wv;
         const uint32_t round_last = umin(last_start, pos + span - 1u);
-        // ---- probe ----
-        uint32_t hs[kG][4], dd[kG][4];
-        bool hd[kG][4];
-        {
-            uint32_t v[kG][4], t[kG][4];
-#pragma unroll
-            for (int g = 0; g < kG; g++) {
-                v[g][0] = D0[g];
-                v[g][1] = __builtin_amdgcn_alignbyte(D1[g], D0[g], 1);
-                v[g][2] = __builtin_amdgcn_alignbyte(D1[g], D0[g], 2);
-                v[g][3] = __builtin_amdgcn_alignbyte(D1[g], D0[g], 3);
-#pragma unroll
-                for (int k = 0; k < 4; k++) { hs[g][k] = hash_slot(v[g][k]); t[g][k] = ht.get(hs[g][k]); }
-            }
-            // distance to the slot's position, modulo the 64 KiB lap of the 16-bit table; 0 = no candidate
-#pragma unroll
-            for (int g = 0; g < kG; g++)
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t p = pos + 256u * g + 4u * lane + k;
-                    const uint32_t d = (p - t[g][k]) & 0xffffu;
-                    dd[g][k] = (d != 0u && d <= p && p <= round_last) ? d : 0u;
-                }
-            // Only the FIRST position of a run of equal distances is verified: its followers lie inside its match if it is one, and a
-            // candidate dword is a scattered access — the vector memory path takes ~1.5 cycles per lane for those (64 lanes: ~94 cycles
-            // per instruction and CU, tools/issue_rate_probe.hip), which is what bounds this kernel.  On match-heavy data half of all
-            // positions are followers.
-#pragma unroll
-            for (int g = 0; g < kG; g++) {
-                const uint32_t left0 = dpp_from<kDppWaveShr1>(0u, dd[g][3]);            // lane l - 1's last position; lane 0 of a group starts afresh
-                bool pre[4];
-                pre[0] = dd[g][0] != 0u && dd[g][0] != left0;
-                pre[1] = dd[g][1] != 0u && dd[g][1] != dd[g][0];
-                pre[2] = dd[g][2] != 0u && dd[g][2] != dd[g][1];
-                pre[3] = dd[g][3] != 0u && dd[g][3] != dd[g][2];
-                uint32_t w[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    w[k] = ~v[g][k];
-                    if (pre[k]) w[k] = g32(in, pos + 256u * g + 4u * lane + k - dd[g][k]);
-                }
-#pragma unroll
-                for (int k = 0; k < 4; k++) hd[g][k] = pre[k] && w[k] == v[g][k];
-            }
+        meet();                                                  // the previous round's insertions and toggle reads are done
+        Heads h;
+        probe(gpos, round_last, D0, D1, h);
+        if (wv == 0u && lane < kRound / 32u + 1u) scr[kTogAt + lane] = 0u;      // this round's toggle bitmap
+        // the first window is measured by both wavefronts side by side; then the turns: wavefront 0 selects, then wavefront 1
+        Meas m;
+        if (h.total != 0u) measure(h, gpos, 0u, cur, m);
+        if constexpr (kW > 1) {
+            if (wv != 0u) { meet(); cur = uni(scr[kSharedAt]); q_n = uni(scr[kSharedAt + 1u]); op = uni(scr[kSharedAt + 2u]); }
         }
-        // ---- heads: the verified first positions of runs ----
-        uint64_t hm[kG][4];
-        uint32_t total_heads = 0;
-#pragma unroll
-        for (int g = 0; g < kG; g++)
-#pragma unroll
-            for (int k = 0; k < 4; k++) { hm[g][k] = bal(hd[g][k]); total_heads += (uint32_t)__builtin_popcountll(hm[g][k]); }
-        // toggle bitmap of this round: cleared before the first window writes into it
-        if (lane < kR / 32u + 1u) scr[kTogAt + lane] = 0u;
-        // ---- windows of up to 64 heads in position order ----
-        for (uint32_t w0 = 0; w0 < total_heads; w0 += 64u) {
-            {   // ranks: heads of earlier groups, of lower lanes of this group, of this lane's lower positions
-                uint32_t base = 0;
-#pragma unroll
-                for (int g = 0; g < kG; g++) {
-                    uint32_t r = base;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) r += bits_below_lane(hm[g][k]);
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const bool h = hd[g][k];
-                        if (h && r - w0 < 64u) scr[kHeadsAt + r - w0] = (dd[g][k] << 16) | (256u * g + 4u * lane + k);
-                        r += h ? 1u : 0u;
-                        base += (uint32_t)__builtin_popcountll(hm[g][k]);
-                    }
-                }
-            }
-            const uint32_t mw = umin(total_heads - w0, 64u);
-            const bool is_head = lane < mw;
-            const uint32_t hv = is_head ? scr[kHeadsAt + lane] : (1u << 16);
-            const uint32_t P = pos + (hv & 0xffffu), d = hv >> 16, C = P - d;
-            // ---- measure: ONE round trip carries the first two forward blocks and the backward block of every head ----
-            const uint32_t a = P + 4u;
-            uint32_t fwd = 0, back = 0;
-            bool more = is_head, back_more = false;
-            {
-                const bool blk0 = is_head && a + 16u <= n, blk1 = is_head && a + 32u <= n;
-                const uint32_t room = P - cur;                       // P >= pos >= cur in the first window; a later window may start behind cur (BS is not used then)
-                const uint32_t blim = umin(room, C);
-                const bool bk_on = is_head && blim > 0u, bk_blk = bk_on && C >= 16u;
-                uint4 x0 = make_uint4(0, 0, 0, 0), y0 = make_uint4(0, 0, 0, 1), x1 = x0, y1 = y0, bx = x0, by = y0;
-#ifndef CJ_EXP_NO_EXT_LOADS      // (experiment x01: what the measuring pass's loads cost — the matches come out short, the work is the same)
-                if (blk0) { x0 = g128(in, a); y0 = g128(in, a - d); }
-                if (blk1) { x1 = g128(in, a + 16u); y1 = g128(in, a + 16u - d); }
-                if (bk_blk) { bx = g128(in, P - 16u); by = g128(in, C - 16u); }
-#endif
-                if (blk0) {
-                    const uint32_t e0 = first_diff(x0, y0), e1 = first_diff(x1, y1);
-                    fwd = e0 == 16u && blk1 ? 16u + e1 : e0;       // (no second block this close to the end: the loop below goes on from 16)
-                    more = fwd == (blk1 ? 32u : 16u);
-                }
-                if (bk_blk) {
-                    const uint32_t sm = last_same(bx, by);
-                    back = umin(sm, blim);
-                    back_more = sm == 16u && blim > 16u;
-                } else if (bk_on) {                                  // candidate within the first 16 bytes of the piece
-                    while (back < blim && g8(in, P - 1u - back) == g8(in, C - 1u - back)) back += 1u;
-                }
-            }
-            // the rare rest: matches beyond 4 + 32 bytes block by block, the last 16 bytes of the input byte by byte
-            for (uint32_t it = 2; it <= kFwdBlocks; it++) {
-                if (bal(more) == 0ull) break;
-                const bool blk = more && it < kFwdBlocks && a + fwd + 16u <= n;
-                if (more && !blk && a + fwd + 16u > n) {
-                    while (a + fwd < limit && g8(in, a + fwd) == g8(in, a + fwd - d)) fwd += 1u;
-                    more = false;
-                }
-                if (blk) {
-                    const uint32_t e = first_diff(g128(in, a + fwd), g128(in, a + fwd - d));
-                    fwd += e;
-                    more = e == 16u;
-                }
-            }
-            if (a + fwd >= limit) { fwd = limit - a; more = false; }      // (a <= limit: P <= last_start)
-            uint32_t E = is_head ? a + fwd : 0u;                     // E = 0: never selected
-            const uint32_t BS = P - back;
-            const uint64_t fwd_more_mask = bal(is_head && more);
-            // ---- greedy walk: the chain carries `cur` only ----
-            const uint32_t cur0 = cur;
-            uint64_t sel = 0ull;
-            uint32_t PE = 0u;
-            bool slow = fwd_more_mask != 0ull;
-            if (!slow) {
-                for (;;) {
-                    if (cur > last_start) break;
-                    const uint64_t m = bal(E >= cur + 4u);
-                    if (m == 0ull) break;
-                    const uint32_t first = ctz64(m);
-                    PE = (uint32_t)cj_llvm_writelane((int)cur, (int)first, (int)PE);
-                    sel |= 1ull << first;
-                    cur = rdlane(E, first);
-                }
-                const bool selected = ((sel >> lane) & 1ull) != 0ull;
-                const uint32_t s = umax(BS, PE);
-                const uint32_t lit = s - PE, code = E - s - 4u;
-                const bool needs_wave = selected && (lit >= kMaxLit || code >= kMaxCode || (back_more && P >= PE && P - PE > 16u));
-                slow = bal(needs_wave) != 0ull;
-                if (!slow) {
-                    const uint32_t ns = (uint32_t)__builtin_popcountll(sel);
-                    if (q_n + ns > kQueueCap) flush();
-                    if (selected) {
-                        const uint32_t slot = kQueueAt + 2u * (q_n + bits_below_lane(sel));
-                        scr[slot] = PE;
-                        scr[slot + 1u] = d | (lit << 16) | (code << 24);
-                        // coverage toggles: positions s + 1 .. E - kTail - 1 (relative to pos, clamped to the round) are inside this match
-                        const uint32_t sx = s + 1u > pos ? s + 1u - pos : 0u;
-                        const uint32_t ex = umin(E - kTail - pos, kR);                    // E - kTail > s + 1 >= ... may lie before pos: then ex wraps — excluded below
-                        if (E - kTail > pos && ex > sx) {
-                            atomicXor(&scr[kTogAt + (sx >> 5)], 1u << (sx & 31u));
-                            atomicXor(&scr[kTogAt + (ex >> 5)], 1u << (ex & 31u));
-                        }
-                    }
-                    q_n = uni(q_n + ns);
-                }
-            }
-            if (slow) {
-                // ---- serial cooperative path: same decisions, extensions finished by the whole wavefront, every selected sequence
-                //      of this window emitted by the whole wavefront ----
-                cur = cur0;
-                const uint32_t flags = (more ? kFlagFwdMore : 0u) | (back_more ? kFlagBackMore : 0u);
-                for (uint32_t i = 0; i < mw; i++) {
-                    if (cur > last_start) break;
-                    const uint32_t Pi = rdlane(P, i), di = rdlane(d, i), fl = rdlane(flags, i);
-                    uint32_t Ei = rdlane(E, i);
-                    if (fl & kFlagFwdMore) Ei += wave_extend((const uint8_t*)in, Ei, Ei - di, limit);
-                    if (Ei < cur + 4u) continue;
-                    uint32_t s = cur;
-                    if (Pi >= cur) {
-                        const uint32_t room = Pi - cur;
-                        uint32_t bk = umin(Pi - rdlane(BS, i), room);
-                        if ((fl & kFlagBackMore) && bk == 16u && room > 16u) bk += wave_extend_back((const uint8_t*)in, Pi - 16u, Pi - di - 16u, room - 16u);
-                        s = Pi - bk;
-                    }
-                    flush();
-                    op = Fmt::emit_wave(in, out, op, cur, s - cur, di, Ei - s);
-                    if (lane == 0u) {
-                        const uint32_t sx = s + 1u > pos ? s + 1u - pos : 0u;
-                        const uint32_t ex = umin(Ei - kTail - pos, kR);
-                        if (Ei - kTail > pos && ex > sx) {
-                            scr[kTogAt + (sx >> 5)] ^= 1u << (sx & 31u);
-                            scr[kTogAt + (ex >> 5)] ^= 1u << (ex & 31u);
-                        }
-                    }
-                    cur = Ei;
-                }
-            }
+        for (uint32_t w0 = 0; w0 < h.total; w0 += 64u) {
+            if (w0 != 0u) measure(h, gpos, w0, cur, m);
+            select(m, pos, cur);
+        }
+        if constexpr (kW > 1) {
+            if (lane == 0u) { scr[kSharedAt] = cur; scr[kSharedAt + 1u] = q_n; scr[kSharedAt + 2u] = op; }
+            if (wv == 0u) meet();
+            meet();                                              // both turns are over
+            cur = uni(scr[kSharedAt]); q_n = uni(scr[kSharedAt + 1u]); op = uni(scr[kSharedAt + 2u]);
+            if (wv != 0u) meet();                                // group 0 inserts first: the later group wins a contested slot
         }
         // ---- insert the positions that are not inside an emitted match ----
         {
-            uint32_t carry = 0;          // parity of the toggles before this group
+            uint32_t carry = 0;          // parity of the toggles of the groups before this one
+            if constexpr (kW > 1) {
+                const uint32_t lower = scr[kTogAt + (lane & 7u)];
+                carry = (uint32_t)__builtin_popcountll(bal(wv != 0u && lane < 8u && (__builtin_popcount(lower) & 1) != 0));
+            }
+            const uint32_t word = scr[kTogAt + 8u * wv + (lane >> 3)];
+            const uint32_t bits = (word >> (4u * (lane & 7u))) & 15u;
+            const uint32_t pre = bits ^ (bits << 1) ^ (bits << 2) ^ (bits << 3);               // bit k = parity of the toggles at positions 4 l .. 4 l + k
+            const uint64_t odd = bal((__builtin_popcount(bits) & 1) != 0);
+            const uint32_t before = (bits_below_lane(odd) + carry) & 1u;
 #pragma unroll
-            for (int g = 0; g < kG; g++) {
-                const uint32_t word = scr[kTogAt + 8u * g + (lane >> 3)];
-                const uint32_t bits = (word >> (4u * (lane & 7u))) & 15u;
-                const uint32_t pre = bits ^ (bits << 1) ^ (bits << 2) ^ (bits << 3);               // bit k = parity of the toggles at positions 4 l .. 4 l + k
-                const uint64_t odd = bal((__builtin_popcount(bits) & 1) != 0);
-                const uint32_t before = (bits_below_lane(odd) + carry) & 1u;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t p = pos + 256u * g + 4u * lane + k;
-                    const bool covered = (((pre >> k) ^ before) & 1u) != 0u;
-                    if (p <= round_last && !covered) ht.set(hs[g][k], p);
-                }
-                carry += (uint32_t)__builtin_popcountll(odd);
+            for (int k = 0; k < 4; k++) {
+                const uint32_t p = gpos + 4u * lane + k;
+                const bool covered = (((pre >> k) ^ before) & 1u) != 0u;
+                if (p <= round_last && !covered) ht.set(h.hs[k], p);
             }
             ht.settle();
         }
+        if constexpr (kW > 1) { if (wv == 0u) meet(); }
         cur_io = cur;
     }
 
     // the whole range [q0, n): rounds, then the queue; returns the end of the last match (the final literals start there)
     __device__ __forceinline__ uint32_t run(uint32_t q0) {
         const uint32_t lane = lane_id();
-        q0 = uni(q0); n = uni(n); last_start = uni(last_start); limit = uni(limit); op = uni(op);
+        q0 = uni(q0); n = uni(n); last_start = uni(last_start); limit = uni(limit); op = uni(op); wv = uni(wv);
         uint32_t pos = q0, cur = q0;
-        uint32_t span = q0 == 0u ? 64u : kR;          // short first rounds while the table is empty (a sub-piece's table is pre-indexed)
-        uint32_t D0[kG], D1[kG], own_pos = ~0u;
+        uint32_t span = q0 == 0u ? 64u : kRound;      // short first rounds while the table is empty (a sub-piece's table is pre-indexed)
+        uint32_t D0 = 0, D1 = 0, own_pos = ~0u;
         while (pos <= last_start) {
             if (own_pos != pos) {
-#pragma unroll
-                for (int g = 0; g < kG; g++) {
-                    const uint32_t b = pos + 256u * g + 4u * lane;
-                    D0[g] = D1[g] = 0u;
-                    if (b <= last_start) { D0[g] = g32(in, b); D1[g] = g32(in, b + 4u); }
-                }
+                const uint32_t b = pos + 256u * wv + 4u * lane;
+                D0 = D1 = 0u;
+                if (b <= last_start) { D0 = g32(in, b); D1 = g32(in, b + 4u); }
             }
             // the next round's dwords travel while this round runs
             const uint32_t round_end = pos + span;
-            uint32_t N0[kG], N1[kG];
-#pragma unroll
-            for (int g = 0; g < kG; g++) {
-                const uint32_t b = round_end + 256u * g + 4u * lane;
-                N0[g] = N1[g] = 0u;
-                if (b <= last_start) { N0[g] = g32(in, b); N1[g] = g32(in, b + 4u); }
+            uint32_t N0 = 0, N1 = 0;
+            {
+                const uint32_t b = round_end + 256u * wv + 4u * lane;
+                if (b <= last_start) { N0 = g32(in, b); N1 = g32(in, b + 4u); }
             }
             round(pos, span, D0, D1, cur);
-#pragma unroll
-            for (int g = 0; g < kG; g++) { D0[g] = N0[g]; D1[g] = N1[g]; }
+            D0 = N0; D1 = N1;
             own_pos = round_end;
-            span = span * 2u < kR ? span * 2u : kR;
+            span = span * 2u < kRound ? span * 2u : kRound;
             cur = uni(cur);
             pos = cur > round_end ? cur : round_end;
         }
-        flush();
+        if (wv == 0u) flush();
         return cur;
     }
 };

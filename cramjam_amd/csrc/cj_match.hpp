@@ -28,9 +28,10 @@ struct HashTab {
     uint16_t* p;
     __device__ __forceinline__ uint32_t get(uint32_t h) const { return p[h]; }
     __device__ __forceinline__ void set(uint32_t h, uint32_t v) const { p[h] = (uint16_t)v; }
-    __device__ __forceinline__ void clear() const {
+    // (by all `threads` threads of the chunk's workgroup)
+    __device__ __forceinline__ void clear(uint32_t tid, uint32_t threads) const {
         uint32_t* q = reinterpret_cast<uint32_t*>(p);
-        for (uint32_t i = lane_id(); i < kHashSize / 2; i += 64u) q[i] = 0u;
+        for (uint32_t i = tid; i < kHashSize / 2; i += threads) q[i] = 0u;
     }
     // after a group of stores, before the lookups that follow: only the COMPILER has to be told — clear() stores dwords through a
     // punned pointer, and nothing else keeps the 16-bit lookups from being scheduled above them
@@ -106,37 +107,51 @@ __device__ __forceinline__ uint32_t bits_below_lane(uint64_t m) {
 }
 
 // ---- persistent encoder blocks ------------------------------------------------------------------------------
-// One wavefront per block, chunks from a shared counter: a batch of at least kEncBlocksPerCu x CUs chunks runs as nine blocks per CU
-// (16 KiB table + 1 KiB matcher scratch each: what 160 KiB of LDS hold), which also evens out the CUs.  Enc::chunk(a, c, table,
-// scratch) = one chunk.  (Rounds 2-4 gave the wave slots the LDS leaves empty to blocks with their table in global memory; with the
-// round-based matcher those slow the LDS blocks down more than they add — every table access of theirs is a scattered global
-// access, the resource this kernel is short of: 9 + 3 per CU 126 GB/s, 9 + 0 141 GB/s, profiles/r05/experiments e05.)
+// One workgroup of Enc::kWaves wavefronts per chunk, chunks from a shared counter: a batch of at least 9 x CUs chunks runs as nine
+// blocks per CU (16 KiB table + the matcher's scratch each: what 160 KiB of LDS hold), which also evens out the CUs.
+// Enc::chunk(a, c, table, scratch, wave) = one chunk.  (Rounds 2-4 gave the wave slots the LDS leaves empty to blocks with their table
+// in global memory; with the round-based matcher those slow the LDS blocks down more than they add — every table access of theirs is
+// a scattered global access: 9 + 3 per CU 126 GB/s, 9 + 0 141 GB/s, profiles/r05/experiments e05.)
+#ifndef CJ_ENC_W2_EU
+#define CJ_ENC_W2_EU 5
+#endif
 template <class Enc>
-__device__ __forceinline__ void encode_persistent_body(const BatchArgs& a, uint32_t* counter, uint16_t* ht, uint32_t* scr) {
+__device__ __forceinline__ void encode_persistent_body(const BatchArgs& a, uint32_t* counter, uint16_t* ht, uint32_t* scr, uint32_t* next) {
+    const uint32_t wave = uni(threadIdx.x >> 6);
     for (;;) {
-        uint32_t c = 0;
-        if (threadIdx.x == 0) c = atomicAdd(counter, 1u);
-        const uint32_t chunk = uni(c);                               // lane 0's value (one wavefront per block)
+        uint32_t chunk;
+        if constexpr (Enc::kWaves == 1) {
+            uint32_t c = 0;
+            if (threadIdx.x == 0) c = atomicAdd(counter, 1u);
+            chunk = uni(c);                                          // lane 0's value
+        } else {
+            if (threadIdx.x == 0) *next = atomicAdd(counter, 1u);
+            __syncthreads();
+            chunk = uni(*next);
+            __syncthreads();                                         // both have read it before thread 0 fetches the next one
+        }
         if (chunk >= a.n_chunks) return;
-        Enc::chunk(a, chunk, HashTab{ht}, scr);
+        Enc::chunk(a, chunk, HashTab{ht}, scr, wave);
     }
 }
-// (four wavefronts per SIMD as the register target: 128 VGPRs; the LDS admits 2.25 per SIMD, the compiler's -Wpass-failed note
-//  about that is expected)
+// (128 VGPRs: four wavefronts per SIMD as the register target for one wavefront per chunk — the LDS admits 2.25 — and five for two
+//  per chunk, where nine workgroups are eighteen wavefronts per CU; the compiler's -Wpass-failed note about the LDS is expected)
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wpass-failed"
 template <class Enc>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void encode_blocks_kernel(BatchArgs a, uint32_t* counter) {
+__global__ __launch_bounds__(64 * Enc::kWaves) __attribute__((amdgpu_waves_per_eu(Enc::kWaves == 1 ? 4 : CJ_ENC_W2_EU, Enc::kWaves == 1 ? 4 : CJ_ENC_W2_EU)))
+void encode_blocks_kernel(BatchArgs a, uint32_t* counter) {
     __shared__ uint16_t ht_lds[kHashSize];
     __shared__ uint32_t scr[Enc::kScratchWords];
-    encode_persistent_body<Enc>(a, counter, ht_lds, scr);
+    __shared__ uint32_t next;
+    encode_persistent_body<Enc>(a, counter, ht_lds, scr, &next);
 }
 #pragma clang diagnostic pop
 
 template <class Enc>
 inline void launch_encode_persistent(const BatchArgs& a, hipStream_t s, const EncFill& f) {
     (void)hipMemsetAsync(f.counter, 0, 4, s);
-    hipLaunchKernelGGL((encode_blocks_kernel<Enc>), dim3(f.blocks), dim3(64), 0, s, a, f.counter);
+    hipLaunchKernelGGL((encode_blocks_kernel<Enc>), dim3(f.blocks), dim3(64 * Enc::kWaves), 0, s, a, f.counter);
 }
 
 #endif

@@ -130,7 +130,10 @@ int launch_decode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a, hipStrea
 // LZ4 block / Snappy raw encode of a batch of independent chunks, one wavefront per chunk.  A CU holds nine wavefronts with a 16 KiB
 // hash table + 1 KiB of matcher scratch in LDS.  A batch with at least that many chunks (fewer: every chunk gets its wavefront at
 // once) runs as persistent blocks, nine per CU, all taking chunks from one counter (cj_match.hpp), which also evens out the CUs.
-constexpr uint32_t kEncBlocksPerCu = 9;
+#ifndef CJ_ENC_BLOCKS_PER_CU
+#define CJ_ENC_BLOCKS_PER_CU 9
+#endif
+constexpr uint32_t kEncBlocksPerCu = CJ_ENC_BLOCKS_PER_CU;
 
 int launch_encode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a, hipStream_t s) {
     const bool lz4 = codec == CJ_CODEC_LZ4_BLOCK;

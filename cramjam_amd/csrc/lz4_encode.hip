@@ -61,8 +61,8 @@ struct Lz4Fmt {
 // piece is cut into split_per(flags) = 16 or 4 consecutive sub-pieces, one wavefront each — the chunks of the batch ARE the sub-pieces,
 // position 0 of a walk = the start of its piece.  Each wavefront first indexes the data BEFORE its sub-piece (HashTab::preindex), so it
 // finds what a serial walk over the piece would; each writes its own stream, and the streams are stitched like any other pieces.
-template <bool kSplit>
-__device__ __forceinline__ void lz4_encode_chunk(const BatchArgs& a, uint32_t chunk, const HashTab& ht, uint32_t* scr) {
+template <bool kSplit, int kW>
+__device__ __forceinline__ void lz4_encode_chunk(const BatchArgs& a, uint32_t chunk, const HashTab& ht, uint32_t* scr, uint32_t wave) {
     const uint64_t base_off = kSplit ? a.in_off[chunk & ~(split_per(a.flags) - 1u)] : a.in_off[chunk];      // the piece's first sub-piece
     const uint8_t* in = a.in_base + base_off;               // position 0 = start of the piece
     const uint32_t q0 = (uint32_t)(a.in_off[chunk] - base_off);      // this wave's range = [q0, n)
@@ -72,24 +72,26 @@ __device__ __forceinline__ void lz4_encode_chunk(const BatchArgs& a, uint32_t ch
     const uint32_t lane = lane_id();
     const bool prefix = (a.flags & CJ_FLAG_LZ4_SIZE_PREFIX) != 0;
 
-    if (n64 > 0x7E000000ull) { if (lane == 0) a.result[chunk] = CJ_E_INPUT_TOO_LARGE; return; }
+    const bool first = wave == 0u;              // the chunk's first wavefront writes everything outside the rounds
+    if (n64 > 0x7E000000ull) { if (first && lane == 0) a.result[chunk] = CJ_E_INPUT_TOO_LARGE; return; }
     const uint32_t n = (uint32_t)n64;
     // the engine only launches with capacity >= LZ4_compressBound(n) (+4); anything smaller is refused here
     const uint64_t need = (uint64_t)(n - q0) + (n - q0) / 255u + 16u + (prefix ? 4u : 0u);
-    if (cap64 < need) { if (lane == 0) a.result[chunk] = CJ_E_COMPRESS_FAILED; return; }
+    if (cap64 < need) { if (first && lane == 0) a.result[chunk] = CJ_E_COMPRESS_FAILED; return; }
     if (prefix) {
-        if (lane < 4) out[lane] = (uint8_t)(n >> (8u * lane));
+        if (first && lane < 4) out[lane] = (uint8_t)(n >> (8u * lane));
         out += 4;
     }
     uint32_t anchor = q0, op = 0;
     if (n - q0 >= 13u) {
-        ht.clear();
+        ht.clear(threadIdx.x, 64u * kW);
         if constexpr (kSplit) ht.preindex(in, q0);
         ht.settle();
-        enc2::Walk<Lz4Fmt> w{enc2::uniform_gptr(in), (enc2::gptr)enc2::uniform_gptr(out), n, Lz4Fmt::last_start(n), Lz4Fmt::limit(n), scr, ht, 0u, 0u};
+        enc2::Walk<Lz4Fmt, kW> w{enc2::uniform_gptr(in), (enc2::gptr)enc2::uniform_gptr(out), n, Lz4Fmt::last_start(n), Lz4Fmt::limit(n), scr, ht, 0u, 0u, wave};
         anchor = w.run(q0);
         op = w.op;
     }
+    if (!first) return;
     uint64_t tail_report = 0;
     {   // last literals
         const uint32_t lit = n - anchor;
@@ -103,25 +105,29 @@ __device__ __forceinline__ void lz4_encode_chunk(const BatchArgs& a, uint32_t ch
     if (lane == 0) a.result[chunk] = (int64_t)(((uint64_t)op + (prefix ? 4u : 0u)) | tail_report);
 }
 
-template <bool kSplit>
-__global__ __launch_bounds__(64) void lz4_encode_kernel(BatchArgs a) {
+template <bool kSplit, int kW>
+__global__ __launch_bounds__(64 * kW) void lz4_encode_kernel(BatchArgs a) {
     __shared__ uint16_t ht_lds[kHashSize];
-    __shared__ uint32_t scr[enc2::kScratchWords];
+    __shared__ uint32_t scr[enc2::Walk<Lz4Fmt, kW>::kWords];
     const uint32_t chunk = blockIdx.x;
     if (chunk >= a.n_chunks) return;
-    lz4_encode_chunk<kSplit>(a, chunk, HashTab{ht_lds}, scr);
+    lz4_encode_chunk<kSplit, kW>(a, chunk, HashTab{ht_lds}, scr, uni(threadIdx.x >> 6));
 }
 
+#ifndef CJ_ENC_WAVES
+#define CJ_ENC_WAVES 2
+#endif
 struct Lz4Enc {
-    static constexpr uint32_t kScratchWords = enc2::kScratchWords;
-    static __device__ __forceinline__ void chunk(const BatchArgs& a, uint32_t c, const HashTab& ht, uint32_t* scr) { lz4_encode_chunk<false>(a, c, ht, scr); }
+    static constexpr int kWaves = CJ_ENC_WAVES;
+    static constexpr uint32_t kScratchWords = enc2::Walk<Lz4Fmt, kWaves>::kWords;
+    static __device__ __forceinline__ void chunk(const BatchArgs& a, uint32_t c, const HashTab& ht, uint32_t* scr, uint32_t wave) { lz4_encode_chunk<false, kWaves>(a, c, ht, scr, wave); }
 };
 
 void launch_lz4_encode(const BatchArgs& a, hipStream_t s, const EncFill* fill) {
     if (a.n_chunks == 0) return;
-    if (a.flags & kFlagSplitPieces) hipLaunchKernelGGL(lz4_encode_kernel<true>, dim3(a.n_chunks), dim3(64), 0, s, a);
+    if (a.flags & kFlagSplitPieces) hipLaunchKernelGGL((lz4_encode_kernel<true, 1>), dim3(a.n_chunks), dim3(64), 0, s, a);
     else if (fill) launch_encode_persistent<Lz4Enc>(a, s, *fill);
-    else hipLaunchKernelGGL(lz4_encode_kernel<false>, dim3(a.n_chunks), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((lz4_encode_kernel<false, Lz4Enc::kWaves>), dim3(a.n_chunks), dim3(64 * Lz4Enc::kWaves), 0, s, a);
 }
 
 }  // namespace cj

@@ -100,8 +100,8 @@ struct SnappyFmt {
 };
 
 // kSplit: the chunks are consecutive sub-pieces of 64 KiB pieces, each wavefront with its own pre-indexed hash table — see lz4_encode.hip
-template <bool kSplit>
-__device__ __forceinline__ void snappy_encode_chunk(const BatchArgs& a, uint32_t chunk, const HashTab& ht, uint32_t* scr) {
+template <bool kSplit, int kW>
+__device__ __forceinline__ void snappy_encode_chunk(const BatchArgs& a, uint32_t chunk, const HashTab& ht, uint32_t* scr, uint32_t wave) {
     const uint64_t base_off = kSplit ? a.in_off[chunk & ~(split_per(a.flags) - 1u)] : a.in_off[chunk];      // the piece's first sub-piece
     const uint8_t* in = a.in_base + base_off;               // position 0 = start of the piece
     const uint32_t q0 = (uint32_t)(a.in_off[chunk] - base_off);      // this wave's range = [q0, n)
@@ -111,51 +111,57 @@ __device__ __forceinline__ void snappy_encode_chunk(const BatchArgs& a, uint32_t
     const uint32_t lane = lane_id();
 
     // snap: TooBig above u32::MAX (we also keep positions in 32 bits); BufferTooSmall below max_compress_len
-    if (n64 > 0xFFFFFFFFull - 64u) { if (lane == 0) a.result[chunk] = CJ_E_SNAPPY_TOO_BIG; return; }
+    const bool first = wave == 0u;              // the chunk's first wavefront writes everything outside the rounds
+    if (n64 > 0xFFFFFFFFull - 64u) { if (first && lane == 0) a.result[chunk] = CJ_E_SNAPPY_TOO_BIG; return; }
     const uint64_t need = 32u + (n64 - q0) + (n64 - q0) / 6u;
-    if (need > 0xFFFFFFFFull) { if (lane == 0) a.result[chunk] = CJ_E_SNAPPY_TOO_BIG; return; }
-    if (cap64 < need) { if (lane == 0) a.result[chunk] = CJ_E_SNAPPY_BUF_SMALL; return; }
+    if (need > 0xFFFFFFFFull) { if (first && lane == 0) a.result[chunk] = CJ_E_SNAPPY_TOO_BIG; return; }
+    if (cap64 < need) { if (first && lane == 0) a.result[chunk] = CJ_E_SNAPPY_BUF_SMALL; return; }
     const uint32_t n = (uint32_t)n64;
 
     uint32_t op = 0;
     {   // varint preamble
         uint32_t v = n - q0;
-        while (v >= 0x80u) { if (lane == 0) out[op] = (uint8_t)(v | 0x80u); op += 1; v >>= 7; }
-        if (lane == 0) out[op] = (uint8_t)v;
+        while (v >= 0x80u) { if (first && lane == 0) out[op] = (uint8_t)(v | 0x80u); op += 1; v >>= 7; }
+        if (first && lane == 0) out[op] = (uint8_t)v;
         op += 1;
     }
     uint32_t anchor = q0;
     if (n - q0 >= 8u) {
-        ht.clear();
+        ht.clear(threadIdx.x, 64u * kW);
         if constexpr (kSplit) ht.preindex(in, q0);
         ht.settle();
-        enc2::Walk<SnappyFmt> w{enc2::uniform_gptr(in), (enc2::gptr)enc2::uniform_gptr(out), n, SnappyFmt::last_start(n), SnappyFmt::limit(n), scr, ht, op, 0u};
+        enc2::Walk<SnappyFmt, kW> w{enc2::uniform_gptr(in), (enc2::gptr)enc2::uniform_gptr(out), n, SnappyFmt::last_start(n), SnappyFmt::limit(n), scr, ht, op, 0u, wave};
         anchor = w.run(q0);
         op = w.op;
     }
+    if (!first) return;
     if (anchor < n) op = emit_snappy_literal(out, op, in + anchor, n - anchor);
     if (lane == 0) a.result[chunk] = (int64_t)op;
 }
 
-template <bool kSplit>
-__global__ __launch_bounds__(64) void snappy_encode_kernel(BatchArgs a) {
+template <bool kSplit, int kW>
+__global__ __launch_bounds__(64 * kW) void snappy_encode_kernel(BatchArgs a) {
     __shared__ uint16_t ht_lds[kHashSize];
-    __shared__ uint32_t scr[enc2::kScratchWords];
+    __shared__ uint32_t scr[enc2::Walk<SnappyFmt, kW>::kWords];
     const uint32_t chunk = blockIdx.x;
     if (chunk >= a.n_chunks) return;
-    snappy_encode_chunk<kSplit>(a, chunk, HashTab{ht_lds}, scr);
+    snappy_encode_chunk<kSplit, kW>(a, chunk, HashTab{ht_lds}, scr, uni(threadIdx.x >> 6));
 }
 
+#ifndef CJ_ENC_WAVES
+#define CJ_ENC_WAVES 2
+#endif
 struct SnappyEnc {
-    static constexpr uint32_t kScratchWords = enc2::kScratchWords;
-    static __device__ __forceinline__ void chunk(const BatchArgs& a, uint32_t c, const HashTab& ht, uint32_t* scr) { snappy_encode_chunk<false>(a, c, ht, scr); }
+    static constexpr int kWaves = CJ_ENC_WAVES;
+    static constexpr uint32_t kScratchWords = enc2::Walk<SnappyFmt, kWaves>::kWords;
+    static __device__ __forceinline__ void chunk(const BatchArgs& a, uint32_t c, const HashTab& ht, uint32_t* scr, uint32_t wave) { snappy_encode_chunk<false, kWaves>(a, c, ht, scr, wave); }
 };
 
 void launch_snappy_encode(const BatchArgs& a, hipStream_t s, const EncFill* fill) {
     if (a.n_chunks == 0) return;
-    if (a.flags & kFlagSplitPieces) hipLaunchKernelGGL(snappy_encode_kernel<true>, dim3(a.n_chunks), dim3(64), 0, s, a);
+    if (a.flags & kFlagSplitPieces) hipLaunchKernelGGL((snappy_encode_kernel<true, 1>), dim3(a.n_chunks), dim3(64), 0, s, a);
     else if (fill) launch_encode_persistent<SnappyEnc>(a, s, *fill);
-    else hipLaunchKernelGGL(snappy_encode_kernel<false>, dim3(a.n_chunks), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((snappy_encode_kernel<false, SnappyEnc::kWaves>), dim3(a.n_chunks), dim3(64 * SnappyEnc::kWaves), 0, s, a);
 }
 
 }  // namespace cj

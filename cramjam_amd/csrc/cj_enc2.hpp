@@ -35,6 +35,7 @@ constexpr uint32_t kTail = 2u;                      // the last kTail positions 
 constexpr uint32_t kQueueCap = 64u;
 constexpr uint32_t kFwdBlocks = 4u;                 // forward measurement cap: 4 + 64 bytes, longer matches are finished cooperatively
 constexpr uint32_t kFlagFwdMore = 1u, kFlagBackMore = 2u;
+constexpr uint32_t kSelPasses = 8u;                 // parallel selection passes before a window falls back to the serial walk
 constexpr uint32_t kMaxLit = 256u, kMaxCode = 255u; // a queue entry packs lit < 256 and mlen - 4 < 255 into a byte each
 
 // the wave mask of a condition straight from the compare (HIP's __ballot goes through an integer: v_cndmask + v_cmp per call)
@@ -107,6 +108,18 @@ __device__ __forceinline__ void lane_copy(gptr out, uint32_t o, gcptr in, uint32
 // wavefront 1's (`cur`, the queue count and the output position travel through LDS) — and insert, group 0 first.  A wavefront issues
 // one instruction per ~5 cycles whatever it holds (tools/issue_rate_probe.hip) and a CU's LDS holds nine tables: two wavefronts per
 // table are how the CU gets more instruction streams.  tests/hostsim/enc2_model.c with R = 512 states exactly what this computes.
+#ifdef CJ_ENC_PROFILE
+// phase cycle counters of the matcher (debug builds: tools/exp_r05_encprofile.sh): [0] rounds, [1] probe, [2] measure, [3] select + push,
+// [4] insert, [5] flushes (inside 3), [6] waiting for the other wavefront, [7] windows
+__device__ unsigned long long g_enc_prof[16];
+__device__ __forceinline__ uint64_t prof_now() { uint64_t t; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return t; }
+#define CJ_PROF(i, expr) do { const uint64_t t_ = prof_now(); expr; const uint64_t d_ = prof_now() - t_; if (lane_id() == 0) atomicAdd(&g_enc_prof[i], d_); } while (0)
+#define CJ_PROF_COUNT(i, v) do { if (lane_id() == 0) atomicAdd(&g_enc_prof[i], (unsigned long long)(v)); } while (0)
+#else
+#define CJ_PROF(i, expr) do { expr; } while (0)
+#define CJ_PROF_COUNT(i, v) do { } while (0)
+#endif
+
 template <class Fmt, int kW>
 struct Walk {
     static constexpr uint32_t kRound = 256u * kW;
@@ -273,23 +286,44 @@ struct Walk {
         uint32_t PE = 0u;
         bool slow = bal(m.more) != 0ull;
         if (!slow) {
-            for (;;) {                                           // the chain carries `cur` only
-                if (cur > last_start) break;
-                const uint64_t mm = bal(E >= cur + 4u);
-                if (mm == 0ull) break;
-                const uint32_t first = ctz64(mm);
-                PE = (uint32_t)cj_llvm_writelane((int)cur, (int)first, (int)PE);
-                sel |= 1ull << first;
-                cur = rdlane(E, first);
+            // The greedy rule — head i is selected iff E_i >= cur_i + 4, cur_i = the end of the last selected head before it — has ONE
+            // solution, and every set that reproduces itself under the rule IS it (head i's decision follows from the decisions before
+            // it).  So the selection is iterated in parallel instead of walked: start from "every head", take the prefix maximum of
+            // the selected ends (DPP scan), re-decide all heads at once, until nothing changes — two or three passes of ~15
+            // instructions where the serial walk cost ~400 cycles per match (VALU -> SGPR -> SALU -> VALU round trips and three taken
+            // branches per match: 3.5 k of a round's 6.7 k cycles, tools/exp_r05_encprofile.sh).  Each pass fixes at least one more
+            // head from the front; a window that has not settled after kSelPasses takes the walk.
+            bool s_me = E != 0u;
+            uint64_t smask = bal(s_me);
+            bool settled = false;
+            uint32_t cp = 0, top = cur;
+            for (uint32_t pass = 0; pass < kSelPasses; pass++) {
+                cp = wave_excl_max(s_me ? E : 0u, cur, top);      // the end of the last selected head below this lane (or cur)
+                s_me = E >= cp + 4u && cp <= last_start;
+                const uint64_t nm = bal(s_me);
+                if (nm == smask) { settled = true; break; }
+                smask = nm;
             }
-            const bool selected = ((sel >> lane) & 1ull) != 0ull;
+            if (settled) { sel = smask; PE = cp; cur = top; }
+            else {
+                for (;;) {                                       // the walk: the chain carries `cur` only
+                    if (cur > last_start) break;
+                    const uint64_t mm = bal(E >= cur + 4u);
+                    if (mm == 0ull) break;
+                    const uint32_t first = ctz64(mm);
+                    PE = (uint32_t)cj_llvm_writelane((int)cur, (int)first, (int)PE);
+                    sel |= 1ull << first;
+                    cur = rdlane(E, first);
+                }
+            }
+            const bool selected = settled ? s_me : ((sel >> lane) & 1ull) != 0ull;
             const uint32_t s = umax(BS, PE);
             const uint32_t lit = s - PE, code = E - s - 4u;
             const bool needs_wave = selected && (lit >= kMaxLit || code >= kMaxCode || (m.back_more && P >= PE && P - PE > 16u));
             slow = bal(needs_wave) != 0ull;
             if (!slow) {
                 const uint32_t ns = (uint32_t)__builtin_popcountll(sel);
-                if (q_n + ns > kQueueCap) flush();
+                if (q_n + ns > kQueueCap) CJ_PROF(5, flush());
                 if (selected) {
                     const uint32_t slot = kQueueAt + 2u * (q_n + bits_below_lane(sel));
                     scr[slot] = PE;
@@ -338,6 +372,28 @@ struct Walk {
         }
     }
 
+    // insert this wavefront's positions that are not inside an emitted match (the toggle bitmap holds where coverage begins and ends)
+    __device__ __forceinline__ void insert(const Heads& h, uint32_t gpos, uint32_t round_last) {
+        const uint32_t lane = lane_id();
+        uint32_t carry = 0;          // parity of the toggles of the groups before this one
+        if constexpr (kW > 1) {
+            const uint32_t lower = scr[kTogAt + (lane & 7u)];
+            carry = (uint32_t)__builtin_popcountll(bal(wv != 0u && lane < 8u && (__builtin_popcount(lower) & 1) != 0));
+        }
+        const uint32_t word = scr[kTogAt + 8u * wv + (lane >> 3)];
+        const uint32_t bits = (word >> (4u * (lane & 7u))) & 15u;
+        const uint32_t pre = bits ^ (bits << 1) ^ (bits << 2) ^ (bits << 3);               // bit k = parity of the toggles at positions 4 l .. 4 l + k
+        const uint64_t odd = bal((__builtin_popcount(bits) & 1) != 0);
+        const uint32_t before = (bits_below_lane(odd) + carry) & 1u;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t p = gpos + 4u * lane + k;
+            const bool covered = (((pre >> k) ^ before) & 1u) != 0u;
+            if (p <= round_last && !covered) ht.set(h.hs[k], p);
+        }
+        ht.settle();
+    }
+
     // one round over [pos, pos + span); cur = end of the last selected match on entry and exit (the same in every wavefront of the chunk)
     __device__ __forceinline__ void round(uint32_t pos, uint32_t span, uint32_t D0, uint32_t D1, uint32_t& cur_io) {
         const uint32_t lane = lane_id();
@@ -347,19 +403,23 @@ struct Walk {
         pos = uni(pos); span = uni(span);
         const uint32_t gpos = pos + 256u * wv;
         const uint32_t round_last = umin(last_start, pos + span - 1u);
-        meet();                                                  // the previous round's insertions and toggle reads are done
+        CJ_PROF(6, meet());                                      // the previous round's insertions and toggle reads are done
         Heads h;
-        probe(gpos, round_last, D0, D1, h);
+        CJ_PROF_COUNT(0, 1);
+        CJ_PROF(1, probe(gpos, round_last, D0, D1, h));
         if (wv == 0u && lane < kRound / 32u + 1u) scr[kTogAt + lane] = 0u;      // this round's toggle bitmap
-        // the first window is measured by both wavefronts side by side; then the turns: wavefront 0 selects, then wavefront 1
+        // every wavefront measures its first window at once; then the turns: wavefront 0 selects (all its windows), then wavefront 1
         Meas m;
-        if (h.total != 0u) measure(h, gpos, 0u, cur, m);
-        if constexpr (kW > 1) {
-            if (wv != 0u) { meet(); cur = uni(scr[kSharedAt]); q_n = uni(scr[kSharedAt + 1u]); op = uni(scr[kSharedAt + 2u]); }
-        }
         for (uint32_t w0 = 0; w0 < h.total; w0 += 64u) {
-            if (w0 != 0u) measure(h, gpos, w0, cur, m);
-            select(m, pos, cur);
+            CJ_PROF(2, measure(h, gpos, w0, cur, m));
+            CJ_PROF_COUNT(7, 1);
+            if constexpr (kW > 1) {
+                if (w0 == 0u && wv != 0u) { CJ_PROF(6, meet()); cur = uni(scr[kSharedAt]); q_n = uni(scr[kSharedAt + 1u]); op = uni(scr[kSharedAt + 2u]); }
+            }
+            CJ_PROF(3, select(m, pos, cur));
+        }
+        if constexpr (kW > 1) {
+            if (h.total == 0u && wv != 0u) { meet(); cur = uni(scr[kSharedAt]); q_n = uni(scr[kSharedAt + 1u]); op = uni(scr[kSharedAt + 2u]); }
         }
         if constexpr (kW > 1) {
             if (lane == 0u) { scr[kSharedAt] = cur; scr[kSharedAt + 1u] = q_n; scr[kSharedAt + 2u] = op; }
@@ -368,26 +428,7 @@ struct Walk {
             cur = uni(scr[kSharedAt]); q_n = uni(scr[kSharedAt + 1u]); op = uni(scr[kSharedAt + 2u]);
             if (wv != 0u) meet();                                // group 0 inserts first: the later group wins a contested slot
         }
-        // ---- insert the positions that are not inside an emitted match ----
-        {
-            uint32_t carry = 0;          // parity of the toggles of the groups before this one
-            if constexpr (kW > 1) {
-                const uint32_t lower = scr[kTogAt + (lane & 7u)];
-                carry = (uint32_t)__builtin_popcountll(bal(wv != 0u && lane < 8u && (__builtin_popcount(lower) & 1) != 0));
-            }
-            const uint32_t word = scr[kTogAt + 8u * wv + (lane >> 3)];
-            const uint32_t bits = (word >> (4u * (lane & 7u))) & 15u;
-            const uint32_t pre = bits ^ (bits << 1) ^ (bits << 2) ^ (bits << 3);               // bit k = parity of the toggles at positions 4 l .. 4 l + k
-            const uint64_t odd = bal((__builtin_popcount(bits) & 1) != 0);
-            const uint32_t before = (bits_below_lane(odd) + carry) & 1u;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t p = gpos + 4u * lane + k;
-                const bool covered = (((pre >> k) ^ before) & 1u) != 0u;
-                if (p <= round_last && !covered) ht.set(h.hs[k], p);
-            }
-            ht.settle();
-        }
+        CJ_PROF(4, insert(h, gpos, round_last));
         if constexpr (kW > 1) { if (wv == 0u) meet(); }
         cur_io = cur;
     }

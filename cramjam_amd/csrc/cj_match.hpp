@@ -100,6 +100,18 @@ __device__ __forceinline__ uint32_t wave_excl_add(uint32_t v, uint32_t& total) {
 }
 __device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 __device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+// max over the lanes BELOW this one and `first` (lane 0 receives `first`); total = max over first and all 64 lanes
+__device__ __forceinline__ uint32_t wave_excl_max(uint32_t v, uint32_t first, uint32_t& total) {
+    uint32_t x = v;
+    x = umax(x, dpp_from<kDppRowShr + 1u>(0u, x));
+    x = umax(x, dpp_from<kDppRowShr + 2u>(0u, x));
+    x = umax(x, dpp_from<kDppRowShr + 4u>(0u, x));
+    x = umax(x, dpp_from<kDppRowShr + 8u>(0u, x));
+    x = umax(x, dpp_from<kDppBcast15, 0xau>(0u, x));
+    x = umax(x, dpp_from<kDppBcast31, 0xcu>(0u, x));
+    total = umax(rdlane(x, 63), first);
+    return umax(dpp_from<kDppWaveShr1>(first, x), first);
+}
 
 // number of set bits of m below this lane
 __device__ __forceinline__ uint32_t bits_below_lane(uint64_t m) {

@@ -148,7 +148,8 @@ int launch_encode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a, hipStrea
     if (!e->d_enc.reserve(256)) return CJ_E_OOM;
     cj::EncFill f;
     f.counter = (uint32_t*)e->d_enc.p;
-    f.blocks = kEncBlocksPerCu * (uint32_t)e->n_cu;
+    static const uint32_t env_blocks = [] { const char* v = std::getenv("CJ_ENC_BLOCKS"); return v ? (uint32_t)std::atoi(v) : kEncBlocksPerCu; }();      // (experiment knob of round 5)
+    f.blocks = env_blocks * (uint32_t)e->n_cu;
     if (lz4) cj::launch_lz4_encode(a, s, &f); else cj::launch_snappy_encode(a, s, &f);
     HIP_TRY(hipEventRecord(e->enc_free, s), CJ_E_NO_DEVICE);
     return 0;

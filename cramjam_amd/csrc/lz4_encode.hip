@@ -123,6 +123,14 @@ struct Lz4Enc {
     static __device__ __forceinline__ void chunk(const BatchArgs& a, uint32_t c, const HashTab& ht, uint32_t* scr, uint32_t wave) { lz4_encode_chunk<false, kWaves>(a, c, ht, scr, wave); }
 };
 
+#ifdef CJ_ENC_PROFILE
+extern "C" __attribute__((visibility("default"))) int cj_debug_enc_profile(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(enc2::g_enc_prof), 16 * 8) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(enc2::g_enc_prof), z, sizeof z); }
+    return 0;
+}
+#endif
+
 void launch_lz4_encode(const BatchArgs& a, hipStream_t s, const EncFill* fill) {
     if (a.n_chunks == 0) return;
     if (a.flags & kFlagSplitPieces) hipLaunchKernelGGL((lz4_encode_kernel<true, 1>), dim3(a.n_chunks), dim3(64), 0, s, a);

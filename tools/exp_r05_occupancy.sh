@@ -1,7 +1,12 @@
+#!/bin/bash
+# round 5: encoder throughput by resident workgroups per CU — bash tools/exp_r05_occupancy.sh "variant ..." "blocks ..."
 cd $GRAFT_REPO_ROOT
-for l in 2 3 5 7 9; do
-  export CJ_ENC_LDS_BLOCKS=$l CJ_ENC_TABLE_BLOCKS=0
-  python bench.py --op compress --codec lz4 --no-cpu-baseline --traffic off --steps 3 --warmup 1 2>/dev/null | python -c "
+for v in $1; do
+  export CJ_HIP_LIB=$GRAFT_REPO_ROOT/cramjam_amd/variants/libcramjam_hip_$v.so
+  [ "$v" = "product" ] && unset CJ_HIP_LIB
+  for l in $2; do
+    CJ_ENC_BLOCKS=$l python bench.py --op compress --codec lz4 --no-cpu-baseline --traffic off --steps 3 --warmup 1 --experiment-no-verify 2>/dev/null | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('lds_blocks/CU $l: %.1f GB/s' % d['value'])"
+d=json.loads(sys.stdin.read()); print('$v blocks/CU $l: %.1f GB/s' % d['value'])"
+  done
 done

@@ -616,13 +616,8 @@ def cpu_baseline(args, batches, op, rt_batch=None):
 
 
 def encode_kernel_names(N, codec, nch):
-    """the kernels a compress batch of nch chunks runs as (engine.hip: launch_encode) — the names rocprofv3 prints"""
-    import torch
-    cus = torch.cuda.get_device_properties(0).multi_processor_count
-    tag = "Lz4Enc" if codec == "lz4" else "SnappyEnc"
-    if nch >= 9 * cus:
-        return "encode_blocks_kernel<%s>" % tag
-    return "%s_encode_kernel" % codec
+    """the kernel a compress batch runs as (lz4_encode.hip / snappy_encode.hip: one workgroup of two wavefronts per chunk) — the name rocprofv3 prints"""
+    return "%s_encode_kernel<false, 2>" % codec
 
 
 def measure_kernels():

@@ -31,7 +31,7 @@ namespace cj {
 #if defined(__HIPCC__)
 namespace enc2 {
 
-constexpr uint32_t kTail = 2u;                      // the last kTail positions of a match are inserted (text +1..4 %, benchmark data -0.4 % against none)
+constexpr uint32_t kTail = 1u;                      // the last kTail positions of a match are inserted (text +1..3 %, benchmark data -0.1 % against none)
 constexpr uint32_t kQueueCap = 64u;
 constexpr uint32_t kFwdBlocks = 4u;                 // forward measurement cap: 4 + 64 bytes, longer matches are finished cooperatively
 constexpr uint32_t kFlagFwdMore = 1u, kFlagBackMore = 2u;
@@ -113,8 +113,9 @@ __device__ __forceinline__ void lane_copy(gptr out, uint32_t o, gcptr in, uint32
 // [4] insert, [5] flushes (inside 3), [6] waiting for the other wavefront, [7] windows
 __device__ unsigned long long g_enc_prof[16];
 __device__ __forceinline__ uint64_t prof_now() { uint64_t t; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return t; }
-#define CJ_PROF(i, expr) do { const uint64_t t_ = prof_now(); expr; const uint64_t d_ = prof_now() - t_; if (lane_id() == 0) atomicAdd(&g_enc_prof[i], d_); } while (0)
-#define CJ_PROF_COUNT(i, v) do { if (lane_id() == 0) atomicAdd(&g_enc_prof[i], (unsigned long long)(v)); } while (0)
+// (accumulated in registers, written once per chunk: an atomic per phase would sit in the next phase's vmcnt wait)
+#define CJ_PROF(i, expr) do { const uint64_t t_ = prof_now(); expr; prof_acc[i] += prof_now() - t_; } while (0)
+#define CJ_PROF_COUNT(i, v) do { prof_acc[i] += (v); } while (0)
 #else
 #define CJ_PROF(i, expr) do { expr; } while (0)
 #define CJ_PROF_COUNT(i, v) do { } while (0)
@@ -136,6 +137,9 @@ struct Walk {
     uint32_t op;            // output position after the last EMITTED sequence (queued ones are not counted yet)
     uint32_t q_n;           // queued sequences
     uint32_t wv;            // this wavefront's index in the chunk's workgroup (0 when kW == 1)
+#ifdef CJ_ENC_PROFILE
+    uint64_t prof_acc[8] = {};
+#endif
 
     // both wavefronts of a chunk meet: LDS writes before it are visible behind it
     __device__ __forceinline__ void meet() const {
@@ -461,6 +465,9 @@ struct Walk {
             pos = cur > round_end ? cur : round_end;
         }
         if (wv == 0u) flush();
+#ifdef CJ_ENC_PROFILE
+        if (lane == 0u) for (int i = 0; i < 8; i++) atomicAdd(&g_enc_prof[i], (unsigned long long)prof_acc[i]);
+#endif
         return cur;
     }
 };

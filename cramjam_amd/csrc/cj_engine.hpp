@@ -95,9 +95,6 @@ struct cj_engine {
     cj::DevBuf d_biglist, d_bigrecs, d_bigmisc, d_bigslabtab;   // chunks of 64 KiB .. 256 KiB in a device batch (big_chunks.hpp, CJ_FLAG_BIG_CHUNKS): record areas; list + summaries + slab items; the slab decoder's tables
     uint32_t* h_count = nullptr;   // pinned word: the number of big chunks of a batch above kBigCap chunks (engine.hip launch_decode)
     cj::DevBuf d_big, d_bigtab;    // large.hip: parse scratch / record tables of one large stream (under `mu`)
-    // encoders, large batches (cj::EncFill): the persistent blocks' chunk counter
-    hipEvent_t enc_free = nullptr;
-    cj::DevBuf d_enc;
     int n_cu = 0;
 };
 

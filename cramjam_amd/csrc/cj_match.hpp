@@ -1,5 +1,5 @@
 // cj_match.hpp — what the LZ4-block and Snappy-raw encoders share below the matcher (cj_enc2.hpp): the per-wavefront hash table in
-// LDS, whole-wave match extension for the long matches, the wave scan the emission uses, and the persistent-block launch.
+// LDS, whole-wave match extension for the long matches, and the wave scans the selection and the emission use.
 //
 // The CPU encoders the reference links (LZ4_compress_default, snap's compress_block) probe ONE hash slot per step on one core.
 // Here a wavefront probes a round of consecutive positions at once against its own 8192 x u16 table; the output is a valid stream
@@ -116,54 +116,6 @@ __device__ __forceinline__ uint32_t wave_excl_max(uint32_t v, uint32_t first, ui
 // number of set bits of m below this lane
 __device__ __forceinline__ uint32_t bits_below_lane(uint64_t m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
-
-// ---- persistent encoder blocks ------------------------------------------------------------------------------
-// One workgroup of Enc::kWaves wavefronts per chunk, chunks from a shared counter: a batch of at least 9 x CUs chunks runs as nine
-// blocks per CU (16 KiB table + the matcher's scratch each: what 160 KiB of LDS hold), which also evens out the CUs.
-// Enc::chunk(a, c, table, scratch, wave) = one chunk.  (Rounds 2-4 gave the wave slots the LDS leaves empty to blocks with their table
-// in global memory; with the round-based matcher those slow the LDS blocks down more than they add — every table access of theirs is
-// a scattered global access: 9 + 3 per CU 126 GB/s, 9 + 0 141 GB/s, profiles/r05/experiments e05.)
-#ifndef CJ_ENC_W2_EU
-#define CJ_ENC_W2_EU 5
-#endif
-template <class Enc>
-__device__ __forceinline__ void encode_persistent_body(const BatchArgs& a, uint32_t* counter, uint16_t* ht, uint32_t* scr, uint32_t* next) {
-    const uint32_t wave = uni(threadIdx.x >> 6);
-    for (;;) {
-        uint32_t chunk;
-        if constexpr (Enc::kWaves == 1) {
-            uint32_t c = 0;
-            if (threadIdx.x == 0) c = atomicAdd(counter, 1u);
-            chunk = uni(c);                                          // lane 0's value
-        } else {
-            if (threadIdx.x == 0) *next = atomicAdd(counter, 1u);
-            __syncthreads();
-            chunk = uni(*next);
-            __syncthreads();                                         // both have read it before thread 0 fetches the next one
-        }
-        if (chunk >= a.n_chunks) return;
-        Enc::chunk(a, chunk, HashTab{ht}, scr, wave);
-    }
-}
-// (128 VGPRs: four wavefronts per SIMD as the register target for one wavefront per chunk — the LDS admits 2.25 — and five for two
-//  per chunk, where nine workgroups are eighteen wavefronts per CU; the compiler's -Wpass-failed note about the LDS is expected)
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wpass-failed"
-template <class Enc>
-__global__ __launch_bounds__(64 * Enc::kWaves) __attribute__((amdgpu_waves_per_eu(Enc::kWaves == 1 ? 4 : CJ_ENC_W2_EU, Enc::kWaves == 1 ? 4 : CJ_ENC_W2_EU)))
-void encode_blocks_kernel(BatchArgs a, uint32_t* counter) {
-    __shared__ uint16_t ht_lds[kHashSize];
-    __shared__ uint32_t scr[Enc::kScratchWords];
-    __shared__ uint32_t next;
-    encode_persistent_body<Enc>(a, counter, ht_lds, scr, &next);
-}
-#pragma clang diagnostic pop
-
-template <class Enc>
-inline void launch_encode_persistent(const BatchArgs& a, hipStream_t s, const EncFill& f) {
-    (void)hipMemsetAsync(f.counter, 0, 4, s);
-    hipLaunchKernelGGL((encode_blocks_kernel<Enc>), dim3(f.blocks), dim3(64 * Enc::kWaves), 0, s, a, f.counter);
 }
 
 #endif

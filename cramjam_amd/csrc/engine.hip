@@ -127,31 +127,9 @@ int launch_decode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a, hipStrea
     return 0;
 }
 
-// LZ4 block / Snappy raw encode of a batch of independent chunks, one wavefront per chunk.  A CU holds nine wavefronts with a 16 KiB
-// hash table + 1 KiB of matcher scratch in LDS.  A batch with at least that many chunks (fewer: every chunk gets its wavefront at
-// once) runs as persistent blocks, nine per CU, all taking chunks from one counter (cj_match.hpp), which also evens out the CUs.
-#ifndef CJ_ENC_BLOCKS_PER_CU
-#define CJ_ENC_BLOCKS_PER_CU 9
-#endif
-constexpr uint32_t kEncBlocksPerCu = CJ_ENC_BLOCKS_PER_CU;
-
-int launch_encode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a, hipStream_t s) {
-    const bool lz4 = codec == CJ_CODEC_LZ4_BLOCK;
-    std::lock_guard<std::mutex> lock(e->scratch_mu);
-    if (e->n_cu == 0) HIP_TRY(hipDeviceGetAttribute(&e->n_cu, hipDeviceAttributeMultiprocessorCount, e->device), CJ_E_NO_DEVICE);
-    if (a.n_chunks < kEncBlocksPerCu * (uint32_t)e->n_cu || (a.flags & cj::kFlagSplitPieces)) {
-        if (lz4) cj::launch_lz4_encode(a, s); else cj::launch_snappy_encode(a, s);
-        return 0;
-    }
-    if (!e->enc_free) HIP_TRY(hipEventCreateWithFlags(&e->enc_free, hipEventDisableTiming), CJ_E_NO_DEVICE);
-    else HIP_TRY(hipStreamWaitEvent(s, e->enc_free, 0), CJ_E_NO_DEVICE);      // the previous batch (maybe on another stream) is done with the counter
-    if (!e->d_enc.reserve(256)) return CJ_E_OOM;
-    cj::EncFill f;
-    f.counter = (uint32_t*)e->d_enc.p;
-    static const uint32_t env_blocks = [] { const char* v = std::getenv("CJ_ENC_BLOCKS"); return v ? (uint32_t)std::atoi(v) : kEncBlocksPerCu; }();      // (experiment knob of round 5)
-    f.blocks = env_blocks * (uint32_t)e->n_cu;
-    if (lz4) cj::launch_lz4_encode(a, s, &f); else cj::launch_snappy_encode(a, s, &f);
-    HIP_TRY(hipEventRecord(e->enc_free, s), CJ_E_NO_DEVICE);
+// LZ4 block / Snappy raw encode of a batch of independent chunks: one workgroup of two wavefronts per chunk (lz4_encode.hip)
+int launch_encode(cj_engine*, cj_codec codec, const cj::BatchArgs& a, hipStream_t s) {
+    if (codec == CJ_CODEC_LZ4_BLOCK) cj::launch_lz4_encode(a, s); else cj::launch_snappy_encode(a, s);
     return 0;
 }
 
@@ -323,8 +301,7 @@ void cj_engine_destroy(cj_engine* e) {
     e->d_in.release(); e->d_out.release(); e->d_meta.release(); e->d_sync.release(); e->d_bigrecs.release(); e->d_bigmisc.release(); e->d_biglist.release(); if (e->h_count) (void)hipHostFree(e->h_count); e->d_bigslabtab.release(); e->d_pmeta.release(); e->d_lanelist.release(); e->d_frame.release(); e->d_tab.release(); e->d_big.release(); e->d_bigtab.release();
     e->h_in.release(); e->h_out.release();
     if (e->scratch_free) (void)hipEventDestroy(e->scratch_free);
-    e->d_enc.release();
-    if (e->enc_free) (void)hipEventDestroy(e->enc_free);
+   
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }

@@ -114,14 +114,11 @@ __global__ __launch_bounds__(64 * kW) void lz4_encode_kernel(BatchArgs a) {
     lz4_encode_chunk<kSplit, kW>(a, chunk, HashTab{ht_lds}, scr, uni(threadIdx.x >> 6));
 }
 
-#ifndef CJ_ENC_WAVES
-#define CJ_ENC_WAVES 2
-#endif
-struct Lz4Enc {
-    static constexpr int kWaves = CJ_ENC_WAVES;
-    static constexpr uint32_t kScratchWords = enc2::Walk<Lz4Fmt, kWaves>::kWords;
-    static __device__ __forceinline__ void chunk(const BatchArgs& a, uint32_t c, const HashTab& ht, uint32_t* scr, uint32_t wave) { lz4_encode_chunk<false, kWaves>(a, c, ht, scr, wave); }
-};
+// Two wavefronts per chunk (cj_enc2.hpp): a CU's LDS holds nine tables, a wavefront issues one instruction per ~5 cycles — two per
+// table give the CU eighteen instruction streams.  One workgroup per chunk, launched plainly: the hardware dispatches the next
+// workgroup when one finishes (a persistent grid with a chunk counter measured 152 GB/s against 170: its loop costs the kernel its
+// register budget).  The sub-pieces of split pieces (large.hip: 4 / 16 KiB each, pre-indexed tables) take one wavefront.
+constexpr int kEncWaves = 2;
 
 #ifdef CJ_ENC_PROFILE
 extern "C" __attribute__((visibility("default"))) int cj_debug_enc_profile(unsigned long long* out16, int reset) {
@@ -131,11 +128,10 @@ extern "C" __attribute__((visibility("default"))) int cj_debug_enc_profile(unsig
 }
 #endif
 
-void launch_lz4_encode(const BatchArgs& a, hipStream_t s, const EncFill* fill) {
+void launch_lz4_encode(const BatchArgs& a, hipStream_t s) {
     if (a.n_chunks == 0) return;
     if (a.flags & kFlagSplitPieces) hipLaunchKernelGGL((lz4_encode_kernel<true, 1>), dim3(a.n_chunks), dim3(64), 0, s, a);
-    else if (fill) launch_encode_persistent<Lz4Enc>(a, s, *fill);
-    else hipLaunchKernelGGL((lz4_encode_kernel<false, Lz4Enc::kWaves>), dim3(a.n_chunks), dim3(64 * Lz4Enc::kWaves), 0, s, a);
+    else hipLaunchKernelGGL((lz4_encode_kernel<false, kEncWaves>), dim3(a.n_chunks), dim3(64 * kEncWaves), 0, s, a);
 }
 
 }  // namespace cj

@@ -14,7 +14,7 @@
 #define HASH_BITS 13
 #define HASH_SIZE (1u << HASH_BITS)
 #define RMAX 1024
-#define TAIL 2u
+#define TAIL 1u
 
 static inline uint32_t ld32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
 static inline uint32_t hash_slot(uint32_t v) { return (v * 2654435761u) >> (32 - HASH_BITS); }

@@ -1,6 +1,6 @@
 """The encoders' kernels (cramjam_amd/csrc/cj_enc2.hpp, lz4_encode.hip, snappy_encode.hip) against their scalar model
-(tests/hostsim/enc2_model.c): byte-identical streams on every input shape, through the one-block-per-chunk kernels (small
-batch) and through the persistent blocks of both kinds (large batch: hash table in LDS / in global memory).  The model's own
+(tests/hostsim/enc2_model.c): byte-identical streams on every input shape, in a small batch and in a large one (thousands of
+workgroups in flight, every copy of a chunk must come out the same).  The model's own
 streams are checked against the oracle's decoders in tests/test_enc2_model.py; here the kernels' bytes are decoded once more."""
 import os
 
@@ -22,7 +22,7 @@ def caps_for(codec, raws):
     return [L.cj_lz4_block_compress_bound(len(r), 0) if codec == LZ4 else L.cj_snappy_raw_max_compress_len(len(r)) for r in raws]
 
 
-R = int(os.environ.get("CJ_TEST_ENC2_R", "256"))          # positions per round of the library under test (a -DCJ_ENC2_GROUPS=2 variant: 512)
+R = int(os.environ.get("CJ_TEST_ENC2_R", "512"))          # positions per round of the library under test: 256 per wavefront of a chunk, two wavefronts (an experiment build with one: 256)
 
 
 def expected(codec, raws):
@@ -35,7 +35,7 @@ def decode(codec, blk, n):
 
 
 @pytest.mark.parametrize("codec", [LZ4, SNAPPY])
-def test_one_block_per_chunk_kernel_emits_the_models_bytes(codec):
+def test_small_batch_emits_the_models_bytes(codec):
     e = N.Engine(0)
     cs = cases()
     raws = [r for _, r in cs]
@@ -49,7 +49,7 @@ def test_one_block_per_chunk_kernel_emits_the_models_bytes(codec):
 
 
 @pytest.mark.parametrize("codec", [LZ4, SNAPPY])
-def test_persistent_blocks_of_both_kinds_emit_the_models_bytes(codec):
+def test_every_copy_in_a_large_batch_emits_the_models_bytes(codec):
     e = N.Engine(0)
     uniq = [r for _, r in cases() if len(r) <= 70000] + [synth(200 + i) for i in range(24)]
     U, n = len(uniq), 6000

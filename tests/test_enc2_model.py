@@ -27,13 +27,13 @@ def model_lib():
     return L
 
 
-def model_lz4(L, raw, R=256):
+def model_lz4(L, raw, R=512):
     out = C.create_string_buffer(len(raw) + len(raw) // 255 + 32)
     n = L.enc2_model_lz4(raw, len(raw), out, R)
     return out.raw[:n]
 
 
-def model_snappy(L, raw, R=256):
+def model_snappy(L, raw, R=512):
     out = C.create_string_buffer(64 + len(raw) + len(raw) // 6)
     n = L.enc2_model_snappy(raw, len(raw), out, R)
     return out.raw[:n]

@@ -16,15 +16,17 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VMEM_RD --output-format csv -d $O/sq2 -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --traffic off > $O/sq2.log 2>&1
 for c in lz4 snappy; do rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $O/sq3_$c -- python bench.py --op compress --codec $c --steps 2 --warmup 1 --no-cpu-baseline --traffic off > $O/sq3_$c.log 2>&1; done
 python - "$O/sq" "$O/sq2" "$O/sq3_lz4" "$O/sq3_snappy" <<'PY' | tee $O/sq_counters_per_chunk.txt
-import csv,glob,collections,sys
-agg=collections.defaultdict(lambda: collections.defaultdict(list))
+import csv,glob,collections,sys,os
 for d in sys.argv[1:]:
-  for f in glob.glob(d+'/*/*counter_collection.csv'):
-    for r in csv.DictReader(open(f)):
-        k=r['Kernel_Name'].split('(')[0]
-        if 'cj::' in k: agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
-for k in sorted(agg):
-    print(k, ' '.join('%s=%.0f' % (c.replace('SQ_',''), sum(v)/len(v)/1e5) for c,v in sorted(agg[k].items())), '(per chunk of the 100 k)')
+    agg=collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(d+'/*/*counter_collection.csv'):
+        for r in csv.DictReader(open(f)):
+            k=r['Kernel_Name'].split('(')[0]
+            want = ('encode' in k) if 'sq3' in d else ('encode' not in k)          # the compress passes run the decoders only to verify
+            if 'cj::' in k and want: agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
+    print('#', os.path.basename(d), '(default decompress batch)' if 'sq3' not in d else '(compress batch)')
+    for k in sorted(agg):
+        print(k, ' '.join('%s=%.0f' % (c.replace('SQ_',''), max(v)/1e5) for c,v in sorted(agg[k].items())), '(per chunk of the 100 k; the launch over the full batch)')
 PY
 # the corpus lines carry their own traffic and cpu_baseline (all 20 files, liblz4 / libsnappy streams)
 python bench.py --data corpus64k --steps 20 --traffic on --cpu-seconds 10 2>/dev/null | tail -1 >> $O/other_paths.jsonl

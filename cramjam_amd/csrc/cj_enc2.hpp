@@ -16,8 +16,8 @@
 //            pass per ~64 sequences instead of one per round.
 //   insert   positions that are not strictly inside an emitted match (its last kTail positions count as outside) enter the table:
 //            a toggle bitmap in LDS written by the selected lanes, read back as a parity prefix by the position lanes.
-// Windows of heads that hold a capped forward extension, a selected literal run of 256 bytes or a selected match of 259 bytes and
-// more are redone by a serial cooperative path (same decisions, whole-wave extension and emission).
+// A window with a selected literal run of 256 bytes or more (or a backward extension beyond 16 bytes) is redone by a serial cooperative
+// path (same decisions, whole-wave extension and emission).
 #pragma once
 #include "cj_match.hpp"
 
@@ -33,10 +33,10 @@ namespace enc2 {
 
 constexpr uint32_t kTail = 1u;                      // the last kTail positions of a match are inserted (text +1..3 %, benchmark data -0.1 % against none)
 constexpr uint32_t kQueueCap = 64u;
-constexpr uint32_t kFwdBlocks = 4u;                 // forward measurement cap: 4 + 64 bytes, longer matches are finished cooperatively
-constexpr uint32_t kFlagFwdMore = 1u, kFlagBackMore = 2u;
+constexpr uint32_t kFwdBlocks = 16u;                // forward measurement in the lanes: 4 + 256 bytes; longer matches are finished by the whole wavefront, head by head
+constexpr uint32_t kFlagBackMore = 2u;
 constexpr uint32_t kSelPasses = 8u;                 // parallel selection passes before a window falls back to the serial walk
-constexpr uint32_t kMaxLit = 256u, kMaxCode = 255u; // a queue entry packs lit < 256 and mlen - 4 < 255 into a byte each
+constexpr uint32_t kMaxLit = 256u;                  // a queued sequence has fewer literals (one lane copies them); longer runs are written by the whole wavefront
 
 // the wave mask of a condition straight from the compare (HIP's __ballot goes through an integer: v_cndmask + v_cmp per call)
 __device__ __forceinline__ uint64_t bal(bool p) { return __builtin_amdgcn_ballot_w64(p); }
@@ -100,7 +100,7 @@ __device__ __forceinline__ void lane_copy(gptr out, uint32_t o, gcptr in, uint32
 
 // The state of one chunk's walk.  Fmt supplies the stream format:
 //   Fmt::last_start(n), Fmt::limit(n)          last position a match may start at / must end by
-//   Fmt::seq_size(lit, code, off)               encoded bytes of one queued sequence (code = mlen - 4)
+//   Fmt::seq_size(lit, code, off)               encoded bytes of one queued sequence (code = mlen - 4, any; lit < 256)
 //   Fmt::emit_lane(in, out, o, lit0, lit, code, off)   one lane writes one queued sequence at output offset o
 //   Fmt::emit_wave(in, out, op, lit0, lit, off, mlen) -> new op   the whole wavefront writes one sequence of any size
 // kW = wavefronts per chunk (1 or 2).  With two, a round is 512 positions and wavefront w owns its group w of 256: both probe the table
@@ -124,8 +124,8 @@ __device__ __forceinline__ uint64_t prof_now() { uint64_t t; asm volatile("s_wai
 template <class Fmt, int kW>
 struct Walk {
     static constexpr uint32_t kRound = 256u * kW;
-    // LDS scratch in dwords: heads (64 per wavefront) · toggle bitmap · queue (2 per entry) · shared scalars
-    static constexpr uint32_t kHeadsAt = 0u, kTogAt = 64u * kW, kQueueAt = kTogAt + 32u, kSharedAt = kQueueAt + 2u * kQueueCap, kWords = kSharedAt + 8u;
+    // LDS scratch in dwords: heads (64 per wavefront) · toggle bitmap · queue (3 per entry) · shared scalars
+    static constexpr uint32_t kHeadsAt = 0u, kTogAt = 64u * kW, kQueueAt = kTogAt + 32u, kSharedAt = kQueueAt + 3u * kQueueCap, kWords = kSharedAt + 8u;
     static_assert(kRound / 32u + 1u <= 32u, "toggle bitmap");
 
     gcptr in;               // position 0 (start of the piece), uniform
@@ -154,8 +154,8 @@ struct Walk {
         if (q_n == 0u) return;
         const uint32_t lane = lane_id();
         const bool on = lane < q_n;
-        const uint32_t lit0 = scr[kQueueAt + 2u * lane], pk = scr[kQueueAt + 2u * lane + 1u];
-        const uint32_t off = pk & 0xffffu, lit = (pk >> 16) & 0xffu, code = pk >> 24;
+        const uint32_t lit0 = scr[kQueueAt + 3u * lane], pk = scr[kQueueAt + 3u * lane + 1u], code = scr[kQueueAt + 3u * lane + 2u];
+        const uint32_t off = pk & 0xffffu, lit = pk >> 16;
         uint32_t total;
         const uint32_t before = wave_excl_add(on ? Fmt::seq_size(lit, code, off) : 0u, total);
         if (on) Fmt::emit_lane(in, out, op + before, lit0, lit, code, off);
@@ -172,7 +172,7 @@ struct Walk {
     };
     struct Meas {             // one window of up to 64 heads, measured: lane i = head i
         uint32_t mw, P, d, E, BS;
-        bool more, back_more;
+        bool back_more;
     };
 
     // probe the 256 positions gpos + 4 lane + k against the table
@@ -275,10 +275,18 @@ struct Walk {
             }
         }
         if (a + fwd >= limit) { fwd = limit - a; more = false; }      // (a <= limit: P <= last_start)
+        uint32_t E = is_head ? a + fwd : 0u;                      // E = 0: never selected
+        // matches beyond 4 + 256 bytes (long runs, repeated records): the whole wavefront finishes them, one head at a time
+        for (uint64_t lm = bal(is_head && more); lm != 0ull; lm &= lm - 1ull) {
+            const uint32_t i = ctz64(lm);
+            const uint32_t Ei = rdlane(E, i);
+            const uint32_t Ex = Ei + wave_extend((const uint8_t*)in, Ei, Ei - rdlane(d, i), limit);
+            E = (uint32_t)cj_llvm_writelane((int)Ex, (int)i, (int)E);
+        }
         m.P = P; m.d = d;
-        m.E = is_head ? a + fwd : 0u;                             // E = 0: never selected
+        m.E = E;
         m.BS = P - back;
-        m.more = is_head && more; m.back_more = back_more;
+        m.back_more = back_more;
     }
 
     // the greedy walk over one measured window, its sequences into the queue, its coverage into the toggle bitmap
@@ -288,8 +296,8 @@ struct Walk {
         const uint32_t cur0 = cur;
         uint64_t sel = 0ull;
         uint32_t PE = 0u;
-        bool slow = bal(m.more) != 0ull;
-        if (!slow) {
+        bool slow = false;
+        {
             // The greedy rule — head i is selected iff E_i >= cur_i + 4, cur_i = the end of the last selected head before it — has ONE
             // solution, and every set that reproduces itself under the rule IS it (head i's decision follows from the decisions before
             // it).  So the selection is iterated in parallel instead of walked: start from "every head", take the prefix maximum of
@@ -323,15 +331,16 @@ struct Walk {
             const bool selected = settled ? s_me : ((sel >> lane) & 1ull) != 0ull;
             const uint32_t s = umax(BS, PE);
             const uint32_t lit = s - PE, code = E - s - 4u;
-            const bool needs_wave = selected && (lit >= kMaxLit || code >= kMaxCode || (m.back_more && P >= PE && P - PE > 16u));
+            const bool needs_wave = selected && (lit >= kMaxLit || (m.back_more && P >= PE && P - PE > 16u));
             slow = bal(needs_wave) != 0ull;
             if (!slow) {
                 const uint32_t ns = (uint32_t)__builtin_popcountll(sel);
                 if (q_n + ns > kQueueCap) CJ_PROF(5, flush());
                 if (selected) {
-                    const uint32_t slot = kQueueAt + 2u * (q_n + bits_below_lane(sel));
+                    const uint32_t slot = kQueueAt + 3u * (q_n + bits_below_lane(sel));
                     scr[slot] = PE;
-                    scr[slot + 1u] = d | (lit << 16) | (code << 24);
+                    scr[slot + 1u] = d | (lit << 16);
+                    scr[slot + 2u] = code;
                     // coverage toggles: positions s + 1 .. E - kTail - 1 (relative to pos, clamped to the round) are inside this match
                     const uint32_t sx = s + 1u > pos ? s + 1u - pos : 0u;
                     const uint32_t ex = umin(E - kTail - pos, kRound);                // (E - kTail may lie before pos: ex wraps — excluded below)
@@ -347,12 +356,11 @@ struct Walk {
             // serial cooperative path: same decisions, extensions finished by the whole wavefront, every selected sequence of this
             // window emitted by the whole wavefront
             cur = cur0;
-            const uint32_t flags = (m.more ? kFlagFwdMore : 0u) | (m.back_more ? kFlagBackMore : 0u);
+            const uint32_t flags = m.back_more ? kFlagBackMore : 0u;
             for (uint32_t i = 0; i < m.mw; i++) {
                 if (cur > last_start) break;
                 const uint32_t Pi = rdlane(P, i), di = rdlane(d, i), fl = rdlane(flags, i);
-                uint32_t Ei = rdlane(E, i);
-                if (fl & kFlagFwdMore) Ei += wave_extend((const uint8_t*)in, Ei, Ei - di, limit);
+                const uint32_t Ei = rdlane(E, i);
                 if (Ei < cur + 4u) continue;
                 uint32_t s = cur;
                 if (Pi >= cur) {

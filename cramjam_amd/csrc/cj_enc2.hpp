@@ -16,8 +16,8 @@
 //            pass per ~64 sequences instead of one per round.
 //   insert   positions that are not strictly inside an emitted match (its last kTail positions count as outside) enter the table:
 //            a toggle bitmap in LDS written by the selected lanes, read back as a parity prefix by the position lanes.
-// A window with a selected literal run of 256 bytes or more (or a backward extension beyond 16 bytes) is redone by a serial cooperative
-// path (same decisions, whole-wave extension and emission).
+// Long matches and long backward extensions are finished by the whole wavefront inside `measure`, literal runs of 256 bytes and more are copied
+// by the whole wavefront inside the flush; only a literal run of 64 KiB and more (an input above 64 KiB) sends its window down a serial path.
 #pragma once
 #include "cj_match.hpp"
 
@@ -34,9 +34,9 @@ namespace enc2 {
 constexpr uint32_t kTail = 1u;                      // the last kTail positions of a match are inserted (text +1..3 %, benchmark data -0.1 % against none)
 constexpr uint32_t kQueueCap = 64u;
 constexpr uint32_t kFwdBlocks = 16u;                // forward measurement in the lanes: 4 + 256 bytes; longer matches are finished by the whole wavefront, head by head
-constexpr uint32_t kFlagBackMore = 2u;
 constexpr uint32_t kSelPasses = 8u;                 // parallel selection passes before a window falls back to the serial walk
-constexpr uint32_t kMaxLit = 256u;                  // a queued sequence has fewer literals (one lane copies them); longer runs are written by the whole wavefront
+constexpr uint32_t kLaneLit = 256u;                 // a lane copies its sequence's literals itself below this; longer runs are copied by the whole wavefront after the lanes' pass
+constexpr uint32_t kMaxLit = 65536u;                // a queue entry holds the literal count in 16 bits; a longer run (inputs above 64 KiB) takes the serial path
 
 // the wave mask of a condition straight from the compare (HIP's __ballot goes through an integer: v_cndmask + v_cmp per call)
 __device__ __forceinline__ uint64_t bal(bool p) { return __builtin_amdgcn_ballot_w64(p); }
@@ -100,8 +100,9 @@ __device__ __forceinline__ void lane_copy(gptr out, uint32_t o, gcptr in, uint32
 
 // The state of one chunk's walk.  Fmt supplies the stream format:
 //   Fmt::last_start(n), Fmt::limit(n)          last position a match may start at / must end by
-//   Fmt::seq_size(lit, code, off)               encoded bytes of one queued sequence (code = mlen - 4, any; lit < 256)
-//   Fmt::emit_lane(in, out, o, lit0, lit, code, off)   one lane writes one queued sequence at output offset o
+//   Fmt::seq_size(lit, code, off)               encoded bytes of one queued sequence (code = mlen - 4, any; lit < 65536)
+//   Fmt::emit_lane(in, out, o, lit0, lit, code, off) -> where its literals go   one lane writes one queued sequence at output offset o
+//                                               (the literal bytes themselves only below kLaneLit)
 //   Fmt::emit_wave(in, out, op, lit0, lit, off, mlen) -> new op   the whole wavefront writes one sequence of any size
 // kW = wavefronts per chunk (1 or 2).  With two, a round is 512 positions and wavefront w owns its group w of 256: both probe the table
 // as it was when the round began, measure their heads side by side, then select in position order — wavefront 0's heads, then
@@ -158,7 +159,12 @@ struct Walk {
         const uint32_t off = pk & 0xffffu, lit = pk >> 16;
         uint32_t total;
         const uint32_t before = wave_excl_add(on ? Fmt::seq_size(lit, code, off) : 0u, total);
-        if (on) Fmt::emit_lane(in, out, op + before, lit0, lit, code, off);
+        uint32_t lit_at = 0;
+        if (on) lit_at = Fmt::emit_lane(in, out, op + before, lit0, lit, code, off);        // (copies its literals itself below kLaneLit)
+        for (uint64_t lm = bal(on && lit >= kLaneLit); lm != 0ull; lm &= lm - 1ull) {      // long literal runs: by the whole wavefront
+            const uint32_t i = ctz64(lm);
+            wave_copy((uint8_t*)out + rdlane(lit_at, i), (const uint8_t*)in + rdlane(lit0, i), rdlane(lit, i));
+        }
         op = uni(op + total);
         q_n = 0u;
     }
@@ -172,7 +178,6 @@ struct Walk {
     };
     struct Meas {             // one window of up to 64 heads, measured: lane i = head i
         uint32_t mw, P, d, E, BS;
-        bool back_more;
     };
 
     // probe the 256 positions gpos + 4 lane + k against the table
@@ -283,10 +288,16 @@ struct Walk {
             const uint32_t Ex = Ei + wave_extend((const uint8_t*)in, Ei, Ei - rdlane(d, i), limit);
             E = (uint32_t)cj_llvm_writelane((int)Ex, (int)i, (int)E);
         }
+        // backward extensions beyond 16 bytes likewise (within blim: the selection clamps to the literals actually pending)
+        for (uint64_t lm = bal(back_more); lm != 0ull; lm &= lm - 1ull) {
+            const uint32_t i = ctz64(lm);
+            const uint32_t Pi = rdlane(P, i), Ci = rdlane(C, i), room = umin(Pi - cur, Ci);      // (= this head's blim)
+            const uint32_t bk = 16u + wave_extend_back((const uint8_t*)in, Pi - 16u, Ci - 16u, room - 16u);
+            back = (uint32_t)cj_llvm_writelane((int)bk, (int)i, (int)back);
+        }
         m.P = P; m.d = d;
         m.E = E;
         m.BS = P - back;
-        m.back_more = back_more;
     }
 
     // the greedy walk over one measured window, its sequences into the queue, its coverage into the toggle bitmap
@@ -331,7 +342,7 @@ struct Walk {
             const bool selected = settled ? s_me : ((sel >> lane) & 1ull) != 0ull;
             const uint32_t s = umax(BS, PE);
             const uint32_t lit = s - PE, code = E - s - 4u;
-            const bool needs_wave = selected && (lit >= kMaxLit || (m.back_more && P >= PE && P - PE > 16u));
+            const bool needs_wave = selected && lit >= kMaxLit;
             slow = bal(needs_wave) != 0ull;
             if (!slow) {
                 const uint32_t ns = (uint32_t)__builtin_popcountll(sel);
@@ -356,18 +367,15 @@ struct Walk {
             // serial cooperative path: same decisions, extensions finished by the whole wavefront, every selected sequence of this
             // window emitted by the whole wavefront
             cur = cur0;
-            const uint32_t flags = m.back_more ? kFlagBackMore : 0u;
             for (uint32_t i = 0; i < m.mw; i++) {
                 if (cur > last_start) break;
-                const uint32_t Pi = rdlane(P, i), di = rdlane(d, i), fl = rdlane(flags, i);
+                const uint32_t Pi = rdlane(P, i), di = rdlane(d, i);
                 const uint32_t Ei = rdlane(E, i);
                 if (Ei < cur + 4u) continue;
                 uint32_t s = cur;
                 if (Pi >= cur) {
                     const uint32_t room = Pi - cur;
-                    uint32_t bk = umin(Pi - rdlane(BS, i), room);
-                    if ((fl & kFlagBackMore) && bk == 16u && room > 16u) bk += wave_extend_back((const uint8_t*)in, Pi - 16u, Pi - di - 16u, room - 16u);
-                    s = Pi - bk;
+                    s = Pi - umin(Pi - rdlane(BS, i), room);
                 }
                 flush();
                 op = Fmt::emit_wave(in, out, op, cur, s - cur, di, Ei - s);

@@ -25,16 +25,21 @@ struct Lz4Fmt {
     static __device__ __forceinline__ uint32_t last_start(uint32_t n) { return n - 12u; }      // a match may start here at the latest
     static __device__ __forceinline__ uint32_t limit(uint32_t n) { return n - 5u; }            // and must end here at the latest
     static __device__ __forceinline__ uint32_t seq_size(uint32_t lit, uint32_t code, uint32_t) {
-        return 3u + lit + (lit >= 15u ? 1u : 0u) + (code >= 15u ? 1u + (code - 15u) / 255u : 0u);      // lit < 256: one length byte at most
+        return 3u + lit + (lit >= 15u ? 1u + (lit - 15u) / 255u : 0u) + (code >= 15u ? 1u + (code - 15u) / 255u : 0u);
     }
-    static __device__ __forceinline__ void emit_lane(enc2::gcptr in, enc2::gptr out, uint32_t o, uint32_t lit0, uint32_t lit, uint32_t code, uint32_t off) {
+    static __device__ __forceinline__ uint32_t emit_lane(enc2::gcptr in, enc2::gptr out, uint32_t o, uint32_t lit0, uint32_t lit, uint32_t code, uint32_t off) {
 #ifdef CJ_EXP_NO_EMIT
-        return;             // (experiment x01: what the emission's scattered stores and literal loads cost)
+        return 0u;          // (experiment x01: what the emission's scattered stores and literal loads cost)
 #endif
         enc2::s8(out, o, ((lit < 15u ? lit : 15u) << 4) | (code < 15u ? code : 15u));
         uint32_t q = o + 1u;
-        if (lit >= 15u) { enc2::s8(out, q, lit - 15u); q += 1u; }
-        enc2::lane_copy(out, q, in, lit0, lit);
+        if (lit >= 15u) {
+            uint32_t v = lit - 15u;
+            while (v >= 255u) { enc2::s8(out, q, 255u); q += 1u; v -= 255u; }
+            enc2::s8(out, q, v); q += 1u;
+        }
+        const uint32_t lit_at = q;
+        if (lit < enc2::kLaneLit) enc2::lane_copy(out, q, in, lit0, lit);
         q += lit;
         enc2::s8(out, q, off); enc2::s8(out, q + 1u, off >> 8);
         if (code >= 15u) {
@@ -43,6 +48,7 @@ struct Lz4Fmt {
             while (v >= 255u) { enc2::s8(out, q, 255u); q += 1u; v -= 255u; }
             enc2::s8(out, q, v);
         }
+        return lit_at;
     }
     static __device__ __forceinline__ uint32_t emit_wave(enc2::gcptr gin, enc2::gptr gout, uint32_t op, uint32_t lit0, uint32_t lit, uint32_t off, uint32_t mlen) {
         const uint8_t* in = (const uint8_t*)gin; uint8_t* out = (uint8_t*)gout;

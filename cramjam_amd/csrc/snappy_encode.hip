@@ -78,12 +78,15 @@ struct SnappyFmt {
     static __device__ __forceinline__ uint32_t seq_size(uint32_t lit, uint32_t code, uint32_t off) {
         return snappy_literal_size(lit) + snappy_copy_size(off, code + 4u);
     }
-    static __device__ __forceinline__ void emit_lane(enc2::gcptr in, enc2::gptr out, uint32_t o, uint32_t lit0, uint32_t lit, uint32_t code, uint32_t off) {
-        if (lit) {          // lit < 256: one or two header bytes
+    static __device__ __forceinline__ uint32_t emit_lane(enc2::gcptr in, enc2::gptr out, uint32_t o, uint32_t lit0, uint32_t lit, uint32_t code, uint32_t off) {
+        uint32_t lit_at = o;
+        if (lit) {          // lit < 65536: one to three header bytes
             const uint32_t n1 = lit - 1u;
             if (n1 < 60u) { enc2::s8(out, o, n1 << 2); o += 1u; }
-            else { enc2::s8(out, o, 60u << 2); enc2::s8(out, o + 1u, n1); o += 2u; }
-            enc2::lane_copy(out, o, in, lit0, lit);
+            else if (n1 < 256u) { enc2::s8(out, o, 60u << 2); enc2::s8(out, o + 1u, n1); o += 2u; }
+            else { enc2::s8(out, o, 61u << 2); enc2::s8(out, o + 1u, n1); enc2::s8(out, o + 2u, n1 >> 8); o += 3u; }
+            lit_at = o;
+            if (lit < enc2::kLaneLit) enc2::lane_copy(out, o, in, lit0, lit);
             o += lit;
         }
         uint32_t len = code + 4u;
@@ -91,6 +94,7 @@ struct SnappyFmt {
         if (len > 64u) { enc2::s8(out, o, 2u | (59u << 2)); enc2::s8(out, o + 1u, off); enc2::s8(out, o + 2u, off >> 8); o += 3u; len -= 60u; }
         if (len < 12u && off < 2048u) { enc2::s8(out, o, 1u | ((len - 4u) << 2) | ((off >> 8) << 5)); enc2::s8(out, o + 1u, off); }
         else { enc2::s8(out, o, 2u | ((len - 1u) << 2)); enc2::s8(out, o + 1u, off); enc2::s8(out, o + 2u, off >> 8); }
+        return lit_at;
     }
     static __device__ __forceinline__ uint32_t emit_wave(enc2::gcptr gin, enc2::gptr gout, uint32_t op, uint32_t lit0, uint32_t lit, uint32_t off, uint32_t mlen) {
         const uint8_t* in = (const uint8_t*)gin; uint8_t* out = (uint8_t*)gout;

@@ -54,6 +54,9 @@ def cases():
     out.append(("back_ext", b"x" * 40 + bytes(rnd.getrandbits(8) for _ in range(5000)) + b"x" * 40 + b"yz" * 30))
     long_lit_then_match = bytes(rnd.getrandbits(8) for _ in range(300))
     out.append(("lit300_match", long_lit_then_match + long_lit_then_match[10:90] + bytes(20)))
+    r70k = bytes(rnd.getrandbits(8) for _ in range(70000))
+    out.append(("lit70000_match", r70k + r70k[69000:69900] + b"the end of it"))      # a literal run above 64 KiB in front of a match: the serial path
+    out.append(("back_ext_far", b"q" * 300 + bytes(rnd.getrandbits(8) for _ in range(3000)) + b"Z" + b"q" * 300 + bytes(50)))   # backward extension far beyond 16 bytes
     base = bytes(rnd.getrandbits(8) for _ in range(2000))
     for t in range(0, 72, 3):                                    # a match that runs into the end-of-block zone, every distance from the end
         out.append(("tail_match_%d" % t, base + base[100:140 + t]))

@@ -178,6 +178,7 @@ struct Walk {
     };
     struct Meas {             // one window of up to 64 heads, measured: lane i = head i
         uint32_t mw, P, d, E, BS;
+        bool back_more;           // 16 bytes before the head matched and more literals may be pending: the selection decides whether it matters
     };
 
     // probe the 256 positions gpos + 4 lane + k against the table
@@ -288,16 +289,10 @@ struct Walk {
             const uint32_t Ex = Ei + wave_extend((const uint8_t*)in, Ei, Ei - rdlane(d, i), limit);
             E = (uint32_t)cj_llvm_writelane((int)Ex, (int)i, (int)E);
         }
-        // backward extensions beyond 16 bytes likewise (within blim: the selection clamps to the literals actually pending)
-        for (uint64_t lm = bal(back_more); lm != 0ull; lm &= lm - 1ull) {
-            const uint32_t i = ctz64(lm);
-            const uint32_t Pi = rdlane(P, i), Ci = rdlane(C, i), room = umin(Pi - cur, Ci);      // (= this head's blim)
-            const uint32_t bk = 16u + wave_extend_back((const uint8_t*)in, Pi - 16u, Ci - 16u, room - 16u);
-            back = (uint32_t)cj_llvm_writelane((int)bk, (int)i, (int)back);
-        }
         m.P = P; m.d = d;
         m.E = E;
         m.BS = P - back;
+        m.back_more = back_more;
     }
 
     // the greedy walk over one measured window, its sequences into the queue, its coverage into the toggle bitmap
@@ -340,7 +335,16 @@ struct Walk {
                 }
             }
             const bool selected = settled ? s_me : ((sel >> lane) & 1ull) != 0ull;
-            const uint32_t s = umax(BS, PE);
+            // a selected head whose 16 measured bytes backwards all matched, with more than 16 literals pending in front of it: the
+            // whole wavefront finishes its backward extension (rare: the start of the match moves, nobody else's decision does)
+            uint32_t BSx = BS;
+            for (uint64_t lm = bal(selected && m.back_more && P >= PE && P - PE > 16u); lm != 0ull; lm &= lm - 1ull) {
+                const uint32_t i = ctz64(lm);
+                const uint32_t Pi = rdlane(P, i), Ci = Pi - rdlane(d, i), room = Pi - rdlane(PE, i);
+                const uint32_t bk = 16u + wave_extend_back((const uint8_t*)in, Pi - 16u, Ci - 16u, room - 16u);
+                BSx = (uint32_t)cj_llvm_writelane((int)(Pi - bk), (int)i, (int)BSx);
+            }
+            const uint32_t s = umax(BSx, PE);
             const uint32_t lit = s - PE, code = E - s - 4u;
             const bool needs_wave = selected && lit >= kMaxLit;
             slow = bal(needs_wave) != 0ull;
@@ -375,7 +379,9 @@ struct Walk {
                 uint32_t s = cur;
                 if (Pi >= cur) {
                     const uint32_t room = Pi - cur;
-                    s = Pi - umin(Pi - rdlane(BS, i), room);
+                    uint32_t bk = umin(Pi - rdlane(BS, i), room);
+                    if (rdlane(m.back_more ? 1u : 0u, i) != 0u && bk == 16u && room > 16u) bk += wave_extend_back((const uint8_t*)in, Pi - 16u, Pi - di - 16u, room - 16u);
+                    s = Pi - bk;
                 }
                 flush();
                 op = Fmt::emit_wave(in, out, op, cur, s - cur, di, Ei - s);

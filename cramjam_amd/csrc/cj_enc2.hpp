@@ -33,7 +33,7 @@ namespace enc2 {
 
 constexpr uint32_t kTail = 1u;                      // the last kTail positions of a match are inserted (text +1..3 %, benchmark data -0.1 % against none)
 constexpr uint32_t kQueueCap = 64u;
-constexpr uint32_t kFwdBlocks = 16u;                // forward measurement in the lanes: 4 + 256 bytes; longer matches are finished by the whole wavefront, head by head
+constexpr uint32_t kFwdTrips = 8u;                  // forward measurement in the lanes: 32 bytes per round trip, 4 + 256 bytes; longer matches are finished by the whole wavefront, head by head
 constexpr uint32_t kSelPasses = 8u;                 // parallel selection passes before a window falls back to the serial walk
 constexpr uint32_t kLaneLit = 256u;                 // a lane copies its sequence's literals itself below this; longer runs are copied by the whole wavefront after the lanes' pass
 constexpr uint32_t kMaxLit = 65536u;                // a queue entry holds the literal count in 16 bits; a longer run (inputs above 64 KiB) takes the serial path
@@ -266,18 +266,22 @@ struct Walk {
                 while (back < blim && g8(in, P - 1u - back) == g8(in, C - 1u - back)) back += 1u;
             }
         }
-        // the rare rest: matches beyond 4 + 32 bytes block by block, the last 16 bytes of the input byte by byte
-        for (uint32_t it = 2; it <= kFwdBlocks; it++) {
+        // the rest: matches beyond 4 + 32 bytes two blocks per round trip, the last 16 bytes of the input byte by byte
+        for (uint32_t it = 1; it < kFwdTrips; it++) {
             if (bal(more) == 0ull) break;
-            const bool blk = more && it < kFwdBlocks && a + fwd + 16u <= n;
-            if (more && !blk && a + fwd + 16u > n) {
+            const bool b0 = more && a + fwd + 16u <= n, b1 = more && a + fwd + 32u <= n;
+            uint4 x0 = make_uint4(0, 0, 0, 0), y0 = make_uint4(0, 0, 0, 1), x1 = x0, y1 = y0;
+            if (b0) { x0 = g128(in, a + fwd); y0 = g128(in, a + fwd - d); }
+            if (b1) { x1 = g128(in, a + fwd + 16u); y1 = g128(in, a + fwd + 16u - d); }
+            if (more && !b0) {
                 while (a + fwd < limit && g8(in, a + fwd) == g8(in, a + fwd - d)) fwd += 1u;
                 more = false;
             }
-            if (blk) {
-                const uint32_t e = first_diff(g128(in, a + fwd), g128(in, a + fwd - d));
-                fwd += e;
-                more = e == 16u;
+            if (b0) {
+                const uint32_t e0 = first_diff(x0, y0), e1 = first_diff(x1, y1);
+                const uint32_t step = e0 == 16u && b1 ? 16u + e1 : e0;
+                fwd += step;
+                more = step == (b1 ? 32u : 16u);
             }
         }
         if (a + fwd >= limit) { fwd = limit - a; more = false; }      // (a <= limit: P <= last_start)

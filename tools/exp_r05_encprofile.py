@@ -15,7 +15,15 @@ L.cj_debug_enc_profile.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 e = N.Engine(0)
 S, n = 65536, int(os.environ.get("CHUNKS", "20000"))
 raw = e.alloc(n * S)
-N.check(L.cj_bench_synth_v1(raw, S, S, 0, n, 0x5EED, None))
+if os.environ.get("CORPUS_FILE"):          # the chunks of one file of the reference's benchmark corpus, tiled
+    os.environ["CJ_CORPUS_FILES"] = os.environ["CORPUS_FILE"]
+    import bench
+    cc, _ = bench.corpus_chunks(S)
+    tile = np.frombuffer(b"".join(cc), np.uint8)
+    reps = (n * S + tile.size - 1) // tile.size
+    e.h2d(raw, np.tile(tile, reps)[:n * S])
+else:
+    N.check(L.cj_bench_synth_v1(raw, S, S, 0, n, 0x5EED, None))
 bound = L.cj_lz4_block_compress_bound(S, 0)
 stride = (bound + 15) & ~15
 out = e.alloc(n * stride)
@@ -32,5 +40,5 @@ L.cj_debug_enc_profile(buf, 0)
 v = list(buf)
 rounds = max(v[0], 1)
 names = ["rounds", "probe", "measure", "select+push", "insert", "flush (in select)", "waiting for the other wave", "windows"]
-print("blocks/CU %s: rounds per chunk %.1f (wave-rounds), windows per round %.2f" % (os.environ.get("CJ_ENC_BLOCKS", "default"), v[0] / n, v[7] / rounds))
+print("%s, blocks/CU %s: rounds per chunk %.1f (wave-rounds), windows per round %.2f" % (os.environ.get("CORPUS_FILE") or "synth-v1", os.environ.get("CJ_ENC_BLOCKS", "default"), v[0] / n, v[7] / rounds))
 print("  cycles per wave-round: " + ", ".join("%s %.0f" % (names[i], v[i] / rounds) for i in (1, 2, 3, 4, 5, 6)) + ", sum %.0f" % (sum(v[i] for i in (1, 2, 3, 4, 6)) / rounds))

@@ -34,7 +34,10 @@ namespace enc2 {
 constexpr uint32_t kTail = 1u;                      // the last kTail positions of a match are inserted (text +1..3 %, benchmark data -0.1 % against none)
 constexpr uint32_t kQueueCap = 64u;
 constexpr uint32_t kFwdTrips = 8u;                  // forward measurement in the lanes: 32 bytes per round trip, 4 + 256 bytes; longer matches are finished by the whole wavefront, head by head
-constexpr uint32_t kSelPasses = 8u;                 // parallel selection passes before a window falls back to the serial walk
+#ifndef CJ_SEL_PASSES
+#define CJ_SEL_PASSES 8
+#endif
+constexpr uint32_t kSelPasses = CJ_SEL_PASSES;                // parallel selection passes before a window falls back to the serial walk
 constexpr uint32_t kLaneLit = 256u;                 // a lane copies its sequence's literals itself below this; longer runs are copied by the whole wavefront after the lanes' pass
 constexpr uint32_t kMaxLit = 65536u;                // a queue entry holds the literal count in 16 bits; a longer run (inputs above 64 KiB) takes the serial path
 
@@ -139,7 +142,7 @@ struct Walk {
     uint32_t q_n;           // queued sequences
     uint32_t wv;            // this wavefront's index in the chunk's workgroup (0 when kW == 1)
 #ifdef CJ_ENC_PROFILE
-    uint64_t prof_acc[8] = {};
+    uint64_t prof_acc[12] = {};      // [8] selection passes, [9] windows that fell back to the serial walk, [10] heads
 #endif
 
     // both wavefronts of a chunk meet: LDS writes before it are visible behind it
@@ -290,7 +293,7 @@ struct Walk {
         for (uint64_t lm = bal(is_head && more); lm != 0ull; lm &= lm - 1ull) {
             const uint32_t i = ctz64(lm);
             const uint32_t Ei = rdlane(E, i);
-            const uint32_t Ex = Ei + wave_extend((const uint8_t*)in, Ei, Ei - rdlane(d, i), limit);
+            const uint32_t Ex = Ei + wave_extend((const uint8_t*)in, Ei, Ei - rdlane(d, i), limit, n);
             E = (uint32_t)cj_llvm_writelane((int)Ex, (int)i, (int)E);
         }
         m.P = P; m.d = d;
@@ -323,11 +326,13 @@ struct Walk {
                 cp = wave_excl_max(s_me ? E : 0u, cur, top);      // the end of the last selected head below this lane (or cur)
                 s_me = E >= cp + 4u && cp <= last_start;
                 const uint64_t nm = bal(s_me);
+                CJ_PROF_COUNT(8, 1);
                 if (nm == smask) { settled = true; break; }
                 smask = nm;
             }
             if (settled) { sel = smask; PE = cp; cur = top; }
             else {
+                CJ_PROF_COUNT(9, 1);
                 for (;;) {                                       // the walk: the chain carries `cur` only
                     if (cur > last_start) break;
                     const uint64_t mm = bal(E >= cur + 4u);
@@ -443,6 +448,7 @@ struct Walk {
         for (uint32_t w0 = 0; w0 < h.total; w0 += 64u) {
             CJ_PROF(2, measure(h, gpos, w0, cur, m));
             CJ_PROF_COUNT(7, 1);
+            CJ_PROF_COUNT(10, m.mw);
             if constexpr (kW > 1) {
                 if (w0 == 0u && wv != 0u) { CJ_PROF(6, meet()); cur = uni(scr[kSharedAt]); q_n = uni(scr[kSharedAt + 1u]); op = uni(scr[kSharedAt + 2u]); }
             }
@@ -492,7 +498,7 @@ struct Walk {
         }
         if (wv == 0u) flush();
 #ifdef CJ_ENC_PROFILE
-        if (lane == 0u) for (int i = 0; i < 8; i++) atomicAdd(&g_enc_prof[i], (unsigned long long)prof_acc[i]);
+        if (lane == 0u) for (int i = 0; i < 12; i++) atomicAdd(&g_enc_prof[i], (unsigned long long)prof_acc[i]);
 #endif
         return cur;
     }

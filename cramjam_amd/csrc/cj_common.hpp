@@ -77,7 +77,11 @@ void launch_snappy_encode(const BatchArgs& a, hipStream_t s);
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+#ifdef CJ_BALLOT_BUILTIN
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+#else
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __ballot(p); }
+#endif
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return __builtin_amdgcn_readlane(v, l); }
 
 __device__ __forceinline__ uint32_t ctz64(uint64_t m) { return (uint32_t)__builtin_ctzll(m); }

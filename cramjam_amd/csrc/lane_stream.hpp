@@ -121,8 +121,10 @@ __device__ __forceinline__ void refill_round(LaneStream& st, bool want, uint32_t
         v[r] = make_uint4(0, 0, 0, 0);
         dsta[r] = 0xffffffffu;
         if ((th[r] & 1u) && off < plan.end[r]) {
-            const uint8_t* src = reinterpret_cast<const uint8_t*>(((uint64_t)plan.bhi[r] << 32) | plan.blo[r]) + off;
-            v[r] = *reinterpret_cast<const uint4*>(src);               // 16 B aligned, never crosses into a page past the stream
+            // (a pointer rebuilt from integers is a FLAT pointer to the compiler: flat_load counts against lgkmcnt too, so every LDS wait
+            //  of the walk would also wait for these — the address space is spelled out)
+            typedef const uint4 __attribute__((address_space(1)))* GlobalVec;
+            v[r] = *(GlobalVec)(uintptr_t)((((uint64_t)plan.bhi[r] << 32) | plan.blo[r]) + off);      // 16 B aligned, never crosses into a page past the stream
             dsta[r] = wave_ring + (uint32_t)t * kRingStride + (off & (kRingBytes - 1u));
         }
     }

@@ -123,8 +123,10 @@ __device__ __forceinline__ void refill_round(LaneStream& st, bool want, uint32_t
         if ((th[r] & 1u) && off < plan.end[r]) {
             // (a pointer rebuilt from integers is a FLAT pointer to the compiler: flat_load counts against lgkmcnt too, so every LDS wait
             //  of the walk would also wait for these — the address space is spelled out)
-            typedef const uint4 __attribute__((address_space(1)))* GlobalVec;
-            v[r] = *(GlobalVec)(uintptr_t)((((uint64_t)plan.bhi[r] << 32) | plan.blo[r]) + off);      // 16 B aligned, never crosses into a page past the stream
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            typedef const u32x4 __attribute__((address_space(1)))* GlobalVec;
+            const u32x4 q = *(GlobalVec)(uintptr_t)((((uint64_t)plan.bhi[r] << 32) | plan.blo[r]) + off);      // 16 B aligned, never crosses into a page past the stream
+            v[r] = make_uint4(q.x, q.y, q.z, q.w);
             dsta[r] = wave_ring + (uint32_t)t * kRingStride + (off & (kRingBytes - 1u));
         }
     }

@@ -7,8 +7,9 @@
 //   heads    a verified position whose left neighbour is verified with the SAME offset lies inside its neighbour's match: only
 //            the first position of such a run (its head) is a candidate.  On match-heavy data half of all positions verify and
 //            one in fifteen is a head; the heads are compacted into consecutive lanes (ranks from v_mbcnt, a 256-byte LDS list).
-//   extend   ONE pass over the compacted heads measures every candidate forwards (4 + 64 bytes at most, 16-byte blocks) and
-//            backwards (16 bytes) — the previous matcher ran this code once per 64 positions with a lane or two active.
+//   extend   ONE pass over the compacted heads measures every candidate forwards (32 bytes per lane and round trip; the last few
+//            long ones of a window by sixteen lanes each, 256 bytes per round trip) and backwards (16 bytes) — the previous
+//            matcher ran this code once per 64 positions with a lane or two active.
 //   select   greedy walk over the heads in position order: the first head whose interval still has four bytes past the end of the
 //            previous match wins (a head the previous match ran over still offers its tail).  The chain carries `cur` only:
 //            v_cmp + s_ff1 + v_readlane + v_writelane per selected match; starts, lengths and sizes follow lane-parallel.
@@ -16,7 +17,7 @@
 //            pass per ~64 sequences instead of one per round.
 //   insert   positions that are not strictly inside an emitted match (its last kTail positions count as outside) enter the table:
 //            a toggle bitmap in LDS written by the selected lanes, read back as a parity prefix by the position lanes.
-// Long matches and long backward extensions are finished by the whole wavefront inside `measure`, literal runs of 256 bytes and more are copied
+// Long backward extensions are finished by the whole wavefront after the selection, literal runs of 256 bytes and more are copied
 // by the whole wavefront inside the flush; only a literal run of 64 KiB and more (an input above 64 KiB) sends its window down a serial path.
 #pragma once
 #include "cj_match.hpp"
@@ -33,7 +34,8 @@ namespace enc2 {
 
 constexpr uint32_t kTail = 1u;                      // the last kTail positions of a match are inserted (text +1..3 %, benchmark data -0.1 % against none)
 constexpr uint32_t kQueueCap = 64u;
-constexpr uint32_t kFwdTrips = 8u;                  // forward measurement in the lanes: 32 bytes per round trip, 4 + 256 bytes; longer matches are finished by the whole wavefront, head by head
+constexpr uint32_t kFwdTrips = 8u;                  // forward measurement in the lanes: 32 bytes per round trip, 4 + 256 bytes at most
+constexpr uint32_t kGroupHeads = 4u;                // ... until at most this many heads of the window still match: those are finished four at a time, sixteen lanes each
 #ifndef CJ_SEL_PASSES
 #define CJ_SEL_PASSES 8
 #endif
@@ -271,7 +273,7 @@ struct Walk {
         }
         // the rest: matches beyond 4 + 32 bytes two blocks per round trip, the last 16 bytes of the input byte by byte
         for (uint32_t it = 1; it < kFwdTrips; it++) {
-            if (bal(more) == 0ull) break;
+            if ((uint32_t)__builtin_popcountll(bal(more)) <= kGroupHeads) break;      // few enough for the groups below (or none)
             const bool b0 = more && a + fwd + 16u <= n, b1 = more && a + fwd + 32u <= n;
             uint4 x0 = make_uint4(0, 0, 0, 0), y0 = make_uint4(0, 0, 0, 1), x1 = x0, y1 = y0;
             if (b0) { x0 = g128(in, a + fwd); y0 = g128(in, a + fwd - d); }
@@ -289,12 +291,41 @@ struct Walk {
         }
         if (a + fwd >= limit) { fwd = limit - a; more = false; }      // (a <= limit: P <= last_start)
         uint32_t E = is_head ? a + fwd : 0u;                      // E = 0: never selected
-        // matches beyond 4 + 256 bytes (long runs, repeated records): the whole wavefront finishes them, one head at a time
-        for (uint64_t lm = bal(is_head && more); lm != 0ull; lm &= lm - 1ull) {
-            const uint32_t i = ctz64(lm);
-            const uint32_t Ei = rdlane(E, i);
-            const uint32_t Ex = Ei + wave_extend((const uint8_t*)in, Ei, Ei - rdlane(d, i), limit, n);
-            E = (uint32_t)cj_llvm_writelane((int)Ex, (int)i, (int)E);
+        // longer matches (repeated records, runs): FOUR heads at a time, sixteen lanes each — 256 bytes per head and round trip.  (One
+        // head at a time by the whole wavefront made every long match of a window a round trip of its own: geo.protodata, xml and
+        // mr spent half of a round there, r05 e27.)
+        for (uint64_t lm = bal(is_head && more); lm != 0ull; ) {
+            uint32_t idx[4]; uint32_t nb = 0;
+#pragma unroll
+            for (int g = 0; g < 4; g++) { idx[g] = lm != 0ull ? ctz64(lm) : 0u; nb += lm != 0ull ? 1u : 0u; lm &= lm - 1ull; }
+            const uint32_t grp = lane >> 4, sub = lane & 15u;
+            const uint32_t hi = grp == 0u ? idx[0] : grp == 1u ? idx[1] : grp == 2u ? idx[2] : idx[3];
+            const uint32_t Eh = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(hi << 2), (int)E);
+            const uint32_t dh = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(hi << 2), (int)d);
+            bool act = grp < nb;
+            uint32_t cnt = 0;
+            for (;;) {
+                uint32_t e = 0;
+                const uint32_t j = Eh + cnt + 16u * sub;
+                if (act && j < limit) {
+                    if (j + 16u <= n) e = first_diff(g128(in, j), g128(in, j - dh));
+                    else while (e < 16u && j + e < n && g8(in, j + e) == g8(in, j + e - dh)) e += 1u;
+                    e = umin(e, limit - j);
+                }
+                const uint64_t full = bal(act && e == 16u);
+                const uint32_t bits = (uint32_t)(full >> (lane & 48u)) & 0xffffu;
+                const uint32_t first = ffbl_raw(~bits) & 15u;                                  // (all sixteen full: not used)
+                const uint32_t ef = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane & 48u) + first) << 2), (int)e);
+                if (act) {
+                    if (bits == 0xffffu) cnt += 256u;
+                    else { cnt += 16u * first + ef; act = false; }
+                }
+                if (bal(act) == 0ull) break;
+            }
+            const uint32_t Ex = Eh + cnt;
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                if ((uint32_t)g < nb) E = (uint32_t)cj_llvm_writelane((int)rdlane(Ex, 16u * g), (int)idx[g], (int)E);
         }
         m.P = P; m.d = d;
         m.E = E;
@@ -444,6 +475,8 @@ struct Walk {
         CJ_PROF(1, probe(gpos, round_last, D0, D1, h));
         if (wv == 0u && lane < kRound / 32u + 1u) scr[kTogAt + lane] = 0u;      // this round's toggle bitmap
         // every wavefront measures its first window at once; then the turns: wavefront 0 selects (all its windows), then wavefront 1
+        // (measuring a wavefront's first TWO windows ahead of the turns — text and tables have two to four — takes 96 registers and
+        //  gives the corpus +2 %, synthetic data -2 %: r05 e32, not kept)
         Meas m;
         for (uint32_t w0 = 0; w0 < h.total; w0 += 64u) {
             CJ_PROF(2, measure(h, gpos, w0, cur, m));

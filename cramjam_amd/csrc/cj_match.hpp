@@ -1,5 +1,5 @@
 // cj_match.hpp — what the LZ4-block and Snappy-raw encoders share below the matcher (cj_enc2.hpp): the per-wavefront hash table in
-// LDS, whole-wave match extension for the long matches, and the wave scans the selection and the emission use.
+// LDS, whole-wave backward extension, and the wave scans the selection and the emission use.
 //
 // The CPU encoders the reference links (LZ4_compress_default, snap's compress_block) probe ONE hash slot per step on one core.
 // Here a wavefront probes a round of consecutive positions at once against its own 8192 x u16 table; the output is a valid stream
@@ -42,36 +42,6 @@ struct HashTab {
         for (uint32_t pos = lane_id(); pos < q0; pos += 64u) set(hash_slot(ld32u(in + pos)), pos);
     }
 };
-
-// count equal bytes of in[a..] vs in[b..] (b < a), stopping at position `limit` for a (limit <= n, the end of the readable input).
-// Sixteen bytes per lane and step — 1 KiB per step: the long runs of real data (zero pages, repeated records) are where this is called.
-__device__ __forceinline__ uint32_t wave_extend(const uint8_t* in, uint32_t a, uint32_t b, uint32_t limit, uint32_t n) {
-    uint32_t cnt = 0;
-    const uint32_t lane = lane_id();
-    for (;;) {
-        const uint32_t j = a + cnt + 16u * lane;
-        uint32_t e = 0;                                           // equal bytes of this lane's 16 (fewer where `limit` cuts them)
-        if (j < limit) {
-            const uint32_t room = limit - j;
-            if (j + 16u <= n) {
-                uint4 x, y;
-                __builtin_memcpy(&x, in + j, 16); __builtin_memcpy(&y, in + (b + cnt + 16u * lane), 16);
-                const uint32_t d0 = x.x ^ y.x, d1 = x.y ^ y.y, d2 = x.z ^ y.z, d3 = x.w ^ y.w;
-                e = d0 ? (uint32_t)__builtin_ctz(d0) >> 3 : d1 ? 4u + ((uint32_t)__builtin_ctz(d1) >> 3) : d2 ? 8u + ((uint32_t)__builtin_ctz(d2) >> 3)
-                       : d3 ? 12u + ((uint32_t)__builtin_ctz(d3) >> 3) : 16u;
-            } else {
-                while (e < 16u && j + e < n && in[j + e] == in[b + cnt + 16u * lane + e]) e += 1u;
-            }
-            e = e < room ? e : room;
-        }
-        const uint64_t full = ballot64(e == 16u);
-        if (full == ~0ull) { cnt += 1024u; continue; }
-        const uint32_t first = ctz64(~full);
-        cnt += 16u * first + rdlane(e, first);
-        break;
-    }
-    return cnt;
-}
 
 // backward extension ("catch-up"): how many bytes before a / b also match, limited to `room` (bytes back to the anchor) and to b
 // itself.  The probe often hits a repeated region a few bytes after its start; without this the head of every such match is

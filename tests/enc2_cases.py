@@ -63,6 +63,27 @@ def cases():
         out.append(("tail_match_lit_%d" % t, base + base[100:170] + bytes(rnd.getrandbits(8) for _ in range(t))))
     for k in range(24):                                          # ragged sizes: the last round's positions end anywhere in a lane's four
         out.append(("synth_ragged_%d" % k, synth(300 + k, 30000 + 37 * k + k * k)))
+    # long matches finished by groups of sixteen lanes, four heads at a time: windows with fewer / more than four heads that still match
+    # after the lanes' first trips, lengths on both sides of every step (32 per lane trip, 256 per group trip), ends in the end-of-block zone
+    dic = [bytes(rnd.getrandbits(8) for _ in range(1400)) for _ in range(8)]
+    for name, lens in (("slices_short", (40, 45, 52, 60)), ("slices_mixed", (37, 44, 70, 100, 259, 260, 261, 300, 516, 517, 600, 1100)), ("slices_long", (300, 520, 800, 1290))):
+        body = b"".join(dic)
+        for _ in range(400):
+            L = rnd.choice(lens)
+            a = rnd.randrange(0, 1400 - L)
+            body += rnd.choice(dic)[a:a + L]
+        out.append((name, body[:65536]))
+    rec = bytes(rnd.getrandbits(8) for _ in range(700))
+    recs = bytearray()
+    for k in range(90):                                           # repeated records with a few bytes changed each (what geo.protodata / xml look like)
+        r = bytearray(rec)
+        for _ in range(rnd.randrange(1, 6)): r[rnd.randrange(700)] = rnd.getrandbits(8)
+        if k % 7 == 0: rec = bytes(r)
+        recs += r
+    out.append(("records_mutated", bytes(recs)))
+    for t in range(0, 40, 3):                                    # long matches (one, then two side by side) that run into the end of the input
+        out.append(("tail_long_%d" % t, base + base[100:700 + t]))
+        out.append(("tail_long2_%d" % t, base + base[100:400] + base[900:1500 + t]))
     for n in (0, 1, 4, 7, 8, 9, 12, 13, 14, 15, 16, 17, 20, 31, 63, 64, 65, 67, 68, 255, 256, 257, 260, 511, 512, 513, 1023, 1024):
         out.append(("abab_%d" % n, (b"abcab" * 300)[:n]))
         out.append(("text_%d" % n, text[1000:1000 + n]))

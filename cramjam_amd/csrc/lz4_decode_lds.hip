@@ -63,6 +63,9 @@ constexpr uint32_t kD2LongRun = CJ_D2_LONG;      // literal runs at least this l
 #ifndef CJ_D3_MASK64
 #define CJ_D3_MASK64 1
 #endif
+#ifndef CJ_LZ4_D1_FAST
+#define CJ_LZ4_D1_FAST 1
+#endif
 #ifndef CJ_SN_D1_FAST
 #define CJ_SN_D1_FAST 1
 #endif
@@ -548,6 +551,47 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             const uint2 p = sp == tid ? p_first : csync[sp];
             uint32_t ip = p.x, op = p.y;
             uint32_t s = sp * kSyncEvery, near = 0;
+#if CJ_LZ4_D1_FAST
+            // ONE dependent LDS read per sequence: the offset field is read as 8 bytes, and the token behind it (2 or 3 bytes further) and
+            // that token's first length byte come with it — what lz4_parse_kernel does since r04 x03, and the Snappy loop above since g04.
+            // Only a length of 270 or more (a second length byte) reads on byte by byte.
+            uint32_t t4 = lds_ld32a(a_in + ip);                     // token + 3 following bytes (may over-read: harmless)
+            for (uint32_t j = 0; j < kSyncEvery && s < nseq; j++, s++) {
+                const uint32_t token = t4 & 0xffu;
+                ip += 1;
+                uint32_t lit = token >> 4;
+                if (lit == 15u) {
+                    uint32_t b = (t4 >> 8) & 0xffu;
+                    ip += 1; lit += b;
+                    while (b == 255u) { b = lds_ld8(a_in + ip); ip += 1; lit += b; }
+                }
+                const uint32_t lit_src = ip;
+                ip += lit; op += lit;
+                uint32_t w = 0, mlen = 0;
+                if (s + 1u < nseq) {
+                    const uint2 o8 = lds_ld64a(a_in + ip);
+                    const uint32_t offset = o8.x & 0xffffu;
+                    mlen = token & 15u;
+                    const bool ext = mlen == 15u;
+                    const uint32_t b0 = (o8.x >> 16) & 0xffu;
+                    ip += ext ? 3u : 2u;
+                    t4 = __builtin_amdgcn_alignbyte(o8.y, o8.x, ext ? 3u : 2u);
+                    if (ext) {
+                        mlen += b0;
+                        if (b0 == 255u) {
+                            uint32_t b = b0;
+                            while (b == 255u) { b = lds_ld8(a_in + ip); ip += 1; mlen += b; }
+                            t4 = lds_ld32a(a_in + ip);
+                        }
+                    }
+                    mlen += 4u;
+                    w = offset | (mlen << 16);
+                    near += offset < kFwdNear ? 1u : 0u;
+                }
+                rec_store(s, lit_src, lit, op, w);
+                op += mlen;
+            }
+#else
             for (uint32_t j = 0; j < kSyncEvery && s < nseq; j++, s++) {
                 const uint32_t t4 = lds_ld32a(a_in + ip);           // token + 3 following bytes (may over-read: harmless)
                 const uint32_t token = t4 & 0xffu;
@@ -578,6 +622,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 rec_store(s, lit_src, lit, op, w);
                 op += mlen;
             }
+#endif
             if (near) atomicAdd(s_small, near);
         }
         if constexpr (kCompact && !kFused) { if (tid == 0) table2[nseq] = make_uint2(0u, U & 0xffffu); }      // sentinel: where the last record's match ends

@@ -1,6 +1,6 @@
 # d10: D3 — wavefronts whose batch lies more than N batches behind the completed ones sleep between polls (-DCJ_D3_FAR=N -DCJ_D3_FAR_SLEEP=k)
 cd $GRAFT_REPO_ROOT
-for v in ${VARIANTS:-product far1 far2 far3s1 far1s4}; do
+for v in ${VARIANTS:-front32 front8 front32p1}; do
   export CJ_HIP_LIB=$GRAFT_REPO_ROOT/cramjam_amd/variants/libcramjam_hip_$v.so
   [ "$v" = "product" ] && unset CJ_HIP_LIB
   [ "$v" != "product" ] && echo "$v: $(timeout 900 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | tail -1)"

@@ -1,4 +1,5 @@
-// cj_enc2.hpp — the round-based LZ77 matcher of the LZ4-block and Snappy-raw encoders (gfx950, one wavefront per chunk).
+// cj_enc2.hpp — the round-based LZ77 matcher of the LZ4-block and Snappy-raw encoders (gfx950; one workgroup of two wavefronts per chunk,
+// one wavefront per sub-piece of a split large buffer).
 //
 // What a round does (tests/hostsim/enc2_model.c states the same thing as scalar C; the kernels emit exactly its bytes):
 //   probe    kR consecutive positions — lane l owns the FOUR CONSECUTIVE positions 4 l .. 4 l + 3 of every group of 256, so two
@@ -10,9 +11,10 @@
 //   extend   ONE pass over the compacted heads measures every candidate forwards (32 bytes per lane and round trip; the last few
 //            long ones of a window by sixteen lanes each, 256 bytes per round trip) and backwards (16 bytes) — the previous
 //            matcher ran this code once per 64 positions with a lane or two active.
-//   select   greedy walk over the heads in position order: the first head whose interval still has four bytes past the end of the
-//            previous match wins (a head the previous match ran over still offers its tail).  The chain carries `cur` only:
-//            v_cmp + s_ff1 + v_readlane + v_writelane per selected match; starts, lengths and sizes follow lane-parallel.
+//   select   greedy, in position order: the first head whose interval still has four bytes past the end of the previous match wins
+//            (a head the previous match ran over still offers its tail).  The rule has one solution, so it is ITERATED in parallel —
+//            every head re-decided against the prefix maximum of the selected ends (DPP scan) until the mask reproduces itself —
+//            instead of walked; a window that has not settled after kSelPasses takes the serial walk (`cur` through SGPRs).
 //   queue    selected sequences are appended to a 64-entry queue in LDS and emitted lane-parallel when it is full — one emission
 //            pass per ~64 sequences instead of one per round.
 //   insert   positions that are not strictly inside an emitted match (its last kTail positions count as outside) enter the table:

@@ -1,7 +1,7 @@
 # e31: long matches finished by four groups of sixteen lanes (256 bytes per head and round trip) instead of the whole wavefront head by head;
 # lane trips before that 8 / 4 / 2
 cd $GRAFT_REPO_ROOT
-for V in ${VARIANTS:-ga4 ga8 ga12 ga16}; do
+for V in ${VARIANTS:-product}; do
   [ $V = product ] && unset CJ_HIP_LIB || export CJ_HIP_LIB=$PWD/cramjam_amd/variants/libcramjam_hip_$V.so
   echo "== $V: $(timeout 900 python -m pytest tests/test_enc2_gpu.py -x -q 2>&1 | tail -1)  $(N=1500 timeout 600 python tests/perf/fuzz_enc2.py 2>&1 | tail -1)"
   for F in alice29.txt mr kppkn.gtb geo.protodata xml html_x_4; do

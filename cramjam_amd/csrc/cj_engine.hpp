@@ -88,7 +88,9 @@ struct cj_engine {
     std::mutex scratch_mu;         // LZ4 parse->decode scratch (sync points, per-chunk meta), reused across calls
     cj::DevBuf d_sync, d_pmeta, d_lanelist;   // d_lanelist: word [2] = the workgroup decoder's chunk counter
     hipEvent_t scratch_free = nullptr;    // recorded after the last kernel that reads the scratch
-    cj::PinnedBuf h_in, h_out;
+    cj::PinnedBuf h_in, h_out, h_res;   // h_res: the results of a sliced host batch (engine.hip: batch_host_sliced)
+    hipStream_t stream_back = nullptr;  // ... its copies back to the host (the engine's stream keeps uploading and decoding the next slice)
+    std::vector<hipEvent_t> slice_ev;
     std::vector<uint64_t> h_meta;
     cj::DevBuf d_frame;            // frame.hip: assembled / staged framed stream
     cj::DevBuf d_tab;              // LDS decoder variant 2: per-workgroup record tables

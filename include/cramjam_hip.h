@@ -202,7 +202,8 @@ CJ_API int cj_engine_sync(cj_engine* e);
 CJ_API int cj_stream_sync(cj_engine* e, void* hip_stream);
 
 /* Host batch: host pointers; the engine packs inputs into pinned staging, copies H2D, runs the
- * kernels, copies D2H and scatters.  Synchronous. result[i] as above. */
+ * kernels, copies D2H and scatters — a batch of 128 MiB and more in slices of ~64 MiB, so that those
+ * steps overlap (same results as one pass).  Synchronous. result[i] as above. */
 CJ_API int cj_batch_host(cj_engine* e, cj_codec codec, cj_op op, uint32_t flags, size_t n_chunks,
                   const uint8_t* const* in_ptrs, const size_t* in_lens,
                   uint8_t* const* out_ptrs, const size_t* out_caps, int64_t* result);

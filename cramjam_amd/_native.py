@@ -151,17 +151,11 @@ class Engine:
         return ms
 
     def batch_host(self, codec, op, flags, inputs, out_caps):
-        """inputs: list of bytes-like; out_caps: list of capacities.  Returns (results, outputs)."""
-        import numpy as np
-        n = len(inputs)
-        ins = [np.frombuffer(bytes(b), dtype=np.uint8) if not isinstance(b, np.ndarray) else np.ascontiguousarray(b).view(np.uint8).ravel()
-               for b in inputs]
-        outs = [np.zeros(max(int(c), 1), dtype=np.uint8) for c in out_caps]
-        in_ptrs = (_vp * n)(*[a.ctypes.data if a.size else None for a in ins])
-        in_lens = (_sz * n)(*[a.size for a in ins])
-        out_ptrs = (_vp * n)(*[a.ctypes.data for a in outs])
-        caps = (_sz * n)(*[int(c) for c in out_caps])
-        res = (_i64 * n)()
-        check(lib().cj_batch_host(self.h, codec, op, flags, n, in_ptrs, in_lens, out_ptrs, caps, res))
-        results = list(res)
-        return results, [outs[i][:max(results[i], 0)].tobytes() for i in range(n)]
+        """inputs: list of bytes-like (anything with the buffer protocol: borrowed, not copied); out_caps: list of capacities.
+        Returns (results, outputs): results[i] = bytes produced or a negative CJ_E_* code, outputs[i] = bytes."""
+        from . import _cramjam                      # the CPython host layer: the engine scatters straight into the bytes objects
+        try:
+            return _cramjam.batch_host(self.h.value or 0, int(codec), int(op), int(flags), inputs, out_caps)
+        except RuntimeError as ex:                  # (a CJ_E_* return code of the call itself, not of a chunk)
+            raise EngineError(str(ex)) from None
+

@@ -159,3 +159,12 @@ class Engine:
         except RuntimeError as ex:                  # (a CJ_E_* return code of the call itself, not of a chunk)
             raise EngineError(str(ex)) from None
 
+    def batch_host_into(self, codec, op, flags, inputs, out_caps, out, offsets=None):
+        """the same batch into ONE writable buffer (bytearray, numpy array, ...): chunk i at out[offsets[i] : offsets[i] + out_caps[i]],
+        back to back when offsets is None.  Returns results."""
+        from . import _cramjam
+        try:
+            return _cramjam.batch_host_into(self.h.value or 0, int(codec), int(op), int(flags), inputs, out_caps, out, offsets)
+        except RuntimeError as ex:
+            raise EngineError(str(ex)) from None
+

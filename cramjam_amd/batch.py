@@ -13,7 +13,34 @@ def _engine(device):
     return _engines[device]
 
 
-def _run(codec, op, flags, inputs, out_caps, devices):
+def _run_into(codec, op, flags, inputs, out_caps, devices, out):
+    """results + memoryviews into `out` (one writable buffer, chunk i behind chunk i - 1's capacity): no object per output byte"""
+    devices = list(devices) if devices is not None else [0]
+    n = len(inputs)
+    offsets, run = [], 0
+    for c in out_caps:
+        offsets.append(run); run += int(c)
+    mv = memoryview(out).cast("B")
+    if len(devices) == 1:
+        res = _engine(devices[0]).batch_host_into(codec, op, flags, inputs, out_caps, out, offsets)
+    else:
+        shards = [list(range(g, n, len(devices))) for g in range(len(devices))]
+
+        def work(g):
+            idx = shards[g]
+            return _engine(devices[g]).batch_host_into(codec, op, flags, [inputs[i] for i in idx], [out_caps[i] for i in idx], out, [offsets[i] for i in idx])
+        with ThreadPoolExecutor(len(devices)) as ex:
+            parts = list(ex.map(work, range(len(devices))))
+        res = [None] * n
+        for g, r in enumerate(parts):
+            for k, i in enumerate(shards[g]):
+                res[i] = r[k]
+    return res, [mv[offsets[i]:offsets[i] + max(res[i], 0)] for i in range(n)]
+
+
+def _run(codec, op, flags, inputs, out_caps, devices, out=None):
+    if out is not None:
+        return _run_into(codec, op, flags, inputs, out_caps, devices, out)
     devices = list(devices) if devices is not None else [0]
     n = len(inputs)
     if len(devices) == 1:
@@ -32,31 +59,34 @@ def _run(codec, op, flags, inputs, out_caps, devices):
     return res, outs
 
 
-def lz4_decompress_blocks(blocks, output_lens, store_size=False, devices=None):
-    """decode many LZ4 blocks; returns (results, outputs) with results[i] = length or a negative CJ_E_* code"""
-    return _run(N.CODEC_LZ4_BLOCK, N.OP_DECOMPRESS, N.FLAG_LZ4_SIZE_PREFIX if store_size else 0, blocks, output_lens, devices)
+def lz4_decompress_blocks(blocks, output_lens, store_size=False, devices=None, out=None):
+    """decode many LZ4 blocks; returns (results, outputs) with results[i] = length or a negative CJ_E_* code.
+    out: ONE writable buffer (bytearray, numpy array) of at least sum(output_lens) bytes — the outputs are then memoryviews into it
+    (chunk i behind chunk i - 1's capacity) instead of new `bytes` objects: the C-ABI's host rate without an allocation per chunk."""
+    return _run(N.CODEC_LZ4_BLOCK, N.OP_DECOMPRESS, N.FLAG_LZ4_SIZE_PREFIX if store_size else 0, blocks, output_lens, devices, out)
 
 
-def lz4_compress_blocks(chunks, store_size=True, devices=None):
+def lz4_compress_blocks(chunks, store_size=True, devices=None, out=None):
+    """out: as in lz4_decompress_blocks; it has to hold sum(compress_block_bound(len(chunk))) bytes"""
     L = N.lib()
     caps = [L.cj_lz4_block_compress_bound(len(c), 1 if store_size else 0) for c in chunks]
-    return _run(N.CODEC_LZ4_BLOCK, N.OP_COMPRESS, N.FLAG_LZ4_SIZE_PREFIX if store_size else 0, chunks, caps, devices)
+    return _run(N.CODEC_LZ4_BLOCK, N.OP_COMPRESS, N.FLAG_LZ4_SIZE_PREFIX if store_size else 0, chunks, caps, devices, out)
 
 
-def snappy_decompress_raw_many(blocks, devices=None):
+def snappy_decompress_raw_many(blocks, devices=None, out=None):
     L = N.lib()
     import ctypes as C
     caps = []
     for b in blocks:
         b = bytes(b)
         caps.append(max(L.cj_snappy_raw_decompress_len(C.cast(C.c_char_p(b), C.c_void_p), len(b)), 0))
-    return _run(N.CODEC_SNAPPY_RAW, N.OP_DECOMPRESS, 0, blocks, caps, devices)
+    return _run(N.CODEC_SNAPPY_RAW, N.OP_DECOMPRESS, 0, blocks, caps, devices, out)
 
 
-def snappy_compress_raw_many(chunks, devices=None):
+def snappy_compress_raw_many(chunks, devices=None, out=None):
     L = N.lib()
     caps = [L.cj_snappy_raw_max_compress_len(len(c)) for c in chunks]
-    return _run(N.CODEC_SNAPPY_RAW, N.OP_COMPRESS, 0, chunks, caps, devices)
+    return _run(N.CODEC_SNAPPY_RAW, N.OP_COMPRESS, 0, chunks, caps, devices, out)
 
 
 # ---- device-resident batches: no host copy, no ctypes at the call site ---------------------------------------------------------

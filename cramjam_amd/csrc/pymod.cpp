@@ -1386,7 +1386,63 @@ PyObject* root_batch_host(PyObject*, PyObject* args) {
     return t;
 }
 
+// batch_host_into(engine_handle, codec, op, flags, inputs, out_caps, out, offsets=None) -> results: the same batch into ONE writable buffer
+// of the caller's (chunk i at out[offsets[i] : offsets[i] + out_caps[i]], back to back when offsets is None) — no object per output
+PyObject* root_batch_host_into(PyObject*, PyObject* args) {
+    unsigned long long handle; int codec, op; unsigned int flags; PyObject *inputs_o, *caps_o, *out_o, *offs_o = Py_None;
+    if (!PyArg_ParseTuple(args, "KiiIOOO|O", &handle, &codec, &op, &flags, &inputs_o, &caps_o, &out_o, &offs_o)) return nullptr;
+    Py_buffer ob;
+    if (PyObject_GetBuffer(out_o, &ob, PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS) != 0) return nullptr;
+    PyObject* inputs = PySequence_Fast(inputs_o, "inputs must be a sequence of bytes-like objects");
+    PyObject* caps = inputs ? PySequence_Fast(caps_o, "out_caps must be a sequence of integers") : nullptr;
+    PyObject* offs = (caps && offs_o != Py_None) ? PySequence_Fast(offs_o, "offsets must be a sequence of integers") : nullptr;
+    bool ok = inputs && caps && (offs_o == Py_None || offs);
+    const Py_ssize_t n = ok ? PySequence_Fast_GET_SIZE(inputs) : 0;
+    if (ok && (PySequence_Fast_GET_SIZE(caps) != n || (offs && PySequence_Fast_GET_SIZE(offs) != n))) { PyErr_SetString(PyExc_ValueError, "inputs, out_caps and offsets differ in length"); ok = false; }
+    std::vector<Py_buffer> views((size_t)n);
+    std::vector<const uint8_t*> in_ptrs((size_t)n);
+    std::vector<size_t> in_lens((size_t)n), out_caps((size_t)n);
+    std::vector<uint8_t*> out_ptrs((size_t)n);
+    std::vector<int64_t> res((size_t)n);
+    Py_ssize_t got = 0;
+    size_t run = 0;
+    for (Py_ssize_t i = 0; ok && i < n; i++) {
+        if (PyObject_GetBuffer(PySequence_Fast_GET_ITEM(inputs, i), &views[(size_t)i], PyBUF_CONTIG_RO) != 0) { ok = false; break; }
+        got = i + 1;
+        in_lens[(size_t)i] = (size_t)views[(size_t)i].len;
+        in_ptrs[(size_t)i] = views[(size_t)i].len ? (const uint8_t*)views[(size_t)i].buf : nullptr;
+        const size_t cap = PyLong_AsSize_t(PySequence_Fast_GET_ITEM(caps, i));
+        if (cap == (size_t)-1 && PyErr_Occurred()) { ok = false; break; }
+        size_t off = run;
+        if (offs) { off = PyLong_AsSize_t(PySequence_Fast_GET_ITEM(offs, i)); if (off == (size_t)-1 && PyErr_Occurred()) { ok = false; break; } }
+        if (off > (size_t)ob.len || cap > (size_t)ob.len - off) { PyErr_SetString(PyExc_ValueError, "out is too small for the capacities given"); ok = false; break; }
+        out_caps[(size_t)i] = cap;
+        out_ptrs[(size_t)i] = (uint8_t*)ob.buf + off;
+        run = off + cap;
+    }
+    int rc = 0;
+    if (ok && n > 0) {
+        Py_BEGIN_ALLOW_THREADS
+        rc = cj_batch_host((cj_engine*)(uintptr_t)handle, (cj_codec)codec, (cj_op)op, flags, (size_t)n, in_ptrs.data(), in_lens.data(), out_ptrs.data(), out_caps.data(), res.data());
+        Py_END_ALLOW_THREADS
+    }
+    for (Py_ssize_t i = 0; i < got; i++) PyBuffer_Release(&views[(size_t)i]);
+    PyBuffer_Release(&ob);
+    Py_XDECREF(inputs); Py_XDECREF(caps); Py_XDECREF(offs);
+    if (ok && rc != 0) { PyErr_Format(PyExc_RuntimeError, "cramjam_hip error %d: %s (%s)", rc, cj_strerror(rc), cj_last_hip_error()); ok = false; }
+    if (!ok) return nullptr;
+    PyObject* results = PyList_New(n);
+    if (!results) return nullptr;
+    for (Py_ssize_t i = 0; i < n; i++) {
+        PyObject* r = PyLong_FromLongLong((long long)res[(size_t)i]);
+        if (!r) { Py_DECREF(results); return nullptr; }
+        PyList_SET_ITEM(results, i, r);
+    }
+    return results;
+}
+
 PyMethodDef root_methods[] = {
+    {"batch_host_into", (PyCFunction)Guarded<root_batch_host_into>::call, METH_VARARGS, "batch_host_into(engine_handle, codec, op, flags, inputs, out_caps, out, offsets=None) -> results"},
     {"batch_host", (PyCFunction)Guarded<root_batch_host>::call, METH_VARARGS, "batch_host(engine_handle, codec, op, flags, inputs, out_caps) -> (results, outputs)"},
     {nullptr, nullptr, 0, nullptr}};
 

@@ -23,3 +23,11 @@ for rep in range(3):
     dt = time.perf_counter() - t0
     assert oracle.lz4_decompress_raw(bytes(outs[7]), 65536)[1] == raws[7]
     print("batch.lz4_compress_blocks, %d x 64 KiB: %.1f ms -> %.2f GB/s uncompressed" % (n, dt * 1e3, n * 65536 / dt / 1e9), flush=True)
+import numpy as np
+out = np.empty(n * 65536, np.uint8)
+for rep in range(3):
+    t0 = time.perf_counter()
+    res, outs = batch.lz4_decompress_blocks(ins, lens, out=out)
+    dt = time.perf_counter() - t0
+    assert res[7] == 65536 and bytes(outs[7]) == raws[7]
+    print("batch.lz4_decompress_blocks(out=one buffer), %d x 64 KiB: %.1f ms -> %.2f GB/s uncompressed" % (n, dt * 1e3, n * 65536 / dt / 1e9), flush=True)

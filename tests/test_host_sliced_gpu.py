@@ -72,3 +72,41 @@ def test_sliced_host_batch_compress(codec):
     for i in range(0, n, 131):
         if res[i] > 0: assert dec(outs[i], len(ins[i])) == (len(ins[i]), ins[i])
     eng.close()
+
+
+@pytest.mark.parametrize("codec", [N.CODEC_LZ4_BLOCK, N.CODEC_SNAPPY_RAW])
+def test_batch_into_one_output_buffer(codec):
+    """cramjam_amd.batch.*(out=...): the outputs land back to back in ONE caller buffer, results and bytes as with bytes objects"""
+    from cramjam_amd import batch
+    raws, comp = _streams(codec)
+    rnd = random.Random(3)
+    pick = [rnd.randrange(len(raws)) for _ in range(700)]
+    ins = [comp[k] for k in pick]
+    lens = [len(raws[k]) for k in pick]
+    ins[5] = ins[5][:-3] if len(ins[5]) > 3 else ins[5]            # a damaged stream in the middle
+    if codec == N.CODEC_LZ4_BLOCK:
+        res0, outs0 = batch.lz4_decompress_blocks(ins, lens)
+        out = bytearray(sum(lens))
+        res1, outs1 = batch.lz4_decompress_blocks(ins, lens, out=out)
+    else:
+        res0, outs0 = batch.snappy_decompress_raw_many(ins)
+        out = np.zeros(sum(max(len(o), 1) for o in raws) * 20, np.uint8)      # (more than enough; capacities come from the preambles)
+        res1, outs1 = batch.snappy_decompress_raw_many(ins, out=out)
+    assert res0 == res1
+    assert all(bytes(a) == b for a, b in zip(outs1, outs0))
+    assert isinstance(outs1[0], memoryview)
+    # compress into one buffer, decode the views again
+    chunks = [raws[k] for k in pick[:300]]
+    if codec == N.CODEC_LZ4_BLOCK:
+        L = N.lib()
+        buf = bytearray(sum(L.cj_lz4_block_compress_bound(len(c), 0) for c in chunks))
+        r, views = batch.lz4_compress_blocks(chunks, store_size=False, out=buf)
+        back = [oracle.lz4_decompress_raw(bytes(v), len(c))[1] for v, c in zip(views, chunks)]
+    else:
+        L = N.lib()
+        buf = bytearray(sum(L.cj_snappy_raw_max_compress_len(len(c)) for c in chunks))
+        r, views = batch.snappy_compress_raw_many(chunks, out=buf)
+        back = [oracle.snappy_decompress(bytes(v))[1] for v in views]
+    assert back == chunks
+    with pytest.raises(ValueError):
+        batch.lz4_decompress_blocks(ins[:4], lens[:4], out=bytearray(10)) if codec == N.CODEC_LZ4_BLOCK else batch.snappy_compress_raw_many(chunks[:4], out=bytearray(10))

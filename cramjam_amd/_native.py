@@ -96,6 +96,12 @@ def check(rc):
         raise EngineError("%s (%s)" % (strerror(rc), lib().cj_last_hip_error().decode()))
 
 
+def _batch_host_addr():
+    """address of cj_batch_host in the library the engines of this process come from (CJ_HIP_LIB may name a tuning variant; the
+    CPython module links the product library)"""
+    return C.cast(lib().cj_batch_host, C.c_void_p).value
+
+
 class Engine:
     """One engine per GPU (cj_engine).  Thin: device memory + batch submission."""
 
@@ -155,7 +161,7 @@ class Engine:
         Returns (results, outputs): results[i] = bytes produced or a negative CJ_E_* code, outputs[i] = bytes."""
         from . import _cramjam                      # the CPython host layer: the engine scatters straight into the bytes objects
         try:
-            return _cramjam.batch_host(self.h.value or 0, int(codec), int(op), int(flags), inputs, out_caps)
+            return _cramjam.batch_host(self.h.value or 0, int(codec), int(op), int(flags), inputs, out_caps, _batch_host_addr())
         except RuntimeError as ex:                  # (a CJ_E_* return code of the call itself, not of a chunk)
             raise EngineError(str(ex)) from None
 
@@ -164,7 +170,7 @@ class Engine:
         back to back when offsets is None.  Returns results."""
         from . import _cramjam
         try:
-            return _cramjam.batch_host_into(self.h.value or 0, int(codec), int(op), int(flags), inputs, out_caps, out, offsets)
+            return _cramjam.batch_host_into(self.h.value or 0, int(codec), int(op), int(flags), inputs, out_caps, out, offsets, _batch_host_addr())
         except RuntimeError as ex:
             raise EngineError(str(ex)) from None
 

@@ -1324,9 +1324,12 @@ PyMethodDef snappy_methods[] = {
 // (src/lz4.rs:78-131, src/snappy.rs:52-78); this is the same borrowing (buffer protocol, no copy of the inputs) for a list of
 // them, and the outputs are `bytes` objects the engine scatters INTO — the ctypes marshalling this replaces copied every
 // input and every output once more and spent 130 ms of a 160 ms call on 16 384 chunks in Python objects.
+typedef int (*batch_host_fn)(cj_engine*, cj_codec, cj_op, uint32_t, size_t, const uint8_t* const*, const size_t*, uint8_t* const*, const size_t*, int64_t*);
 PyObject* root_batch_host(PyObject*, PyObject* args) {
-    unsigned long long handle; int codec, op; unsigned int flags; PyObject *inputs_o, *caps_o;
-    if (!PyArg_ParseTuple(args, "KiiIOO", &handle, &codec, &op, &flags, &inputs_o, &caps_o)) return nullptr;
+    unsigned long long handle, fn_addr = 0; int codec, op; unsigned int flags; PyObject *inputs_o, *caps_o;
+    if (!PyArg_ParseTuple(args, "KiiIOO|K", &handle, &codec, &op, &flags, &inputs_o, &caps_o, &fn_addr)) return nullptr;
+    // (fn_addr: cj_batch_host of the library the engine handle came from — a tuning variant loaded through CJ_HIP_LIB; 0 = the one this module links)
+    const batch_host_fn call = fn_addr ? (batch_host_fn)(uintptr_t)fn_addr : &cj_batch_host;
     PyObject* inputs = PySequence_Fast(inputs_o, "inputs must be a sequence of bytes-like objects");
     if (!inputs) return nullptr;
     PyObject* caps = PySequence_Fast(caps_o, "out_caps must be a sequence of integers");
@@ -1357,7 +1360,7 @@ PyObject* root_batch_host(PyObject*, PyObject* args) {
     int rc = 0;
     if (ok && n > 0) {
         Py_BEGIN_ALLOW_THREADS
-        rc = cj_batch_host((cj_engine*)(uintptr_t)handle, (cj_codec)codec, (cj_op)op, flags, (size_t)n, in_ptrs.data(), in_lens.data(), out_ptrs.data(), out_caps.data(), res.data());
+        rc = call((cj_engine*)(uintptr_t)handle, (cj_codec)codec, (cj_op)op, flags, (size_t)n, in_ptrs.data(), in_lens.data(), out_ptrs.data(), out_caps.data(), res.data());
         Py_END_ALLOW_THREADS
     }
     for (Py_ssize_t i = 0; i < got; i++) PyBuffer_Release(&views[(size_t)i]);
@@ -1389,8 +1392,9 @@ PyObject* root_batch_host(PyObject*, PyObject* args) {
 // batch_host_into(engine_handle, codec, op, flags, inputs, out_caps, out, offsets=None) -> results: the same batch into ONE writable buffer
 // of the caller's (chunk i at out[offsets[i] : offsets[i] + out_caps[i]], back to back when offsets is None) — no object per output
 PyObject* root_batch_host_into(PyObject*, PyObject* args) {
-    unsigned long long handle; int codec, op; unsigned int flags; PyObject *inputs_o, *caps_o, *out_o, *offs_o = Py_None;
-    if (!PyArg_ParseTuple(args, "KiiIOOO|O", &handle, &codec, &op, &flags, &inputs_o, &caps_o, &out_o, &offs_o)) return nullptr;
+    unsigned long long handle, fn_addr = 0; int codec, op; unsigned int flags; PyObject *inputs_o, *caps_o, *out_o, *offs_o = Py_None;
+    if (!PyArg_ParseTuple(args, "KiiIOOO|OK", &handle, &codec, &op, &flags, &inputs_o, &caps_o, &out_o, &offs_o, &fn_addr)) return nullptr;
+    const batch_host_fn call = fn_addr ? (batch_host_fn)(uintptr_t)fn_addr : &cj_batch_host;
     Py_buffer ob;
     if (PyObject_GetBuffer(out_o, &ob, PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS) != 0) return nullptr;
     PyObject* inputs = PySequence_Fast(inputs_o, "inputs must be a sequence of bytes-like objects");
@@ -1423,7 +1427,7 @@ PyObject* root_batch_host_into(PyObject*, PyObject* args) {
     int rc = 0;
     if (ok && n > 0) {
         Py_BEGIN_ALLOW_THREADS
-        rc = cj_batch_host((cj_engine*)(uintptr_t)handle, (cj_codec)codec, (cj_op)op, flags, (size_t)n, in_ptrs.data(), in_lens.data(), out_ptrs.data(), out_caps.data(), res.data());
+        rc = call((cj_engine*)(uintptr_t)handle, (cj_codec)codec, (cj_op)op, flags, (size_t)n, in_ptrs.data(), in_lens.data(), out_ptrs.data(), out_caps.data(), res.data());
         Py_END_ALLOW_THREADS
     }
     for (Py_ssize_t i = 0; i < got; i++) PyBuffer_Release(&views[(size_t)i]);

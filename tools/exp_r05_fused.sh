@@ -1,6 +1,6 @@
 # f-series: the in-kernel parse of the fused kernel (batches up to 16 384 chunks)
 cd $GRAFT_REPO_ROOT
-for v in ${VARIANTS:-product p2pp product p2pp}; do
+for v in ${VARIANTS:-product carry product carry}; do
   export CJ_HIP_LIB=$GRAFT_REPO_ROOT/cramjam_amd/variants/libcramjam_hip_$v.so
   [ "$v" = "product" ] && unset CJ_HIP_LIB
   [ "$v" != "product" ] && echo "$v: $(timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_corpus_gpu.py -x -q 2>&1 | tail -1)"

@@ -508,6 +508,7 @@ __device__ __forceinline__ bool fused_parse(uint32_t a_in, uint32_t iend, uint32
     uint32_t* s_tot = aux + 2u * kFusedLanes;            // [0..8): per-wave counts, [8..16): per-wave bytes, [16..24): verdict words
     const uint32_t a_bits = (uint32_t)(uintptr_t)bits;
     const auto rd = [a_in](uint32_t q) { return lds_ld32a(a_in + q); };
+    const auto rd8 = [a_in](uint32_t q) { return lds_ld64a(a_in + q); };
     const bool plane = tid < kFusedLanes;                  // the parse lanes (wavefronts 0-3); everyone takes the barriers
 
     uint32_t nl = (iend + 63u) / 64u;
@@ -519,12 +520,13 @@ __device__ __forceinline__ bool fused_parse(uint32_t a_in, uint32_t iend, uint32
 
     // ---- P1a ----
     uint32_t p = active ? tid * seg : kPosEnd;
+    WalkCarry wc = {0u, 0xFFFFFFFFu};                     // (the walks carry the next element's first bytes: one dependent read per element)
     if (plane) {
         while (ballot64(p < seg_end && p < iend) != 0ull) {
             if (p < seg_end && p < iend) {
                 asm volatile("ds_or_b32 %0, %1" :: "v"(a_bits + 4u * (p >> 5)), "v"(1u << (p & 31u)) : "memory");
                 Seq sq;
-                p = walk_step<G>(rd, p, iend, sq) ? sq.next : kPosErr;
+                p = walk_step_carry<G>(rd, rd8, p, iend, sq, wc, true) ? sq.next : kPosErr;
             }
         }
     }
@@ -535,12 +537,15 @@ __device__ __forceinline__ bool fused_parse(uint32_t a_in, uint32_t iend, uint32
         bool going = active && p < iend;
         while (ballot64(going) != 0ull) {
             if (going) {
+                // the mark word and the element travel together (the step is thrown away where the position is marked)
                 uint32_t w;
-                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(a_bits + 4u * (p >> 5)) : "memory");
+                asm volatile("ds_read_b32 %0, %1" : "=v"(w) : "v"(a_bits + 4u * (p >> 5)) : "memory");
+                Seq sq;
+                const uint32_t nx = walk_step_carry<G>(rd, rd8, p, iend, sq, wc, true) ? sq.next : kPosErr;
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w) :: "memory");
                 if ((w >> (p & 31u)) & 1u) { merge_pos = p; going = false; }
                 else {
-                    Seq sq;
-                    p = walk_step<G>(rd, p, iend, sq) ? sq.next : kPosErr;
+                    p = nx;
                     if (p >= iend) { merge_pos = p; going = false; }
                 }
             }
@@ -578,10 +583,11 @@ __device__ __forceinline__ bool fused_parse(uint32_t a_in, uint32_t iend, uint32
     uint32_t cnt = 0, outb = 0;
     if (plane) {
         uint32_t q = on_chain ? entry : kPosEnd;
+        WalkCarry c3 = {0u, 0xFFFFFFFFu};
         while (ballot64(q < iend && q != piece_end) != 0ull) {
             if (q < iend && q != piece_end) {
                 Seq sq;
-                if (walk_step<G>(rd, q, iend, sq)) { cnt += 1; outb += sq.lit + sq.mlen; q = sq.next; }
+                if (walk_step_carry<G>(rd, rd8, q, iend, sq, c3, true)) { cnt += 1; outb += sq.lit + sq.mlen; q = sq.next; }
                 else q = kPosErr;
             }
         }
@@ -607,12 +613,13 @@ __device__ __forceinline__ bool fused_parse(uint32_t a_in, uint32_t iend, uint32
         bool bad = false, saw_last = false;
         uint32_t final_op = 0, near = 0;
         uint32_t q = on_chain ? entry : kPosEnd, idx = base_idx, op = base_op;
+        WalkCarry c4 = {0u, 0xFFFFFFFFu};
         while (ballot64(q < iend && q != piece_end && !bad) != 0ull) {
             if (q < iend && q != piece_end && !bad) {
                 Seq sq;
                 bool fin = false;
                 uint32_t op2 = op;
-                if (!walk_step<G>(rd, q, iend, sq) || !G::check(sq, op2, cap, fin) || idx >= total_seq) bad = true;
+                if (!walk_step_carry<G>(rd, rd8, q, iend, sq, c4, true) || !G::check(sq, op2, cap, fin) || idx >= total_seq) bad = true;
                 else {
                     const uint32_t w = sq.mlen == 0u ? 0u : ((sq.offset & 0xffffu) | (sq.mlen << 16));       // (a Snappy stream may END with a copy)
                     table2[idx] = make_uint2(sq.lit_at | (sq.lit << 16), (op & 0xffffu) | (w << 16));      // 8-byte record (lds2_body)

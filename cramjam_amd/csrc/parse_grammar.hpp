@@ -231,6 +231,51 @@ __device__ __forceinline__ bool walk_step(const Rd& rd, uint32_t ip, uint32_t ie
         return ok;
     }
 }
+
+// The same step with ONE dependent read per Snappy record where the stream allows it: the copy element behind a literal is read as
+// 8 bytes, and the first 4 bytes of the NEXT record come with it (its tag sits 2 or 3 bytes behind a copy-1 / copy-2 tag) — carried
+// to the next call in `c`.  A wavefront whose lanes all carry their element
+// skips the first read altogether.  rd8(p) = the 8 bytes at p.  (The fused parse walks every piece three times, a wavefront at the
+// pace of its slowest lane: 129 k of the fused kernel's 201 k cycles per chunk were these walks, r05 f02.)
+struct WalkCarry { uint32_t t4, at; };          // the 4 bytes at position `at` (0xFFFFFFFF: nothing carried)
+template <class G, class Rd, class Rd8>
+__device__ __forceinline__ bool walk_step_carry(const Rd& rd, const Rd8& rd8, uint32_t ip, uint32_t iend, Seq& s, WalkCarry& c, bool on) {
+    if constexpr (std::is_same<G, Lz4Grammar>::value) {
+        // (LZ4: the two 4-byte reads of walk_step stay — with the offset field as a misaligned 8-byte read and the first read under a
+        //  branch the fused kernel lost 4 %, 379 -> 363 GB/s on 8 192 chunks: these walks are bound by the LDS pipe's misaligned accesses,
+        //  not by its latency)
+        (void)rd8; (void)c; (void)on;
+        return walk_step<G>(rd, ip, iend, s);
+    } else {
+        const bool have = c.at == ip;
+        uint32_t t4 = c.t4;
+        if (ballot64(on && !have) != 0ull) { if (!have) t4 = rd(ip); }
+        c.at = 0xFFFFFFFFu;
+        const uint32_t tag = t4 & 0xffu, l6 = tag >> 2;
+        const bool is_lit = (tag & 3u) == 0u;
+        const uint32_t lhdr = is_lit ? (l6 == 60u ? 2u : 1u) : 0u;
+        const uint32_t lit = is_lit ? (l6 == 60u ? ((t4 >> 8) & 0xffu) + 1u : l6 + 1u) : 0u;
+        const uint32_t ip2 = ip + lhdr + lit;
+        const bool in2 = ip2 + 4u <= iend && ip2 >= ip;
+        uint2 c8 = make_uint2(t4, 0u);
+        if (ballot64(on && is_lit) != 0ull) { if (is_lit) c8 = rd8(in2 ? ip2 : ip); }
+        const uint32_t c4 = c8.x;
+        const uint32_t ctag = c4 & 0xffu, kind = ctag & 3u;
+        const uint32_t clen = kind == 1u ? 4u + ((ctag >> 2) & 7u) : 1u + (ctag >> 2);
+        const uint32_t off = kind == 1u ? ((ctag >> 5) << 8) | ((c4 >> 8) & 0xffu) : (c4 >> 8) & 0xffffu;
+        const uint32_t ip3 = kind == 0u ? ip2 : ip2 + (kind == 1u ? 2u : 3u);
+        const bool fast = !(is_lit && l6 > 60u) && in2 && kind != 3u && ip3 < iend && (kind != 0u || is_lit);
+        bool ok = true;
+        if (fast) {
+            s.lit = lit; s.lit_at = ip + lhdr; s.last = false; s.next = ip3;
+            s.mlen = kind == 0u ? 0u : clen; s.offset = kind == 0u ? 0u : off;
+            // the element behind a copy that followed a literal came with the 8 bytes; behind a literal alone the 4 bytes at ip2 ARE the next element
+            if (is_lit) { c.t4 = kind == 0u ? c4 : __builtin_amdgcn_alignbyte(c8.y, c8.x, kind == 1u ? 2u : 3u); c.at = ip3; }
+        }
+        if (ballot64(on && !fast) != 0ull) { if (!fast) ok = G::at(rd, ip, iend, s, nullptr); }
+        return ok;
+    }
+}
 #endif
 
 }  // namespace cj

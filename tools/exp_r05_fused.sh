@@ -3,8 +3,8 @@ cd $GRAFT_REPO_ROOT
 for v in ${VARIANTS:-product carry product carry}; do
   export CJ_HIP_LIB=$GRAFT_REPO_ROOT/cramjam_amd/variants/libcramjam_hip_$v.so
   [ "$v" = "product" ] && unset CJ_HIP_LIB
-  [ "$v" != "product" ] && echo "$v: $(timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_corpus_gpu.py -x -q 2>&1 | tail -1)"
-  for args in "--chunks 1024 --unique 1024" "--chunks 8192 --unique 2048" "--codec snappy --chunks 8192 --unique 2048" "--data corpus64k --chunks 8192"; do
+  [ "$v" != "product" ] && echo "$v: $(timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_corpus_gpu.py tests/test_frames_gpu.py -x -q 2>&1 | tail -1)"
+  for args in "--chunks 1024 --unique 1024" "--chunks 8192 --unique 2048" "--codec snappy --chunks 1024 --unique 1024" "--codec snappy --chunks 8192 --unique 2048" "--data corpus64k --chunks 8192" "--data corpus64k --codec snappy --chunks 8192"; do
   python bench.py $args --no-cpu-baseline --traffic off --steps 30 2>&1 | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('$v [$args]: %.1f GB/s %.3f ms' % (d['value'], d['ms_per_step']))"

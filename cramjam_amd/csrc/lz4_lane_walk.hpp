@@ -16,8 +16,11 @@ constexpr uint32_t kSyncPitch = 2048 + 16;      // distance (entries) between tw
                                               // (the 64 lanes of a parse wave would otherwise store into the same memory channel)
 constexpr uint32_t kSyncStride = 2048;    // sync points reserved per chunk (=> at most 16 384 sequences on the LDS path: a 64 KiB chunk of LZ4 has at most
                                           // 16 384; real text has ~10 000, which the 1 024 points of rounds 1-2 sent to the one-wavefront kernel)
-constexpr uint32_t kLdsOutMax = 65536;    // the LDS decoder holds at most this much output ...
-constexpr uint32_t kLdsInMax = 65504;     // ... and this much compressed input: variant 2 stages it in the 64 KiB output window (<= 15 B misalignment + 15 B round-up)
+#ifndef CJ_L2_WINDOW
+#define CJ_L2_WINDOW 65536                // (tuning variants only: a smaller window for experiments with more workgroups per CU)
+#endif
+constexpr uint32_t kLdsOutMax = CJ_L2_WINDOW;    // the LDS decoder holds at most this much output ...
+constexpr uint32_t kLdsInMax = CJ_L2_WINDOW - 32;     // ... and this much compressed input: variant 2 stages it in the 64 KiB output window (<= 15 B misalignment + 15 B round-up)
 
 struct ParseMeta {       // one per chunk, written by lz4_parse_kernel
     uint32_t nseq;       // sequences incl. the final literal-only one; 0 = nothing left for the LDS decoder

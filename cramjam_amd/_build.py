@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libcramjam_hip.so")
 SOURCES = ["engine.hip", "lz4_decode.hip", "lz4_decode_lanes.hip", "lz4_decode_lds.hip", "big_chunks.hip", "lz4_encode.hip", "snappy_decode.hip", "snappy_encode.hip", "frame_kernels.hip", "frame.hip", "large.hip", "big_parse.hip", "bench_util.hip"]
-HEADERS = ["lds_shared.hpp", "big_chunks.hpp", "cj_common.hpp", "cj_engine.hpp", "cj_match.hpp", "cj_enc2.hpp", "crc32c_lanes.hpp", "lane_stream.hpp", "snappy_records.hpp", "parse_grammar.hpp", "big_parse.hpp", "xxh32_host.hpp", "lz4_lane_walk.hpp", os.path.join("..", "..", "include", "cramjam_hip.h")]
+HEADERS = ["lds_shared.hpp", "big_chunks.hpp", "cj_common.hpp", "cj_engine.hpp", "cj_match.hpp", "cj_enc2.hpp", "crc32c_lanes.hpp", "lane_stream.hpp", "snappy_records.hpp", "parse_grammar.hpp", "big_parse.hpp", "xxh32_host.hpp", "lz4_lane_walk.hpp", os.path.join("..", "..", "include", "cramjam_hip.h"), os.path.join("..", "..", "include", "cramjam_hip_debug.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"] + os.environ.get("CJ_EXTRA_HIPCC_FLAGS", "").split()
 

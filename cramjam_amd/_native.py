@@ -12,6 +12,8 @@ FLAG_LZ4_SIZE_PREFIX = 1
 FLAG_FORCE_WAVE_PER_CHUNK = 0x100
 FLAG_FORCE_LANE_PER_CHUNK = 0x200
 FLAG_FORCE_LDS_PER_CHUNK = 0x400
+FLAG_FORCE_FUSED_PARSE = 0x10     # the workgroup decoder's parse stage inside the decoder kernel / as its own kernel, at any batch size
+FLAG_FORCE_PARSE_KERNEL = 0x20
 FLAG_BIG_CHUNKS = 0x800            # decompress: reserve record areas for chunks of 64 KiB .. 256 KiB (cramjam_hip.h)
 E_NO_DEVICE = -100
 
@@ -55,7 +57,7 @@ SYMBOLS = {
     "cj_memcpy_d2d": (_int, [_vp, _vp, _vp, _sz]),
     "cj_memset_dev": (_int, [_vp, _vp, _int, _sz]),
 }
-# benchmark/test utilities exported next to the engine (cramjam_amd/csrc/bench_util.hip); not part of the drop-in ABI
+# benchmark/test utilities exported next to the engine (include/cramjam_hip_debug.h); not part of the drop-in ABI
 BENCH_SYMBOLS = {
     "cj_bench_synth_v1": (_int, [_vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _vp]),
     "cj_debug_lds_phase_cycles": (_int, [_vp, _int]),
@@ -63,6 +65,7 @@ BENCH_SYMBOLS = {
     "cj_debug_forwarded_chunks": (C.c_longlong, [_int]),
     "cj_debug_big_parse": (C.c_int64, [_int, _u32, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
     "cj_bench_compare": (_int, [_vp, _vp, _vp, C.c_uint64, _u32, C.c_uint64, _u32, _vp, _vp]),
+    "cj_debug_big_scratch_bytes": (C.c_uint64, [_vp]),
 }
 
 _lib = None

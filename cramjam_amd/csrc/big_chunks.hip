@@ -364,13 +364,13 @@ __global__ __launch_bounds__(256) void big_sum_kernel(BatchArgs a, const uint32_
     else chunk_ok = chunk_ok && total <= cap;
     chunk_ok = chunk_ok && total > kLdsOutMax && nseq >= 1u;      // (a chunk that decodes to at most 64 KiB: the wavefront kernel — rare, and the slab walk below assumes two slabs)
 
-    // ---- the record that holds output byte 65536 * s: the live lane whose output range contains it searches its region ----
+    // ---- the record that holds output byte kBigSlabBytes * s: the live lane whose output range contains it searches its region ----
     BigMeta* bm = bigmeta + bi;
     uint32_t sf[kBigSlabs];                                      // slab s's first record, known to all 32 lanes of the chunk after the reduction
     sf[0] = 0u;
     for (uint32_t sb = 1; sb < kBigSlabs; sb++) {
         uint32_t mine = 0xFFFFFFFFu;
-        const uint32_t b = sb * 65536u;
+        const uint32_t b = sb * kBigSlabBytes;
         if (exists && chunk_ok && live && b < total && b >= opb && b < opb + r) {      // in this lane's part (r > 0 here)
             const uint32_t rel = b - opb;
             uint32_t lo = 0, hi = cnt;                             // largest idx in [0, cnt) with lit_start[idx] <= rel (idx 0 has lit_start 0)
@@ -391,12 +391,12 @@ __global__ __launch_bounds__(256) void big_sum_kernel(BatchArgs a, const uint32_
     // four output bytes, so a 64 KiB slab never has more — a Snappy stream may (copies and literals of one byte): such a chunk
     // stays with the wavefront kernel.
     for (uint32_t sb = 0; sb < kBigSlabs; sb++) {
-        if (sb * 65536u >= total) break;
-        const uint32_t r0 = sf[sb], r1 = (sb + 1u) * 65536u < total ? sf[sb + 1u] : nseq - 1u;
+        if (sb * kBigSlabBytes >= total) break;
+        const uint32_t r0 = sf[sb], r1 = (sb + 1u) * kBigSlabBytes < total ? sf[sb + 1u] : nseq - 1u;
         if (r0 == 0xFFFFFFFFu || r1 == 0xFFFFFFFFu || r1 < r0 || r1 - r0 + 1u > kBigSlabRecs) chunk_ok = false;
     }
     if (exists && chunk_ok && j == 0u)
-        for (uint32_t sb = 1; sb < kBigSlabs; sb++) if (sb * 65536u < total) bm->slab_first[sb] = sf[sb];
+        for (uint32_t sb = 1; sb < kBigSlabs; sb++) if (sb * kBigSlabBytes < total) bm->slab_first[sb] = sf[sb];
     if (exists) {
         if (chunk_ok) {
             bm->first[j] = first;
@@ -413,34 +413,45 @@ __global__ __launch_bounds__(256) void big_sum_kernel(BatchArgs a, const uint32_
     }
 }
 
-__global__ __launch_bounds__(256) void big_items_kernel(BatchArgs a, const uint32_t* list, uint32_t base_i, const BigMeta* bigmeta, uint32_t cap,
+__global__ __launch_bounds__(256) void big_items_kernel(BatchArgs a, const uint32_t* list, uint32_t base_i, const BigMeta* bigmeta, const uint4* recs, uint32_t cap,
                                                         uint64_t* rows, ParseMeta* item_meta, uint32_t* done) {
     const uint32_t w = blockIdx.x * 256u + threadIdx.x, items = kBigSlabs * cap;
     if (w >= items) return;
     const uint32_t bi = w % cap, sl = w / cap;
     const uint32_t listed = big_group_count(list, base_i, cap);
     uint64_t in_off = 0, in_len = 0, out_off = 0, out_cap = 0, res = 0;
-    uint32_t nrec = 0;
+    uint32_t nrec = 0, pf = 0;
     if (bi < listed) {
         const BigMeta* bm = bigmeta + bi;
         const uint32_t U = bm->U, nseq = bm->nseq;
-        if (nseq != 0u && sl * 65536u < U) {
+        if (nseq != 0u && sl * kBigSlabBytes < U) {
             const uint32_t c = bm->chunk;
-            const uint32_t R0 = bm->slab_first[sl], R1 = (sl + 1u) * 65536u < U ? bm->slab_first[sl + 1u] : nseq - 1u;
+            const uint32_t R0 = bm->slab_first[sl], R1 = (sl + 1u) * kBigSlabBytes < U ? bm->slab_first[sl + 1u] : nseq - 1u;
             nrec = R1 - R0 + 1u;
             in_off = a.in_off[c] + bm->in_skip; in_len = a.in_len[c] - bm->in_skip;
-            out_off = a.out_off[c] + (uint64_t)sl * 65536u; out_cap = (uint64_t)sl * 65536u;      // (out_cap = the slab's first output position in its chunk: what the slab mode calls the stream position)
-            res = U - sl * 65536u < 65536u ? U - sl * 65536u : 65536u;
+            out_off = a.out_off[c] + (uint64_t)sl * kBigSlabBytes; out_cap = (uint64_t)sl * kBigSlabBytes;      // (out_cap = the slab's first output position in its chunk: what the slab mode calls the stream position)
+            res = U - sl * kBigSlabBytes < kBigSlabBytes ? U - sl * kBigSlabBytes : kBigSlabBytes;
+            // the 128-byte lines (relative to the element stream) that hold the slab's literals: from its first record's literal source to
+            // the end of its last record's literals — the slab decoder touches them while it expands the records (kRecFeed)
+            const auto rec_at = [&](uint32_t gi) {
+                uint32_t t = 0;
+                for (uint32_t step = kBigLanes / 2u; step != 0u; step >>= 1) t += gi >= bm->first[t + step] ? step : 0u;
+                return recs[(size_t)bi * kBigRecPitch + gi + t * kBigRegion + (bm->opb[t] >> 28) - (t ? bm->first[t] : 0u)];
+            };
+            const uint4 ra = rec_at(R0), rb = rec_at(R1);
+            const uint32_t lo = (ra.x & 0x00ffffffu) >> 7, hi = ((rb.x & 0x00ffffffu) + rb.y + 127u) >> 7;
+            const uint32_t nl = hi > lo ? hi - lo + 1u : 1u;
+            pf = (lo & 0xfffu) | ((nl < 1023u ? nl : 1023u) << 12);
         }
     }
     rows[w] = in_off; rows[items + w] = in_len; rows[2 * (size_t)items + w] = out_off; rows[3 * (size_t)items + w] = out_cap; rows[4 * (size_t)items + w] = res;
-    item_meta[w] = ParseMeta{nrec, 0u};
+    item_meta[w] = ParseMeta{nrec, pf};
     done[w] = 0u;
 }
 
-void launch_big_items(const BatchArgs& a, const uint32_t* list, uint32_t base, const void* bigmeta, uint32_t cap, uint64_t* rows, void* item_meta, uint32_t* done, hipStream_t s) {
+void launch_big_items(const BatchArgs& a, const uint32_t* list, uint32_t base, const void* bigmeta, const void* recs, uint32_t cap, uint64_t* rows, void* item_meta, uint32_t* done, hipStream_t s) {
     if (cap == 0) return;
-    hipLaunchKernelGGL(big_items_kernel, dim3((kBigSlabs * cap + 255u) / 256u), dim3(256), 0, s, a, list, base, (const BigMeta*)bigmeta, cap, rows, (ParseMeta*)item_meta, done);
+    hipLaunchKernelGGL(big_items_kernel, dim3((kBigSlabs * cap + 255u) / 256u), dim3(256), 0, s, a, list, base, (const BigMeta*)bigmeta, (const uint4*)recs, cap, rows, (ParseMeta*)item_meta, done);
 }
 
 size_t big_recs_bytes(size_t cap) { return cap * (size_t)kBigRecPitch * sizeof(uint4); }

@@ -4,7 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "../../include/cramjam_hip.h"
+#include "../../include/cramjam_hip_debug.h"      // (the drop-in ABI + the test / benchmark exports)
 
 namespace cj {
 

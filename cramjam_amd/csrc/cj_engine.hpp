@@ -95,7 +95,11 @@ struct cj_engine {
     cj::DevBuf d_frame;            // frame.hip: assembled / staged framed stream
     cj::DevBuf d_tab;              // LDS decoder variant 2: per-workgroup record tables
     cj::DevBuf d_biglist, d_bigrecs, d_bigmisc, d_bigslabtab;   // chunks of 64 KiB .. 256 KiB in a device batch (big_chunks.hpp, CJ_FLAG_BIG_CHUNKS): record areas; list + summaries + slab items; the slab decoder's tables
-    uint32_t* h_count = nullptr;   // pinned word: the number of big chunks of a batch above kBigCap chunks (engine.hip launch_decode)
+    uint32_t* h_count = nullptr;   // pinned words: the number of big chunks of the last flagged batches, copied back without waiting (engine.hip plan_big)
+    hipEvent_t big_ev[8] = {};     // ... one event per slot (the copy has landed)
+    uint32_t big_obs[8] = {};      // ... the counts that have
+    int big_state[8] = {};         // 0 = empty, 1 = copy in flight, 2 = count known
+    int big_next = 0;
     cj::DevBuf d_big, d_bigtab;    // large.hip: parse scratch / record tables of one large stream (under `mu`)
     int n_cu = 0;
 };

@@ -52,7 +52,48 @@ int lds_scratch(cj_engine* e, const cj::BatchArgs& a, hipStream_t s, bool with_s
 //                      pass over the input (100 k chunks: 18 ms fused, 10.6 ms with the parse kernel)
 //   then               the wavefront-per-chunk kernel on what the parse left over (errors, chunks above 64 KiB, few long runs)
 //   flags              CJ_FLAG_FORCE_WAVE_PER_CHUNK / _LANE_PER_CHUNK: one mapping for every chunk (tests, comparisons)
-constexpr size_t kBigCap = 8192;          // big chunks (CJ_FLAG_BIG_CHUNKS) decoded per group: each holds a record area of 1 MiB while its group is in flight
+constexpr size_t kBigCap = 8192;
+constexpr int kBigObs = 8;                // counts of big chunks the engine remembers (cj_engine::big_obs)
+
+// CJ_FLAG_BIG_CHUNKS: which chunks lie in (64 KiB, 256 KiB] is known on the device only (big_list_kernel), but the record areas
+// (1 MiB per listed chunk), the number of groups and the slab decoder's tables are decided here.  The engine sizes them from what it
+// has SEEN: every flagged call copies its list's count to a pinned slot without waiting for it, and the next calls plan for the largest of
+// the last kBigObs counts that have arrived.  What a batch holds beyond the plan stays with the wavefront kernel (slower, never wrong)
+// and raises the plan of the calls behind it.  Only an engine that has not seen any count yet reads its first one back (the call
+// waits for the stream once, like every call that grows the engine's scratch); after that a flagged call only enqueues.
+int plan_big(cj_engine* e, cj_codec codec, const cj::BatchArgs& a, hipStream_t s, uint32_t** list_out, uint32_t* n_plan) {
+    *n_plan = 0; *list_out = nullptr;
+    const size_t big_list_bytes = ((4 + (size_t)a.n_chunks) * 4 + 255) & ~(size_t)255;
+    if (!e->d_biglist.reserve(big_list_bytes)) { (void)hipGetLastError(); return 0; }      // no room for the list: the chunks stay with the wavefront kernel
+    uint32_t* big_list = (uint32_t*)e->d_biglist.p;
+    if (!e->h_count) {
+        HIP_TRY(hipHostMalloc((void**)&e->h_count, 64, hipHostMallocDefault), CJ_E_OOM);
+        for (int i = 0; i < kBigObs; i++) HIP_TRY(hipEventCreateWithFlags(&e->big_ev[i], hipEventDisableTiming), CJ_E_NO_DEVICE);
+    }
+    cj::launch_big_list(a, codec, big_list, s);
+    // counts that have arrived since the last call
+    bool any = false;
+    uint32_t plan = 0;
+    for (int i = 0; i < kBigObs; i++) {
+        if (e->big_state[i] == 1 && hipEventQuery(e->big_ev[i]) == hipSuccess) { e->big_obs[i] = e->h_count[i]; e->big_state[i] = 2; }
+        if (e->big_state[i] == 2) { any = true; plan = std::max(plan, e->big_obs[i]); }
+    }
+    (void)hipGetLastError();                                  // (hipErrorNotReady from the queries)
+    const int slot = e->big_next;
+    e->big_next = (slot + 1) % kBigObs;
+    if (e->big_state[slot] == 1) HIP_TRY(hipEventSynchronize(e->big_ev[slot]), CJ_E_NO_DEVICE);   // (eight flagged calls in flight: the oldest copy must have landed before its slot is reused)
+    HIP_TRY(hipMemcpyAsync(e->h_count + slot, big_list, 4, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
+    HIP_TRY(hipEventRecord(e->big_ev[slot], s), CJ_E_NO_DEVICE);
+    e->big_state[slot] = 1;
+    if (!any) {                                                // an engine that has seen nothing yet: this batch's own count
+        HIP_TRY(hipStreamSynchronize(s), CJ_E_NO_DEVICE);
+        e->big_obs[slot] = e->h_count[slot]; e->big_state[slot] = 2;
+        plan = e->big_obs[slot];
+    }
+    *n_plan = (uint32_t)std::min<size_t>(plan, a.n_chunks);
+    *list_out = big_list;
+    return 0;
+}          // big chunks (CJ_FLAG_BIG_CHUNKS) decoded per group: each holds a record area of 1 MiB while its group is in flight
 
 int launch_decode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a, hipStream_t s) {
     const bool lz4 = codec == CJ_CODEC_LZ4_BLOCK;
@@ -62,30 +103,21 @@ int launch_decode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a, hipStrea
     if (a.flags & CJ_FLAG_FORCE_LDS_PER_CHUNK) mode = 2;
     if (mode == 0) { if (lz4) cj::launch_lz4_decode(a, s); else cj::launch_snappy_decode(a, s); return 0; }
     if (mode == 1) { if (lz4) cj::launch_lz4_decode_lanes(a, s); else cj::launch_snappy_decode_lanes(a, s); return 0; }
-    // the workgroup decoder (lz4_decode_lds.hip).  CJ_FUSED=0 / 1 forces the separate / in-kernel parse at any batch size (tests
-    // exercise both sides of the threshold with it)
-    static const int force_fused = [] { const char* v = std::getenv("CJ_FUSED"); return v ? std::atoi(v) : -1; }();
-    const bool fused = force_fused >= 0 ? force_fused != 0 : a.n_chunks <= (uint32_t)CJ_FUSED_MAX_CHUNKS;
+    // the workgroup decoder (lz4_decode_lds.hip): its parse stage inside the decoder kernel for small batches, as a kernel of its own
+    // in front of it for large ones (CJ_FLAG_FORCE_FUSED_PARSE / _PARSE_KERNEL: one of them at any batch size — tests, comparisons)
+    bool fused = a.n_chunks <= (uint32_t)CJ_FUSED_MAX_CHUNKS;
+    if (a.flags & CJ_FLAG_FORCE_FUSED_PARSE) fused = true;
+    if (a.flags & CJ_FLAG_FORCE_PARSE_KERNEL) fused = false;
     std::lock_guard<std::mutex> lock(e->scratch_mu);
-    // CJ_FLAG_BIG_CHUNKS: which chunks lie in (64 KiB, 256 KiB], and how many?  Listed on the device first; a batch of up to kBigCap
-    // chunks needs no count (one group, sized by the batch), a larger one reads the count back — the one place where a decode
-    // call waits for the stream (it sizes the record areas, 1 MiB per chunk, and the number of groups).
-    uint32_t n_big = 0;
-    const size_t big_list_bytes = ((4 + (size_t)a.n_chunks) * 4 + 255) & ~(size_t)255;
-    uint32_t* big_list = nullptr;
-    if ((a.flags & CJ_FLAG_BIG_CHUNKS) && e->d_biglist.reserve(big_list_bytes)) {
-        big_list = (uint32_t*)e->d_biglist.p;
-        cj::launch_big_list(a, codec, big_list, s);
-        n_big = a.n_chunks;
-        if (a.n_chunks > kBigCap) {
-            if (!e->h_count) HIP_TRY(hipHostMalloc((void**)&e->h_count, 64, hipHostMallocDefault), CJ_E_OOM);
-            HIP_TRY(hipMemcpyAsync(e->h_count, big_list, 4, hipMemcpyDeviceToHost, s), CJ_E_NO_DEVICE);
-            HIP_TRY(hipStreamSynchronize(s), CJ_E_NO_DEVICE);
-            n_big = *e->h_count;
-        }
-    } else if (a.flags & CJ_FLAG_BIG_CHUNKS) (void)hipGetLastError();
+    // (first: it makes `s` wait for the previous user of the engine's shared scratch — the big-chunk list below is part of it)
     const int rc = lds_scratch(e, a, s, !fused);
     if (rc != 0) return rc;
+    uint32_t n_big = 0;
+    uint32_t* big_list = nullptr;
+    if (a.flags & CJ_FLAG_BIG_CHUNKS) {
+        const int brc = plan_big(e, codec, a, s, &big_list, &n_big);
+        if (brc != 0) return brc;
+    }
     uint32_t* lists = (uint32_t*)e->d_lanelist.p;
     const uint32_t grid = kWgsPerCu * (uint32_t)e->n_cu;          // two persistent workgroups per CU
     if (fused) {
@@ -103,27 +135,30 @@ int launch_decode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a, hipStrea
         // (1 MiB each); what that stage does not take stays flagged for the wavefront kernel
         const uint32_t cap = (uint32_t)std::min<size_t>(n_big, kBigCap);
         const uint32_t items = cj::kBigSlabs * cap;
-        const uint32_t tab_stride = 4u * (cj::kBigSlabRecs + 64u), cross_stride = 3u * (cj::kBigSlabRecs + 64u);
+        // (per workgroup: a slab's records + at most one extra record each — the literals of a match that is cut at the slab's start — and at most one
+        //  cross copy each; no forwarding in this mode: nothing stages the input)
+        const uint32_t tab_stride = 2u * (cj::kBigSlabRecs + 64u), cross_stride = cj::kBigSlabRecs + 64u;
         // d_bigmisc: BigMeta x cap | item rows (5 x 8 bytes x items) | item meta | done flags | counter | walk scratch
         const size_t o_meta = 0, o_rows = (o_meta + cj::big_meta_bytes(cap) + 255) & ~(size_t)255,
                      o_imeta = o_rows + cj::kBigItemRows * 8 * (size_t)items, o_done = o_imeta + 8 * (size_t)items, o_ctr = o_done + 4 * (size_t)items,
                      o_walk = o_ctr + 256, total = o_walk + cj::big_walk_scratch_bytes(cap);
         // no room for the record areas: the chunks stay with the wavefront kernel (slower, never wrong)
+        const uint32_t sgrid = std::min(cj::kBigSlabWgsPerCu * (uint32_t)e->n_cu, items);          // the slab decoder's persistent workgroups (their tables are 0.9 MiB each)
         const bool room = e->d_bigrecs.reserve_exact(cj::big_recs_bytes(cap)) && e->d_bigmisc.reserve(total)
-            && e->d_bigslabtab.reserve((size_t)grid * tab_stride * 16 + (size_t)grid * cross_stride * 16 + (size_t)grid * (tab_stride + 512u) * 4);
+            && e->d_bigslabtab.reserve((size_t)sgrid * tab_stride * 16 + (size_t)sgrid * cross_stride * 16 + (size_t)sgrid * (tab_stride + 512u) * 4);
         if (!room) (void)hipGetLastError();
         uint8_t* m = (uint8_t*)e->d_bigmisc.p;
         for (uint32_t base = 0; room && base < n_big; base += cap) {
             HIP_TRY(hipMemsetAsync(m + o_ctr, 0, 256, s), CJ_E_NO_DEVICE);
             cj::launch_big_parse(a, codec, big_list, base, cap, e->d_bigrecs.p, m + o_meta, e->d_pmeta.p, m + o_walk, s);
             uint64_t* rows = (uint64_t*)(m + o_rows);
-            cj::launch_big_items(a, big_list, base, m + o_meta, cap, rows, m + o_imeta, (uint32_t*)(m + o_done), s);
+            cj::launch_big_items(a, big_list, base, m + o_meta, e->d_bigrecs.p, cap, rows, m + o_imeta, (uint32_t*)(m + o_done), s);
             cj::BatchArgs it = a;
             it.in_off = rows; it.in_len = rows + items; it.out_off = rows + 2 * (size_t)items; it.out_cap = rows + 3 * (size_t)items;
             it.result = (int64_t*)(rows + 4 * (size_t)items); it.n_chunks = items; it.flags = a.flags & CJ_FLAG_DEBUG_PROFILE;
             uint8_t* t = (uint8_t*)e->d_bigslabtab.p;
             cj::launch_lz4_decode_big_slabs(it, m + o_imeta, e->d_bigrecs.p, m + o_meta, cap, t, (uint32_t*)(m + o_ctr), (uint32_t*)(m + o_done),
-                                            t + (size_t)grid * tab_stride * 16, tab_stride, cross_stride, std::min(grid, items), s, codec);
+                                            t + (size_t)sgrid * tab_stride * 16, tab_stride, cross_stride, sgrid, s, codec);
         }
     }
     if (lz4) cj::launch_lz4_decode_routed(a, e->d_pmeta.p, s);                // few long runs / oversize chunks / errors
@@ -153,11 +188,15 @@ int launch_slice(cj_engine* e, cj_codec codec, cj_op op, const cj::BatchArgs& a,
 // 1 M chunks in one go ran at 299 GB/s vs 430 GB/s at 100 k), and the parse/LDS scratch stays bounded.
 
 int cj::launch(cj_engine* e, cj_codec codec, cj_op op, const cj::BatchArgs& a, hipStream_t s) {
-    static const size_t kSliceChunks = [] {
+#ifdef CJ_DEBUG_KNOBS
+    static const size_t kSliceChunks = [] {                   // (tuning builds only: the shipped library reads no environment)
         const char* v = std::getenv("CJ_SLICE_CHUNKS");
         size_t x = v ? (size_t)std::strtoull(v, nullptr, 10) : (size_t)CJ_SLICE_CHUNKS_DEFAULT;
         return x < 8192 ? (size_t)8192 : x;
     }();
+#else
+    constexpr size_t kSliceChunks = CJ_SLICE_CHUNKS_DEFAULT;
+#endif
     if (op != CJ_OP_DECOMPRESS || a.n_chunks <= kSliceChunks) return launch_slice(e, codec, op, a, s);
     for (size_t start = 0; start < a.n_chunks; start += kSliceChunks) {
         cj::BatchArgs b = a;
@@ -177,8 +216,10 @@ int g_default_rc = CJ_E_NO_DEVICE;
 
 cj_engine* cj::default_engine() {
     std::call_once(g_default_once, [] {
-        int dev = 0;
+        int dev = 0;                                          // (the single-buffer entry points: device 0 of what HIP_VISIBLE_DEVICES shows)
+#ifdef CJ_DEBUG_KNOBS
         if (const char* s = std::getenv("CJ_DEVICE")) dev = std::atoi(s);
+#endif
         g_default_rc = cj_engine_create(dev, &g_default);
     });
     return g_default_rc == 0 ? g_default : nullptr;
@@ -376,7 +417,7 @@ int cj_engine_create(int device, cj_engine** out) {
 void cj_engine_destroy(cj_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
-    e->d_in.release(); e->d_out.release(); e->d_meta.release(); e->d_sync.release(); e->d_bigrecs.release(); e->d_bigmisc.release(); e->d_biglist.release(); if (e->h_count) (void)hipHostFree(e->h_count); e->d_bigslabtab.release(); e->d_pmeta.release(); e->d_lanelist.release(); e->d_frame.release(); e->d_tab.release(); e->d_big.release(); e->d_bigtab.release();
+    e->d_in.release(); e->d_out.release(); e->d_meta.release(); e->d_sync.release(); e->d_bigrecs.release(); e->d_bigmisc.release(); e->d_biglist.release(); if (e->h_count) { (void)hipHostFree(e->h_count); for (auto& ev : e->big_ev) if (ev) (void)hipEventDestroy(ev); } e->d_bigslabtab.release(); e->d_pmeta.release(); e->d_lanelist.release(); e->d_frame.release(); e->d_tab.release(); e->d_big.release(); e->d_bigtab.release();
     e->h_in.release(); e->h_out.release(); e->h_res.release();
     for (hipEvent_t ev : e->slice_ev) (void)hipEventDestroy(ev);
     if (e->stream_back) (void)hipStreamDestroy(e->stream_back);
@@ -390,7 +431,7 @@ int cj_engine_device(const cj_engine* e) { return e ? e->device : -1; }
 
 // the flag bits a C-ABI caller may set; everything else (piece splitting, tail reports, linked-frame parse: cj_common.hpp) belongs
 // to large.hip / frame.hip, which call cj::launch directly — a stray bit would make a kernel read descriptors that are not there
-static constexpr uint32_t kPublicFlags = CJ_FLAG_LZ4_SIZE_PREFIX | CJ_FLAG_FORCE_WAVE_PER_CHUNK | CJ_FLAG_FORCE_LANE_PER_CHUNK | CJ_FLAG_FORCE_LDS_PER_CHUNK | CJ_FLAG_BIG_CHUNKS
+static constexpr uint32_t kPublicFlags = CJ_FLAG_LZ4_SIZE_PREFIX | CJ_FLAG_FORCE_FUSED_PARSE | CJ_FLAG_FORCE_PARSE_KERNEL | CJ_FLAG_FORCE_WAVE_PER_CHUNK | CJ_FLAG_FORCE_LANE_PER_CHUNK | CJ_FLAG_FORCE_LDS_PER_CHUNK | CJ_FLAG_BIG_CHUNKS
                                          | CJ_FLAG_DEBUG_PROFILE;
 
 int cj_batch_device(cj_engine* e, cj_codec codec, cj_op op, uint32_t flags, size_t n_chunks,
@@ -637,3 +678,9 @@ int cj_memset_dev(cj_engine* e, void* d, int v, size_t n) {
 }
 
 }  // extern "C"
+
+extern "C" uint64_t cj_debug_big_scratch_bytes(cj_engine* e) {
+    if (!e) return 0;
+    std::lock_guard<std::mutex> lock(e->scratch_mu);
+    return (uint64_t)e->d_biglist.cap + e->d_bigrecs.cap + e->d_bigmisc.cap + e->d_bigslabtab.cap;
+}

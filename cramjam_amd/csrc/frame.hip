@@ -21,6 +21,15 @@ void launch_lz4_frame_chain(const uint8_t* in, const uint64_t* blk_off, const ui
 }
 
 namespace {
+// (tuning builds only: every linked-block frame through the chain kernel; the shipped library reads no environment)
+inline bool lz4f_chain_only() {
+#ifdef CJ_DEBUG_KNOBS
+    static const bool v = std::getenv("CJ_LZ4F_CHAIN_ONLY") != nullptr;
+    return v;
+#else
+    return false;
+#endif
+}
 
 constexpr size_t kPiece = 65536;          // snap MAX_BLOCK_SIZE
 constexpr size_t kMaxChunk = 76490;       // snap MAX_COMPRESS_BLOCK_SIZE = max_compress_len(65536)
@@ -381,7 +390,11 @@ int lz4_frame_linked_lds(cj_engine* e, const Lz4Frame& f, const uint8_t* d_in, s
         if (i + 1 < nb && (uint64_t)res[i] != B) return 1;            // a short block in the middle: positions are not k * 64 KiB
         if (res[i] == 0 && !(in_skip & 0x20000000u)) return 1;
     }
-    static const bool one_wg = std::getenv("CJ_LZ4F_ONE_WORKGROUP") != nullptr;
+#ifdef CJ_DEBUG_KNOBS
+    static const bool one_wg = std::getenv("CJ_LZ4F_ONE_WORKGROUP") != nullptr;      // (tuning builds only: the older one-workgroup path, tests/perf/linked_frame_rate.py)
+#else
+    constexpr bool one_wg = false;
+#endif
     if (one_wg) {
         // one workgroup walks the frame's blocks in order, the previous block in a second LDS window
         cj::launch_lz4_decode_lds2_linked(a, e->d_sync.p, e->d_pmeta.p, e->d_tab.p, (uint32_t*)e->d_lanelist.p + 2,
@@ -623,7 +636,7 @@ int64_t cj_lz4_frame_decompress(const uint8_t* in, size_t n, uint8_t* out, size_
             HIP_TRY(hipMemcpyAsync(d_meta + r_g, m.data() + r_g, 3 * nb * 8, hipMemcpyHostToDevice, s), CJ_E_NO_DEVICE);
             cj::launch_copy_segments(d_meta + r_g, d_final, d_meta + r_g + nb, d_meta + r_g + 2 * nb, nullptr, 0, (uint32_t)nb, s);
             HIP_TRY(hipGetLastError(), CJ_E_NO_DEVICE);
-        } else if (B == 65536 && !std::getenv("CJ_LZ4F_CHAIN_ONLY") && lz4_frame_linked_lds(e, f, d_in, res, &d_final) == 0) {
+        } else if (B == 65536 && !lz4f_chain_only() && lz4_frame_linked_lds(e, f, d_in, res, &d_final) == 0) {
             // linked 64 KiB blocks, decoded by the two-window LDS workgroup decoder (results in res, bytes at d_final)
         } else {
             // linked blocks: the chain kernel decodes straight into the contiguous output

@@ -466,8 +466,15 @@ bool large_few_elements(int codec, uint32_t flags, const uint8_t* in, size_t n, 
     return false;
 }
 
-// debug aid: CJ_SLAB_PROFILE=1 switches the slab decoder's per-phase cycle counters on (read with cj_debug_lds_phase_cycles)
-static uint32_t slab_profile_flag() { static const uint32_t f = std::getenv("CJ_SLAB_PROFILE") ? CJ_FLAG_DEBUG_PROFILE : 0u; return f; }
+// debug aid (tuning builds, -DCJ_DEBUG_KNOBS): CJ_SLAB_PROFILE=1 switches the slab decoder's per-phase cycle counters on (read with cj_debug_lds_phase_cycles)
+static uint32_t slab_profile_flag() {
+#ifdef CJ_DEBUG_KNOBS
+    static const uint32_t f = std::getenv("CJ_SLAB_PROFILE") ? CJ_FLAG_DEBUG_PROFILE : 0u;
+    return f;
+#else
+    return 0u;
+#endif
+}
 
 static std::vector<uint32_t>* g_dbg_sync = nullptr;       // set by cj_debug_big_parse only (single-threaded test hook)
 static uint64_t g_dbg_nseq = 0;

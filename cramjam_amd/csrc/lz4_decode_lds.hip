@@ -55,8 +55,10 @@ __device__ unsigned long long g_lds_phase_cycles[16];
 constexpr uint32_t kL2Threads = CJ_L2_THREADS;
 constexpr uint32_t kL2OffBits = CJ_L2_WINDOW;
 constexpr uint32_t kL2BitWords = kL2OffBits / 32u;    // ready bitmap: one bit per byte of the window
-constexpr uint32_t kL2OffVars = kL2OffBits + kL2OffBits / 8u;         // [0] fail flag, [8] current chunk, [64,128) dummy bytes, [128,384) dummy dwords
-constexpr uint32_t kL2Bytes = kL2OffVars + 384 + 128;      // 74880 B (the last 128: phase counters, the next chunk's descriptors): two workgroups fit one CU's LDS
+// LDS of a workgroup with a window of `win` bytes: window | ready bitmap | [0] fail flag, [8] current chunk, [64,128) dummy bytes, [128,384) dummy dwords |
+// 128 bytes of phase counters and the next chunk's descriptors
+constexpr uint32_t lds2_bytes(uint32_t win) { return win + win / 8u + 384u + 128u; }
+constexpr uint32_t kL2Bytes = lds2_bytes(kL2OffBits);      // 74880 B: two workgroups fit one CU's LDS
 #ifndef CJ_D2_LONG
 #define CJ_D2_LONG 256u
 #endif
@@ -108,7 +110,6 @@ __device__ unsigned long long g_slab_trace[8192 * 8];
 #define CJ_TRACE_T0(slot) do {} while (0)
 #endif
 __device__ unsigned long long g_fwd_chunks = 0ull;            // test hook: chunks / slabs that went through D1f
-constexpr uint32_t kFwdMaxRecords = 6144u * (CJ_L2_WINDOW / 1024u) / 64u;      // D1f (match forwarding): 10 bytes of index per record in the 64 KiB window
 #ifndef CJ_FWD_ROUNDS_BATCH
 #define CJ_FWD_ROUNDS_BATCH 2u
 #endif
@@ -134,10 +135,18 @@ constexpr uint32_t kSlabPatience = CJ_SLAB_PATIENCE;
 // to the slab exactly like the walking D1 of the large-stream slabs — instead of one thread per eight sequences walking tokens.
 struct FeedArgs { const uint4* recs; const BigMeta* bigmeta; uint32_t cap; };
 
-template <int kCodec, bool kLinked, bool kSlab, bool kFused = false, bool kRecFeed = false>
+// kWinT / kThreadsT: the window and the workgroup of an instantiation.  The chains-in-flight sweep of round 6 (profiles/r06/experiments
+// h01-h04): at 16 wavefronts per CU, four workgroups of four on 32 KiB windows decode 32 KiB pieces 32 % faster than two of eight, eight
+// of two on 16 KiB windows 16 KiB pieces 87 % faster — what a CU's LDS and registers hold in flight is what bounds this decoder.
+template <int kCodec, bool kLinked, bool kSlab, bool kFused = false, bool kRecFeed = false, uint32_t kWinT = CJ_L2_WINDOW, uint32_t kThreadsT = CJ_L2_THREADS>
 __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync, const ParseMeta* meta, uint4* tabs, uint32_t* counter,
                                           const uint2* frames, uint32_t n_frames, const SlabArgs& sl, const FeedArgs& fd = FeedArgs{nullptr, nullptr, 0u}) {
     static_assert(!kRecFeed || (kSlab && !kLinked && !kFused), "records are fed to the slab mode");
+    static_assert(!kLinked || kWinT == 65536u, "the two-window mode holds 64 KiB blocks");
+    // (these shadow the file's defaults: everything below is written in terms of them)
+    constexpr uint32_t kL2Threads = kThreadsT, kL2OffBits = kWinT, kL2BitWords = kWinT / 32u, kL2Bytes = lds2_bytes(kWinT);
+    constexpr uint32_t kFwdMaxRecords = 6144u * (kWinT / 1024u) / 64u;      // D1f: 10 bytes of index per record in the window
+    constexpr uint32_t kWinInMax = kWinT - 32u;                             // compressed bytes staged in the window (<= 15 B misalignment + 15 B round-up)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr uint32_t kOffBits = kLinked ? 131072u : kL2OffBits, kOffVars = kOffBits + (kLinked ? 8192u : kL2OffBits / 8u);
     constexpr uint32_t kBitWords = kLinked ? 2048u : kL2BitWords;
@@ -274,7 +283,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                         ulen |= (uint64_t)(bb & 0x7fu) << shift;
                         shift += 7; i += 1;
                     }
-                    if (!ok || ulen > 0xFFFFFFFFull || ulen > cap64 || ulen == 0 || ulen > kLdsOutMax || n64 - hdr > kLdsInMax || hdr == (uint32_t)n64) route = true;
+                    if (!ok || ulen > 0xFFFFFFFFull || ulen > cap64 || ulen == 0 || ulen > kWinT || n64 - hdr > kWinInMax || hdr == (uint32_t)n64) route = true;
                     skip = hdr; cap64 = ulen;
                 }
             } else {
@@ -282,7 +291,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 if (lz4_block_prologue(a.flags, inp, n64, cap64) != 0) route = true;
                 else {
                     skip = (uint32_t)(inp - in0);
-                    if (cap64 == 0 || n64 == 0 || cap64 > kLdsOutMax || n64 > kLdsInMax) route = true;
+                    if (cap64 == 0 || n64 == 0 || cap64 > kWinT || n64 > kWinInMax) route = true;
                 }
             }
             if (route) { if (tid == 0) meta_w[c] = ParseMeta{0u, kRouteWave}; continue; }
@@ -361,7 +370,26 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         uint8_t* out = a.out_base + d_out_off;
         const uint2* csync = kRecFeed ? nullptr : kSlab ? sync + frames[c].x : sync + (size_t)c * kSyncPitch;
         const uint32_t nsp = (nseq + kSyncEvery - 1u) / kSyncEvery;
-        const bool staged = !kRecFeed && (!kSlab || iend <= kLdsInMax);   // kSlab: a slab inside a long literal run may span more input than the window holds; kRecFeed: nothing walks the bytes
+        if constexpr (kRecFeed) {
+            // Nothing stages this mode's input, so D2's literal loads would come from HBM one dependent round trip per batch (~5 k cycles
+            // under this kernel's load; the 64 KiB path's S0 leaves the chunk's bytes in L2 as a side effect).  The item's meta names the
+            // 128-byte lines its literals lie in (big_items_kernel): every thread touches one by LDS-DMA into the dummy dwords — no
+            // register, nobody waits — while D1 runs.
+            const uint32_t lo_line = pm.in_skip & 0xfffu, n_lines = (pm.in_skip >> 12) & 0x3ffu;
+            const uint32_t dummy = (uint32_t)(uintptr_t)(smem + kOffVars + 128u);
+            const uint8_t* p0 = in + 128u * lo_line;
+            p0 -= reinterpret_cast<uintptr_t>(p0) & 127u;
+            const uint8_t* p_last = in + iend - 1u;
+            for (uint32_t l = tid; l < n_lines; l += kL2Threads) {
+                const uint8_t* g = p0 + 128u * l;
+                if (g <= p_last) {
+                    uint32_t keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(g), "s"(dummy) : "memory");
+                }
+            }
+        }
+        const bool staged = !kRecFeed && (!kSlab || iend <= kWinInMax);   // kSlab: a slab inside a long literal run may span more input than the window holds; kRecFeed: nothing walks the bytes
         // ---- S0: stage the compressed chunk in the (still unused) output window so that D1's dependent token
         //      reads are LDS reads; D2 re-reads the literal bytes from global memory (L2 hits) because it overwrites
         //      the window while other lanes still need their sources ----
@@ -818,7 +846,11 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         const uint32_t i0 = wave * 64u + lane;
         const auto fetch_batch = [&](uint32_t b) { return rec_fetch(b < nrec_all ? b + lane : i0, nseq, nrec_all); };   // past the wave's last batch: its FIRST again — D3 starts on it
         uint4 raw_nx = rec_fetch(i0, nseq, nrec_all);
-        if constexpr (kCompact) {
+        // kRecFeed (round 6): the same pipeline with exact stores — the slab's literals come from HBM (nothing staged the input), and a
+        // batch that requests its bytes only when it is placed is a global round trip per batch on the wave's chain (D2 43.8 k of a
+        // slab's 102 k cycles for 6.5 batches per wavefront, profiles/r06/experiments b01).
+        constexpr bool kPipeD2 = kCompact || kRecFeed;
+        if constexpr (kPipeD2) {
             // A sequence whose match this lane copies in D3 OWNS the bytes behind its literals (lds_store_own): up to 32 literal
             // bytes per sequence go the lean way, and their 32 source bytes are requested one batch ahead (two loads per record,
             // no branch around them: the wait for the batch that is placed must not cover the requests of the next one).
@@ -826,7 +858,8 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             const uint8_t* lit_base = iend >= 32u ? in : reinterpret_cast<const uint8_t*>(table);      // 32 readable bytes for the lanes that load nothing
             const auto own_issue = [&](const uint4& rec, OwnLit& L) {
                 L.n = rec.y; L.src = rec.x; L.dst = rec.z - rec.y;
-                const bool own = (rec.w & 0xffffu) != 0u && (rec.w >> 16) >= 4u && L.src + 32u <= safe_end && L.n < kD2LongRun;
+                // (slab records: the bytes behind the literals may belong to a cross copy that another wavefront has already made — exact stores there)
+                const bool own = (!kCompact || ((rec.w & 0xffffu) != 0u && (rec.w >> 16) >= 4u)) && L.src + 32u <= safe_end && L.n < kD2LongRun;
                 L.nl = own ? (L.n < 32u ? L.n : 32u) : 0u;
                 const uint8_t* g = lit_base + (L.nl ? L.src : 0u);
                 uint4 q0, q1;
@@ -835,8 +868,22 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                 L.v[0] = q0.x; L.v[1] = q0.y; L.v[2] = q0.z; L.v[3] = q0.w; L.v[4] = q1.x; L.v[5] = q1.y; L.v[6] = q1.z; L.v[7] = q1.w;
             };
             const auto own_place = [&](OwnLit& L) {
-                if (ballot64(L.nl > 16u)) lds_store_own<32>(L.v, a_out + L.dst, L.nl);
-                else lds_store_own<16>(L.v, a_out + L.dst, L.nl);
+                if constexpr (kCompact) {
+                    if (ballot64(L.nl > 16u)) lds_store_own<32>(L.v, a_out + L.dst, L.nl);
+                    else lds_store_own<16>(L.v, a_out + L.dst, L.nl);
+                } else if (ballot64(L.nl > 16u)) {
+                    DW<10> r;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) r.w[i] = L.v[i];
+                    r.w[8] = 0u; r.w[9] = 0u;
+                    lds_store_tier<32>(r, a_out + L.dst, 0u, L.nl, dm);
+                } else {
+                    DW<6> r;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) r.w[i] = L.v[i];
+                    r.w[4] = 0u; r.w[5] = 0u;
+                    lds_store_tier<16>(r, a_out + L.dst, 0u, L.nl, dm);
+                }
                 bits_set32(s_bits, L.dst, L.nl);
                 if (ballot64(L.n > L.nl)) place_from_global(L.n - L.nl, L.src + L.nl, L.dst + L.nl);
             };
@@ -932,7 +979,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         uint32_t* dlist = nullptr;
         uint32_t ndef = 0, dpos = 0;
         bool pass2 = false;
-        if constexpr (kSlab) dlist = sl.defer + (size_t)blockIdx.x * sl.defer_stride + (size_t)wave * (sl.defer_stride / 8u);
+        if constexpr (kSlab) dlist = sl.defer + (size_t)blockIdx.x * sl.defer_stride + (size_t)wave * (sl.defer_stride / (kL2Threads / 64u));
         // ---- D3, batches of independent chunks: the poll step as ONE hand-scheduled block.  The resolver is bound by how long a
         //      trip round the poll loop takes (the dependency chain is 21-33 levels deep on the benchmark data and every level
         //      costs a producer's publish + a consumer's poll + its copy), and the loop below this one compiles to ~100
@@ -1318,9 +1365,9 @@ __global__ __launch_bounds__(kL2Threads) __attribute__((amdgpu_waves_per_eu(4, 4
 
 // the slabs of the big chunks of a device batch, records fed by big_parse_kernel (kRecFeed)
 template <int kCodec>
-__global__ __launch_bounds__(kL2Threads) __attribute__((amdgpu_waves_per_eu(4, 4))) void lz4_decode_bigslabs_kernel(
+__global__ __launch_bounds__(kBigSlabThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void lz4_decode_bigslabs_kernel(
         BatchArgs a, const ParseMeta* meta, uint4* tabs, uint32_t* counter, SlabArgs sl, FeedArgs fd) {
-    lds2_body<kCodec, false, true, false, true>(a, nullptr, meta, tabs, counter, nullptr, 0u, sl, fd);
+    lds2_body<kCodec, false, true, false, true, kBigSlabBytes, kBigSlabThreads>(a, nullptr, meta, tabs, counter, nullptr, 0u, sl, fd);
 }
 
 // parse + decode in one kernel (batches of independent chunks).  meta: written here (kRouteWave for the chunks left to the wave kernel)
@@ -1350,15 +1397,15 @@ void launch_lz4_decode_big_slabs(const BatchArgs& items, const void* meta, const
     const SlabArgs sl = {done, (uint4*)cross, tab_stride, cross_stride, 0u,
                          reinterpret_cast<uint32_t*>((uint4*)cross + (size_t)grid * cross_stride), defer_stride, cap};
     const FeedArgs fd = {(const uint4*)recs, (const BigMeta*)bigmeta, cap};
-    constexpr uint32_t bytes = kL2Bytes + 3u * kBigLanes * 4u;          // + the regions' table (kRecFeed)
-    static_assert(2u * bytes <= 163840u, "two workgroups per CU");
+    constexpr uint32_t bytes = lds2_bytes(kBigSlabBytes) + 3u * kBigLanes * 4u;          // + the regions' table (kRecFeed)
+    static_assert(kBigSlabWgsPerCu * bytes <= 163840u, "workgroups per CU");
     if (codec == CJ_CODEC_SNAPPY_RAW) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_bigslabs_kernel<CJ_CODEC_SNAPPY_RAW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        hipLaunchKernelGGL((lz4_decode_bigslabs_kernel<CJ_CODEC_SNAPPY_RAW>), dim3(grid), dim3(kL2Threads), bytes, s, items, (const ParseMeta*)meta, (uint4*)tabs, counter, sl, fd);
+        hipLaunchKernelGGL((lz4_decode_bigslabs_kernel<CJ_CODEC_SNAPPY_RAW>), dim3(grid), dim3(kBigSlabThreads), bytes, s, items, (const ParseMeta*)meta, (uint4*)tabs, counter, sl, fd);
         return;
     }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_bigslabs_kernel<CJ_CODEC_LZ4_BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    hipLaunchKernelGGL((lz4_decode_bigslabs_kernel<CJ_CODEC_LZ4_BLOCK>), dim3(grid), dim3(kL2Threads), bytes, s, items, (const ParseMeta*)meta, (uint4*)tabs, counter, sl, fd);
+    hipLaunchKernelGGL((lz4_decode_bigslabs_kernel<CJ_CODEC_LZ4_BLOCK>), dim3(grid), dim3(kBigSlabThreads), bytes, s, items, (const ParseMeta*)meta, (uint4*)tabs, counter, sl, fd);
 }
 
 size_t lz4_lds2_tab_bytes(uint32_t grid) { return (size_t)grid * kL2TabRecords * sizeof(uint4); }

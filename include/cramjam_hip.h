@@ -162,11 +162,19 @@ typedef enum { CJ_OP_DECOMPRESS = 0, CJ_OP_COMPRESS = 1 } cj_op;
 #define CJ_FLAG_FORCE_WAVE_PER_CHUNK 0x100u
 #define CJ_FLAG_FORCE_LANE_PER_CHUNK 0x200u
 #define CJ_FLAG_FORCE_LDS_PER_CHUNK  0x400u
-/* decompress: the batch may hold chunks of 64 KiB .. 256 KiB (capacity / announced length) and they matter — the engine reserves
- * record areas for up to 8 192 of them per slice (1 MiB each) and decodes them slab by slab with workgroups;
- * without the flag (and for what exceeds the reservation) such chunks take one wavefront each: correct, ~2.5x slower in bulk */
+/* ... and, for the workgroup decoder, where its parse stage runs: inside the decoder kernel / as the lane-per-chunk kernel in front of
+ * it, at any batch size (default: by CJ_FUSED_MAX_CHUNKS below).  Tests exercise both sides of the threshold with them. */
+#define CJ_FLAG_FORCE_FUSED_PARSE   0x10u
+#define CJ_FLAG_FORCE_PARSE_KERNEL  0x20u
+/* decompress: the batch may hold chunks of 64 KiB .. 256 KiB (capacity / announced length) and they matter — the engine lists them on
+ * the device, parses them with 32 lanes each into record areas (1 MiB per listed chunk, groups of up to 8 192) and decodes them slab by
+ * slab with workgroups.  How many there are is known on the device only: every flagged call copies its count back
+ * WITHOUT waiting for it, and a call reserves for the largest of the last eight counts that have arrived; what a batch holds beyond
+ * that — and every such chunk without the flag — takes one wavefront: correct, ~2.5x slower in bulk.  Only the first flagged call
+ * on an engine waits for the stream once (it reads its own count); like every call, one that has to GROW the engine's scratch waits
+ * for the device while it reallocates.  After that cj_batch_device with this flag only enqueues. */
 #define CJ_FLAG_BIG_CHUNKS          0x800u
-/* debug aid: the workgroup decoder accumulates per-phase cycle counters (read with cj_debug_lds_phase_cycles; results unchanged) */
+/* debug aid: the workgroup decoder accumulates per-phase cycle counters (read with cj_debug_lds_phase_cycles, cramjam_hip_debug.h; results unchanged) */
 #define CJ_FLAG_DEBUG_PROFILE        0x1000u
 /* decode batches up to this many chunks run parse + decode as ONE kernel (the segmented parse inside the workgroup decoder:
  * 1 chunk 0.16 ms instead of 0.25, 8 192 chunks 348 instead of 178 GB/s); above, a lane-per-chunk parse kernel in front of the
@@ -174,7 +182,7 @@ typedef enum { CJ_OP_DECOMPRESS = 0, CJ_OP_COMPRESS = 1 } cj_op;
  * chunk, i.e. its sequence count: benchmark data (2.7 k sequences per 64 KiB) ~13 000 chunks for LZ4 and ~10 500 for Snappy,
  * the reference's corpus (~8 k) above 24 000 (profiles/r04/experiments, c02); 16 384 loses at most ~11 % on either side */
 #define CJ_FUSED_MAX_CHUNKS 16384
-/* decode batches larger than this are submitted in slices of this many chunks (env CJ_SLICE_CHUNKS) */
+/* decode batches larger than this are submitted in slices of this many chunks */
 #define CJ_SLICE_CHUNKS_DEFAULT 131072
 
 CJ_API int  cj_engine_create(int device, cj_engine** out);
@@ -223,21 +231,8 @@ CJ_API int   cj_memcpy_d2h(cj_engine* e, void* dst_host, const void* src_dev, si
 CJ_API int   cj_memcpy_d2d(cj_engine* e, void* dst_dev, const void* src_dev, size_t bytes);
 CJ_API int   cj_memset_dev(cj_engine* e, void* dst_dev, int value, size_t bytes);
 
-/* ---- test and benchmark utilities exported next to the engine (NOT part of the drop-in ABI: cramjam_amd/csrc/bench_util.hip
- *      and debug counters of the decoders) ---- */
-/* n chunks of S bytes at d_out + i*stride = synth-v1(S, first_index + i, seed), generated on the device */
-CJ_API int cj_bench_synth_v1(void* d_out, uint64_t stride, uint64_t S, uint64_t first_index, uint64_t n, uint64_t seed, void* stream);
-/* *d_mismatches += chunks i in [0, n) with got[got_off[i] .. +S) != want[(i % n_unique)*want_stride .. +S) */
-CJ_API int cj_bench_compare(const void* d_got, const uint64_t* d_got_off, const void* d_want, uint64_t want_stride,
-                            uint32_t n_unique, uint64_t S, uint32_t n, void* d_mismatches, void* stream);
-/* per-phase cycle counters of the workgroup decoder (CJ_FLAG_DEBUG_PROFILE on a device batch): S0, D1, D2, D3, D4, chunks, 6.. sub-phases.
- * out16 must hold SIXTEEN 64-bit slots (128 bytes; it was eight until round 3) */
-CJ_API int cj_debug_lds_phase_cycles(unsigned long long* out16, int reset);
-CJ_API long long cj_debug_forwarded_chunks(int reset);            /* chunks / slabs that went through the forwarding phase */
-CJ_API unsigned long long cj_debug_linked_lds_frames(void);       /* linked-block LZ4 frames decoded by the two-window decoder */
-/* large-stream path with its parse stage's absolute sync points handed back (tests compare them with a serial walk) */
-CJ_API int64_t cj_debug_big_parse(int codec, uint32_t flags, const uint8_t* in, size_t n, uint8_t* out, size_t cap,
-                                  uint32_t* sync_pairs, size_t max_pairs, uint64_t* n_seq);
+/* The test / benchmark utilities and debug counters the library also exports (cj_bench_*, cj_debug_*) are declared in
+ * cramjam_hip_debug.h: they are NOT part of the drop-in ABI. */
 
 #ifdef __cplusplus
 }

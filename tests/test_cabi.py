@@ -8,25 +8,34 @@ from conftest import ROOT
 from cramjam_amd import _native as N
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "cramjam_hip.h")).read()
+def _declared_symbols(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(cj_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_every_declared_symbol_is_exported_and_bound():
-    names = _declared_symbols()
-    assert len(names) >= 24
+    abi = _declared_symbols("cramjam_hip.h")                  # the drop-in ABI: what a binding of the reference's call sites uses
+    dbg = _declared_symbols("cramjam_hip_debug.h")            # test / benchmark utilities and debug counters, declared apart
+    assert len(abi) >= 24 and not set(abi) & set(dbg)
+    assert all(n.startswith(("cj_bench_", "cj_debug_")) for n in dbg) and not any(n.startswith(("cj_bench_", "cj_debug_")) for n in abi)
     L = C.CDLL(N.LIB_PATH)
-    for n in names:
+    for n in abi + dbg:
         assert hasattr(L, n), "libcramjam_hip.so does not export %s" % n
-        assert n in N.SYMBOLS or n in N.BENCH_SYMBOLS, "cramjam_amd/_native.py has no binding for %s" % n
-    # the drop-in ABI and the test / benchmark utilities declared behind it: nothing else is bound, nothing else exported
-    assert sorted(list(N.SYMBOLS) + list(N.BENCH_SYMBOLS)) == names
+    # each list is bound as what it is: nothing else is bound, nothing else exported
+    assert sorted(N.SYMBOLS) == abi, sorted(set(N.SYMBOLS) ^ set(abi))
+    assert sorted(N.BENCH_SYMBOLS) == dbg, sorted(set(N.BENCH_SYMBOLS) ^ set(dbg))
     import subprocess
     exported = subprocess.run(["nm", "-D", "--defined-only", N.LIB_PATH], capture_output=True, text=True).stdout
     c_syms = sorted(ln.split()[-1] for ln in exported.splitlines() if ln.split() and not ln.split()[-1].startswith("_Z") and ln.split()[1] in "TtWw")
-    assert c_syms == names, "exported C symbols that the header does not declare: %s" % sorted(set(c_syms) - set(names))
+    assert c_syms == sorted(abi + dbg), "exported C symbols that no header declares: %s" % sorted(set(c_syms) - set(abi + dbg))
+
+
+def test_shipped_library_reads_no_pipeline_environment():
+    # the knobs of tuning builds (-DCJ_DEBUG_KNOBS) must not be in the product: no getenv of a CJ_ name in the shipped binary
+    blob = open(N.LIB_PATH, "rb").read()
+    for knob in (b"CJ_FUSED", b"CJ_SLICE_CHUNKS", b"CJ_DEVICE", b"CJ_LZ4F_ONE_WORKGROUP", b"CJ_LZ4F_CHAIN_ONLY", b"CJ_SLAB_PROFILE"):
+        assert knob + b"\0" not in blob, knob
 
 
 def test_pure_helpers_and_error_strings():

@@ -78,6 +78,7 @@ import bz2, json, os, sys
 import oracle
 from cramjam_amd import _native as N
 corpus = sys.argv[1]
+PARSE = {"1": N.FLAG_FORCE_FUSED_PARSE, "0": N.FLAG_FORCE_PARSE_KERNEL}[sys.argv[2]]     # where the workgroup decoder's parse stage runs
 mf = json.load(open(os.path.join(corpus, "manifest.json")))
 man = mf["files"]
 chunks = []
@@ -94,7 +95,7 @@ for codec, comp, dec in ((N.CODEC_LZ4_BLOCK, lambda c: oracle.lz4_compress_raw(c
                          (N.CODEC_SNAPPY_RAW, lambda c: oracle.snappy_compress(c)[1], lambda b, n: oracle.snappy_decompress(b))):
     blobs = [comp(c) for c in chunks]
     for flags in (0, N.FLAG_FORCE_LDS_PER_CHUNK, N.FLAG_FORCE_WAVE_PER_CHUNK):
-        res, outs = eng.batch_host(codec, N.OP_DECOMPRESS, flags, blobs, [len(c) for c in chunks])
+        res, outs = eng.batch_host(codec, N.OP_DECOMPRESS, flags | PARSE, blobs, [len(c) for c in chunks])
         assert [int(r) for r in res] == [len(c) for c in chunks], (codec, flags)
         assert all(bytes(o) == c for o, c in zip(outs, chunks)), (codec, flags)
     caps = [(L.cj_lz4_block_compress_bound(len(c), 0) if codec == N.CODEC_LZ4_BLOCK else L.cj_snappy_raw_max_compress_len(len(c))) for c in chunks]
@@ -114,6 +115,6 @@ def test_every_corpus_chunk_against_the_oracle(fused):
     workgroup decoder forced and with the one-wavefront kernel, on both sides of the parse-in-kernel threshold (real text has ~10 000
     sequences per chunk and dependency chains a hundred levels deep); the GPU encoders' blocks decode with the oracle"""
     import subprocess, sys
-    env = dict(os.environ, CJ_FUSED=fused, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    r = subprocess.run([sys.executable, "-c", _CHUNK_CHECK, CORPUS], env=env, capture_output=True, text=True, timeout=900)
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", _CHUNK_CHECK, CORPUS, fused], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "corpus chunks ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -3,8 +3,10 @@
 //
 // What a round does (tests/hostsim/enc2_model.c states the same thing as scalar C; the kernels emit exactly its bytes):
 //   probe    kR consecutive positions — lane l owns the FOUR CONSECUTIVE positions 4 l .. 4 l + 3 of every group of 256, so two
-//            dwords per lane yield the four position dwords with three v_alignbyte — against the 8192 x u16 hash table as it was
-//            when the round began: hash, table read, candidate dword, compare.  Straight-line code, no branches.
+//            dwords per lane yield the four position dwords with three v_alignbyte — against the 8192 x u16 hash table, in BLOCKS of
+//            128 positions (half a wavefront): a block reads its slots and then stores its own positions into them before the next block
+//            reads (the DS queue of a wavefront executes in order; the second wavefront starts behind the first one's stores), so the
+//            table a position sees is at most 128 positions stale.  Then candidate dword, compare.  Straight-line code.
 //   heads    a verified position whose left neighbour is verified with the SAME offset lies inside its neighbour's match: only
 //            the first position of such a run (its head) is a candidate.  On match-heavy data half of all positions verify and
 //            one in fifteen is a head; the heads are compacted into consecutive lanes (ranks from v_mbcnt, a 256-byte LDS list).
@@ -17,8 +19,9 @@
 //            instead of walked; a window that has not settled after kSelPasses takes the serial walk (`cur` through SGPRs).
 //   queue    selected sequences are appended to a 64-entry queue in LDS and emitted lane-parallel when it is full — one emission
 //            pass per ~64 sequences instead of one per round.
-//   insert   positions that are not strictly inside an emitted match (its last kTail positions count as outside) enter the table:
-//            a toggle bitmap in LDS written by the selected lanes, read back as a parity prefix by the position lanes.
+//   (until round 5 a round probed the table as it was when the round began and inserted at its end, only the positions outside the emitted
+//    matches: on repetitive data that cost 4-9 % of the ratio — html 4.15 against liblz4's 4.58 — and a coverage bitmap, a parity scan and a
+//    fourth meeting of the two wavefronts per round.  Every position entering the table at once: html 4.48, the corpus 1.850 -> 1.898.)
 // Long backward extensions are finished by the whole wavefront after the selection, literal runs of 256 bytes and more are copied
 // by the whole wavefront inside the flush; only a literal run of 64 KiB and more (an input above 64 KiB) sends its window down a serial path.
 #pragma once
@@ -34,7 +37,6 @@ namespace cj {
 #if defined(__HIPCC__)
 namespace enc2 {
 
-constexpr uint32_t kTail = 1u;                      // the last kTail positions of a match are inserted (text +1..3 %, benchmark data -0.1 % against none)
 constexpr uint32_t kQueueCap = 64u;
 constexpr uint32_t kFwdTrips = 8u;                  // forward measurement in the lanes: 32 bytes per round trip, 4 + 256 bytes at most
 constexpr uint32_t kGroupHeads = 4u;                // ... until at most this many heads of the window still match: those are finished four at a time, sixteen lanes each
@@ -111,14 +113,14 @@ __device__ __forceinline__ void lane_copy(gptr out, uint32_t o, gcptr in, uint32
 //   Fmt::emit_lane(in, out, o, lit0, lit, code, off) -> where its literals go   one lane writes one queued sequence at output offset o
 //                                               (the literal bytes themselves only below kLaneLit)
 //   Fmt::emit_wave(in, out, op, lit0, lit, off, mlen) -> new op   the whole wavefront writes one sequence of any size
-// kW = wavefronts per chunk (1 or 2).  With two, a round is 512 positions and wavefront w owns its group w of 256: both probe the table
-// as it was when the round began, measure their heads side by side, then select in position order — wavefront 0's heads, then
-// wavefront 1's (`cur`, the queue count and the output position travel through LDS) — and insert, group 0 first.  A wavefront issues
+// kW = wavefronts per chunk (1 or 2).  With two, a round is 512 positions and wavefront w owns its group w of 256: wavefront 0 probes and
+// inserts its two blocks, then wavefront 1 its two (one meeting in between); both measure their heads side by side, then select in position
+// order — wavefront 0's heads, then wavefront 1's (`cur`, the queue count and the output position travel through LDS).  A wavefront issues
 // one instruction per ~5 cycles whatever it holds (tools/issue_rate_probe.hip) and a CU's LDS holds nine tables: two wavefronts per
 // table are how the CU gets more instruction streams.  tests/hostsim/enc2_model.c with R = 512 states exactly what this computes.
 #ifdef CJ_ENC_PROFILE
 // phase cycle counters of the matcher (debug builds: tools/exp_r05_encprofile.sh): [0] rounds, [1] probe, [2] measure, [3] select + push,
-// [4] insert, [5] flushes (inside 3), [6] waiting for the other wavefront, [7] windows
+// [4] table reads + inserts (inside 1), [5] flushes (inside 3), [6] waiting for the other wavefront, [7] windows
 __device__ unsigned long long g_enc_prof[16];
 __device__ __forceinline__ uint64_t prof_now() { uint64_t t; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return t; }
 // (accumulated in registers, written once per chunk: an atomic per phase would sit in the next phase's vmcnt wait)
@@ -132,9 +134,8 @@ __device__ __forceinline__ uint64_t prof_now() { uint64_t t; asm volatile("s_wai
 template <class Fmt, int kW>
 struct Walk {
     static constexpr uint32_t kRound = 256u * kW;
-    // LDS scratch in dwords: heads (64 per wavefront) · toggle bitmap · queue (3 per entry) · shared scalars
-    static constexpr uint32_t kHeadsAt = 0u, kTogAt = 64u * kW, kQueueAt = kTogAt + 32u, kSharedAt = kQueueAt + 3u * kQueueCap, kWords = kSharedAt + 8u;
-    static_assert(kRound / 32u + 1u <= 32u, "toggle bitmap");
+    // LDS scratch in dwords: heads (64 per wavefront) · queue (3 per entry) · shared scalars
+    static constexpr uint32_t kHeadsAt = 0u, kQueueAt = 64u * kW, kSharedAt = kQueueAt + 3u * kQueueCap, kWords = kSharedAt + 8u;
 
     gcptr in;               // position 0 (start of the piece), uniform
     gptr out;               // uniform
@@ -177,8 +178,8 @@ struct Walk {
     }
 
     struct Heads {            // one wavefront's verified run heads of a round
-        uint32_t hs[4];       // hash slots of the lane's four positions
-        uint32_t dd[4];       // candidate distances (0: none)
+        uint32_t dd[4];       // candidate distances of the lane's four positions (0: none)
+        bool pre[4];          // has a candidate and is not a follower (same distance as its left neighbour)
         bool hd[4];           // is a verified head
         uint64_t hm[4];
         uint32_t total;
@@ -188,42 +189,66 @@ struct Walk {
         bool back_more;           // 16 bytes before the head matched and more literals may be pending: the selection decides whether it matters
     };
 
-    // probe the 256 positions gpos + 4 lane + k against the table
-    __device__ __forceinline__ void probe(uint32_t gpos, uint32_t round_last, uint32_t D0, uint32_t D1, Heads& h) {
+    // the table part of the probe: the 256 positions gpos + 4 lane + k read their slots and enter them, block by block (lanes 0-31, then
+    // lanes 32-63: a wavefront's DS operations execute in order, so the second block's reads see the first block's stores); within a
+    // block one store instruction per k, the highest lane winning a contested slot — the model's order
+    __device__ __forceinline__ void probe_table(uint32_t gpos, uint32_t round_last, uint32_t D0, uint32_t D1, uint32_t (&v)[4], Heads& h) {
         const uint32_t lane = lane_id();
-        uint32_t v[4], t[4];
+        uint32_t hs[4], t[4] = {0u, 0u, 0u, 0u};
         v[0] = D0;
         v[1] = __builtin_amdgcn_alignbyte(D1, D0, 1);
         v[2] = __builtin_amdgcn_alignbyte(D1, D0, 2);
         v[3] = __builtin_amdgcn_alignbyte(D1, D0, 3);
 #pragma unroll
-        for (int k = 0; k < 4; k++) { h.hs[k] = hash_slot(v[k]); t[k] = ht.get(h.hs[k]); }
-        // distance to the slot's position, modulo the 64 KiB lap of the 16-bit table; 0 = no candidate
+        for (int k = 0; k < 4; k++) hs[k] = hash_slot(v[k]);
+        const uint32_t p0 = gpos + 4u * lane;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t p = gpos + 4u * lane + k;
-            const uint32_t d = (p - t[k]) & 0xffffu;
-            h.dd[k] = (d != 0u && d <= p && p <= round_last) ? d : 0u;
+        for (int k = 0; k < 4; k++) h.dd[k] = 0u;
+#pragma unroll
+        for (int blk = 0; blk < 2; blk++) {
+            const bool mine = (lane >> 5) == (uint32_t)blk;
+            if (mine) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) t[k] = ht.get(hs[k]);
+            }
+            // distance to the slot's position, modulo the 64 KiB lap of the 16-bit table; 0 = no candidate
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t p = p0 + k;
+                const uint32_t d = (p - t[k]) & 0xffffu;
+                if (mine) h.dd[k] = (d != 0u && d <= p && p <= round_last) ? d : 0u;
+            }
+            // A FOLLOWER — same candidate distance as its left neighbour — lies inside that neighbour's match if it is one: it is neither
+            // verified (probe_verify) nor inserted.  (The DPP move runs with every lane: lane 32's left neighbour belongs to block 0.)
+            const uint32_t left0 = dpp_from<kDppWaveShr1>(0u, h.dd[3]);            // lane l - 1's last position; lane 0 of a group starts afresh
+            if (mine) {
+                h.pre[0] = h.dd[0] != 0u && h.dd[0] != left0;
+                h.pre[1] = h.dd[1] != 0u && h.dd[1] != h.dd[0];
+                h.pre[2] = h.dd[2] != 0u && h.dd[2] != h.dd[1];
+                h.pre[3] = h.dd[3] != 0u && h.dd[3] != h.dd[2];
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (p0 + k <= round_last && (h.dd[k] == 0u || h.pre[k])) ht.set(hs[k], p0 + k);
+            }
+            ht.settle();
         }
-        // Only the FIRST position of a run of equal distances is verified: its followers lie inside its match if it is one, and a
+    }
+
+    // the rest of the probe: candidate dwords, heads
+    __device__ __forceinline__ void probe_verify(uint32_t gpos, const uint32_t (&v)[4], Heads& h) {
+        const uint32_t lane = lane_id();
+        // Only the FIRST position of a run of equal distances (h.pre) is verified: its followers lie inside its match if it is one, and a
         // candidate dword is a scattered access — the vector memory path takes ~1.5 cycles per lane for those (64 lanes: ~94 cycles per
         // instruction and CU, tools/issue_rate_probe.hip).  On match-heavy data half of all positions are followers.
-        const uint32_t left0 = dpp_from<kDppWaveShr1>(0u, h.dd[3]);            // lane l - 1's last position; lane 0 of a group starts afresh
-        bool pre[4];
-        pre[0] = h.dd[0] != 0u && h.dd[0] != left0;
-        pre[1] = h.dd[1] != 0u && h.dd[1] != h.dd[0];
-        pre[2] = h.dd[2] != 0u && h.dd[2] != h.dd[1];
-        pre[3] = h.dd[3] != 0u && h.dd[3] != h.dd[2];
         uint32_t w[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             w[k] = ~v[k];
-            if (pre[k]) w[k] = g32(in, gpos + 4u * lane + k - h.dd[k]);
+            if (h.pre[k]) w[k] = g32(in, gpos + 4u * lane + k - h.dd[k]);
         }
         h.total = 0u;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            h.hd[k] = pre[k] && w[k] == v[k];
+            h.hd[k] = h.pre[k] && w[k] == v[k];
             h.hm[k] = bal(h.hd[k]);
             h.total += (uint32_t)__builtin_popcountll(h.hm[k]);
         }
@@ -335,8 +360,8 @@ struct Walk {
         m.back_more = back_more;
     }
 
-    // the greedy walk over one measured window, its sequences into the queue, its coverage into the toggle bitmap
-    __device__ __forceinline__ void select(const Meas& m, uint32_t pos, uint32_t& cur) {
+    // the greedy walk over one measured window, its sequences into the queue
+    __device__ __forceinline__ void select(const Meas& m, uint32_t& cur) {
         const uint32_t lane = lane_id();
         const uint32_t P = m.P, d = m.d, E = m.E, BS = m.BS;
         const uint32_t cur0 = cur;
@@ -398,13 +423,6 @@ struct Walk {
                     scr[slot] = PE;
                     scr[slot + 1u] = d | (lit << 16);
                     scr[slot + 2u] = code;
-                    // coverage toggles: positions s + 1 .. E - kTail - 1 (relative to pos, clamped to the round) are inside this match
-                    const uint32_t sx = s + 1u > pos ? s + 1u - pos : 0u;
-                    const uint32_t ex = umin(E - kTail - pos, kRound);                // (E - kTail may lie before pos: ex wraps — excluded below)
-                    if (E - kTail > pos && ex > sx) {
-                        atomicXor(&scr[kTogAt + (sx >> 5)], 1u << (sx & 31u));
-                        atomicXor(&scr[kTogAt + (ex >> 5)], 1u << (ex & 31u));
-                    }
                 }
                 q_n = uni(q_n + ns);
             }
@@ -427,39 +445,9 @@ struct Walk {
                 }
                 flush();
                 op = Fmt::emit_wave(in, out, op, cur, s - cur, di, Ei - s);
-                if (lane == 0u) {
-                    const uint32_t sx = s + 1u > pos ? s + 1u - pos : 0u;
-                    const uint32_t ex = umin(Ei - kTail - pos, kRound);
-                    if (Ei - kTail > pos && ex > sx) {
-                        scr[kTogAt + (sx >> 5)] ^= 1u << (sx & 31u);
-                        scr[kTogAt + (ex >> 5)] ^= 1u << (ex & 31u);
-                    }
-                }
                 cur = Ei;
             }
         }
-    }
-
-    // insert this wavefront's positions that are not inside an emitted match (the toggle bitmap holds where coverage begins and ends)
-    __device__ __forceinline__ void insert(const Heads& h, uint32_t gpos, uint32_t round_last) {
-        const uint32_t lane = lane_id();
-        uint32_t carry = 0;          // parity of the toggles of the groups before this one
-        if constexpr (kW > 1) {
-            const uint32_t lower = scr[kTogAt + (lane & 7u)];
-            carry = (uint32_t)__builtin_popcountll(bal(wv != 0u && lane < 8u && (__builtin_popcount(lower) & 1) != 0));
-        }
-        const uint32_t word = scr[kTogAt + 8u * wv + (lane >> 3)];
-        const uint32_t bits = (word >> (4u * (lane & 7u))) & 15u;
-        const uint32_t pre = bits ^ (bits << 1) ^ (bits << 2) ^ (bits << 3);               // bit k = parity of the toggles at positions 4 l .. 4 l + k
-        const uint64_t odd = bal((__builtin_popcount(bits) & 1) != 0);
-        const uint32_t before = (bits_below_lane(odd) + carry) & 1u;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t p = gpos + 4u * lane + k;
-            const bool covered = (((pre >> k) ^ before) & 1u) != 0u;
-            if (p <= round_last && !covered) ht.set(h.hs[k], p);
-        }
-        ht.settle();
     }
 
     // one round over [pos, pos + span); cur = end of the last selected match on entry and exit (the same in every wavefront of the chunk)
@@ -471,11 +459,15 @@ struct Walk {
         pos = uni(pos); span = uni(span);
         const uint32_t gpos = pos + 256u * wv;
         const uint32_t round_last = umin(last_start, pos + span - 1u);
-        CJ_PROF(6, meet());                                      // the previous round's insertions and toggle reads are done
         Heads h;
+        uint32_t v[4];
         CJ_PROF_COUNT(0, 1);
-        CJ_PROF(1, probe(gpos, round_last, D0, D1, h));
-        if (wv == 0u && lane < kRound / 32u + 1u) scr[kTogAt + lane] = 0u;      // this round's toggle bitmap
+        // the table, in position order: wavefront 0's two blocks, then wavefront 1's.  (Wavefront 1's stores of the PREVIOUS round lie
+        // before that round's turns in its program, and both wavefronts have met twice since: no meeting at the start of a round.)
+        if constexpr (kW > 1) { if (wv != 0u) CJ_PROF(6, meet()); }
+        CJ_PROF(4, probe_table(gpos, round_last, D0, D1, v, h));
+        if constexpr (kW > 1) { if (wv == 0u) meet(); }
+        CJ_PROF(1, probe_verify(gpos, v, h));
         // every wavefront measures its first window at once; then the turns: wavefront 0 selects (all its windows), then wavefront 1
         // (measuring a wavefront's first TWO windows ahead of the turns — text and tables have two to four — takes 96 registers and
         //  gives the corpus +2 %, synthetic data -2 %: r05 e32, not kept)
@@ -487,7 +479,7 @@ struct Walk {
             if constexpr (kW > 1) {
                 if (w0 == 0u && wv != 0u) { CJ_PROF(6, meet()); cur = uni(scr[kSharedAt]); q_n = uni(scr[kSharedAt + 1u]); op = uni(scr[kSharedAt + 2u]); }
             }
-            CJ_PROF(3, select(m, pos, cur));
+            CJ_PROF(3, select(m, cur));
         }
         if constexpr (kW > 1) {
             if (h.total == 0u && wv != 0u) { meet(); cur = uni(scr[kSharedAt]); q_n = uni(scr[kSharedAt + 1u]); op = uni(scr[kSharedAt + 2u]); }
@@ -497,10 +489,7 @@ struct Walk {
             if (wv == 0u) meet();
             meet();                                              // both turns are over
             cur = uni(scr[kSharedAt]); q_n = uni(scr[kSharedAt + 1u]); op = uni(scr[kSharedAt + 2u]);
-            if (wv != 0u) meet();                                // group 0 inserts first: the later group wins a contested slot
         }
-        CJ_PROF(4, insert(h, gpos, round_last));
-        if constexpr (kW > 1) { if (wv == 0u) meet(); }
         cur_io = cur;
     }
 
@@ -511,6 +500,7 @@ struct Walk {
         uint32_t pos = q0, cur = q0;
         uint32_t span = q0 == 0u ? 64u : kRound;      // short first rounds while the table is empty (a sub-piece's table is pre-indexed)
         uint32_t D0 = 0, D1 = 0, own_pos = ~0u;
+        meet();                                               // both wavefronts have cleared their half of the table
         while (pos <= last_start) {
             if (own_pos != pos) {
                 const uint32_t b = pos + 256u * wv + 4u * lane;

@@ -1,10 +1,13 @@
 /* enc2_model.c — scalar CPU statement of the round-based matcher of cramjam_amd/csrc/cj_enc2.hpp (TEST INFRASTRUCTURE).
  *
- * The GPU encoders are specified by this model: a round probes R consecutive positions against the hash table as it was when the
- * round began; only the HEADS of runs of equal candidate distances are verified and become candidates; every head is extended to its true length forwards and backwards; the heads are walked in
- * position order, greedily (the first head whose interval still has four bytes after the previous match ends wins); positions that
- * are not strictly inside an emitted match — its last TAIL positions count as outside — are inserted into the table.  tests/test_enc2_gpu.py asserts that the kernels emit
- * exactly these bytes, tests/test_enc2_model.py that the streams decode with the oracle and keep the CPU encoders' ratio.
+ * The GPU encoders are specified by this model: a round covers R consecutive positions in BLOCKS of 128 — a block's positions are probed
+ * against the hash table and then enter it (all but the followers of a run of equal candidate distances), before the next block is probed (round 6: the table a position sees is at most
+ * 128 positions stale; until round 5 a round probed the table as it was when the round began and inserted at its end, only the positions
+ * outside the emitted matches — html 4.15 -> 4.48, kppkn.gtb 2.08 -> 2.17, the whole corpus 1.850 -> 1.898 against liblz4's 1.906);
+ * only the HEADS of runs of equal candidate distances are verified and become candidates; every head is extended to its true length
+ * forwards and backwards; the heads are walked in position order, greedily (the first head whose interval still has four bytes after the
+ * previous match ends wins).  tests/test_enc2_gpu.py asserts that the kernels emit exactly these bytes, tests/test_enc2_model.py that the
+ * streams decode with the oracle and keep the CPU encoders' ratio — per file of the reference's corpus.
  */
 #include <stdint.h>
 #include <stddef.h>
@@ -14,7 +17,7 @@
 #define HASH_BITS 13
 #define HASH_SIZE (1u << HASH_BITS)
 #define RMAX 1024
-#define TAIL 1u
+#define BLOCK 128u
 
 static inline uint32_t ld32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
 static inline uint32_t hash_slot(uint32_t v) { return (v * 2654435761u) >> (32 - HASH_BITS); }
@@ -25,18 +28,31 @@ typedef struct { uint32_t s, e, off; } sel_t;
 static int model_round(const uint8_t* in, uint32_t n, uint16_t* tab, uint32_t pos, uint32_t span, uint32_t R, uint32_t last_start,
                        uint32_t limit, uint32_t* cur_io, sel_t* sel) {
     static uint32_t hs[RMAX], d[RMAX];
-    static uint8_t ok[RMAX], valid[RMAX], covered[RMAX];
+    static uint8_t ok[RMAX], valid[RMAX];
     (void)n;
     const uint32_t anchor = *cur_io;
-    /* candidates: the slot's position, as a distance modulo the 64 KiB lap of the 16-bit table */
-    for (uint32_t i = 0; i < R; i++) {
-        const uint32_t p = pos + i;
-        valid[i] = i < span && p <= last_start;
-        ok[i] = 0; d[i] = 0; covered[i] = 0;
-        if (!valid[i]) continue;
-        hs[i] = hash_slot(ld32(in + p));
-        const uint32_t dist = (p - tab[hs[i]]) & 0xffffu;
-        if (dist != 0u && dist <= p) d[i] = dist;
+    /* block by block: candidates (the slot's position, as a distance modulo the 64 KiB lap of the 16-bit table), then the block's own
+     * positions into the table — k-major (lane l owns positions 4 l + k of its group of 256, half a wavefront is a block): the kernel issues
+     * one store instruction per (block, k), and within an instruction the highest lane wins a contested slot */
+    for (uint32_t b0 = 0; b0 < R; b0 += BLOCK) {
+        for (uint32_t i = b0; i < b0 + BLOCK; i++) {
+            const uint32_t p = pos + i;
+            valid[i] = i < span && p <= last_start;
+            ok[i] = 0; d[i] = 0;
+            if (!valid[i]) continue;
+            hs[i] = hash_slot(ld32(in + p));
+            const uint32_t dist = (p - tab[hs[i]]) & 0xffffu;
+            if (dist != 0u && dist <= p) d[i] = dist;
+        }
+        /* ... except the FOLLOWERS: a position whose candidate distance equals its left neighbour's lies inside that neighbour's match if
+         * it is one — what the coverage rule of rounds 1-5 kept out of the table, decided here before anything is verified (benchmark
+         * data 1.616 -> 1.622, xml 4.31 -> 4.39; the corpus 1.898 -> 1.901) */
+        for (uint32_t k = 0; k < 4u; k++)
+            for (uint32_t i = b0 + k; i < b0 + BLOCK; i += 4u) {
+                if (!valid[i]) continue;
+                if (d[i] != 0u && (i & 255u) != 0u && d[i - 1] == d[i]) continue;
+                tab[hs[i]] = (uint16_t)(pos + i);
+            }
     }
     /* Only the FIRST position of a run of equal distances is verified (its left neighbour IN THE SAME GROUP OF 256 has another distance or
      * no candidate): the positions behind it lie inside its match if it is one, and a candidate dword costs a scattered memory access
@@ -62,18 +78,8 @@ static int model_round(const uint8_t* in, uint32_t n, uint16_t* tab, uint32_t po
         } else s = cur;
         if (e < s + 4u || s > last_start) continue;
         sel[ns].s = s; sel[ns].e = e; sel[ns].off = d[i]; ns++;
-        for (uint32_t k = 0; k < R; k++) if (pos + k > s && pos + k + TAIL < e) covered[k] = 1;
         cur = e;
     }
-    /* insertion: k-major order (lane l owns positions 4 l + k of every group of 256): the kernel issues one store instruction per
-     * (group, k), and within an instruction the highest lane wins a contested slot */
-    for (uint32_t g = 0; g < R; g += 256u)
-        for (uint32_t k = 0; k < 4u; k++)
-            for (uint32_t l = 0; l < 64u; l++) {
-                const uint32_t i = g + 4u * l + k;
-                if (i >= R || !valid[i]) continue;
-                if (!covered[i]) tab[hs[i]] = (uint16_t)(pos + i);
-            }
     *cur_io = cur;
     return ns;
 }

@@ -8,7 +8,7 @@ import pytest
 
 import oracle
 from enc2_cases import cases, synth
-from test_enc2_model import model_lib, model_lz4, model_snappy
+from test_enc2_model import corpus_files, model_lib, model_lz4, model_snappy
 
 pytestmark = pytest.mark.gpu
 
@@ -58,4 +58,17 @@ def test_every_copy_in_a_large_batch_emits_the_models_bytes(codec):
     res, outs = e.batch_host(codec, ENC, 0, raws, caps_for(codec, raws))
     bad = [i for i in range(n) if res[i] != len(want[i % U]) or bytes(outs[i]) != want[i % U]]
     assert not bad, (len(bad), bad[:8], [i % U for i in bad[:8]])
+    e.close()
+
+
+@pytest.mark.parametrize("codec", [LZ4, SNAPPY])
+def test_every_corpus_chunk_emits_the_models_bytes(codec):
+    """real data (the reference's benchmark corpus, every 64 KiB chunk that travels with the tests): the kernels' bytes are the model's, so the
+    per-file ratio bounds of tests/test_enc2_model.py hold for the GPU encoders"""
+    e = N.Engine(0)
+    raws = [c for _, chunks in corpus_files() for c in chunks]
+    want = expected(codec, raws)
+    res, outs = e.batch_host(codec, ENC, 0, raws, caps_for(codec, raws))
+    bad = [i for i in range(len(raws)) if res[i] != len(want[i]) or bytes(outs[i]) != want[i]]
+    assert not bad, (len(bad), bad[:8])
     e.close()

@@ -62,8 +62,9 @@ def test_lz4_compress_block_large(name, data, store_size):
     # to 32 MiB are cut into sub-pieces (16 or 4 wavefronts per 64 KiB, each pre-indexing what lies before it in the piece) —
     # a few percent of ratio at most
     pieces = [data[i:i + PIECE] for i in range(0, len(data), PIECE)]
-    # (+ 12 bytes per sub-piece: a run that liblz4 writes as ONE sequence is one sequence per sub-piece here)
-    assert len(body) <= 1.06 * sum(len(oracle.lz4_compress_raw(p)[1]) for p in pieces) + 12 * ((len(data) + 4095) // 4096) + 64
+    # (+ 16 bytes per sub-piece: a run that liblz4 writes as ONE sequence is one sequence per sub-piece here — 238 000 bytes of 300-byte
+    #  runs: 2 047 bytes against liblz4's 1 178; 12 until round 6, when a position still saw the table of the round's start: 1 812)
+    assert len(body) <= 1.06 * sum(len(oracle.lz4_compress_raw(p)[1]) for p in pieces) + 16 * ((len(data) + 4095) // 4096) + 64
 
 
 @pytest.mark.parametrize("name,data", CASES, ids=IDS)

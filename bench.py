@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--phase-profile", action="store_true", help="debug: per-phase cycle counters of the LDS decoder")
     ap.add_argument("--experiment-no-verify", action="store_true",
                     help="kernel experiments that deliberately produce wrong bytes (a phase switched off): skips the comparison and marks the line invalid")
+    ap.add_argument("--parse", default="auto", choices=["auto", "fused", "kernel"], help="debug: the workgroup decoder's parse stage inside the decoder kernel / as its own kernel at any batch size (CJ_FLAG_FORCE_FUSED_PARSE / _PARSE_KERNEL)")
     ap.add_argument("--lz4-mode", default="auto", choices=["auto", "wave", "lane", "lds"],
                     help="LZ4 decoder mapping override (results identical; auto = engine default)")
     return ap.parse_args()
@@ -320,7 +321,7 @@ def main():
     codec = N.CODEC_LZ4_BLOCK if args.codec == "lz4" else N.CODEC_SNAPPY_RAW
     dec = args.op in ("decompress", "roundtrip")
     mode_flag = {"auto": 0, "wave": N.FLAG_FORCE_WAVE_PER_CHUNK, "lane": N.FLAG_FORCE_LANE_PER_CHUNK,
-                 "lds": N.FLAG_FORCE_LDS_PER_CHUNK}[args.lz4_mode] | (0x1000 if args.phase_profile else 0) | (N.FLAG_BIG_CHUNKS if S > 65536 and args.lz4_mode == "auto" else 0)
+                 "lds": N.FLAG_FORCE_LDS_PER_CHUNK}[args.lz4_mode] | (0x1000 if args.phase_profile else 0) | {"auto": 0, "fused": N.FLAG_FORCE_FUSED_PARSE, "kernel": N.FLAG_FORCE_PARSE_KERNEL}[args.parse] | (N.FLAG_BIG_CHUNKS if S > 65536 and args.lz4_mode == "auto" else 0) | (N.FLAG_CHUNKS_LE_16K if S <= 16384 else N.FLAG_CHUNKS_LE_32K if S <= 32768 else 0)      # (what the caller of a device batch knows about its chunks)
 
     # ---- workload: distinct synth-v1 chunk indices per rank (rank r generates indices r*U .. r*U+U-1) ----
     first_index = rank * U

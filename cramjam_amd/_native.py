@@ -14,6 +14,8 @@ FLAG_FORCE_LANE_PER_CHUNK = 0x200
 FLAG_FORCE_LDS_PER_CHUNK = 0x400
 FLAG_FORCE_FUSED_PARSE = 0x10     # the workgroup decoder's parse stage inside the decoder kernel / as its own kernel, at any batch size
 FLAG_FORCE_PARSE_KERNEL = 0x20
+FLAG_CHUNKS_LE_32K = 0x40          # decompress: a promise that no chunk is larger (windows of that size: more workgroups per CU); host batches set them themselves
+FLAG_CHUNKS_LE_16K = 0x80
 FLAG_BIG_CHUNKS = 0x800            # decompress: reserve record areas for chunks of 64 KiB .. 256 KiB (cramjam_hip.h)
 E_NO_DEVICE = -100
 

@@ -41,13 +41,14 @@ void launch_lz4_parse(const BatchArgs& a, void* sync, void* meta, hipStream_t s)
 void launch_lz4_decode_routed(const BatchArgs& a, const void* meta, hipStream_t s);   // wave kernel on chunks the parse kernel routed to it
 // variant 2: persistent grid (2 workgroups per CU), record tables in the global scratch `tabs`, chunk indices from *counter
 // codec: CJ_CODEC_LZ4_BLOCK or CJ_CODEC_SNAPPY_RAW (only the record expansion D1 differs)
-void launch_lz4_decode_lds2(const BatchArgs& a, const void* sync, const void* meta, void* tabs, uint32_t* counter, uint32_t grid, hipStream_t s, int codec = 0);
+void launch_lz4_decode_lds2(const BatchArgs& a, const void* sync, const void* meta, void* tabs, uint32_t* counter, uint32_t grid, hipStream_t s, int codec = 0, uint32_t win = 65536u);
+uint32_t lz4_lds2_wgs_per_cu(uint32_t win);
 // linked LZ4-frame blocks: one workgroup walks the blocks of a frame in order, previous block kept as a second LDS window
 void launch_lz4_decode_lds2_linked(const BatchArgs& a, const void* sync, const void* meta, void* tabs, uint32_t* counter,
                                    const void* frames, uint32_t n_frames, uint32_t grid, hipStream_t s);
 // parse + decode in ONE kernel: the segmented parse runs inside the workgroup on the staged chunk; meta[c] = kRouteWave for chunks it leaves to the wave kernel
 void launch_lz4_decode_fused(const BatchArgs& a, void* meta, void* tabs, uint32_t* counter, uint32_t grid, hipStream_t s, int codec = 0);
-size_t lz4_lds2_tab_bytes(uint32_t grid);
+size_t lz4_lds2_tab_bytes(uint32_t grid, uint32_t win = 65536u);
 size_t lz4_lds_scratch_sync_bytes(size_t n_chunks);
 size_t lz4_lds_scratch_meta_bytes(size_t n_chunks);
 // encoders: one workgroup of two wavefronts per chunk (one wavefront per sub-piece of a split piece, large.hip)

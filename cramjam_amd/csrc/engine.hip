@@ -53,6 +53,9 @@ int lds_scratch(cj_engine* e, const cj::BatchArgs& a, hipStream_t s, bool with_s
 //   then               the wavefront-per-chunk kernel on what the parse left over (errors, chunks above 64 KiB, few long runs)
 //   flags              CJ_FLAG_FORCE_WAVE_PER_CHUNK / _LANE_PER_CHUNK: one mapping for every chunk (tests, comparisons)
 constexpr size_t kBigCap = 8192;
+// batches of small chunks (CJ_FLAG_CHUNKS_LE_*) take the parse kernel + small-window decoder from here on (profiles/r06/experiments w03:
+// 32 KiB chunks cross between 4 096 and 8 192, 16 KiB chunks at 2 048)
+constexpr uint32_t kSmallMinChunks32 = 6144, kSmallMinChunks16 = 2048;
 constexpr int kBigObs = 8;                // counts of big chunks the engine remembers (cj_engine::big_obs)
 
 // CJ_FLAG_BIG_CHUNKS: which chunks lie in (64 KiB, 256 KiB] is known on the device only (big_list_kernel), but the record areas
@@ -95,8 +98,11 @@ int plan_big(cj_engine* e, cj_codec codec, const cj::BatchArgs& a, hipStream_t s
     return 0;
 }          // big chunks (CJ_FLAG_BIG_CHUNKS) decoded per group: each holds a record area of 1 MiB while its group is in flight
 
-int launch_decode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a, hipStream_t s) {
+int launch_decode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a_in, hipStream_t s) {
     const bool lz4 = codec == CJ_CODEC_LZ4_BLOCK;
+    cj::BatchArgs a = a_in;                                   // the batch as the kernels see it (the window promise only where it applies)
+    const uint32_t small = a.flags & (CJ_FLAG_CHUNKS_LE_32K | CJ_FLAG_CHUNKS_LE_16K);
+    a.flags &= ~(CJ_FLAG_CHUNKS_LE_32K | CJ_FLAG_CHUNKS_LE_16K);
     int mode = 2;
     if (a.flags & CJ_FLAG_FORCE_WAVE_PER_CHUNK) mode = 0;
     if (a.flags & CJ_FLAG_FORCE_LANE_PER_CHUNK) mode = 1;
@@ -106,8 +112,13 @@ int launch_decode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a, hipStrea
     // the workgroup decoder (lz4_decode_lds.hip): its parse stage inside the decoder kernel for small batches, as a kernel of its own
     // in front of it for large ones (CJ_FLAG_FORCE_FUSED_PARSE / _PARSE_KERNEL: one of them at any batch size — tests, comparisons)
     bool fused = a.n_chunks <= (uint32_t)CJ_FUSED_MAX_CHUNKS;
+    // a batch of small chunks (CJ_FLAG_CHUNKS_LE_32K / _16K): the parse kernel + the decoder on windows of that size, from kSmallMinChunks32 / 16
+    // chunks on (below that the GPU is not full either way and the one-kernel path's latency counts)
+    if (small != 0u && a.n_chunks >= ((small & CJ_FLAG_CHUNKS_LE_16K) ? kSmallMinChunks16 : kSmallMinChunks32)) fused = false;
     if (a.flags & CJ_FLAG_FORCE_FUSED_PARSE) fused = true;
     if (a.flags & CJ_FLAG_FORCE_PARSE_KERNEL) fused = false;
+    if (!fused) a.flags |= small;
+    const uint32_t win = cj::lds_window(a.flags);
     std::lock_guard<std::mutex> lock(e->scratch_mu);
     // (first: it makes `s` wait for the previous user of the engine's shared scratch — the big-chunk list below is part of it)
     const int rc = lds_scratch(e, a, s, !fused);
@@ -119,7 +130,7 @@ int launch_decode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a, hipStrea
         if (brc != 0) return brc;
     }
     uint32_t* lists = (uint32_t*)e->d_lanelist.p;
-    const uint32_t grid = kWgsPerCu * (uint32_t)e->n_cu;          // two persistent workgroups per CU
+    const uint32_t grid = (win >= 65536u ? kWgsPerCu : cj::lz4_lds2_wgs_per_cu(win)) * (uint32_t)e->n_cu;          // persistent workgroups: two per CU on 64 KiB windows
     if (fused) {
         cj::launch_lz4_decode_fused(a, e->d_pmeta.p, e->d_tab.p, lists + 2, grid, s, codec);
     } else {
@@ -127,7 +138,7 @@ int launch_decode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a, hipStrea
         // validate, size, count sequences, sync points, route
         if (lz4) cj::launch_lz4_parse(a, e->d_sync.p, e->d_pmeta.p, s);
         else cj::launch_snappy_parse(a, e->d_sync.p, e->d_pmeta.p, s);
-        cj::launch_lz4_decode_lds2(a, e->d_sync.p, e->d_pmeta.p, e->d_tab.p, lists + 2, grid, s, codec);
+        cj::launch_lz4_decode_lds2(a, e->d_sync.p, e->d_pmeta.p, e->d_tab.p, lists + 2, grid, s, codec, win);
     }
     if (n_big != 0u) {
         // chunks of 64 KiB .. 256 KiB (flagged kRouteWave above): listed, parsed by 32 lanes each into records, decoded slab by slab
@@ -431,7 +442,7 @@ int cj_engine_device(const cj_engine* e) { return e ? e->device : -1; }
 
 // the flag bits a C-ABI caller may set; everything else (piece splitting, tail reports, linked-frame parse: cj_common.hpp) belongs
 // to large.hip / frame.hip, which call cj::launch directly — a stray bit would make a kernel read descriptors that are not there
-static constexpr uint32_t kPublicFlags = CJ_FLAG_LZ4_SIZE_PREFIX | CJ_FLAG_FORCE_FUSED_PARSE | CJ_FLAG_FORCE_PARSE_KERNEL | CJ_FLAG_FORCE_WAVE_PER_CHUNK | CJ_FLAG_FORCE_LANE_PER_CHUNK | CJ_FLAG_FORCE_LDS_PER_CHUNK | CJ_FLAG_BIG_CHUNKS
+static constexpr uint32_t kPublicFlags = CJ_FLAG_LZ4_SIZE_PREFIX | CJ_FLAG_FORCE_FUSED_PARSE | CJ_FLAG_FORCE_PARSE_KERNEL | CJ_FLAG_CHUNKS_LE_32K | CJ_FLAG_CHUNKS_LE_16K | CJ_FLAG_FORCE_WAVE_PER_CHUNK | CJ_FLAG_FORCE_LANE_PER_CHUNK | CJ_FLAG_FORCE_LDS_PER_CHUNK | CJ_FLAG_BIG_CHUNKS
                                          | CJ_FLAG_DEBUG_PROFILE;
 
 int cj_batch_device(cj_engine* e, cj_codec codec, cj_op op, uint32_t flags, size_t n_chunks,
@@ -518,6 +529,12 @@ int cj_batch_host(cj_engine* e, cj_codec codec, cj_op op, uint32_t flags, size_t
             if (u > (int64_t)kLargeMin && u <= (int64_t)(4u * 65536u)) { any_mid = true; break; }
         }
         if (any_mid) flags |= CJ_FLAG_BIG_CHUNKS;
+    }
+    if (op == CJ_OP_DECOMPRESS && n > 0) {                   // the capacities are on the host here: a batch of small chunks gets windows of its size
+        size_t cap_max = 0;
+        for (size_t i = 0; i < n; i++) cap_max = std::max(cap_max, out_caps[i]);
+        flags &= ~(CJ_FLAG_CHUNKS_LE_32K | CJ_FLAG_CHUNKS_LE_16K);
+        if (cap_max <= 16384) flags |= CJ_FLAG_CHUNKS_LE_16K; else if (cap_max <= 32768) flags |= CJ_FLAG_CHUNKS_LE_32K;
     }
     std::lock_guard<std::mutex> lock(e->mu);
     HIP_TRY(hipSetDevice(e->device), CJ_E_NO_DEVICE);

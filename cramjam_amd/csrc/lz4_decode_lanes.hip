@@ -57,6 +57,7 @@ __global__ __launch_bounds__(64 * kParseWaves) void lz4_parse_kernel(BatchArgs a
     int64_t r = 0;
     bool done = true;
     const bool linked = (a.flags & kFlagLinkedFrame) != 0u;
+    const uint32_t win = lds_window(a.flags);                // the decoder's window for this batch
     uint32_t hist = 0;
     if (exists) {
         in0 = in = a.in_base + a.in_off[c];
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(64 * kParseWaves) void lz4_parse_kernel(BatchArgs a
             const uint32_t cap0 = (uint32_t)cap64, iend0 = (uint32_t)n64;
             if (cap0 == 0) r = (iend0 == 1 && in[0] == 0) ? 0 : (int64_t)CJ_E_CORRUPT;
             else if (iend0 == 0) r = CJ_E_CORRUPT;
-            else if (cap0 > kLdsOutMax || iend0 > kLdsInMax) { r = 0; pm.in_skip = kRouteWave; }   // too big for LDS: wave kernel decodes + validates
+            else if (cap0 > win || iend0 > win - 32u) { r = 0; pm.in_skip = kRouteWave; }   // too big for LDS: wave kernel decodes + validates
             else done = false;
         }
     }
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(64 * kParseWaves) void lz4_parse_kernel(BatchArgs a
                 r = (int64_t)op;
                 done = true;
                 if (r > 0) {
-                    if ((nseq + kSyncEvery - 1u) / kSyncEvery > kSyncStride || (nseq < kLdsMinSeq && !linked)) pm.in_skip = kRouteWave;
+                    if (nseq > lds_window_max_seq(win) || (nseq < lds_window_min_seq(win) && !linked)) pm.in_skip = kRouteWave;
                     else { pm.nseq = nseq; pm.in_skip = (uint32_t)(in - in0); }
                 }
             }

@@ -75,6 +75,10 @@ constexpr uint32_t kD2LongRun = CJ_D2_LONG;      // literal runs at least this l
 #ifndef CJ_DENSE_LANES
 #define CJ_DENSE_LANES 24u
 #endif
+// the record table of a workgroup (16-byte units) by window: the 8-byte records of a chunk + sentinel, then the 16-byte records the forwarding phase appends (at most two per forwarded record)
+constexpr uint32_t lds2_tab_records(uint32_t win) {
+    return win >= 65536u ? 3u * kSyncStride * kSyncEvery : (lds_window_max_seq(win) + 1u) / 2u + 64u + 2u * (6144u * (win / 1024u) / 64u) + 64u;
+}
 constexpr uint32_t kL2TabRecords = 3u * kSyncStride * kSyncEvery;   // records of a chunk (the parse kernel routes chunks with more than 16 384 sequences elsewhere) + the extra literal copies of D1f (at most two per record, D1f takes at most 6 144 records)
 
 
@@ -146,7 +150,9 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
     // (these shadow the file's defaults: everything below is written in terms of them)
     constexpr uint32_t kL2Threads = kThreadsT, kL2OffBits = kWinT, kL2BitWords = kWinT / 32u, kL2Bytes = lds2_bytes(kWinT);
     constexpr uint32_t kFwdMaxRecords = 6144u * (kWinT / 1024u) / 64u;      // D1f: 10 bytes of index per record in the window
-    constexpr uint32_t kWinInMax = kWinT - 32u;                             // compressed bytes staged in the window (<= 15 B misalignment + 15 B round-up)
+    constexpr uint32_t kFwdNear = (uint32_t)CJ_FWD_NEAR * (kWinT / 1024u) / 64u;      // ... for chunks of mostly NEAR matches: a sixteenth of the window (16 KiB chunks have no others below 4 096)
+    constexpr uint32_t kWinInMax = kWinT - 32u;
+    constexpr uint32_t kMaxSeqT = lds_window_max_seq(kWinT);                // records of a chunk (the parse kernels route chunks with more elsewhere)                             // compressed bytes staged in the window (<= 15 B misalignment + 15 B round-up)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr uint32_t kOffBits = kLinked ? 131072u : kL2OffBits, kOffVars = kOffBits + (kLinked ? 8192u : kL2OffBits / 8u);
     constexpr uint32_t kBitWords = kLinked ? 2048u : kL2BitWords;
@@ -159,7 +165,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
     const Dummies dm = {(uint32_t)(uintptr_t)(smem + kOffVars + 64u) + (threadIdx.x & 63u),
                         (uint32_t)(uintptr_t)(smem + kOffVars + 128u) + 4u * (threadIdx.x & 63u)};
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    uint4* table = tabs + (size_t)blockIdx.x * (kSlab ? sl.tab_stride : kL2TabRecords);
+    uint4* table = tabs + (size_t)blockIdx.x * (kSlab ? sl.tab_stride : lds2_tab_records(kWinT));
     // Batches of independent chunks keep 8-BYTE records: { lit_src | lit << 16, lit_start | offset << 16 } — the match
     // destination is lit_start + lit and the match length is the NEXT record's lit_start minus that (mod 2^16: a chunk of exactly
     // 64 KiB ends at position 0x10000), a sentinel { 0, U } follows the last record.  Half the table traffic of the 16-byte
@@ -167,7 +173,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
     // and moved out of position order).  Records appended by the forwarding phase (literal copies, out of position order)
     // keep the 16-byte form in their own region of the slot.
     constexpr bool kCompact = !kSlab && !kLinked;
-    constexpr uint32_t kExtraBase = (kSyncStride * kSyncEvery + 1u) / 2u + 64u;      // first 16-byte slot behind the 8-byte records (+ sentinel)
+    constexpr uint32_t kExtraBase = (kMaxSeqT + 1u) / 2u + 64u;      // first 16-byte slot behind the 8-byte records (+ sentinel)
     uint2* table2 = reinterpret_cast<uint2*>(table);
     const auto rec_store = [&](uint32_t i, uint32_t lit_src, uint32_t lit, uint32_t dst, uint32_t w) {      // a record in position order
         if constexpr (kCompact) table2[i] = make_uint2(lit_src | (lit << 16), ((dst - lit) & 0xffffu) | ((w & 0xffffu) << 16));
@@ -675,7 +681,8 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             // mostly near matches: the chains are deep, forwarding pays (it costs ~25 k cycles + 10 k per round).  kSlab: always
             // when the slab waits for bytes of earlier slabs — the forwarding runs before that wait, what it removes from
             // the dependency depth comes off the serial chain through the slabs
-            if (nseq <= kFwdMaxRecords && staged && (*s_small * CJ_FWD_SHARE_NUM > nseq || (kSlab && *s_ncross > 0u))) {
+            // (batches: only chunks that fill more than half of the window — in a small chunk every match is near, and its chains are short)
+            if (nseq <= kFwdMaxRecords && staged && ((*s_small * CJ_FWD_SHARE_NUM > nseq && (kSlab || U > 8u * kFwdNear)) || (kSlab && *s_ncross > 0u))) {
                 uint32_t* f_w0 = reinterpret_cast<uint32_t*>(s_out);
                 uint32_t* f_st = f_w0 + kFwdMaxRecords;
                 uint16_t* f_ls = reinterpret_cast<uint16_t*>(f_st + kFwdMaxRecords);      // literal source of every record (16 bits: the chunk is staged)
@@ -1349,11 +1356,11 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
     }
 }
 
-template <int kCodec, bool kLinked = false>
-__global__ __launch_bounds__(kL2Threads) CJ_L2_ATTR void lz4_decode_lds2_kernel(BatchArgs a, const uint2* sync, const ParseMeta* meta,
+template <int kCodec, bool kLinked = false, uint32_t kWin = CJ_L2_WINDOW, uint32_t kThreads = CJ_L2_THREADS>
+__global__ __launch_bounds__(kThreads) CJ_L2_ATTR void lz4_decode_lds2_kernel(BatchArgs a, const uint2* sync, const ParseMeta* meta,
                                                                      uint4* tabs, uint32_t* counter,
                                                                      const uint2* frames, uint32_t n_frames) {
-    lds2_body<kCodec, kLinked, false>(a, sync, meta, tabs, counter, frames, n_frames, SlabArgs{nullptr, nullptr, 0u, 0u, 0u, nullptr, 0u});
+    lds2_body<kCodec, kLinked, false, false, false, kWin, kThreads>(a, sync, meta, tabs, counter, frames, n_frames, SlabArgs{nullptr, nullptr, 0u, 0u, 0u, nullptr, 0u});
 }
 
 // the slab mode carries the cross-list copy inside D3's loop: capped at 128 VGPRs so that two workgroups still share a CU
@@ -1408,26 +1415,30 @@ void launch_lz4_decode_big_slabs(const BatchArgs& items, const void* meta, const
     hipLaunchKernelGGL((lz4_decode_bigslabs_kernel<CJ_CODEC_LZ4_BLOCK>), dim3(grid), dim3(kBigSlabThreads), bytes, s, items, (const ParseMeta*)meta, (uint4*)tabs, counter, sl, fd);
 }
 
-size_t lz4_lds2_tab_bytes(uint32_t grid) { return (size_t)grid * kL2TabRecords * sizeof(uint4); }
+size_t lz4_lds2_tab_bytes(uint32_t grid, uint32_t win) { return (size_t)grid * lds2_tab_records(win) * sizeof(uint4); }
+// workgroups per CU by window: what 160 KiB of LDS hold, at 16 wavefronts of 128 registers per CU either way
+uint32_t lz4_lds2_wgs_per_cu(uint32_t win) { return win >= 65536u ? 2u : win >= 32768u ? 4u : 8u; }
 
-void launch_lz4_decode_lds2(const BatchArgs& a, const void* sync, const void* meta, void* tabs, uint32_t* counter,
-                            uint32_t grid, hipStream_t s, int codec) {
-    if (a.n_chunks == 0) return;
+template <int kCodec, uint32_t kWin, uint32_t kThreads>
+static void launch_lds2_window(const BatchArgs& a, const void* sync, const void* meta, void* tabs, uint32_t* counter, uint32_t grid, hipStream_t s) {
 #ifndef CJ_L2_LDS_PAD
 #define CJ_L2_LDS_PAD 0u                  // (tuning variants: unused LDS per workgroup, to hold the workgroups per CU below what the window alone allows)
 #endif
-    constexpr uint32_t bytes = kL2Bytes + CJ_L2_LDS_PAD;
-    if (codec == CJ_CODEC_SNAPPY_RAW) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_lds2_kernel<CJ_CODEC_SNAPPY_RAW, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        hipLaunchKernelGGL((lz4_decode_lds2_kernel<CJ_CODEC_SNAPPY_RAW, false>), dim3(grid), dim3(kL2Threads), bytes, s, a,
-                           (const uint2*)sync, (const ParseMeta*)meta, (uint4*)tabs, counter, (const uint2*)nullptr, 0u);
-        return;
-    }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_lds2_kernel<CJ_CODEC_LZ4_BLOCK, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    hipLaunchKernelGGL((lz4_decode_lds2_kernel<CJ_CODEC_LZ4_BLOCK, false>), dim3(grid), dim3(kL2Threads), bytes, s, a,
-                       (const uint2*)sync, (const ParseMeta*)meta, (uint4*)tabs, counter, (const uint2*)nullptr, 0u);
+    constexpr uint32_t bytes = lds2_bytes(kWin) + CJ_L2_LDS_PAD;
+    const auto k = lz4_decode_lds2_kernel<kCodec, false, kWin, kThreads>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), bytes, s, a, (const uint2*)sync, (const ParseMeta*)meta, (uint4*)tabs, counter, (const uint2*)nullptr, 0u);
+}
+
+// win: the window of this batch (lds_window(flags): 64 KiB, or 32 / 16 KiB for batches of small chunks — four workgroups of four
+// wavefronts / eight of two per CU; profiles/r06/experiments h01-h04)
+void launch_lz4_decode_lds2(const BatchArgs& a, const void* sync, const void* meta, void* tabs, uint32_t* counter,
+                            uint32_t grid, hipStream_t s, int codec, uint32_t win) {
+    if (a.n_chunks == 0) return;
+    const bool sn = codec == CJ_CODEC_SNAPPY_RAW;
+    if (win >= 65536u) { if (sn) launch_lds2_window<CJ_CODEC_SNAPPY_RAW, CJ_L2_WINDOW, CJ_L2_THREADS>(a, sync, meta, tabs, counter, grid, s); else launch_lds2_window<CJ_CODEC_LZ4_BLOCK, CJ_L2_WINDOW, CJ_L2_THREADS>(a, sync, meta, tabs, counter, grid, s); }
+    else if (win >= 32768u) { if (sn) launch_lds2_window<CJ_CODEC_SNAPPY_RAW, 32768u, 256u>(a, sync, meta, tabs, counter, grid, s); else launch_lds2_window<CJ_CODEC_LZ4_BLOCK, 32768u, 256u>(a, sync, meta, tabs, counter, grid, s); }
+    else { if (sn) launch_lds2_window<CJ_CODEC_SNAPPY_RAW, 16384u, 128u>(a, sync, meta, tabs, counter, grid, s); else launch_lds2_window<CJ_CODEC_LZ4_BLOCK, 16384u, 128u>(a, sync, meta, tabs, counter, grid, s); }
 }
 
 void launch_lz4_decode_lds2_linked(const BatchArgs& a, const void* sync, const void* meta, void* tabs, uint32_t* counter,

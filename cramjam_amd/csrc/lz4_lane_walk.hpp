@@ -22,6 +22,13 @@ constexpr uint32_t kSyncStride = 2048;    // sync points reserved per chunk (=> 
 constexpr uint32_t kLdsOutMax = CJ_L2_WINDOW;    // the LDS decoder holds at most this much output ...
 constexpr uint32_t kLdsInMax = CJ_L2_WINDOW - 32;     // ... and this much compressed input: variant 2 stages it in the 64 KiB output window (<= 15 B misalignment + 15 B round-up)
 
+// The window of the workgroup decoder for a batch (CJ_FLAG_CHUNKS_LE_32K / _16K, set by the engine for the parse + decode pipeline only):
+// what the parse kernels route by — capacity and compressed size the window holds, the sequence counts its record table is sized for
+// (an LZ4 sequence with a match covers four bytes) and below which a chunk of few long runs is quicker on one wavefront.
+__host__ __device__ inline uint32_t lds_window(uint32_t flags) { return (flags & CJ_FLAG_CHUNKS_LE_16K) ? 16384u : (flags & CJ_FLAG_CHUNKS_LE_32K) ? 32768u : kLdsOutMax; }
+__host__ __device__ constexpr uint32_t lds_window_max_seq(uint32_t win) { return win >= 65536u ? kSyncStride * kSyncEvery : win / 4u; }
+__host__ __device__ constexpr uint32_t lds_window_min_seq(uint32_t win) { return win >= 65536u ? 256u : win / 256u; }
+
 struct ParseMeta {       // one per chunk, written by lz4_parse_kernel
     uint32_t nseq;       // sequences incl. the final literal-only one; 0 = nothing left for the LDS decoder
     uint32_t in_skip;    // low bits: 4 when a size prefix was consumed; kRouteWave: decode with the wave-per-chunk kernel

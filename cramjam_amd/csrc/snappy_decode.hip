@@ -232,6 +232,7 @@ __global__ __launch_bounds__(64 * kParseWaves) void snappy_parse_kernel(BatchArg
     int64_t r = 0;
     bool done = true;
     uint32_t dn = 0, hdr = 0;
+    const uint32_t win = lds_window(a.flags);                // the decoder's window for this batch
     if (exists) {
         in = a.in_base + a.in_off[c];
         n64 = a.in_len[c];
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(64 * kParseWaves) void snappy_parse_kernel(BatchArg
             if (!ok) r = CJ_E_SNAPPY_HEADER;
             else if (ulen > 0xFFFFFFFFull) r = CJ_E_SNAPPY_TOO_BIG;
             else if (ulen > cap64) r = CJ_E_SNAPPY_BUF_SMALL;
-            else if (ulen > kLdsOutMax || n64 - hdr > kLdsInMax || ulen == 0) {
+            else if (ulen > win || n64 - hdr > win - 32u || ulen == 0) {
                 if (ulen == 0) r = (hdr == (uint32_t)n64) ? 0 : (int64_t)CJ_E_SNAPPY_CORRUPT;   // nothing to decode: trailing elements are errors
                 else pm.in_skip = kRouteWave;              // too big for the LDS window: the wave kernel decodes + validates
             } else { dn = (uint32_t)ulen; done = false; }
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(64 * kParseWaves) void snappy_parse_kernel(BatchArg
                 if (op != dn) r = CJ_E_SNAPPY_CORRUPT;
                 else {
                     r = (int64_t)dn;
-                    if ((nrec + kSyncEvery - 1u) / kSyncEvery > kSyncStride || nrec < kLdsMinSeq) pm.in_skip = kRouteWave;
+                    if (nrec > lds_window_max_seq(win) || nrec < lds_window_min_seq(win)) pm.in_skip = kRouteWave;
                     else { pm.nseq = nrec; pm.in_skip = hdr; }
                 }
             }

@@ -166,6 +166,12 @@ typedef enum { CJ_OP_DECOMPRESS = 0, CJ_OP_COMPRESS = 1 } cj_op;
  * it, at any batch size (default: by CJ_FUSED_MAX_CHUNKS below).  Tests exercise both sides of the threshold with them. */
 #define CJ_FLAG_FORCE_FUSED_PARSE   0x10u
 #define CJ_FLAG_FORCE_PARSE_KERNEL  0x20u
+/* decompress, a promise about the batch: every chunk's output capacity (LZ4) / announced length (Snappy) is at most 32 KiB / 16 KiB.
+ * The workgroup decoder then runs on windows of that size — four workgroups of four wavefronts / eight of two per CU instead of two of
+ * eight: more chunks' dependency chains in flight for the same wavefronts (32 KiB chunks 635 -> 850 GB/s, 16 KiB 430 -> 810).  A chunk
+ * that breaks the promise is still decoded correctly (one wavefront).  cj_batch_host sets them itself. */
+#define CJ_FLAG_CHUNKS_LE_32K       0x40u
+#define CJ_FLAG_CHUNKS_LE_16K       0x80u
 /* decompress: the batch may hold chunks of 64 KiB .. 256 KiB (capacity / announced length) and they matter — the engine lists them on
  * the device, parses them with 32 lanes each into record areas (1 MiB per listed chunk, groups of up to 8 192) and decodes them slab by
  * slab with workgroups.  How many there are is known on the device only: every flagged call copies its count back

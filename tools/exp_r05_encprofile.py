@@ -39,7 +39,7 @@ for rep in range(2):
 L.cj_debug_enc_profile(buf, 0)
 v = list(buf)
 rounds = max(v[0], 1)
-names = ["rounds", "probe", "measure", "select+push", "insert", "flush (in select)", "waiting for the other wave", "windows"]
+names = ["rounds", "probe (verify)", "measure", "select+push", "table reads + inserts", "flush (in select)", "waiting for the other wave", "windows"]
 print("%s, blocks/CU %s: rounds per chunk %.1f (wave-rounds), windows per round %.2f" % (os.environ.get("CORPUS_FILE") or "synth-v1", os.environ.get("CJ_ENC_BLOCKS", "default"), v[0] / n, v[7] / rounds))
 print("  heads per window %.1f, selection passes per window %.2f, windows that took the serial walk %.2f %%" % (v[10] / max(v[7], 1), v[8] / max(v[7], 1), 100.0 * v[9] / max(v[7], 1)))
 print("  cycles per wave-round: " + ", ".join("%s %.0f" % (names[i], v[i] / rounds) for i in (1, 2, 3, 4, 5, 6)) + ", sum %.0f" % (sum(v[i] for i in (1, 2, 3, 4, 6)) / rounds))

@@ -39,9 +39,11 @@ namespace enc2 {
 
 constexpr uint32_t kQueueCap = 64u;
 constexpr uint32_t kFwdTrips = 8u;                  // forward measurement in the lanes: 32 bytes per round trip, 4 + 256 bytes at most
+constexpr uint32_t kLeaderMin = 4u;
+constexpr uint32_t kLeaders = 6u;                     // long heads finished one at a time by the whole wavefront, each killing the long heads it outlives
 constexpr uint32_t kGroupHeads = 4u;                // ... until at most this many heads of the window still match: those are finished four at a time, sixteen lanes each
 #ifndef CJ_SEL_PASSES
-#define CJ_SEL_PASSES 8
+#define CJ_SEL_PASSES 16
 #endif
 constexpr uint32_t kSelPasses = CJ_SEL_PASSES;                // parallel selection passes before a window falls back to the serial walk
 constexpr uint32_t kLaneLit = 256u;                 // a lane copies its sequence's literals itself below this; longer runs are copied by the whole wavefront after the lanes' pass
@@ -298,7 +300,51 @@ struct Walk {
                 while (back < blim && g8(in, P - 1u - back) == g8(in, C - 1u - back)) back += 1u;
             }
         }
+        // LEADERS (round 6).  Real data is full of long matches whose heads lie INSIDE each other — a run of a thousand zeros is fifty
+        // heads of this window, every one of them a match to the end of the run — and a head whose match ends no later than an earlier
+        // head's is never selected (if that one is selected `cur` has passed it; if not, `cur` was already within four bytes of its end).
+        // So the first long head is finished by the whole wavefront (1 KiB per round trip), and every later long head that starts before
+        // its end E is asked ONE byte: does its own candidate still match AT E?  If not it ends at or before E: dead, without ever being
+        // measured (the groups below took four of them at a time, 256 bytes per head and trip: mr, kppkn, geo, html spent 12-24 k of a
+        // round's 30-37 k cycles there, profiles/r06/experiments e02).  Exact: only heads that can never be selected are dropped.
+        uint32_t E_lead = 0u;                                    // finished leaders' ends (their lanes only)
+        bool led = false;
+        for (uint32_t ld = 0; ld < kLeaders; ld++) {
+            const uint64_t mm = bal(is_head && more);
+            if ((uint32_t)__builtin_popcountll(mm) < 2u) break;
+            const uint32_t i = ctz64(mm);
+            const uint32_t j0 = rdlane(a + fwd, i), di = rdlane(d, i);
+            // ... only where it pays: at least kLeaderMin other long heads start inside the 36 bytes of this one that are already known to
+            // match (a run, a repeated record).  Text has long matches too, but side by side: a leader's serial round trips would only
+            // delay the trips below, which take all of them at once (alice29 7.6 k -> 8.8 k cycles of a round with unconditional leaders).
+            if ((uint32_t)__builtin_popcountll(bal(is_head && more && lane != i && P < j0)) < kLeaderMin) break;
+            uint32_t cnt = 0;
+            for (;;) {                                           // the whole wavefront, 16 bytes per lane
+                const uint32_t j = j0 + cnt + 16u * lane;
+                uint32_t e = 0;
+                if (j < limit) {
+                    if (j + 16u <= n) e = first_diff(g128(in, j), g128(in, j - di));
+                    else while (e < 16u && j + e < n && g8(in, j + e) == g8(in, j + e - di)) e += 1u;
+                    e = umin(e, limit - j);
+                }
+                const uint64_t full = bal(e == 16u);
+                if (full == ~0ull) { cnt += 1024u; continue; }
+                const uint32_t first = ctz64(~full);
+                cnt += 16u * first + rdlane(e, first);
+                break;
+            }
+            const uint32_t Ei = umin(j0 + cnt, limit);           // (uniform; the first round trip may already have run past the limit)
+            if (lane == i) { E_lead = Ei; led = true; more = false; }
+            // the later long heads that start before Ei: one byte at Ei (none there when Ei is the limit of an input that ends with it)
+            const bool ask = is_head && more && P < Ei;
+            if (bal(ask) != 0ull) {
+                bool alive = false;
+                if (ask && Ei < n) alive = g8(in, Ei) == g8(in, Ei - d);
+                if (ask && !alive) { more = false; E_lead = 0u; led = true; }          // dead: E = 0 below
+            }
+        }
         // the rest: matches beyond 4 + 32 bytes two blocks per round trip, the last 16 bytes of the input byte by byte
+        // (four blocks per trip — 64 bytes, 88 registers — measured no faster on any corpus file: r06 e05)
         for (uint32_t it = 1; it < kFwdTrips; it++) {
             if ((uint32_t)__builtin_popcountll(bal(more)) <= kGroupHeads) break;      // few enough for the groups below (or none)
             const bool b0 = more && a + fwd + 16u <= n, b1 = more && a + fwd + 32u <= n;
@@ -318,6 +364,7 @@ struct Walk {
         }
         if (a + fwd >= limit) { fwd = limit - a; more = false; }      // (a <= limit: P <= last_start)
         uint32_t E = is_head ? a + fwd : 0u;                      // E = 0: never selected
+        if (led) E = E_lead;                                      // a finished leader's end, or 0 for a head a leader has outlived
         // longer matches (repeated records, runs): FOUR heads at a time, sixteen lanes each — 256 bytes per head and round trip.  (One
         // head at a time by the whole wavefront made every long match of a window a round trip of its own: geo.protodata, xml and
         // mr spent half of a round there, r05 e27.)

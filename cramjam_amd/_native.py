@@ -101,6 +101,12 @@ def check(rc):
         raise EngineError("%s (%s)" % (strerror(rc), lib().cj_last_hip_error().decode()))
 
 
+def _with_hip_error(ex):
+    """the host module's message; the HIP error text of THIS library's thread-local slot when the call went through its entry point"""
+    msg = str(ex)
+    return msg if msg.endswith(")") else "%s (%s)" % (msg, lib().cj_last_hip_error().decode())
+
+
 def _batch_host_addr():
     """address of cj_batch_host in the library the engines of this process come from (CJ_HIP_LIB may name a tuning variant; the
     CPython module links the product library)"""
@@ -168,7 +174,7 @@ class Engine:
         try:
             return _cramjam.batch_host(self.h.value or 0, int(codec), int(op), int(flags), inputs, out_caps, _batch_host_addr())
         except RuntimeError as ex:                  # (a CJ_E_* return code of the call itself, not of a chunk)
-            raise EngineError(str(ex)) from None
+            raise EngineError(_with_hip_error(ex)) from None
 
     def batch_host_into(self, codec, op, flags, inputs, out_caps, out, offsets=None):
         """the same batch into ONE writable buffer (bytearray, numpy array, ...): chunk i at out[offsets[i] : offsets[i] + out_caps[i]],
@@ -177,5 +183,5 @@ class Engine:
         try:
             return _cramjam.batch_host_into(self.h.value or 0, int(codec), int(op), int(flags), inputs, out_caps, out, offsets, _batch_host_addr())
         except RuntimeError as ex:
-            raise EngineError(str(ex)) from None
+            raise EngineError(_with_hip_error(ex)) from None
 

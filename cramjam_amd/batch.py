@@ -140,7 +140,8 @@ class _DevView:
                     raise ValueError("cramjam_amd.batch: device buffers must be contiguous")
             self.ptr = int(cai["data"][0]) if self.count else 0
             dev = getattr(obj, "device", None)
-            self.device = getattr(dev, "index", None) if dev is not None else None
+            # torch: .device.index; cupy: .device.id (round-5 advisor: a cupy buffer on GPU N fell back to engine 0)
+            self.device = (getattr(dev, "index", None) if getattr(dev, "index", None) is not None else getattr(dev, "id", None)) if dev is not None else None
         elif hasattr(obj, "__dlpack__"):
             cap = obj.__dlpack__()
             api = _C.pythonapi

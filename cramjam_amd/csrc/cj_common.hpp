@@ -52,7 +52,7 @@ size_t lz4_lds2_tab_bytes(uint32_t grid, uint32_t win = 65536u);
 size_t lz4_lds_scratch_sync_bytes(size_t n_chunks);
 size_t lz4_lds_scratch_meta_bytes(size_t n_chunks);
 // encoders: one workgroup of two wavefronts per chunk (one wavefront per sub-piece of a split piece, large.hip)
-void launch_lz4_encode(const BatchArgs& a, hipStream_t s);
+hipError_t launch_lz4_encode(const BatchArgs& a, hipStream_t s);
 void launch_snappy_decode(const BatchArgs& a, hipStream_t s);                                   // one wavefront per chunk
 void launch_snappy_decode_lanes(const BatchArgs& a, hipStream_t s);                            // one lane per chunk
 void launch_snappy_parse(const BatchArgs& a, void* sync, void* meta, hipStream_t s);
@@ -72,7 +72,7 @@ void launch_lz4_decode_lds2_slabs(const BatchArgs& a, const void* sync, const vo
                                   const void* first, uint32_t stream_len, uint32_t* done, void* cross, uint32_t tab_stride,
                                   uint32_t cross_stride, uint32_t grid, hipStream_t s, int codec, bool rel = false);
 void launch_snappy_decode_routed(const BatchArgs& a, const void* meta, hipStream_t s);       // wave kernel on chunks the parse kernel routed to it
-void launch_snappy_encode(const BatchArgs& a, hipStream_t s);
+hipError_t launch_snappy_encode(const BatchArgs& a, hipStream_t s);
 
 #if defined(__HIPCC__)
 

@@ -180,7 +180,7 @@ int launch_decode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a_in, hipSt
 
 // LZ4 block / Snappy raw encode of a batch of independent chunks: one workgroup of two wavefronts per chunk (lz4_encode.hip)
 int launch_encode(cj_engine*, cj_codec codec, const cj::BatchArgs& a, hipStream_t s) {
-    if (codec == CJ_CODEC_LZ4_BLOCK) cj::launch_lz4_encode(a, s); else cj::launch_snappy_encode(a, s);
+    HIP_TRY(codec == CJ_CODEC_LZ4_BLOCK ? cj::launch_lz4_encode(a, s) : cj::launch_snappy_encode(a, s), CJ_E_NO_DEVICE);
     return 0;
 }
 

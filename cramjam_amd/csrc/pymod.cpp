@@ -1366,7 +1366,10 @@ PyObject* root_batch_host(PyObject*, PyObject* args) {
     for (Py_ssize_t i = 0; i < got; i++) PyBuffer_Release(&views[(size_t)i]);
     Py_DECREF(inputs); Py_DECREF(caps);
     if (ok && rc != 0) {
-        PyErr_Format(PyExc_RuntimeError, "cramjam_hip error %d: %s (%s)", rc, cj_strerror(rc), cj_last_hip_error());
+        // (the HIP error text is thread-local PER LIBRARY: through a tuning variant's entry point it lies in that library, and the caller —
+        //  cramjam_amd/_native.py, which holds the variant's handle — appends it; round-5 advisor)
+        if (fn_addr) PyErr_Format(PyExc_RuntimeError, "cramjam_hip error %d: %s", rc, cj_strerror(rc));
+        else PyErr_Format(PyExc_RuntimeError, "cramjam_hip error %d: %s (%s)", rc, cj_strerror(rc), cj_last_hip_error());
         ok = false;
     }
     PyObject* results = ok ? PyList_New(n) : nullptr;
@@ -1433,7 +1436,10 @@ PyObject* root_batch_host_into(PyObject*, PyObject* args) {
     for (Py_ssize_t i = 0; i < got; i++) PyBuffer_Release(&views[(size_t)i]);
     PyBuffer_Release(&ob);
     Py_XDECREF(inputs); Py_XDECREF(caps); Py_XDECREF(offs);
-    if (ok && rc != 0) { PyErr_Format(PyExc_RuntimeError, "cramjam_hip error %d: %s (%s)", rc, cj_strerror(rc), cj_last_hip_error()); ok = false; }
+    if (ok && rc != 0) { // (the HIP error text is thread-local PER LIBRARY: through a tuning variant's entry point it lies in that library, and the caller —
+        //  cramjam_amd/_native.py, which holds the variant's handle — appends it; round-5 advisor)
+        if (fn_addr) PyErr_Format(PyExc_RuntimeError, "cramjam_hip error %d: %s", rc, cj_strerror(rc));
+        else PyErr_Format(PyExc_RuntimeError, "cramjam_hip error %d: %s (%s)", rc, cj_strerror(rc), cj_last_hip_error()); ok = false; }
     if (!ok) return nullptr;
     PyObject* results = PyList_New(n);
     if (!results) return nullptr;

@@ -158,10 +158,21 @@ __global__ __launch_bounds__(64 * kW) void snappy_encode_kernel(BatchArgs a) {
 // register budget).  The sub-pieces of split pieces (large.hip: 4 / 16 KiB each, pre-indexed tables) take one wavefront.
 constexpr int kEncWaves = 2;
 
-void launch_snappy_encode(const BatchArgs& a, hipStream_t s) {
-    if (a.n_chunks == 0) return;
-    if (a.flags & kFlagSplitPieces) hipLaunchKernelGGL((snappy_encode_kernel<true, 1>), dim3(a.n_chunks), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL((snappy_encode_kernel<false, kEncWaves>), dim3(a.n_chunks), dim3(64 * kEncWaves), 0, s, a);
+// One workgroup per chunk, in grids of at most kEncGrid chunks: HIP refuses a grid of 2^32 threads or more (33.5 M chunks of 128), and the
+// batch API takes up to 0xFFFFFFF0.  Returns hipSuccess or the launch's error (round-5 advisor: the launch result was never looked at).
+hipError_t launch_snappy_encode(const BatchArgs& a, hipStream_t s) {
+    constexpr uint32_t kEncGrid = 1u << 24;
+    for (uint32_t start = 0; start < a.n_chunks; start += kEncGrid) {
+        BatchArgs b = a;
+        b.in_off += start; b.in_len += start; b.out_off += start; b.out_cap += start; b.result += start;
+        b.n_chunks = a.n_chunks - start < kEncGrid ? a.n_chunks - start : kEncGrid;
+        // (sub-pieces of a split piece are indexed from their piece's first one: a slice starts on a piece boundary — kEncGrid is a multiple of every split)
+        if (a.flags & kFlagSplitPieces) hipLaunchKernelGGL((snappy_encode_kernel<true, 1>), dim3(b.n_chunks), dim3(64), 0, s, b);
+        else hipLaunchKernelGGL((snappy_encode_kernel<false, kEncWaves>), dim3(b.n_chunks), dim3(64 * kEncWaves), 0, s, b);
+        const hipError_t err = hipGetLastError();
+        if (err != hipSuccess) return err;
+    }
+    return hipSuccess;
 }
 
 }  // namespace cj

@@ -393,7 +393,7 @@ def main():
         nb = max(int(ph[5]), 1)
         if int(ph[5]):
             print("LDS decoder cycles/chunk: S0 %d  D1 %d  D2 %d  D3 %d  D4 %d  (blocks %d)  sub-marks 6.. %s" % (
-                ph[0] // nb, ph[1] // nb, ph[2] // nb, ph[3] // nb, ph[4] // nb, nb, [int(ph[i] // nb) for i in range(6, 16)]), file=sys.stderr)
+                ph[0] // nb, ph[1] // nb, ph[2] // nb, ph[3] // nb, ph[4] // nb, nb, [round(ph[i] / nb, 2) for i in range(6, 16)]), file=sys.stderr)
 
     # ---- verify at full size: every chunk's result and every output byte ----
     bytes_in = sum(b.bytes_in for b in batches)

@@ -143,16 +143,17 @@ def run_batch(cases, seed, verbose=False):
         codec = rnd.choice((N.CODEC_LZ4_BLOCK, N.CODEC_SNAPPY_RAW))
         lz = codec == N.CODEC_LZ4_BLOCK
         streams, caps, want = [], [], []
-        for _ in range(rnd.choice((1, 7, 300, 2500))):
-            n = rnd.randrange(1, 65537) if rnd.randrange(3) else 65536
+        maxn = int(os.environ.get("MAXCHUNK", "65536"))          # 32768 / 16384: the batches take the small-window decoders (the host batch sets the flags itself)
+        for _ in range(rnd.choice((1, 7, 300, 2500) if maxn == 65536 else (1, 300, 2500, 7000))):
+            n = rnd.randrange(1, maxn + 1) if rnd.randrange(3) else maxn
             o = rnd.randrange(len(pool) - n)
             data = pool[o:o + n] if rnd.randrange(6) else rnd.randbytes(n)
             blob = (oracle.lz4_compress_raw if lz else oracle.snappy_compress)(data)[1]
             m = mutate(blob)[0] if rnd.randrange(8) and len(blob) > 8 else blob
-            cap = n if rnd.randrange(5) else rnd.randrange(1, 65537)
+            cap = n if rnd.randrange(5) else rnd.randrange(1, maxn + 1)
             streams.append(m); caps.append(cap)
             want.append(oracle.lz4_decompress_raw(m, cap) if lz else oracle.snappy_decompress(m, cap))
-        flag = rnd.choice((0, 0, N.FLAG_FORCE_WAVE_PER_CHUNK, N.FLAG_FORCE_LANE_PER_CHUNK if lz else 0, N.FLAG_FORCE_LDS_PER_CHUNK))
+        flag = rnd.choice((0, 0, N.FLAG_FORCE_WAVE_PER_CHUNK, N.FLAG_FORCE_LANE_PER_CHUNK if lz else 0, N.FLAG_FORCE_LDS_PER_CHUNK, N.FLAG_FORCE_PARSE_KERNEL, N.FLAG_FORCE_FUSED_PARSE))
         res, outs = eng.batch_host(codec, N.OP_DECOMPRESS, flag, streams, caps)
         for i, ((er, eo), r, o) in enumerate(zip(want, res, outs)):
             if (er < 0) != (r < 0) or (er >= 0 and (r != er or o != eo)): bad.append(("lz4" if lz else "snappy", flag, i, len(streams), er, r)); break

@@ -1,7 +1,7 @@
 # Round-end evidence run (on the GPU box): gpu tests, the default bench line (it measures its HBM traffic itself with two
 # rocprofv3 --pmc child runs), rocprofv3 kernel stats of the same command, SQ / LDS counters, and the secondary-path bench lines.
 # Outputs land in gpurun_out/<tag>/; copy the summaries into profiles/rNN/.
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
 O=gpurun_out/$TAG; rm -rf $O; mkdir -p $O
@@ -31,7 +31,7 @@ PY
 # the corpus lines carry their own traffic and cpu_baseline (all 20 files, liblz4 / libsnappy streams)
 python bench.py --data corpus64k --steps 20 --traffic on --cpu-seconds 10 2>/dev/null | tail -1 >> $O/other_paths.jsonl
 python bench.py --data corpus64k --codec snappy --steps 20 --traffic on --cpu-seconds 10 2>/dev/null | tail -1 >> $O/other_paths.jsonl
-for args in "--codec snappy" "--op compress" "--op compress --codec snappy" "--codec snappy --op roundtrip" "--chunks 1000000 --steps 20" "--workload mixed256k --steps 20" "--codec lz4 --chunk-bytes 262144 --chunks 8192 --unique 2048 --steps 20" "--codec snappy --chunk-bytes 262144 --chunks 8192 --unique 2048 --steps 20" "--chunks 8192 --unique 2048" "--chunks 1024 --unique 1024" "--op compress --data corpus64k --steps 10" "--op compress --data corpus64k --codec snappy --steps 10"; do
+for args in "--codec snappy" "--op compress" "--op compress --codec snappy" "--codec snappy --op roundtrip" "--chunks 1000000 --steps 20" "--workload mixed256k --steps 20" "--codec lz4 --chunk-bytes 262144 --chunks 8192 --unique 2048 --steps 20" "--codec snappy --chunk-bytes 262144 --chunks 8192 --unique 2048 --steps 20" "--chunks 8192 --unique 2048" "--chunks 1024 --unique 1024" "--chunk-bytes 32768 --chunks 200000" "--chunk-bytes 16384 --chunks 400000" "--codec snappy --chunk-bytes 32768 --chunks 200000" "--codec snappy --chunk-bytes 16384 --chunks 400000" "--chunk-bytes 32768 --chunks 16384 --unique 2048" "--chunk-bytes 16384 --chunks 16384 --unique 2048" "--op compress --data corpus64k --steps 10" "--op compress --data corpus64k --codec snappy --steps 10"; do
   python bench.py --cpu-seconds 6 --traffic off $args 2>/dev/null | tail -1 >> $O/other_paths.jsonl
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_mixed -- python bench.py --workload mixed256k --no-cpu-baseline --traffic off --steps 10 > $O/stats_mixed.log 2>&1
@@ -41,6 +41,5 @@ import json
 for l in open('$O/other_paths.jsonl'):
     d=json.loads(l); print('%-95s %8.1f GB/s  %8.3f ms/step  frac %.4f' % (d['config']['workload'][:95], d['value'], d['ms_per_step'], d['roofline']['frac']))
 PY
-N=20000 timeout 1500 python tests/perf/fuzz_enc2.py 2>&1 | tail -2 > $O/fuzz_enc2.txt; cat $O/fuzz_enc2.txt
 timeout 600 python tests/perf/device_api_rate.py 2>&1 | tail -3 > $O/device_api_rate.txt; cat $O/device_api_rate.txt
 rm -rf $O/stats $O/sq $O/sq2 $O/sq3_lz4 $O/sq3_snappy $O/stats_enc $O/stats_mixed

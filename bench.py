@@ -465,6 +465,8 @@ def main():
             "config": {"workload": workload, "chunks_per_gpu": NCH, "chunk_bytes": S, "unique_chunks": U, "ratio": round(ratio, 4),
                        "compressed_by": " | ".join(sorted({b.comp_name for b in batches if b.comp_name})) or None,
                        "batches_in_flight": len(lanes),
+                       # (S > 64 KiB: what the engines hold for the big-chunk path — list, record areas of 1 MiB per planned chunk, summaries, slab tables — next to the bytes a step decodes)
+                       **({"big_chunk_scratch_bytes": int(sum(L.cj_debug_big_scratch_bytes(b.eng.h) for b in batches)), "output_bytes_per_step": int(total_unc // world)} if S > 65536 and dec else {}),
                        "sharding": "chunk i -> gpu (i mod N), no collective; " + ("rank r generates synth-v1 indices r*%d .. r*%d+%d" % (U, U, U - 1) if corpus_files is None else "every rank tiles the same corpus chunks"),
                        "verified": "NOT VERIFIED (--experiment-no-verify): this line is INVALID as a result" if args.experiment_no_verify else
                                    ("all results + all output bytes compared on device" if dec and rt is None else

@@ -65,6 +65,7 @@ BENCH_SYMBOLS = {
     "cj_debug_lds_phase_cycles": (_int, [_vp, _int]),
     "cj_debug_linked_lds_frames": (C.c_ulonglong, []),
     "cj_debug_forwarded_chunks": (C.c_longlong, [_int]),
+    "cj_debug_fused_parse_paths": (_int, [_vp, _int]),
     "cj_debug_big_parse": (C.c_int64, [_int, _u32, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
     "cj_bench_compare": (_int, [_vp, _vp, _vp, C.c_uint64, _u32, C.c_uint64, _u32, _vp, _vp]),
     "cj_debug_big_scratch_bytes": (C.c_uint64, [_vp]),

@@ -482,6 +482,38 @@ constexpr uint32_t kFusedLanes = CJ_FUSED_LANES;          // every thread of the
 constexpr uint32_t kFusedAux = 6144u;                               // merge, next, mark, entry (16 bits per lane each) + totals: behind the decoder's LDS
 static_assert(4u * kFusedLanes * 2u + 128u <= kFusedAux, "aux");
 
+// The walked elements are LISTED (round 6, f04): every step of P1a / P1b also stores what it read — a 12-byte cell { lit_at | lit << 16,
+// mlen | offset << 16, output bytes of the lane's walk before the step } — into the workgroup's table slot, row = the loop's iteration,
+// column = the lane (one coalesced store per wavefront and step; P1b's rows follow the longest P1a of the workgroup).  A piece of the true
+// path is a suffix of its lane's list: it begins at the P1a step that stood on the piece's entry position, and that step's number is the
+// count of the lane's own marks below the entry.  P3 therefore is a subtraction, and P4 needs no walk either: a listed element's output
+// position is the piece's base + the difference of two "output before" words, so every cell is checked and written on its own.  The pieces
+// are cut into GROUPS of four cells, the groups go to a work list in LDS, and every thread takes groups off it — four loads that depend
+// on nothing, then four checks — whatever lane walked them.  (r05 f02 / r06 f04: the walks run at the pace of the workgroup's slowest
+// lane, and a lane whose neighbours' guesses never meet the true path walks 40 .. 90 elements: P1a 11 k, P1b 29 k, P3 24 k, P4 57 k
+// cycles of the fused kernel's 200 k per chunk; listed: P1a 16 k, P1b 41 k, P3 4.5 k, P4 31 k — profiles/r06/experiments f04.)  A chunk
+// whose walks outgrow the rows takes the walking P3 / P4 below, one with more groups than the work list holds (16 384 sequences in
+// pieces of 4 k + 1: out of reach in practice) the walking P4: slower, same records.
+#ifndef CJ_FUSED_LIST
+#define CJ_FUSED_LIST 1
+#endif
+#ifndef CJ_FUSED_ROWS
+#define CJ_FUSED_ROWS 144u
+#endif
+constexpr uint32_t kFlRows = CJ_FUSED_ROWS;                         // (at most 255: step numbers travel in 8 bits)
+constexpr uint32_t kFlBase = 33792u;                                // the lists' place in the slot, in 4-byte units: behind the chunk's records + sentinel (132 KiB; the forwarding phase's extras come later, when the lists are dead)
+#ifndef CJ_FUSED_GROUP
+#define CJ_FUSED_GROUP 4u
+#endif
+#ifndef CJ_FUSED_MAX_GROUPS
+#define CJ_FUSED_MAX_GROUPS 4096u
+#endif
+constexpr uint32_t kFlGroup = CJ_FUSED_GROUP, kFlMaxGroups = CJ_FUSED_MAX_GROUPS;   // cells per group; the work list (16-bit entries: lane | group of its piece << 9) lives in the bitmap's 8 KiB
+static_assert(kFlRows / kFlGroup < 128u, "a piece's group number fits 7 bits");
+static_assert(kFlRows < 256u && (kFlBase + 3u * kFlRows * kFusedLanes) * 4u <= 4u * 16384u * 16u, "the lists fit the table slot of a 64 KiB window");
+struct FlCell { uint32_t x, y, ob; };
+__device__ unsigned long long g_fused_paths[4];          // test hook: chunks whose P3 / P4 came from the lists, walked P4 only, walked both
+
 __device__ __forceinline__ uint32_t wave_excl_scan_add32(uint32_t v, uint32_t& total) {
     const uint32_t lane = lane_id();
     uint32_t x = v;
@@ -498,8 +530,13 @@ __device__ __forceinline__ uint32_t wave_excl_scan_add32(uint32_t v, uint32_t& t
 // On success: nseq_out / U_out, *near_out += matches with an offset below kFwdNear.  Every thread of the workgroup calls it.
 template <class G, uint32_t kThreads>
 __device__ __forceinline__ bool fused_parse(uint32_t a_in, uint32_t iend, uint32_t cap, uint32_t* bits, uint32_t* aux, uint2* table2,
-                                            uint32_t* s_near, uint32_t& nseq_out, uint32_t& U_out) {
+                                            uint32_t* s_near, uint32_t& nseq_out, uint32_t& U_out, uint32_t* sub_prof = nullptr) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    // (CJ_FLAG_DEBUG_PROFILE: cycles of P1a, P1b, P2, P3 + scan, P4 as thread 0 sees them, barriers included -> sub-marks 6 .. 10)
+    unsigned long long t_sub = sub_prof ? __builtin_readcyclecounter() : 0ull;
+    const auto sub_mark = [&](uint32_t k) {
+        if (sub_prof && tid == 0) { const unsigned long long now = __builtin_readcyclecounter(); sub_prof[k] += (uint32_t)(now - t_sub); t_sub = now; }
+    };
     // (positions fit 16 bits: a staged chunk ends below 65 520; 0xFFFF / 0xFFFE stand for kPosErr / kPosEnd)
     uint16_t* s_merge = reinterpret_cast<uint16_t*>(aux);
     uint16_t* s_next = s_merge + kFusedLanes;
@@ -516,40 +553,72 @@ __device__ __forceinline__ bool fused_parse(uint32_t a_in, uint32_t iend, uint32
     const uint32_t seg = (((iend + nl - 1u) / nl + 3u) & ~3u) | 4u;          // 4 x odd: the lanes' start positions spread over the banks
     const bool active = plane && tid < nl && tid * seg < iend;
     const uint32_t seg_end = (tid + 1u) * seg;
-    if (tid < 32u) s_tot[tid] = 0u;
+    if (tid < 24u) s_tot[tid] = 0u;                       // ([24..32): every wavefront's P1a iterations, stored unconditionally)
 
     // ---- P1a ----
     uint32_t p = active ? tid * seg : kPosEnd;
     WalkCarry wc = {0u, 0xFFFFFFFFu};                     // (the walks carry the next element's first bytes: one dependent read per element)
+    uint32_t* const fl_c = reinterpret_cast<uint32_t*>(table2) + kFlBase;      // cell (row, lane) at fl_c + 3 * (row * kFusedLanes + lane)
+    uint32_t fl_na = 0, fl_nb = 0, fl_op = 0;             // listed steps of P1a / P1b, output bytes of the walk so far
+    uint32_t fl_ita = 0, fl_itb = 0, fl_rowb = 0;         // this wavefront's iterations of P1a / P1b, P1b's first row
+    const auto fl_put = [&](uint32_t row, const Seq& sq) {
+        const bool rep = sq.lit <= 0xffffu && sq.mlen <= 0xffffu && sq.offset <= 0xffffu;      // anything else cannot be part of a chunk of at most 64 KiB: P4 refuses it
+        FlCell c;
+        c.x = rep ? sq.lit_at | (sq.lit << 16) : 0xFFFFFFFFu; c.y = rep ? sq.mlen | (sq.offset << 16) : 0xFFFFFFFFu; c.ob = fl_op;
+        __builtin_memcpy(fl_c + 3u * (row * kFusedLanes + tid), &c, 12);
+        fl_op += sq.lit + sq.mlen;
+    };
     if (plane) {
+        uint32_t it = 0;
         while (ballot64(p < seg_end && p < iend) != 0ull) {
             if (p < seg_end && p < iend) {
                 asm volatile("ds_or_b32 %0, %1" :: "v"(a_bits + 4u * (p >> 5)), "v"(1u << (p & 31u)) : "memory");
                 Seq sq;
-                p = walk_step_carry<G>(rd, rd8, p, iend, sq, wc, true) ? sq.next : kPosErr;
+                const bool ok = walk_step_carry<G>(rd, rd8, p, iend, sq, wc, true);
+#if CJ_FUSED_LIST
+                if (ok && it < kFlRows) { fl_put(it, sq); fl_na += 1; }
+#endif
+                p = ok ? sq.next : kPosErr;
             }
+            it += 1;
         }
+        fl_ita = it;
+        if (lane == 0) s_tot[24u + wave] = it;
     }
     __syncthreads();
+    sub_mark(6u);
+#if CJ_FUSED_LIST
+    for (uint32_t w = 0; w < kFusedLanes / 64u; w++) fl_rowb = fl_rowb > s_tot[24u + w] ? fl_rowb : s_tot[24u + w];
+#endif
     // ---- P1b ----
     uint32_t merge_pos = p;
     if (plane) {
         bool going = active && p < iend;
+        uint32_t it = 0;
         while (ballot64(going) != 0ull) {
             if (going) {
                 // the mark word and the element travel together (the step is thrown away where the position is marked)
                 uint32_t w;
                 asm volatile("ds_read_b32 %0, %1" : "=v"(w) : "v"(a_bits + 4u * (p >> 5)) : "memory");
                 Seq sq;
-                const uint32_t nx = walk_step_carry<G>(rd, rd8, p, iend, sq, wc, true) ? sq.next : kPosErr;
+                const bool ok = walk_step_carry<G>(rd, rd8, p, iend, sq, wc, true);
+                const uint32_t nx = ok ? sq.next : kPosErr;
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w) :: "memory");
                 if ((w >> (p & 31u)) & 1u) { merge_pos = p; going = false; }
                 else {
+#if CJ_FUSED_LIST
+                    if (ok && fl_rowb + it < kFlRows) { fl_put(fl_rowb + it, sq); fl_nb += 1; }
+#endif
                     p = nx;
                     if (p >= iend) { merge_pos = p; going = false; }
                 }
             }
+            it += 1;
         }
+#if CJ_FUSED_LIST
+        fl_itb = it;
+        if (fl_rowb + it > kFlRows && lane == 0) atomicOr(&s_tot[20], 1u);      // (s_tot was zeroed in front of the barrier behind P1a)
+#endif
         if (active && merge_pos >= iend && merge_pos != kPosEnd) merge_pos = kPosErr;
         const uint32_t nx0 = merge_pos < iend ? merge_pos / seg : tid;       // a piece that ends the stream points at itself
         s_merge[tid] = (uint16_t)(merge_pos >= 0xFFFEu ? (merge_pos == kPosEnd ? 0xFFFEu : 0xFFFFu) : merge_pos);
@@ -558,6 +627,7 @@ __device__ __forceinline__ bool fused_parse(uint32_t a_in, uint32_t iend, uint32
         s_entry[tid] = 0u;
     }
     __syncthreads();
+    sub_mark(7u);
     // ---- P2: mark the chain from lane 0 by pointer doubling ----
     for (uint32_t round = 0; (1u << round) < kFusedLanes; round++) {
         uint32_t n1 = 0, n2 = 0;
@@ -576,11 +646,113 @@ __device__ __forceinline__ bool fused_parse(uint32_t a_in, uint32_t iend, uint32
         if (on_chain && merge_pos < iend) s_entry[merge_pos / seg] = (uint16_t)merge_pos;
     }
     __syncthreads();
+    sub_mark(8u);
     const uint32_t entry = plane ? s_entry[tid] : 0u;       // lane 0 enters at 0
     const uint32_t piece_end = merge_pos;
 
     // ---- P3: count ----
     uint32_t cnt = 0, outb = 0;
+    uint32_t base_idx = 0, base_op = 0, total_seq = 0;
+    bool p4_done = false;
+#if CJ_FUSED_LIST
+    const bool use_list = s_tot[20] == 0u;                  // (uniform; written before the barrier in front of P2)
+    if (sub_prof && tid == 0 && use_list) sub_prof[11] += 1000u;       // (sub-mark 11: chunks on the list path, per mille)
+    if (use_list) {
+        // the lane's list: steps 0 .. fl_na - 1 in rows 0 .., steps fl_na .. in rows fl_rowb ..
+        const uint32_t fl_n = fl_na + fl_nb;
+        const auto fl_at = [&](uint32_t l2, uint32_t jj, uint32_t na) { return fl_c + 3u * ((jj < na ? jj : fl_rowb + (jj - na)) * kFusedLanes + l2); };
+        uint32_t fl_k = 0, fl_ob = 0;                        // the piece's first step, the walk's output bytes before it
+        if (plane) {
+            if (on_chain) {
+                // the step that stood on `entry` = the number of this lane's marks below it (only the segment's own lane marks in it, in walk order)
+                const uint32_t lo = tid * seg, hi = entry, w0 = lo >> 5;
+                uint32_t mk[6];
+#pragma unroll
+                for (uint32_t u = 0; u < 6u; u++) mk[u] = bits[(w0 + u) < 2047u ? (w0 + u) : 2047u];
+#pragma unroll
+                for (uint32_t u = 0; u < 6u; u++) {
+                    const uint32_t b0 = (w0 + u) * 32u;
+                    uint32_t m = b0 < lo ? ~0u << (lo - b0) : ~0u;
+                    if (b0 + 32u > hi) m &= hi > b0 ? (1u << (hi - b0)) - 1u : 0u;
+                    fl_k += (uint32_t)__builtin_popcount(mk[u] & m);
+                }
+                if (fl_k > fl_n) fl_k = fl_n;              // (cannot happen: every mark below the entry has its listed step)
+                cnt = fl_n - fl_k;
+                if (cnt) { fl_ob = fl_at(tid, fl_k, fl_na)[2]; outb = fl_op - fl_ob; }
+            }
+            uint32_t tc, tb;
+            base_idx = wave_excl_scan_add32(cnt, tc);
+            base_op = wave_excl_scan_add32(outb, tb);
+            if (lane == 0) { s_tot[wave] = tc; s_tot[8u + wave] = tb; }
+        }
+        __syncthreads();
+        sub_mark(9u);
+        if (plane) {
+            for (uint32_t w = 0; w < wave; w++) { base_idx += s_tot[w]; base_op += s_tot[8u + w]; }
+        }
+        for (uint32_t w = 0; w < kFusedLanes / 64u; w++) total_seq += s_tot[w];
+        if (total_seq < kLdsMinSeq || total_seq > kSyncStride * kSyncEvery) return false;       // uniform: too few / too many sequences for this decoder
+        // P4 from the lists.  LDS: the work list in the bitmap's space (every lane has counted its marks: the barrier above), the pieces'
+        // parameters in the lane arrays of P1 / P2 (dead: merge_pos and entry are in registers) — { first record (15) | first step (8) |
+        // steps of P1a (8) | ends the stream (1), output position of the piece - output before its first step (17) | steps (8) }
+        uint16_t* wl = reinterpret_cast<uint16_t*>(bits);
+        uint2* info = reinterpret_cast<uint2*>(aux);
+        if (plane) {
+            const uint32_t ng = (cnt + kFlGroup - 1u) / kFlGroup;
+            if (ng != 0u) {
+                const uint32_t at = atomicAdd(&s_tot[21], ng);
+                if (at + ng <= kFlMaxGroups) { for (uint32_t g = 0; g < ng; g++) wl[at + g] = (uint16_t)(tid | (g << 9)); }
+            }
+            info[tid] = make_uint2(base_idx | (fl_k << 15) | (fl_na << 23) | ((merge_pos == kPosEnd ? 1u : 0u) << 31), ((base_op - fl_ob) & 0x1ffffu) | (fl_n << 17));
+        }
+        __syncthreads();
+        sub_mark(12u);
+        const uint32_t n_groups = s_tot[21];
+        if (n_groups <= kFlMaxGroups) {                      // (uniform; more groups than the list holds: the walking P4 below)
+            p4_done = true;
+            if (tid == 0) atomicAdd(&g_fused_paths[0], 1ull);
+            if (plane) {
+                bool bad = false;
+                uint32_t near = 0;
+                for (uint32_t gi = tid; gi < n_groups; gi += kFusedLanes) {
+                    const uint32_t we = wl[gi], l2 = we & 511u;
+                    const uint2 pi = info[l2];
+                    const uint32_t bidx = pi.x & 0x7fffu, pk = (pi.x >> 15) & 0xffu, pna = (pi.x >> 23) & 0xffu, pn = pi.y >> 17, opd = pi.y & 0x1ffffu;
+                    const bool ends = (pi.x >> 31) != 0u;            // the lane's last step consumed the input exactly
+                    const uint32_t j0 = pk + kFlGroup * (we >> 9);
+                    FlCell c[kFlGroup] = {};
+#pragma unroll
+                    for (uint32_t u = 0; u < kFlGroup; u++) if (j0 + u < pn) __builtin_memcpy(&c[u], fl_at(l2, j0 + u, pna), 12);
+#pragma unroll
+                    for (uint32_t u = 0; u < kFlGroup; u++) {
+                        const uint32_t jj = j0 + u;
+                        if (jj < pn) {
+                            Seq sq;
+                            sq.lit_at = c[u].x & 0xffffu; sq.lit = c[u].x >> 16; sq.mlen = c[u].y & 0xffffu; sq.offset = c[u].y >> 16;
+                            sq.last = ends && jj + 1u == pn; sq.next = 0u;
+                            // (mod 2^17: exact wherever the position is at most `cap`; the first cell of a chunk that is not fails its own check)
+                            const uint32_t idx = bidx + (jj - pk), op = (opd + c[u].ob) & 0x1ffffu;
+                            bool fin = false;
+                            uint32_t op2 = op;
+                            if ((c[u].x & c[u].y) == 0xFFFFFFFFu || op > cap || !G::check(sq, op2, cap, fin) || idx >= total_seq) bad = true;
+                            else {
+                                const uint32_t w = sq.mlen == 0u ? 0u : (sq.offset | (sq.mlen << 16));
+                                table2[idx] = make_uint2(c[u].x, (op & 0xffffu) | (w << 16));         // 8-byte record (lds2_body)
+                                near += (w != 0u && sq.offset < 4096u) ? 1u : 0u;
+                                if (fin) { atomicAdd(&s_tot[17], 1u); s_tot[18] = op2; s_tot[19] = idx + 1u; }
+                            }
+                        }
+                    }
+                }
+                sub_mark(13u);
+                if (near) atomicAdd(s_near, near);
+                if (bad || (on_chain && piece_end == kPosErr)) atomicOr(&s_tot[16], 1u);
+            }
+        } else if (tid == 0) atomicAdd(&g_fused_paths[1], 1ull);
+    } else
+#endif
+    {
+    if (tid == 0) atomicAdd(&g_fused_paths[2], 1ull);
     if (plane) {
         uint32_t q = on_chain ? entry : kPosEnd;
         WalkCarry c3 = {0u, 0xFFFFFFFFu};
@@ -592,7 +764,6 @@ __device__ __forceinline__ bool fused_parse(uint32_t a_in, uint32_t iend, uint32
             }
         }
     }
-    uint32_t base_idx = 0, base_op = 0;
     if (plane) {
         uint32_t tc, tb;
         base_idx = wave_excl_scan_add32(cnt, tc);
@@ -600,15 +771,19 @@ __device__ __forceinline__ bool fused_parse(uint32_t a_in, uint32_t iend, uint32
         if (lane == 0) { s_tot[wave] = tc; s_tot[8u + wave] = tb; }
     }
     __syncthreads();
+    sub_mark(9u);
     if (plane) {
         for (uint32_t w = 0; w < wave; w++) { base_idx += s_tot[w]; base_op += s_tot[8u + w]; }
     }
-    uint32_t total_seq = 0;
     for (uint32_t w = 0; w < kFusedLanes / 64u; w++) total_seq += s_tot[w];
     // (a valid chunk's pieces add up to at most `cap` output bytes; a wild count is caught by the checks of P4)
     if (total_seq < kLdsMinSeq || total_seq > kSyncStride * kSyncEvery) return false;       // uniform: too few / too many sequences for this decoder
+    }
 
     // ---- P4: validate + write the records ----
+    if (p4_done) {
+        // (from the lists, above)
+    } else
     if (plane) {
         bool bad = false, saw_last = false;
         uint32_t final_op = 0, near = 0;
@@ -635,6 +810,7 @@ __device__ __forceinline__ bool fused_parse(uint32_t a_in, uint32_t iend, uint32
         if (on_chain && saw_last) { atomicAdd(&s_tot[17], 1u); s_tot[18] = final_op; s_tot[19] = idx + 1u; }
     }
     __syncthreads();
+    sub_mark(10u);
     const uint32_t op_end = s_tot[18];
     if (s_tot[16] != 0u || s_tot[17] != 1u || s_tot[19] != total_seq || !G::result_ok(op_end, cap) || op_end == 0u) return false;
     nseq_out = total_seq;

@@ -77,9 +77,9 @@ constexpr uint32_t kD2LongRun = CJ_D2_LONG;      // literal runs at least this l
 #endif
 // the record table of a workgroup (16-byte units) by window: the 8-byte records of a chunk + sentinel, then the 16-byte records the forwarding phase appends (at most two per forwarded record)
 constexpr uint32_t lds2_tab_records(uint32_t win) {
-    return win >= 65536u ? 3u * kSyncStride * kSyncEvery : (lds_window_max_seq(win) + 1u) / 2u + 64u + 2u * (6144u * (win / 1024u) / 64u) + 64u;
+    return win >= 65536u ? 4u * kSyncStride * kSyncEvery : (lds_window_max_seq(win) + 1u) / 2u + 64u + 2u * (6144u * (win / 1024u) / 64u) + 64u;
 }
-constexpr uint32_t kL2TabRecords = 3u * kSyncStride * kSyncEvery;   // records of a chunk (the parse kernel routes chunks with more than 16 384 sequences elsewhere) + the extra literal copies of D1f (at most two per record, D1f takes at most 6 144 records)
+constexpr uint32_t kL2TabRecords = 4u * kSyncStride * kSyncEvery;   // records of a chunk (the parse kernel routes chunks with more than 16 384 sequences elsewhere) + the extra literal copies of D1f (at most two per record, D1f takes at most 6 144 records)
 
 
 // kLinked (LZ4 frames with linked blocks, frame.hip): the workgroup takes a whole FRAME (frames[f] = first block index,
@@ -432,7 +432,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         const uint32_t a_in = a_out + mis;
         if constexpr (kFused) {
             using G = typename std::conditional<kCodec == CJ_CODEC_SNAPPY_RAW, SnappyGrammar, Lz4Grammar>::type;
-            const bool ok = fused_parse<G, kL2Threads>(a_in, iend, f_cap, s_bits, reinterpret_cast<uint32_t*>(smem + kL2Bytes), table2, s_small, nseq, U);
+            const bool ok = fused_parse<G, kL2Threads>(a_in, iend, f_cap, s_bits, reinterpret_cast<uint32_t*>(smem + kL2Bytes), table2, s_small, nseq, U, prof ? s_prof : nullptr);
             ParseMeta* meta_w = const_cast<ParseMeta*>(meta);
             if (!ok) { if (tid == 0) meta_w[c] = ParseMeta{0u, kRouteWave}; continue; }      // (uniform)
             if (tid == 0) { meta_w[c] = ParseMeta{0u, 0u}; a.result[c] = (int64_t)U; table2[nseq] = make_uint2(0u, U & 0xffffu); }
@@ -1485,6 +1485,13 @@ extern "C" long long cj_debug_forwarded_chunks(int reset) {
     if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(cj::g_fwd_chunks), 8) != hipSuccess) return -1;
     if (reset) { unsigned long long z = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(cj::g_fwd_chunks), &z, 8) != hipSuccess) return -1; }
     return (long long)v;
+}
+extern "C" int cj_debug_fused_parse_paths(unsigned long long* out3, int reset) {      // chunks of the one-kernel path: P3 / P4 from the lists, walked P4, walked P3 + P4
+    unsigned long long v[4] = {0};
+    if (hipMemcpyFromSymbol(v, HIP_SYMBOL(cj::g_fused_paths), 32) != hipSuccess) return -1;
+    out3[0] = v[0]; out3[1] = v[1]; out3[2] = v[2];
+    if (reset) { unsigned long long z[4] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(cj::g_fused_paths), z, 32) != hipSuccess) return -1; }
+    return 0;
 }
 extern "C" int cj_debug_lds_phase_cycles(unsigned long long* out16, int reset) {
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(cj::g_lds_phase_cycles), 128) != hipSuccess) return -1;

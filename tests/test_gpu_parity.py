@@ -525,6 +525,48 @@ def test_deep_chain_chunks_take_match_forwarding(eng):
         assert L.cj_debug_forwarded_chunks(0) >= len(chunks) // 2, codec
 
 
+def test_one_kernel_parse_lists_its_walks_and_walks_again_where_they_outgrow_the_lists(eng):
+    """the parse inside the decoder kernel (lds_shared.hpp: fused_parse) takes its phases 3 / 4 from the lists its walks wrote, and
+    walks them where the walks outgrow the lists' rows: a stream of 4-byte sequences on which no guessed start ever meets the true
+    path (every lane of the workgroup walks to the end of the chunk).  Both ways decode bit-exactly; the debug counter says which
+    way the chunks went."""
+    import ctypes as C
+    L = N.lib()
+    paths = (C.c_ulonglong * 3)()
+    def never_meets(nseq):
+        b = bytearray(bytes([0x40]) + b"wxyz" + bytes([4, 0]))
+        for i in range(nseq): b += bytes([0x10, 0x61 + (i % 7), 3, 0])
+        return bytes(b + bytes([0xC0]) + b"abcdefghijkl")
+    def dense(nseq):                                    # 3-byte sequences: ~30 per segment, the guesses meet the path
+        return bytes(bytearray([0x10, 0x61, 1, 0]) + bytes([0x00, 1, 0]) * nseq + bytes([0xC0]) + b"abcdefghijkl")
+    ordinary = [oracle.lz4_compress_raw(oracle.synth_v1(65536, i))[1] for i in range(6)]
+    hard = [never_meets(n) for n in (3000, 9000, 12000)]
+    for blobs, slot in ((ordinary + [dense(15000), dense(16300)], 0), (hard, 2)):
+        want = [oracle.lz4_decompress_raw(b, 65536) for b in blobs]
+        assert all(r > 0 for r, _ in want)
+        assert L.cj_debug_fused_parse_paths(paths, 1) == 0
+        res, outs = eng.batch_host(LZ4, DEC, N.FLAG_FORCE_LDS_PER_CHUNK, blobs, [65536] * len(blobs))
+        assert [int(r) for r in res] == [r for r, _ in want]
+        assert all(bytes(o) == w for o, (_, w) in zip(outs, want))
+        assert L.cj_debug_fused_parse_paths(paths, 0) == 0
+        assert paths[slot] == len(blobs) and sum(paths) == len(blobs), (slot, list(paths))
+    # Snappy: 2-byte copy elements behind one literal (66 elements per segment at most: the lists' rows hold them)
+    raw = (b"ab" * 40000)[:65536]
+    body = bytearray(bytes([0x04]) + b"ab")            # literal "ab", then copies of 4 bytes at offset 2: tag 0b000_000_01, offset byte 2
+    while len(body) < 30000: body += bytes([0x01, 0x02])
+    n_out = 2 + 4 * ((len(body) - 3) // 2)
+    hdr = bytearray(); v = n_out
+    while v >= 0x80: hdr.append((v & 0x7f) | 0x80); v >>= 7
+    hdr.append(v)
+    blob = bytes(hdr + body)
+    er, eo = oracle.snappy_decompress(blob, 1 << 17)
+    assert er == n_out and eo == raw[:n_out]
+    assert L.cj_debug_fused_parse_paths(paths, 1) == 0
+    res, outs = eng.batch_host(SNAPPY, DEC, N.FLAG_FORCE_LDS_PER_CHUNK, [blob] * 3, [n_out] * 3)
+    assert [int(r) for r in res] == [n_out] * 3 and all(bytes(o) == eo for o in outs)
+    assert L.cj_debug_fused_parse_paths(paths, 0) == 0 and sum(paths) == 3, list(paths)
+
+
 def test_internal_flag_bits_are_refused_at_the_c_abi(eng):
     """piece splitting / tail report / linked-frame bits (cj_common.hpp) belong to the library's own large-buffer and frame paths; a
     C-ABI caller that sets one gets CJ_E_BAD_ARG instead of a kernel that reads descriptors which are not there"""

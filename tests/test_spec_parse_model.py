@@ -146,28 +146,53 @@ def with_fast(general, fast):
 LANES = 256
 
 
+ROWS = 144                         # lds_shared.hpp: kFlRows (P1b's rows follow the longest P1a of the workgroup)
+GROUP, MAX_GROUPS = 4, 4096         # lds_shared.hpp: kFlGroup / kFlMaxGroups (more groups: the kernel walks its phase 4)
+STATS = {"listed": 0, "walked": 0, "max_b": 0, "groups": 0}
+
+
 def spec_parse(b, cap, seq_at=seq_at, seq_check=lz4_check, lanes=LANES):
     """returns (result, nseq, sync points) like the kernel's fused_parse; result < 0 = corrupt (the kernel hands those to the
-    wave kernel)"""
+    wave kernel).  Round 6: the kernel LISTS what its walks of 1a / 1b read (one row per loop iteration, one column per lane) and
+    takes phase 3 / 4 from the lists — a piece is the suffix of its lane's list that begins at the step standing on the piece's
+    entry, and that step's number is the count of the lane's own marks below the entry; the walking phases 3 / 4 remain for chunks
+    whose walks outgrow the rows.  The model runs both and requires the same verdict, counts and records."""
     seq_at = with_fast(seq_at, lz4_fast_step if seq_at is globals()["seq_at"] else snappy_fast_step)
     iend = len(b)
     nl = min(lanes, (iend + 63) // 64)
     seg = ((((iend + nl - 1) // nl) + 3) & ~3) | 4
     marks = set()
     pos = []
+    lists = [[] for _ in range(lanes)]                       # (lit, mlen, off, output bytes of the walk before the step) or None = not representable in 16-bit fields
+    n_a = [0] * lanes
+    over = False; row_b = 0
+    def put(l, lit, mlen, off):
+        ob = lists[l][-1][3] + lists[l][-1][0] + lists[l][-1][1] if lists[l] else 0
+        rep = lit <= 0xffff and mlen <= 0xffff and off <= 0xffff
+        lists[l].append((lit if rep else 0, mlen if rep else 0, off, ob & 0xffffffff, rep))
     for l in range(lanes):                                   # 1a
         p = l * seg if (l < nl and l * seg < iend) else END
+        it = 0
         while p >= 0 and p < (l + 1) * seg and p < iend:
             marks.add(p)
-            ok, _, _, _, nxt, _ = seq_at(b, p, iend)
+            ok, lit, mlen, off, nxt, _ = seq_at(b, p, iend)
+            if ok and it < ROWS: put(l, lit, mlen, off); n_a[l] += 1
+            it += 1
             p = nxt if ok else ERR
+        row_b = max(row_b, it)
         pos.append(p)
+    own_marks = [sorted(m for m in marks if m // seg == l) for l in range(lanes)]
     merge = []
     for l in range(lanes):                                # 1b
         p = pos[l]
+        it = 0
         while p >= 0 and p < iend and p not in marks:
-            ok, _, _, _, nxt, _ = seq_at(b, p, iend)
+            ok, lit, mlen, off, nxt, _ = seq_at(b, p, iend)
+            if ok and row_b + it < ROWS: put(l, lit, mlen, off)
+            it += 1
             p = nxt if ok else ERR
+        over |= row_b + it > ROWS
+        STATS["max_b"] = max(STATS["max_b"], it)
         if p >= iend: p = ERR
         merge.append(p)
     # 2: the chain from lane 0, marked by pointer doubling (a piece that ends the stream points at itself)
@@ -202,20 +227,58 @@ def spec_parse(b, cap, seq_at=seq_at, seq_check=lz4_check, lanes=LANES):
             ok, lit, mlen, _, nxt, _ = seq_at(b, q, iend)
             if not ok: q = ERR; break
             cnt[l] += 1; outb[l] += lit + mlen; q = nxt
-    sync = {}; bad = False; final = None                  # 4
+    sync = {}; bad = False; final = None; recs = []       # 4
     for l in chain:
         q, idx, op = entry[l], sum(cnt[:l]), sum(outb[:l])
         while q >= 0 and q != merge[l] and not bad:
             if idx % 8 == 0: sync[idx // 8] = (q, op)
             ok, lit, mlen, off, nxt, last = seq_at(b, q, iend)
             if not ok: bad = True; break
+            op0 = op
             ok, op, fin = seq_check(lit, mlen, off, last, op, cap)
             if not ok: bad = True
-            elif fin: final = op; q = END
-            else: q = nxt; idx += 1
+            else:
+                recs.append((idx, lit, mlen, off, op0))
+                if fin: final = op; q = END
+                else: q = nxt; idx += 1
         if merge[l] == ERR: bad = True
-    if bad or final is None: return -7, 0, []
-    return final, sum(cnt), [sync[k] for k in sorted(sync)]
+    walked = (-7, 0, []) if (bad or final is None) else (final, sum(cnt), [sync[k] for k in sorted(sync)])
+    if over or iend > 65504:                             # (the kernel stages at most 65 504 bytes: longer inputs never reach its parse)
+        STATS["walked"] += 1
+        return walked
+    # ---- phases 3 / 4 from the lists ----
+    STATS["listed"] += 1
+    k = [0] * lanes; cnt2 = [0] * lanes; outb2 = [0] * lanes
+    for l in chain:
+        k[l] = sum(1 for m in own_marks[l] if m < entry[l])          # the kernel: popcount of the bitmap words of [l * seg, entry)
+        assert k[l] <= len(lists[l])
+        cnt2[l] = len(lists[l]) - k[l]
+        if cnt2[l]:
+            last_e = lists[l][-1]
+            outb2[l] = (last_e[3] + last_e[0] + last_e[1] - lists[l][k[l]][3]) & 0xffffffff
+    STATS["groups"] = sum((c + GROUP - 1) // GROUP for c in cnt2)
+    bad2 = False; final2 = None; recs2 = []
+    total = sum(cnt2)
+    for l in chain:
+        base_idx, base_op = sum(cnt2[:l]), sum(outb2[:l]) & 0xffffffff
+        ends = merge[l] == END                               # the lane's last step consumed the input exactly
+        for j in range(k[l], len(lists[l])):                 # every cell on its own: its output position is a difference of two list words
+            lit, mlen, off, ob, rep = lists[l][j]
+            idx, op0 = base_idx + j - k[l], (base_op + ob - lists[l][k[l]][3]) & 0xffffffff
+            last = ends and j + 1 == len(lists[l])
+            if not rep or idx >= total or op0 > cap: bad2 = True; continue
+            ok, op, fin = seq_check(lit, mlen, off, last, op0, cap)
+            if not ok: bad2 = True; continue
+            recs2.append((idx, lit, mlen, off, op0))
+            if fin:
+                if final2 is not None: bad2 = True
+                final2 = op
+        if merge[l] == ERR: bad2 = True
+    listed = (-7, 0, []) if (bad2 or final2 is None) else (final2, total, None)
+    assert (listed[0] < 0) == (walked[0] < 0), ("listed / walked verdicts differ", listed[:2], walked[:2])
+    if walked[0] >= 0:
+        assert listed[:2] == walked[:2] and sorted(recs2) == recs, ("listed / walked records differ", listed[:2], walked[:2])
+    return walked
 
 
 def serial_sync(b, cap, seq_at=seq_at):
@@ -300,3 +363,22 @@ def test_snappy_model_on_golden_malformed_and_fuzz(golden):
     for i in range(4):
         _, blob = oracle.snappy_compress(oracle.synth_v1(65536, i))
         check_snappy(blob, ("synth", i))
+
+
+def test_listed_and_walked_phases_agree_where_the_walks_outgrow_the_rows():
+    """hand-made streams for both ends of the round-6 lists: ~30 three-byte sequences per segment (listed; the groups of four cells stay
+    below the work list's 4 096 even at the decoder's 16 384 sequences) and four-byte sequences on which no guessed start ever meets
+    the true path (every lane walks to the end of the chunk: the rows overflow, phases 3 / 4 walk).  spec_parse itself compares the
+    two ways whenever the lists are used."""
+    def dense(nseq):
+        return bytes(bytearray([0x10, 0x61, 1, 0]) + bytes([0x00, 1, 0]) * nseq + bytes([0xC0]) + b"abcdefghijkl")
+    def never_meets(nseq):
+        b = bytearray(bytes([0x40]) + b"wxyz" + bytes([4, 0]))
+        for i in range(nseq): b += bytes([0x10, 0x61 + (i % 7), 3, 0])
+        return bytes(b + bytes([0xC0]) + b"abcdefghijkl")
+    for blob, listed in ((dense(16300), True), (dense(4000), True), (never_meets(1200), False)):
+        er, _ = oracle.lz4_decompress_raw(blob, 65536)
+        STATS.update(listed=0, walked=0, max_b=0, groups=0)
+        r, nseq, _ = spec_parse(blob, er, lanes=512)
+        assert r == er and (STATS["listed"] == 1) == listed, (len(blob), STATS)
+        if listed: assert STATS["groups"] <= MAX_GROUPS

@@ -47,7 +47,7 @@ uint32_t lz4_lds2_wgs_per_cu(uint32_t win);
 void launch_lz4_decode_lds2_linked(const BatchArgs& a, const void* sync, const void* meta, void* tabs, uint32_t* counter,
                                    const void* frames, uint32_t n_frames, uint32_t grid, hipStream_t s);
 // parse + decode in ONE kernel: the segmented parse runs inside the workgroup on the staged chunk; meta[c] = kRouteWave for chunks it leaves to the wave kernel
-void launch_lz4_decode_fused(const BatchArgs& a, void* meta, void* tabs, uint32_t* counter, uint32_t grid, hipStream_t s, int codec = 0);
+void launch_lz4_decode_fused(const BatchArgs& a, void* meta, void* tabs, uint32_t* counter, uint32_t grid, hipStream_t s, int codec = 0, uint32_t win = 65536u);
 size_t lz4_lds2_tab_bytes(uint32_t grid, uint32_t win = 65536u);
 size_t lz4_lds_scratch_sync_bytes(size_t n_chunks);
 size_t lz4_lds_scratch_meta_bytes(size_t n_chunks);

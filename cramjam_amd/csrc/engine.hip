@@ -53,9 +53,6 @@ int lds_scratch(cj_engine* e, const cj::BatchArgs& a, hipStream_t s, bool with_s
 //   then               the wavefront-per-chunk kernel on what the parse left over (errors, chunks above 64 KiB, few long runs)
 //   flags              CJ_FLAG_FORCE_WAVE_PER_CHUNK / _LANE_PER_CHUNK: one mapping for every chunk (tests, comparisons)
 constexpr size_t kBigCap = 8192;
-// batches of small chunks (CJ_FLAG_CHUNKS_LE_*) take the parse kernel + small-window decoder from here on (profiles/r06/experiments w03:
-// 32 KiB chunks cross between 4 096 and 8 192, 16 KiB chunks at 2 048)
-constexpr uint32_t kSmallMinChunks32 = 6144, kSmallMinChunks16 = 2048;
 constexpr int kBigObs = 8;                // counts of big chunks the engine remembers (cj_engine::big_obs)
 
 // CJ_FLAG_BIG_CHUNKS: which chunks lie in (64 KiB, 256 KiB] is known on the device only (big_list_kernel), but the record areas
@@ -112,12 +109,11 @@ int launch_decode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a_in, hipSt
     // the workgroup decoder (lz4_decode_lds.hip): its parse stage inside the decoder kernel for small batches, as a kernel of its own
     // in front of it for large ones (CJ_FLAG_FORCE_FUSED_PARSE / _PARSE_KERNEL: one of them at any batch size — tests, comparisons)
     bool fused = a.n_chunks <= (uint32_t)CJ_FUSED_MAX_CHUNKS;
-    // a batch of small chunks (CJ_FLAG_CHUNKS_LE_32K / _16K): the parse kernel + the decoder on windows of that size, from kSmallMinChunks32 / 16
-    // chunks on (below that the GPU is not full either way and the one-kernel path's latency counts)
-    if (small != 0u && a.n_chunks >= ((small & CJ_FLAG_CHUNKS_LE_16K) ? kSmallMinChunks16 : kSmallMinChunks32)) fused = false;
+    // (a batch of small chunks — CJ_FLAG_CHUNKS_LE_32K / _16K — runs either pipeline on windows of that size: four / eight workgroups per CU.  The
+    //  one-kernel path and the parse kernel cross at ~16 k chunks for 64, 32, 16 and 8 KiB chunks alike: profiles/r06/experiments f04 / f05)
     if (a.flags & CJ_FLAG_FORCE_FUSED_PARSE) fused = true;
     if (a.flags & CJ_FLAG_FORCE_PARSE_KERNEL) fused = false;
-    if (!fused) a.flags |= small;
+    a.flags |= small;                                         // (round 6, f05: the one-kernel path runs on the batch's window too)
     const uint32_t win = cj::lds_window(a.flags);
     std::lock_guard<std::mutex> lock(e->scratch_mu);
     // (first: it makes `s` wait for the previous user of the engine's shared scratch — the big-chunk list below is part of it)
@@ -132,7 +128,7 @@ int launch_decode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a_in, hipSt
     uint32_t* lists = (uint32_t*)e->d_lanelist.p;
     const uint32_t grid = (win >= 65536u ? kWgsPerCu : cj::lz4_lds2_wgs_per_cu(win)) * (uint32_t)e->n_cu;          // persistent workgroups: two per CU on 64 KiB windows
     if (fused) {
-        cj::launch_lz4_decode_fused(a, e->d_pmeta.p, e->d_tab.p, lists + 2, grid, s, codec);
+        cj::launch_lz4_decode_fused(a, e->d_pmeta.p, e->d_tab.p, lists + 2, grid, s, codec, win);
     } else {
         HIP_TRY(hipMemsetAsync(e->d_pmeta.p, 0, cj::lz4_lds_scratch_meta_bytes(a.n_chunks), s), CJ_E_NO_DEVICE);   // no chunk is pre-routed
         // validate, size, count sequences, sync points, route

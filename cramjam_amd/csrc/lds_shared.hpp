@@ -481,6 +481,8 @@ __device__ __forceinline__ DW<T / 4 + 2> gl_ld_exact(const uint8_t* g) {
 constexpr uint32_t kFusedLanes = CJ_FUSED_LANES;          // every thread of the workgroup walks a segment (256, wavefronts 0-3 only: 137 k cycles per chunk)
 constexpr uint32_t kFusedAux = 6144u;                               // merge, next, mark, entry (16 bits per lane each) + totals: behind the decoder's LDS
 static_assert(4u * kFusedLanes * 2u + 128u <= kFusedAux, "aux");
+// (round 6: the parse runs on every window of the workgroup decoder — 512 lanes on 64 KiB, 256 on 32 KiB, 128 on 16 KiB: the workgroup's threads)
+constexpr uint32_t fused_aux_bytes(uint32_t lanes) { return lanes >= 512u ? kFusedAux : 8u * lanes + 128u; }
 
 // The walked elements are LISTED (round 6, f04): every step of P1a / P1b also stores what it read — a 12-byte cell { lit_at | lit << 16,
 // mlen | offset << 16, output bytes of the lane's walk before the step } — into the workgroup's table slot, row = the loop's iteration,
@@ -501,7 +503,9 @@ static_assert(4u * kFusedLanes * 2u + 128u <= kFusedAux, "aux");
 #define CJ_FUSED_ROWS 144u
 #endif
 constexpr uint32_t kFlRows = CJ_FUSED_ROWS;                         // (at most 255: step numbers travel in 8 bits)
-constexpr uint32_t kFlBase = 33792u;                                // the lists' place in the slot, in 4-byte units: behind the chunk's records + sentinel (132 KiB; the forwarding phase's extras come later, when the lists are dead)
+// the lists' place in the slot, in 4-byte units: behind the chunk's records + sentinel (64 KiB window: 132 KiB; the forwarding phase's extras come later, when the lists are dead)
+constexpr uint32_t fl_base(uint32_t win) { return win >= 65536u ? 33792u : ((lds_window_max_seq(win) + 1u) * 2u + 255u) & ~255u; }
+constexpr uint32_t fl_slot_units(uint32_t win, uint32_t lanes) { return (fl_base(win) + 3u * kFlRows * lanes + 3u) / 4u; }      // 16-byte units of a slot that holds the lists
 #ifndef CJ_FUSED_GROUP
 #define CJ_FUSED_GROUP 4u
 #endif
@@ -510,7 +514,7 @@ constexpr uint32_t kFlBase = 33792u;                                // the lists
 #endif
 constexpr uint32_t kFlGroup = CJ_FUSED_GROUP, kFlMaxGroups = CJ_FUSED_MAX_GROUPS;   // cells per group; the work list (16-bit entries: lane | group of its piece << 9) lives in the bitmap's 8 KiB
 static_assert(kFlRows / kFlGroup < 128u, "a piece's group number fits 7 bits");
-static_assert(kFlRows < 256u && (kFlBase + 3u * kFlRows * kFusedLanes) * 4u <= 4u * 16384u * 16u, "the lists fit the table slot of a 64 KiB window");
+static_assert(kFlRows < 256u && fl_slot_units(65536u, kFusedLanes) <= 4u * 16384u, "the lists fit the table slot of a 64 KiB window");
 struct FlCell { uint32_t x, y, ob; };
 __device__ unsigned long long g_fused_paths[4];          // test hook: chunks whose P3 / P4 came from the lists, walked P4 only, walked both
 
@@ -528,10 +532,14 @@ __device__ __forceinline__ uint32_t wave_excl_scan_add32(uint32_t v, uint32_t& t
 
 // a_in: LDS address of stream position 0; aux: kFusedAux bytes of LDS; bits: 8 KiB, zeroed; table2: the record table (8-byte records).
 // On success: nseq_out / U_out, *near_out += matches with an offset below kFwdNear.  Every thread of the workgroup calls it.
-template <class G, uint32_t kThreads>
+template <class G, uint32_t kThreads, uint32_t kWin = 65536u>
 __device__ __forceinline__ bool fused_parse(uint32_t a_in, uint32_t iend, uint32_t cap, uint32_t* bits, uint32_t* aux, uint2* table2,
                                             uint32_t* s_near, uint32_t& nseq_out, uint32_t& U_out, uint32_t* sub_prof = nullptr) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    // (these shadow the file's 64 KiB values: the window's lanes, list base, work-list capacity — the bitmap's space —, sequence limits, "near")
+    constexpr uint32_t kFusedLanes = kThreads, kFlBase = fl_base(kWin), kFlMaxGroups = CJ_FUSED_MAX_GROUPS < kWin / 16u ? CJ_FUSED_MAX_GROUPS : kWin / 16u;
+    constexpr uint32_t kMinSeq = kWin >= 65536u ? kLdsMinSeq : lds_window_min_seq(kWin), kMaxSeq = lds_window_max_seq(kWin), kNear = kWin / 16u;
+    constexpr uint32_t kBitWordsW = kWin / 32u;
     // (CJ_FLAG_DEBUG_PROFILE: cycles of P1a, P1b, P2, P3 + scan, P4 as thread 0 sees them, barriers included -> sub-marks 6 .. 10)
     unsigned long long t_sub = sub_prof ? __builtin_readcyclecounter() : 0ull;
     const auto sub_mark = [&](uint32_t k) {
@@ -668,7 +676,7 @@ __device__ __forceinline__ bool fused_parse(uint32_t a_in, uint32_t iend, uint32
                 const uint32_t lo = tid * seg, hi = entry, w0 = lo >> 5;
                 uint32_t mk[6];
 #pragma unroll
-                for (uint32_t u = 0; u < 6u; u++) mk[u] = bits[(w0 + u) < 2047u ? (w0 + u) : 2047u];
+                for (uint32_t u = 0; u < 6u; u++) mk[u] = bits[(w0 + u) < kBitWordsW - 1u ? (w0 + u) : kBitWordsW - 1u];
 #pragma unroll
                 for (uint32_t u = 0; u < 6u; u++) {
                     const uint32_t b0 = (w0 + u) * 32u;
@@ -691,7 +699,7 @@ __device__ __forceinline__ bool fused_parse(uint32_t a_in, uint32_t iend, uint32
             for (uint32_t w = 0; w < wave; w++) { base_idx += s_tot[w]; base_op += s_tot[8u + w]; }
         }
         for (uint32_t w = 0; w < kFusedLanes / 64u; w++) total_seq += s_tot[w];
-        if (total_seq < kLdsMinSeq || total_seq > kSyncStride * kSyncEvery) return false;       // uniform: too few / too many sequences for this decoder
+        if (total_seq < kMinSeq || total_seq > kMaxSeq) return false;       // uniform: too few / too many sequences for this decoder
         // P4 from the lists.  LDS: the work list in the bitmap's space (every lane has counted its marks: the barrier above), the pieces'
         // parameters in the lane arrays of P1 / P2 (dead: merge_pos and entry are in registers) — { first record (15) | first step (8) |
         // steps of P1a (8) | ends the stream (1), output position of the piece - output before its first step (17) | steps (8) }
@@ -738,7 +746,7 @@ __device__ __forceinline__ bool fused_parse(uint32_t a_in, uint32_t iend, uint32
                             else {
                                 const uint32_t w = sq.mlen == 0u ? 0u : (sq.offset | (sq.mlen << 16));
                                 table2[idx] = make_uint2(c[u].x, (op & 0xffffu) | (w << 16));         // 8-byte record (lds2_body)
-                                near += (w != 0u && sq.offset < 4096u) ? 1u : 0u;
+                                near += (w != 0u && sq.offset < kNear) ? 1u : 0u;
                                 if (fin) { atomicAdd(&s_tot[17], 1u); s_tot[18] = op2; s_tot[19] = idx + 1u; }
                             }
                         }
@@ -777,7 +785,7 @@ __device__ __forceinline__ bool fused_parse(uint32_t a_in, uint32_t iend, uint32
     }
     for (uint32_t w = 0; w < kFusedLanes / 64u; w++) total_seq += s_tot[w];
     // (a valid chunk's pieces add up to at most `cap` output bytes; a wild count is caught by the checks of P4)
-    if (total_seq < kLdsMinSeq || total_seq > kSyncStride * kSyncEvery) return false;       // uniform: too few / too many sequences for this decoder
+    if (total_seq < kMinSeq || total_seq > kMaxSeq) return false;       // uniform: too few / too many sequences for this decoder
     }
 
     // ---- P4: validate + write the records ----
@@ -798,7 +806,7 @@ __device__ __forceinline__ bool fused_parse(uint32_t a_in, uint32_t iend, uint32
                 else {
                     const uint32_t w = sq.mlen == 0u ? 0u : ((sq.offset & 0xffffu) | (sq.mlen << 16));       // (a Snappy stream may END with a copy)
                     table2[idx] = make_uint2(sq.lit_at | (sq.lit << 16), (op & 0xffffu) | (w << 16));      // 8-byte record (lds2_body)
-                    near += (w != 0u && sq.offset < 4096u) ? 1u : 0u;
+                    near += (w != 0u && sq.offset < kNear) ? 1u : 0u;
                     op = op2;
                     if (fin) { final_op = op; saw_last = true; q = kPosEnd; }
                     else { q = sq.next; idx += 1; }

@@ -76,9 +76,13 @@ constexpr uint32_t kD2LongRun = CJ_D2_LONG;      // literal runs at least this l
 #define CJ_DENSE_LANES 24u
 #endif
 // the record table of a workgroup (16-byte units) by window: the 8-byte records of a chunk + sentinel, then the 16-byte records the forwarding phase appends (at most two per forwarded record)
-constexpr uint32_t lds2_tab_records(uint32_t win) {
-    return win >= 65536u ? 4u * kSyncStride * kSyncEvery : (lds_window_max_seq(win) + 1u) / 2u + 64u + 2u * (6144u * (win / 1024u) / 64u) + 64u;
+constexpr uint32_t lds2_tab_records_plain(uint32_t win) { return (lds_window_max_seq(win) + 1u) / 2u + 64u + 2u * (6144u * (win / 1024u) / 64u) + 64u; }
+constexpr uint32_t lds2_tab_records(uint32_t win) {      // ... or the lists of the parse inside the decoder (lds_shared.hpp: fl_slot_units), whichever is larger
+    return win >= 65536u ? 4u * kSyncStride * kSyncEvery
+                         : (lds2_tab_records_plain(win) > fl_slot_units(win, win / 128u) ? lds2_tab_records_plain(win) : fl_slot_units(win, win / 128u));
 }
+static_assert(4u * lds2_tab_records(32768u) <= 2u * lds2_tab_records(65536u) && 8u * lds2_tab_records(16384u) <= 2u * lds2_tab_records(65536u),
+              "the small windows' workgroups (four / eight per CU) fit the slots of the two 64 KiB ones");
 constexpr uint32_t kL2TabRecords = 4u * kSyncStride * kSyncEvery;   // records of a chunk (the parse kernel routes chunks with more than 16 384 sequences elsewhere) + the extra literal copies of D1f (at most two per record, D1f takes at most 6 144 records)
 
 
@@ -432,7 +436,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
         const uint32_t a_in = a_out + mis;
         if constexpr (kFused) {
             using G = typename std::conditional<kCodec == CJ_CODEC_SNAPPY_RAW, SnappyGrammar, Lz4Grammar>::type;
-            const bool ok = fused_parse<G, kL2Threads>(a_in, iend, f_cap, s_bits, reinterpret_cast<uint32_t*>(smem + kL2Bytes), table2, s_small, nseq, U, prof ? s_prof : nullptr);
+            const bool ok = fused_parse<G, kL2Threads, kWinT>(a_in, iend, f_cap, s_bits, reinterpret_cast<uint32_t*>(smem + kL2Bytes), table2, s_small, nseq, U, prof ? s_prof : nullptr);
             ParseMeta* meta_w = const_cast<ParseMeta*>(meta);
             if (!ok) { if (tid == 0) meta_w[c] = ParseMeta{0u, kRouteWave}; continue; }      // (uniform)
             if (tid == 0) { meta_w[c] = ParseMeta{0u, 0u}; a.result[c] = (int64_t)U; table2[nseq] = make_uint2(0u, U & 0xffffu); }
@@ -1378,22 +1382,28 @@ __global__ __launch_bounds__(kBigSlabThreads) __attribute__((amdgpu_waves_per_eu
 }
 
 // parse + decode in one kernel (batches of independent chunks).  meta: written here (kRouteWave for the chunks left to the wave kernel)
-template <int kCodec>
-__global__ __launch_bounds__(kL2Threads) CJ_L2_ATTR void lz4_decode_fused_kernel(BatchArgs a, ParseMeta* meta, uint4* tabs, uint32_t* counter) {
-    lds2_body<kCodec, false, false, true>(a, nullptr, meta, tabs, counter, nullptr, 0u, SlabArgs{nullptr, nullptr, 0u, 0u, 0u, nullptr, 0u});
+template <int kCodec, uint32_t kWin = CJ_L2_WINDOW, uint32_t kThreads = CJ_L2_THREADS>
+__global__ __launch_bounds__(kThreads) CJ_L2_ATTR void lz4_decode_fused_kernel(BatchArgs a, ParseMeta* meta, uint4* tabs, uint32_t* counter) {
+    lds2_body<kCodec, false, false, true, false, kWin, kThreads>(a, nullptr, meta, tabs, counter, nullptr, 0u, SlabArgs{nullptr, nullptr, 0u, 0u, 0u, nullptr, 0u});
 }
 
-void launch_lz4_decode_fused(const BatchArgs& a, void* meta, void* tabs, uint32_t* counter, uint32_t grid, hipStream_t s, int codec) {
+template <int kCodec, uint32_t kWin, uint32_t kThreads>
+static void launch_fused_window(const BatchArgs& a, void* meta, void* tabs, uint32_t* counter, uint32_t grid, hipStream_t s) {
+    constexpr uint32_t bytes = lds2_bytes(kWin) + fused_aux_bytes(kThreads);
+    static_assert((kWin >= 65536u ? 2u : kWin >= 32768u ? 4u : 8u) * bytes <= 163840u, "workgroups per CU");
+    const auto k = lz4_decode_fused_kernel<kCodec, kWin, kThreads>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), bytes, s, a, (ParseMeta*)meta, (uint4*)tabs, counter);
+}
+
+// win: the window of this batch (64 KiB, or 32 / 16 KiB for batches of small chunks: four workgroups of four wavefronts / eight of two per CU,
+// the parse on the workgroup's 256 / 128 lanes)
+void launch_lz4_decode_fused(const BatchArgs& a, void* meta, void* tabs, uint32_t* counter, uint32_t grid, hipStream_t s, int codec, uint32_t win) {
     if (a.n_chunks == 0) return;
-    constexpr uint32_t bytes = kL2Bytes + kFusedAux;
-    static_assert(2u * bytes <= 163840u, "two workgroups per CU");
-    if (codec == CJ_CODEC_SNAPPY_RAW) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_fused_kernel<CJ_CODEC_SNAPPY_RAW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        hipLaunchKernelGGL((lz4_decode_fused_kernel<CJ_CODEC_SNAPPY_RAW>), dim3(grid), dim3(kL2Threads), bytes, s, a, (ParseMeta*)meta, (uint4*)tabs, counter);
-        return;
-    }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_fused_kernel<CJ_CODEC_LZ4_BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    hipLaunchKernelGGL((lz4_decode_fused_kernel<CJ_CODEC_LZ4_BLOCK>), dim3(grid), dim3(kL2Threads), bytes, s, a, (ParseMeta*)meta, (uint4*)tabs, counter);
+    const bool sn = codec == CJ_CODEC_SNAPPY_RAW;
+    if (win >= 65536u) { if (sn) launch_fused_window<CJ_CODEC_SNAPPY_RAW, CJ_L2_WINDOW, CJ_L2_THREADS>(a, meta, tabs, counter, grid, s); else launch_fused_window<CJ_CODEC_LZ4_BLOCK, CJ_L2_WINDOW, CJ_L2_THREADS>(a, meta, tabs, counter, grid, s); }
+    else if (win >= 32768u) { if (sn) launch_fused_window<CJ_CODEC_SNAPPY_RAW, 32768u, 256u>(a, meta, tabs, counter, grid, s); else launch_fused_window<CJ_CODEC_LZ4_BLOCK, 32768u, 256u>(a, meta, tabs, counter, grid, s); }
+    else { if (sn) launch_fused_window<CJ_CODEC_SNAPPY_RAW, 16384u, 128u>(a, meta, tabs, counter, grid, s); else launch_fused_window<CJ_CODEC_LZ4_BLOCK, 16384u, 128u>(a, meta, tabs, counter, grid, s); }
 }
 
 // items: the slab work items' descriptors (a.n_chunks = kBigSlabs * cap of them), meta: their ParseMeta (nseq = records of the slab, 0 = nothing to do)

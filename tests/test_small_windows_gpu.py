@@ -1,6 +1,7 @@
 """Batches of small chunks on windows of their own size (CJ_FLAG_CHUNKS_LE_32K / _16K: the workgroup decoder with four workgroups of four
 wavefronts / eight of two per CU instead of two of eight, profiles/r06/experiments h01-h04) against the oracle and against the 64 KiB
-window: the same results for every chunk — valid, damaged, and chunks that break the promise (they take one wavefront).
+window: the same results for every chunk — valid, damaged, and chunks that break the promise (they take one wavefront) — with the parse
+as its own kernel in front of the decoder and inside it (the one-kernel path on the window's 256 / 128 lanes, f05).
 Reference behaviour: one call of /root/reference/src/lz4.rs:78-95 (decompress_block) / src/snappy.rs:52-60 (decompress_raw) per chunk."""
 import random
 
@@ -54,16 +55,20 @@ def _raws(win):
     return r
 
 
+PLACE = [0, N.FLAG_FORCE_PARSE_KERNEL, N.FLAG_FORCE_FUSED_PARSE]      # the engine's choice (one kernel up to 16 384 chunks), parse kernel, one kernel
+
+
+@pytest.mark.parametrize("place", PLACE)
 @pytest.mark.parametrize("win,flag", [(32768, N.FLAG_CHUNKS_LE_32K), (16384, N.FLAG_CHUNKS_LE_16K)])
 @pytest.mark.parametrize("codec", [LZ4, SN])
-def test_small_windows_against_the_oracle(eng, codec, win, flag):
+def test_small_windows_against_the_oracle(eng, codec, win, flag, place):
     comp = (lambda r: oracle.lz4_compress_raw(r)[1]) if codec == LZ4 else (lambda r: oracle.snappy_compress(r)[1])
     uniq = _raws(win)
     blobs_u = [comp(r) for r in uniq]
-    n = 7000                                                  # above the engine's thresholds for the parse kernel + small-window decoder
+    n = 7000
     idx = [i % len(uniq) for i in range(n)]
     blobs = [blobs_u[i] for i in idx]; want = [uniq[i] for i in idx]
-    res, out, off = _run(eng, codec, blobs, [len(r) for r in want], flag)
+    res, out, off = _run(eng, codec, blobs, [len(r) for r in want], flag | place)
     for i, r in enumerate(want):
         if codec == LZ4 and len(r) == 0:
             assert res[i] == 0
@@ -73,9 +78,10 @@ def test_small_windows_against_the_oracle(eng, codec, win, flag):
         assert (out[int(off[i]) + len(r):int(off[i]) + len(r) + 5] == 0xAB).all(), (codec, win, i)      # nothing past the capacity
 
 
+@pytest.mark.parametrize("place", PLACE[1:])
 @pytest.mark.parametrize("win,flag", [(32768, N.FLAG_CHUNKS_LE_32K), (16384, N.FLAG_CHUNKS_LE_16K)])
 @pytest.mark.parametrize("codec", [LZ4, SN])
-def test_damaged_streams_get_the_same_verdict_on_every_window(eng, codec, win, flag):
+def test_damaged_streams_get_the_same_verdict_on_every_window(eng, codec, win, flag, place):
     comp = (lambda r: oracle.lz4_compress_raw(r)[1]) if codec == LZ4 else (lambda r: oracle.snappy_compress(r)[1])
     rnd = random.Random(99 + win)
     base = [oracle.synth_v1(win, 300 + i) for i in range(8)] + [_text(win, 9), _text(win // 2, 10)]
@@ -91,7 +97,7 @@ def test_damaged_streams_get_the_same_verdict_on_every_window(eng, codec, win, f
             p = rnd.randrange(len(b)); b[p:p + 2] = bytes([rnd.randrange(256), rnd.randrange(256)])
         blobs.append(bytes(b)); caps.append(len(raw))
     ra, oa, off = _run(eng, codec, blobs, caps, N.FLAG_FORCE_PARSE_KERNEL)          # the 64 KiB window
-    rb, ob, _ = _run(eng, codec, blobs, caps, flag)
+    rb, ob, _ = _run(eng, codec, blobs, caps, flag | place)
     assert (ra == rb).all(), [(i, int(ra[i]), int(rb[i])) for i in np.nonzero(ra != rb)[0][:8]]
     for i in np.nonzero(ra > 0)[0]:
         assert (oa[int(off[i]):int(off[i]) + int(ra[i])] == ob[int(off[i]):int(off[i]) + int(ra[i])]).all(), i

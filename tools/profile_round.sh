@@ -31,7 +31,7 @@ PY
 # the corpus lines carry their own traffic and cpu_baseline (all 20 files, liblz4 / libsnappy streams)
 python bench.py --data corpus64k --steps 20 --traffic on --cpu-seconds 10 2>/dev/null | tail -1 >> $O/other_paths.jsonl
 python bench.py --data corpus64k --codec snappy --steps 20 --traffic on --cpu-seconds 10 2>/dev/null | tail -1 >> $O/other_paths.jsonl
-for args in "--codec snappy" "--op compress" "--op compress --codec snappy" "--codec snappy --op roundtrip" "--chunks 1000000 --steps 20" "--workload mixed256k --steps 20" "--codec lz4 --chunk-bytes 262144 --chunks 8192 --unique 2048 --steps 20" "--codec snappy --chunk-bytes 262144 --chunks 8192 --unique 2048 --steps 20" "--chunks 8192 --unique 2048" "--chunks 1024 --unique 1024" "--chunk-bytes 32768 --chunks 200000" "--chunk-bytes 16384 --chunks 400000" "--codec snappy --chunk-bytes 32768 --chunks 200000" "--codec snappy --chunk-bytes 16384 --chunks 400000" "--chunk-bytes 32768 --chunks 16384 --unique 2048" "--chunk-bytes 16384 --chunks 16384 --unique 2048" "--op compress --data corpus64k --steps 10" "--op compress --data corpus64k --codec snappy --steps 10"; do
+for args in "--codec snappy" "--op compress" "--op compress --codec snappy" "--codec snappy --op roundtrip" "--chunks 1000000 --steps 20" "--workload mixed256k --steps 20" "--codec lz4 --chunk-bytes 262144 --chunks 8192 --unique 2048 --steps 20" "--codec snappy --chunk-bytes 262144 --chunks 8192 --unique 2048 --steps 20" "--chunks 16384 --unique 2048" "--chunks 8192 --unique 2048" "--chunks 1024 --unique 1024" "--codec snappy --chunks 8192 --unique 2048" "--codec snappy --chunks 1024 --unique 1024" "--chunk-bytes 32768 --chunks 4096 --unique 2048" "--chunk-bytes 16384 --chunks 4096 --unique 2048" "--codec snappy --chunk-bytes 32768 --chunks 4096 --unique 2048" "--codec snappy --chunk-bytes 16384 --chunks 4096 --unique 2048" "--data corpus64k --chunks 8192" "--chunk-bytes 32768 --chunks 200000" "--chunk-bytes 16384 --chunks 400000" "--codec snappy --chunk-bytes 32768 --chunks 200000" "--codec snappy --chunk-bytes 16384 --chunks 400000" "--chunk-bytes 32768 --chunks 16384 --unique 2048" "--chunk-bytes 16384 --chunks 16384 --unique 2048" "--op compress --data corpus64k --steps 10" "--op compress --data corpus64k --codec snappy --steps 10"; do
   python bench.py --cpu-seconds 6 --traffic off $args 2>/dev/null | tail -1 >> $O/other_paths.jsonl
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_mixed -- python bench.py --workload mixed256k --no-cpu-baseline --traffic off --steps 10 > $O/stats_mixed.log 2>&1

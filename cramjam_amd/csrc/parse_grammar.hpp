@@ -208,21 +208,24 @@ __device__ __forceinline__ bool walk_step(const Rd& rd, uint32_t ip, uint32_t ie
         } else ok = G::at(rd, ip, iend, s, g);
         return ok;
     } else {
-        // Snappy record = optional literal element (1- or 2-byte header) + optional copy-1 / copy-2 element, everything at least
-        // 4 bytes clear of the end: the same two round trips; longer headers, copy-4 and the stream's last record take G::at
+        // Snappy record = optional literal element (header of 1 .. 4 bytes) + optional copy element, everything at least 4 bytes clear of
+        // the end: the same two round trips (a copy-4 element: a third, for its offset); a 5-byte literal header and the stream's last
+        // record take G::at.  (Round 6: a walk from a guessed start meets copy-4 tags and long literal headers at every fourth position —
+        // with only the common shapes here 112 of a chunk's 134 wavefront-steps of P1a took G::at for some lane, 3 do now.)
         const uint32_t t4 = rd(ip);
         const uint32_t tag = t4 & 0xffu, l6 = tag >> 2;
         const bool is_lit = (tag & 3u) == 0u;
-        const uint32_t lhdr = is_lit ? (l6 == 60u ? 2u : 1u) : 0u;
-        const uint32_t lit = is_lit ? (l6 == 60u ? ((t4 >> 8) & 0xffu) + 1u : l6 + 1u) : 0u;
+        const uint32_t lhdr = is_lit ? (l6 < 60u ? 1u : l6 - 58u) : 0u;
+        const uint32_t lit = is_lit ? (l6 < 60u ? l6 + 1u : ((t4 >> 8) & (0xffffffu >> (8u * (62u - (l6 > 62u ? 62u : l6))))) + 1u) : 0u;
         const uint32_t ip2 = ip + lhdr + lit;
         const bool in2 = ip2 + 4u <= iend && ip2 >= ip;
         const uint32_t c4 = is_lit ? rd(in2 ? ip2 : ip) : t4;
         const uint32_t ctag = c4 & 0xffu, kind = ctag & 3u;
         const uint32_t clen = kind == 1u ? 4u + ((ctag >> 2) & 7u) : 1u + (ctag >> 2);
-        const uint32_t off = kind == 1u ? ((ctag >> 5) << 8) | ((c4 >> 8) & 0xffu) : (c4 >> 8) & 0xffffu;
-        const uint32_t ip3 = kind == 0u ? ip2 : ip2 + (kind == 1u ? 2u : 3u);
-        const bool fast = !(is_lit && l6 > 60u) && in2 && kind != 3u && ip3 < iend && (kind != 0u || is_lit);
+        uint32_t off = kind == 1u ? ((ctag >> 5) << 8) | ((c4 >> 8) & 0xffu) : (c4 >> 8) & 0xffffu;
+        const uint32_t ip3 = kind == 0u ? ip2 : ip2 + (kind == 1u ? 2u : kind == 2u ? 3u : 5u);
+        const bool fast = !(is_lit && l6 > 62u) && in2 && ip3 < iend && (kind != 0u || is_lit);
+        if (ballot64(fast && kind == 3u) != 0ull) { if (fast && kind == 3u) off = rd(ip2 + 1u); }
         bool ok = true;
         if (fast) {
             s.lit = lit; s.lit_at = ip + lhdr; s.last = false; s.next = ip3;
@@ -253,8 +256,8 @@ __device__ __forceinline__ bool walk_step_carry(const Rd& rd, const Rd8& rd8, ui
         c.at = 0xFFFFFFFFu;
         const uint32_t tag = t4 & 0xffu, l6 = tag >> 2;
         const bool is_lit = (tag & 3u) == 0u;
-        const uint32_t lhdr = is_lit ? (l6 == 60u ? 2u : 1u) : 0u;
-        const uint32_t lit = is_lit ? (l6 == 60u ? ((t4 >> 8) & 0xffu) + 1u : l6 + 1u) : 0u;
+        const uint32_t lhdr = is_lit ? (l6 < 60u ? 1u : l6 - 58u) : 0u;                // (headers of 1 .. 4 bytes: walk_step above)
+        const uint32_t lit = is_lit ? (l6 < 60u ? l6 + 1u : ((t4 >> 8) & (0xffffffu >> (8u * (62u - (l6 > 62u ? 62u : l6))))) + 1u) : 0u;
         const uint32_t ip2 = ip + lhdr + lit;
         const bool in2 = ip2 + 4u <= iend && ip2 >= ip;
         uint2 c8 = make_uint2(t4, 0u);
@@ -262,15 +265,17 @@ __device__ __forceinline__ bool walk_step_carry(const Rd& rd, const Rd8& rd8, ui
         const uint32_t c4 = c8.x;
         const uint32_t ctag = c4 & 0xffu, kind = ctag & 3u;
         const uint32_t clen = kind == 1u ? 4u + ((ctag >> 2) & 7u) : 1u + (ctag >> 2);
-        const uint32_t off = kind == 1u ? ((ctag >> 5) << 8) | ((c4 >> 8) & 0xffu) : (c4 >> 8) & 0xffffu;
-        const uint32_t ip3 = kind == 0u ? ip2 : ip2 + (kind == 1u ? 2u : 3u);
-        const bool fast = !(is_lit && l6 > 60u) && in2 && kind != 3u && ip3 < iend && (kind != 0u || is_lit);
+        uint32_t off = kind == 1u ? ((ctag >> 5) << 8) | ((c4 >> 8) & 0xffu) : kind == 3u ? (c8.x >> 8) | (c8.y << 24) : (c4 >> 8) & 0xffffu;
+        const uint32_t ip3 = kind == 0u ? ip2 : ip2 + (kind == 1u ? 2u : kind == 2u ? 3u : 5u);
+        const bool fast = !(is_lit && l6 > 62u) && in2 && ip3 < iend && (kind != 0u || is_lit);
+        // (a copy-4 element that is the whole record: its offset's last byte lies behind the four bytes at ip)
+        if (ballot64(on && fast && kind == 3u && !is_lit) != 0ull) { if (fast && kind == 3u && !is_lit) off = rd(ip + 1u); }
         bool ok = true;
         if (fast) {
             s.lit = lit; s.lit_at = ip + lhdr; s.last = false; s.next = ip3;
             s.mlen = kind == 0u ? 0u : clen; s.offset = kind == 0u ? 0u : off;
-            // the element behind a copy that followed a literal came with the 8 bytes; behind a literal alone the 4 bytes at ip2 ARE the next element
-            if (is_lit) { c.t4 = kind == 0u ? c4 : __builtin_amdgcn_alignbyte(c8.y, c8.x, kind == 1u ? 2u : 3u); c.at = ip3; }
+            // the element behind a copy-1 / copy-2 that followed a literal came with the 8 bytes; behind a literal alone the 4 bytes at ip2 ARE the next element
+            if (is_lit && kind != 3u) { c.t4 = kind == 0u ? c4 : __builtin_amdgcn_alignbyte(c8.y, c8.x, kind == 1u ? 2u : 3u); c.at = ip3; }
         }
         if (ballot64(on && !fast) != 0ull) { if (!fast) ok = G::at(rd, ip, iend, s, nullptr); }
         return ok;

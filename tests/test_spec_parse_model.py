@@ -113,23 +113,26 @@ def lz4_fast_step(b, ip, iend):
 
 
 def snappy_fast_step(b, ip, iend):
-    """parse_grammar.hpp walk_step<SnappyGrammar>"""
+    """parse_grammar.hpp walk_step<SnappyGrammar> (round 6: literal headers of up to 4 bytes and copy-4 elements are straight-line too)"""
     def rd32(p):
         return [b[p + k] if p + k < len(b) else 0xA5 for k in range(4)]
     t = rd32(ip)
     tag = t[0]; l6 = tag >> 2
     is_lit = (tag & 3) == 0
-    lhdr = (2 if l6 == 60 else 1) if is_lit else 0
-    lit = ((t[1] + 1) if l6 == 60 else l6 + 1) if is_lit else 0
+    lhdr = (1 if l6 < 60 else l6 - 58) if is_lit else 0
+    v24 = t[1] | (t[2] << 8) | (t[3] << 16)
+    lit = (l6 + 1 if l6 < 60 else (v24 & (0xffffff >> (8 * (62 - min(l6, 62))))) + 1) if is_lit else 0
     ip2 = ip + lhdr + lit
     in2 = ip2 + 4 <= iend
     c = rd32(ip2 if in2 else ip) if is_lit else t
     ctag = c[0]; kind = ctag & 3
     clen = 4 + ((ctag >> 2) & 7) if kind == 1 else 1 + (ctag >> 2)
     off = (((ctag >> 5) << 8) | c[1]) if kind == 1 else (c[1] | (c[2] << 8))
-    ip3 = ip2 if kind == 0 else ip2 + (2 if kind == 1 else 3)
-    fast = not (is_lit and l6 > 60) and in2 and kind != 3 and ip3 < iend and (kind != 0 or is_lit)
+    ip3 = ip2 if kind == 0 else ip2 + (2 if kind == 1 else 3 if kind == 2 else 5)
+    fast = not (is_lit and l6 > 62) and in2 and ip3 < iend and (kind != 0 or is_lit)
     if not fast: return None
+    if kind == 3:
+        o = rd32(ip2 + 1); off = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24)
     return (True, lit, 0 if kind == 0 else clen, 0 if kind == 0 else off, ip3, False)
 
 

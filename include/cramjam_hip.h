@@ -168,7 +168,8 @@ typedef enum { CJ_OP_DECOMPRESS = 0, CJ_OP_COMPRESS = 1 } cj_op;
 #define CJ_FLAG_FORCE_PARSE_KERNEL  0x20u
 /* decompress, a promise about the batch: every chunk's output capacity (LZ4) / announced length (Snappy) is at most 32 KiB / 16 KiB.
  * The workgroup decoder then runs on windows of that size — four workgroups of four wavefronts / eight of two per CU instead of two of
- * eight: more chunks' dependency chains in flight for the same wavefronts (32 KiB chunks 635 -> 850 GB/s, 16 KiB 430 -> 810).  A chunk
+ * eight: more chunks' dependency chains in flight for the same wavefronts (32 KiB chunks 635 -> 850 GB/s, 16 KiB 430 -> 810; batches of
+ * up to CJ_FUSED_MAX_CHUNKS chunks: the one-kernel path on the same windows, 4 096 x 32 / 16 KiB 233 / 153 -> 401 / 309).  A chunk
  * that breaks the promise is still decoded correctly (one wavefront).  cj_batch_host sets them itself. */
 #define CJ_FLAG_CHUNKS_LE_32K       0x40u
 #define CJ_FLAG_CHUNKS_LE_16K       0x80u

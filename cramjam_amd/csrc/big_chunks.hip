@@ -136,11 +136,13 @@ __device__ __forceinline__ BigElem big_elem(Win& w, const uint8_t* base, uint32_
     } else {
         const uint32_t tag = t4 & 0xffu, l6 = tag >> 2;
         const bool is_lit = (tag & 3u) == 0u;
-        const uint32_t lhdr = is_lit ? (l6 == 60u ? 2u : 1u) : 0u;
-        const uint32_t lit = is_lit ? (l6 == 60u ? ((t4 >> 8) & 0xffu) + 1u : l6 + 1u) : 0u;
+        // (literal headers of up to 4 bytes, and below copy-4 elements and a literal behind a literal, are straight-line too: a lane's lead-in
+        //  reads every byte as a tag — a quarter of them copy-4 tags —, and the general function reads through global memory: f06)
+        const uint32_t lhdr = is_lit ? (l6 < 60u ? 1u : l6 - 58u) : 0u;
+        const uint32_t lit = is_lit ? (l6 < 60u ? l6 + 1u : ((t4 >> 8) & (0xffffffu >> (8u * (62u - (l6 > 62u ? 62u : l6))))) + 1u) : 0u;
         ip2 = ip + lhdr + lit;
-        fa = !(is_lit && l6 > 60u) && ip2 + 8u <= iend;
-        e.lit = lit; e.lit_at = ip + lhdr; e.mlen = 0u;
+        fa = !(is_lit && l6 > 62u) && ip2 + 8u <= iend && ip2 >= ip;
+        e.lit = lit; e.lit_at = ip + lhdr; e.mlen = is_lit ? 1u : 0u;      // (mlen: "a literal came first", for the shape test below)
     }
     {   // field B at ip2 and the field A behind it (at most 5 + 4 bytes)
         const bool far = going && fa && !w.covers(ip2, 9u);
@@ -157,10 +159,11 @@ __device__ __forceinline__ BigElem big_elem(Win& w, const uint8_t* base, uint32_
         nxf = 0u;
     } else {
         const uint32_t c4 = o8.x, ctag = c4 & 0xffu, kind = ctag & 3u;
-        const uint32_t ip3 = ip2 + (kind == 1u ? 2u : 3u);
-        fast = fa && (kind == 1u || kind == 2u) && ip3 < iend;
-        e.mlen = kind == 1u ? 4u + ((ctag >> 2) & 7u) : 1u + (ctag >> 2);
-        e.offset = kind == 1u ? ((ctag >> 5) << 8) | ((c4 >> 8) & 0xffu) : (c4 >> 8) & 0xffffu;
+        const bool had_lit = e.mlen != 0u;
+        const uint32_t ip3 = kind == 0u ? ip2 : ip2 + (kind == 1u ? 2u : kind == 2u ? 3u : 5u);
+        fast = fa && (kind != 0u || had_lit) && ip3 < iend;
+        e.mlen = kind == 0u ? 0u : kind == 1u ? 4u + ((ctag >> 2) & 7u) : 1u + (ctag >> 2);
+        e.offset = kind == 0u ? 0u : kind == 1u ? ((ctag >> 5) << 8) | ((c4 >> 8) & 0xffu) : kind == 2u ? (c4 >> 8) & 0xffffu : (o8.x >> 8) | (o8.y << 24);
         e.next = ip3;
         nxf = 0u;
     }

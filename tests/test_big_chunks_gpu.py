@@ -278,3 +278,73 @@ def test_a_flagged_call_only_enqueues_once_the_engine_has_seen_a_count():
         free()
     finally:
         e.close()
+
+
+def _sn_stream(rnd, n_out, weights):
+    """a hand-made Snappy raw stream of n_out bytes from every element form the format has: literals with headers of 1 .. 5 bytes (also
+    non-minimal ones), copies with 1-, 2- and 4-byte offsets, a literal behind a literal.  weights: literal, copy-1, copy-2, copy-4"""
+    body = bytearray(); made = 0
+    def lit(n, form):
+        nonlocal made
+        if form == 0 and n <= 60: body.append((n - 1) << 2)
+        else:
+            nb = max(form, 1 if n <= 256 else 2 if n <= 65536 else 3)
+            body.append((59 + nb) << 2); body.extend((n - 1).to_bytes(nb, "little"))
+        body.extend(rnd.randbytes(n)); made += n
+    lit(rnd.randrange(1, 40), 0)
+    while made < n_out:
+        room = n_out - made
+        k = rnd.choices((0, 1, 2, 3), weights)[0]
+        if k == 0:
+            n = min(room, rnd.choice((3000, 70000)) if rnd.randrange(60) == 0 else rnd.choice((1, 2, 5, 17, 60, 61, 62, 200, 257))); lit(n, rnd.choice((0, 0, 1, 2, 3, 4)))
+        elif k == 1:
+            n = min(room, rnd.randrange(4, 12)); off = rnd.randrange(1, min(made, 2047) + 1)
+            if n < 4: lit(n, 0); continue
+            body.append(1 | ((n - 4) << 2) | ((off >> 8) << 5)); body.append(off & 0xff); made += n
+        else:
+            n = min(room, rnd.randrange(1, 65)); off = rnd.randrange(1, min(made, 65535) + 1)
+            body.append((2 if k == 2 else 3) | ((n - 1) << 2)); body.extend(off.to_bytes(2 if k == 2 else 4, "little")); made += n
+    return bytes(_sn_varint(n_out)) + bytes(body)
+
+
+def test_every_snappy_element_form_on_the_segmented_walk(eng):
+    """round 6 (f06): the walk's straight-line step takes literal headers of up to 4 bytes, copy-4 elements and a literal behind a literal
+    (until then: the grammar's general function, through global memory); 5-byte headers still take that one.  Streams of 70 .. 256 KiB
+    made of every form, against the oracle — and with a flipped byte each, for the verdicts."""
+    rnd = random.Random(606)
+    blobs = [_sn_stream(rnd, rnd.choice((70000, 131072, 200000, 262144)), w) for w in ((1, 3, 3, 3), (3, 1, 1, 3), (1, 0, 1, 6), (2, 4, 4, 0)) for _ in range(6)]
+    dam = []
+    for b in blobs[:12]:
+        d = bytearray(b); d[rnd.randrange(5, len(d))] ^= 1 << rnd.randrange(8); dam.append(bytes(d))
+    allb = blobs + dam
+    caps = [min(max(oracle.snappy_decompress_len(d), 0), 1 << 19) for d in allb]
+    res, out, off = _run(eng, SN, allb, caps, N.FLAG_BIG_CHUNKS)
+    n_ok = 0
+    for k, (d, cap) in enumerate(zip(allb, caps)):
+        er, eo = oracle.snappy_decompress(d, cap)
+        assert res[k] == er, (k, len(d), cap, int(res[k]), er)
+        if er >= 0:
+            assert out[int(off[k]):int(off[k]) + er].tobytes() == eo, k
+            n_ok += 1
+    assert n_ok >= len(blobs)
+
+
+@pytest.mark.parametrize("place", [0, N.FLAG_FORCE_PARSE_KERNEL, N.FLAG_FORCE_FUSED_PARSE])
+def test_every_snappy_element_form_on_the_small_chunk_paths(eng, place):
+    """the same streams at 3 .. 64 KiB through the parse kernel and through the parse inside the decoder (whose walks from guessed starts
+    take the straight-line step for all these forms since f06), intact and with a flipped byte"""
+    rnd = random.Random(607 + place)
+    blobs = [_sn_stream(rnd, rnd.choice((3000, 20000, 50000, 65536)), w) for w in ((1, 3, 3, 3), (3, 1, 1, 3), (1, 0, 1, 6), (2, 4, 4, 0), (1, 6, 1, 1)) for _ in range(8)]
+    dam = []
+    for b in blobs[:20]:
+        d = bytearray(b); d[rnd.randrange(3, len(d))] ^= 1 << rnd.randrange(8); dam.append(bytes(d))
+    allb = (blobs + dam) * 8                                      # (a few hundred chunks: the workgroup decoder's paths, not only the wavefront kernel)
+    caps = [min(max(oracle.snappy_decompress_len(d), 0), 1 << 17) for d in allb]
+    res, out, off = _run(eng, SN, allb, caps, place)
+    for k, (d, cap) in enumerate(zip(allb, caps)):
+        if k >= len(blobs) + len(dam): 
+            assert res[k] == res[k - len(blobs) - len(dam)]
+            continue
+        er, eo = oracle.snappy_decompress(d, cap)
+        assert res[k] == er, (place, k, len(d), cap, int(res[k]), er)
+        if er >= 0: assert out[int(off[k]):int(off[k]) + er].tobytes() == eo, (place, k)

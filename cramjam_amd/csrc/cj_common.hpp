@@ -49,6 +49,12 @@ void launch_lz4_decode_lds2_linked(const BatchArgs& a, const void* sync, const v
 // parse + decode in ONE kernel: the segmented parse runs inside the workgroup on the staged chunk; meta[c] = kRouteWave for chunks it leaves to the wave kernel
 void launch_lz4_decode_fused(const BatchArgs& a, void* meta, void* tabs, uint32_t* counter, uint32_t grid, hipStream_t s, int codec = 0, uint32_t win = 65536u);
 size_t lz4_lds2_tab_bytes(uint32_t grid, uint32_t win = 65536u);
+// the batch decoders' chunk counters (lz4_decode_lds.hip: a workgroup's first chunk is its own index, the others come from counter blockIdx % kClaimCounters)
+#ifndef CJ_CLAIM_COUNTERS
+#define CJ_CLAIM_COUNTERS 32u
+#endif
+constexpr uint32_t kClaimCounters = CJ_CLAIM_COUNTERS, kClaimStride = 64u;      // (stride in 4-byte words: one counter per 256 bytes)
+constexpr size_t kClaimBytes = (size_t)kClaimCounters * kClaimStride * 4u;
 size_t lz4_lds_scratch_sync_bytes(size_t n_chunks);
 size_t lz4_lds_scratch_meta_bytes(size_t n_chunks);
 // encoders: one workgroup of two wavefronts per chunk (one wavefront per sub-piece of a split piece, large.hip)

@@ -31,14 +31,14 @@ constexpr uint32_t kWgsPerCu = CJ_L2_WGS_PER_CU;       // persistent workgroups 
 // scratch of the workgroup decoders (per-chunk verdicts, the chunk counter, record tables), shared by every call on the
 // engine: a call waits (on the stream) for the previous user before it overwrites them
 int lds_scratch(cj_engine* e, const cj::BatchArgs& a, hipStream_t s, bool with_sync) {
-    const size_t list_bytes = 16 + (size_t)a.n_chunks * 8;
+    const size_t list_bytes = 256 + cj::kClaimBytes + (size_t)a.n_chunks * 8;
     const size_t sync_bytes = with_sync ? cj::lz4_lds_scratch_sync_bytes(a.n_chunks) : 0;
     const bool grow = sync_bytes > e->d_sync.cap || cj::lz4_lds_scratch_meta_bytes(a.n_chunks) > e->d_pmeta.cap || list_bytes > e->d_lanelist.cap;
     if (grow && e->scratch_free) HIP_TRY(hipEventSynchronize(e->scratch_free), CJ_E_NO_DEVICE);
     if (!e->d_sync.reserve(sync_bytes) || !e->d_pmeta.reserve(cj::lz4_lds_scratch_meta_bytes(a.n_chunks)) || !e->d_lanelist.reserve(list_bytes)) return CJ_E_OOM;
     if (!e->scratch_free) HIP_TRY(hipEventCreateWithFlags(&e->scratch_free, hipEventDisableTiming), CJ_E_NO_DEVICE);
     else HIP_TRY(hipStreamWaitEvent(s, e->scratch_free, 0), CJ_E_NO_DEVICE);   // previous user of the scratch
-    HIP_TRY(hipMemsetAsync(e->d_lanelist.p, 0, 16, s), CJ_E_NO_DEVICE);        // [2] = the decoder's chunk counter
+    HIP_TRY(hipMemsetAsync(e->d_lanelist.p, 0, 256 + cj::kClaimBytes, s), CJ_E_NO_DEVICE);        // words [64 ..): the decoders' chunk counters
     if (e->n_cu == 0) HIP_TRY(hipDeviceGetAttribute(&e->n_cu, hipDeviceAttributeMultiprocessorCount, e->device), CJ_E_NO_DEVICE);
     if (!e->d_tab.reserve(cj::lz4_lds2_tab_bytes(kWgsPerCu * (uint32_t)e->n_cu))) return CJ_E_OOM;
     return 0;
@@ -128,13 +128,13 @@ int launch_decode(cj_engine* e, cj_codec codec, const cj::BatchArgs& a_in, hipSt
     uint32_t* lists = (uint32_t*)e->d_lanelist.p;
     const uint32_t grid = (win >= 65536u ? kWgsPerCu : cj::lz4_lds2_wgs_per_cu(win)) * (uint32_t)e->n_cu;          // persistent workgroups: two per CU on 64 KiB windows
     if (fused) {
-        cj::launch_lz4_decode_fused(a, e->d_pmeta.p, e->d_tab.p, lists + 2, grid, s, codec, win);
+        cj::launch_lz4_decode_fused(a, e->d_pmeta.p, e->d_tab.p, lists + 64, grid, s, codec, win);
     } else {
         HIP_TRY(hipMemsetAsync(e->d_pmeta.p, 0, cj::lz4_lds_scratch_meta_bytes(a.n_chunks), s), CJ_E_NO_DEVICE);   // no chunk is pre-routed
         // validate, size, count sequences, sync points, route
         if (lz4) cj::launch_lz4_parse(a, e->d_sync.p, e->d_pmeta.p, s);
         else cj::launch_snappy_parse(a, e->d_sync.p, e->d_pmeta.p, s);
-        cj::launch_lz4_decode_lds2(a, e->d_sync.p, e->d_pmeta.p, e->d_tab.p, lists + 2, grid, s, codec, win);
+        cj::launch_lz4_decode_lds2(a, e->d_sync.p, e->d_pmeta.p, e->d_tab.p, lists + 64, grid, s, codec, win);
     }
     if (n_big != 0u) {
         // chunks of 64 KiB .. 256 KiB (flagged kRouteWave above): listed, parsed by 32 lanes each into records, decoded slab by slab

@@ -230,7 +230,12 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
     // batches: thread 0 claims the NEXT chunk right after the current one is known, so the atomic's round trip runs under the
     // descriptor loads instead of in front of them (slabs are claimed when they are started: their order matters)
     uint32_t next_c = 0;
-    if constexpr (!kLinked && !kSlab) { if (tid == 0) next_c = atomicAdd(counter, 1u); }
+    // (the FIRST chunk of a workgroup is its own index: with every workgroup of a launch asking the counter at once — 512 of them, 2 048 on
+    //  16 KiB windows — the atomics queue up at one L2 address, ~40 cycles each, in front of the first chunk: S0 of 4 096 x 16 KiB chunks
+    //  63 k cycles, 12 k without; the counter hands out the chunks from gridDim.x on: profiles/r06/experiments f07)
+    if constexpr (!kLinked && !kSlab) next_c = blockIdx.x;
+    const uint32_t claim_n = gridDim.x >= 64u * kClaimCounters ? kClaimCounters : (gridDim.x >= 64u ? gridDim.x >> 6 : 1u);      // counters of this launch: one per 64 workgroups
+    uint32_t claim_k = blockIdx.x % claim_n;                  // the counter this workgroup asks (its own until that has run dry)
 
     if constexpr (!kSlab && !kLinked) __builtin_amdgcn_s_setprio(2);
     for (;;) {
@@ -254,13 +259,26 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
             for (uint32_t i = tid; i < kBitWords; i += kL2Threads) s_bits[i] = 0u;
             __syncthreads();                                 // also: the previous block's D4 has finished reading its window
         } else {
-            if (tid == 0) { *s_chunk = kSlab ? atomicAdd(counter, 1u) : next_c; *s_fail = 0u; *s_ncross = 0u; *s_nextra = 0u; *s_small = 0u; *s_prevok = 0u; }
+            if (tid == 0) {
+                uint32_t cc = kSlab ? atomicAdd(counter, 1u) : next_c;
+                if constexpr (!kSlab) {
+                    // this workgroup's counter has run dry: the other counters' chunks (only at a batch's end: up to claim_n - 1 round trips, once or twice per workgroup)
+                    for (uint32_t t = 1; cc >= a.n_chunks && t < claim_n && a.n_chunks > gridDim.x; t++) {       // (a batch of at most gridDim.x chunks has nothing behind the first ones)
+                        claim_k = claim_k + 1u == claim_n ? 0u : claim_k + 1u;
+                        cc = gridDim.x + claim_n * atomicAdd(counter + claim_k * kClaimStride, 1u) + claim_k;
+                    }
+                }
+                *s_chunk = cc; *s_fail = 0u; *s_ncross = 0u; *s_nextra = 0u; *s_small = 0u; *s_prevok = 0u;
+            }
             for (uint32_t i = tid; i < kBitWords; i += kL2Threads) s_bits[i] = 0u;
             __syncthreads();
             c = *s_chunk;
             __syncthreads();                                 // everyone has read s_chunk before thread 0 can overwrite it
             if (c >= a.n_chunks) break;
-            if constexpr (!kSlab) { if (tid == 0) next_c = atomicAdd(counter, 1u); }
+            // (... and one counter per 64 workgroups of the launch — 8 / 16 / 32 on 64 / 32 / 16 KiB windows, 256 bytes apart —, counter k handing
+            //  out every n-th chunk behind the first gridDim.x: a launch's first claims, which wait in front of the next barrier, meet 63 others
+            //  at their address instead of 2 047.  A workgroup whose counter has run dry takes the other counters' chunks: above.)
+            if constexpr (!kSlab) { if (tid == 0) next_c = gridDim.x + claim_n * atomicAdd(counter + claim_k * kClaimStride, 1u) + claim_k; }
         }
         ParseMeta pm = {1u, 0u};                            // kFused: nothing has looked at the chunk yet
         uint64_t d_in_off, d_in_len, d_out_off, d_result;

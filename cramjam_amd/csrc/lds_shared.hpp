@@ -516,7 +516,7 @@ constexpr uint32_t kFlGroup = CJ_FUSED_GROUP, kFlMaxGroups = CJ_FUSED_MAX_GROUPS
 static_assert(kFlRows / kFlGroup < 128u, "a piece's group number fits 7 bits");
 static_assert(kFlRows < 256u && fl_slot_units(65536u, kFusedLanes) <= 4u * 16384u, "the lists fit the table slot of a 64 KiB window");
 struct FlCell { uint32_t x, y, ob; };
-__device__ unsigned long long g_fused_paths[4];          // test hook: chunks whose P3 / P4 came from the lists, walked P4 only, walked both
+__device__ unsigned long long g_fused_paths[4];          // test hook (counted under CJ_FLAG_DEBUG_PROFILE only: an atomic per chunk on one address is waited for with the thread's next load): chunks whose P3 / P4 came from the lists, walked P4 only, walked both
 
 __device__ __forceinline__ uint32_t wave_excl_scan_add32(uint32_t v, uint32_t& total) {
     const uint32_t lane = lane_id();
@@ -718,7 +718,7 @@ __device__ __forceinline__ bool fused_parse(uint32_t a_in, uint32_t iend, uint32
         const uint32_t n_groups = s_tot[21];
         if (n_groups <= kFlMaxGroups) {                      // (uniform; more groups than the list holds: the walking P4 below)
             p4_done = true;
-            if (tid == 0) atomicAdd(&g_fused_paths[0], 1ull);
+            if (sub_prof && tid == 0) atomicAdd(&g_fused_paths[0], 1ull);
             if (plane) {
                 bool bad = false;
                 uint32_t near = 0;
@@ -756,11 +756,11 @@ __device__ __forceinline__ bool fused_parse(uint32_t a_in, uint32_t iend, uint32
                 if (near) atomicAdd(s_near, near);
                 if (bad || (on_chain && piece_end == kPosErr)) atomicOr(&s_tot[16], 1u);
             }
-        } else if (tid == 0) atomicAdd(&g_fused_paths[1], 1ull);
+        } else if (sub_prof && tid == 0) atomicAdd(&g_fused_paths[1], 1ull);
     } else
 #endif
     {
-    if (tid == 0) atomicAdd(&g_fused_paths[2], 1ull);
+    if (sub_prof && tid == 0) atomicAdd(&g_fused_paths[2], 1ull);
     if (plane) {
         uint32_t q = on_chain ? entry : kPosEnd;
         WalkCarry c3 = {0u, 0xFFFFFFFFu};

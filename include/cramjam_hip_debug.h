@@ -16,7 +16,7 @@ CJ_API int cj_bench_compare(const void* d_got, const uint64_t* d_got_off, const 
 /* per-phase cycle counters of the workgroup decoder (CJ_FLAG_DEBUG_PROFILE on a device batch): S0, D1, D2, D3, D4, chunks, 6.. sub-phases.
  * out16 must hold SIXTEEN 64-bit slots (128 bytes; it was eight until round 3) */
 CJ_API int cj_debug_lds_phase_cycles(unsigned long long* out16, int reset);
-/* chunks of the one-kernel decode path by how their parse finished: from the listed walks, walked P4, walked P3 + P4 (lds_shared.hpp: fused_parse) */
+/* chunks of the one-kernel decode path (batches with CJ_FLAG_DEBUG_PROFILE) by how their parse finished: from the listed walks, walked P4, walked P3 + P4 (lds_shared.hpp: fused_parse) */
 CJ_API int cj_debug_fused_parse_paths(unsigned long long* out3, int reset);
 CJ_API long long cj_debug_forwarded_chunks(int reset);            /* chunks / slabs that went through the forwarding phase */
 CJ_API unsigned long long cj_debug_linked_lds_frames(void);       /* linked-block LZ4 frames decoded by the two-window decoder */

@@ -545,7 +545,7 @@ def test_one_kernel_parse_lists_its_walks_and_walks_again_where_they_outgrow_the
         want = [oracle.lz4_decompress_raw(b, 65536) for b in blobs]
         assert all(r > 0 for r, _ in want)
         assert L.cj_debug_fused_parse_paths(paths, 1) == 0
-        res, outs = eng.batch_host(LZ4, DEC, N.FLAG_FORCE_LDS_PER_CHUNK, blobs, [65536] * len(blobs))
+        res, outs = eng.batch_host(LZ4, DEC, N.FLAG_FORCE_LDS_PER_CHUNK | 0x1000, blobs, [65536] * len(blobs))      # (0x1000 = CJ_FLAG_DEBUG_PROFILE: the counter counts)
         assert [int(r) for r in res] == [r for r, _ in want]
         assert all(bytes(o) == w for o, (_, w) in zip(outs, want))
         assert L.cj_debug_fused_parse_paths(paths, 0) == 0
@@ -562,7 +562,7 @@ def test_one_kernel_parse_lists_its_walks_and_walks_again_where_they_outgrow_the
     er, eo = oracle.snappy_decompress(blob, 1 << 17)
     assert er == n_out and eo == raw[:n_out]
     assert L.cj_debug_fused_parse_paths(paths, 1) == 0
-    res, outs = eng.batch_host(SNAPPY, DEC, N.FLAG_FORCE_LDS_PER_CHUNK, [blob] * 3, [n_out] * 3)
+    res, outs = eng.batch_host(SNAPPY, DEC, N.FLAG_FORCE_LDS_PER_CHUNK | 0x1000, [blob] * 3, [n_out] * 3)
     assert [int(r) for r in res] == [n_out] * 3 and all(bytes(o) == eo for o in outs)
     assert L.cj_debug_fused_parse_paths(paths, 0) == 0 and sum(paths) == 3, list(paths)
 

@@ -117,7 +117,7 @@ __device__ unsigned long long g_slab_trace[8192 * 8];
 #define CJ_TRACE(slot) do {} while (0)
 #define CJ_TRACE_T0(slot) do {} while (0)
 #endif
-__device__ unsigned long long g_fwd_chunks = 0ull;            // test hook: chunks / slabs that went through D1f
+__device__ unsigned long long g_fwd_chunks = 0ull;            // test hook (batches with CJ_FLAG_DEBUG_PROFILE): chunks / slabs that went through D1f
 #ifndef CJ_FWD_ROUNDS_BATCH
 #define CJ_FWD_ROUNDS_BATCH 2u
 #endif
@@ -720,7 +720,7 @@ __device__ __forceinline__ void lds2_body(const BatchArgs& a, const uint2* sync,
                     // not forwardable: no match, self-overlapping, a cross copy already, the last record
                     f_st[i] = off | (hole ? kHole : 0u) | ((m == 0u || off < m || off > r.z || i + 1u == nseq) ? kStop : 0u);
                 }
-                if (tid == 0) { *s_fwd = 0u; atomicAdd(&g_fwd_chunks, 1ull); }
+                if (tid == 0) { *s_fwd = 0u; if (prof) atomicAdd(&g_fwd_chunks, 1ull); }      // (counted under CJ_FLAG_DEBUG_PROFILE: the thread's next load would wait for the atomic)
                 __syncthreads();
                 for (uint32_t i = tid; i < nseq; i += kL2Threads) {          // blocks whose first byte lies in [start_i, start_{i+1})
                     const uint32_t b0 = ((f_w0[i] & 0xffffu) + 15u) >> 4;

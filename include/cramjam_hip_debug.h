@@ -18,7 +18,7 @@ CJ_API int cj_bench_compare(const void* d_got, const uint64_t* d_got_off, const 
 CJ_API int cj_debug_lds_phase_cycles(unsigned long long* out16, int reset);
 /* chunks of the one-kernel decode path (batches with CJ_FLAG_DEBUG_PROFILE) by how their parse finished: from the listed walks, walked P4, walked P3 + P4 (lds_shared.hpp: fused_parse) */
 CJ_API int cj_debug_fused_parse_paths(unsigned long long* out3, int reset);
-CJ_API long long cj_debug_forwarded_chunks(int reset);            /* chunks / slabs that went through the forwarding phase */
+CJ_API long long cj_debug_forwarded_chunks(int reset);            /* chunks / slabs (of calls with CJ_FLAG_DEBUG_PROFILE) that went through the forwarding phase */
 CJ_API unsigned long long cj_debug_linked_lds_frames(void);       /* linked-block LZ4 frames decoded by the two-window decoder */
 /* large-stream path with its parse stage's absolute sync points handed back (tests compare them with a serial walk) */
 CJ_API int64_t cj_debug_big_parse(int codec, uint32_t flags, const uint8_t* in, size_t n, uint8_t* out, size_t cap,

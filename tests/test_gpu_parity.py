@@ -519,7 +519,7 @@ def test_deep_chain_chunks_take_match_forwarding(eng):
     for codec, comp in ((LZ4, lambda c: oracle.lz4_compress_raw(c)[1]), (SNAPPY, lambda c: oracle.snappy_compress(c)[1])):
         blobs = [comp(c) for c in chunks]
         L.cj_debug_forwarded_chunks(1)
-        res, outs = eng.batch_host(codec, DEC, N.FLAG_FORCE_LDS_PER_CHUNK, blobs, [len(c) for c in chunks])
+        res, outs = eng.batch_host(codec, DEC, N.FLAG_FORCE_LDS_PER_CHUNK | 0x1000, blobs, [len(c) for c in chunks])      # (0x1000 = CJ_FLAG_DEBUG_PROFILE: the counter counts)
         assert [int(r) for r in res] == [len(c) for c in chunks]
         assert all(bytes(o) == c for o, c in zip(outs, chunks))
         assert L.cj_debug_forwarded_chunks(0) >= len(chunks) // 2, codec
